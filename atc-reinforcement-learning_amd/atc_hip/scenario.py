@@ -1,0 +1,271 @@
+"""Sector compiler: sector description -> flat scenario blob (float64 master + float32 device copy).
+
+Construction-time only (runs once per scenario on the host, like the reference's constructors);
+nothing here is on the step path.  Follows the reference's derived quantities:
+
+  * closed rings in input order                      — Shapely 1.6 behaviour behind model.py:266
+  * per-polygon bounds, world bbox                   — model.py:267,294-306
+  * corridor geometry (FAF/IAF/corners/normal)       — model.py:155-186
+  * faf_mva, world diagonal, normalisation vectors   — atc_gym.py:49-58,88-110
+  * aircraft limits and rates                        — model.py:13,45-50
+
+The optional lookup grid is an acceleration structure for Airspace.find_mva (model.py:282-289); cells
+are classified conservatively so results are identical to the ordered polygon scan (see build_grid).
+"""
+import math
+
+import numpy as np
+
+from . import layout as L
+
+
+def close_ring(points):
+    """Vertices in input order, first point repeated at the end (what shapely.geometry.Polygon(...).exterior.coords
+    yields for the reference's inputs, model.py:266)."""
+    pts = [tuple(float(c) for c in np.asarray(p, dtype=np.float64).reshape(-1)[:2]) for p in points]
+    if pts[0] != pts[-1]:
+        pts.append(pts[0])
+    return np.asarray(pts, dtype=np.float64)
+
+
+def rot_matrix(phi_deg):
+    """Compass rotation used by the reference's geometry (model.py:345-348)."""
+    phi = math.radians(phi_deg)
+    return np.array([[math.cos(phi), math.sin(phi)], [-math.sin(phi), math.cos(phi)]])
+
+
+def corridor_geometry(x, y, h, phi_from_runway):
+    """Approach-corridor geometry (model.py:155-186): returns dict of float64 values."""
+    faf_threshold_distance = 7.4
+    faf_angle = 45
+    faf_iaf_distance = 3
+    corner_dist = faf_iaf_distance / math.cos(math.radians(faf_angle))
+    r_from = rot_matrix(phi_from_runway)
+    origin = np.array([[x], [y]], dtype=np.float64)
+    normal = np.dot(r_from, np.array([[0], [1]]))
+    faf = origin + np.dot(r_from, np.array([[0], [faf_threshold_distance]]))
+    along = np.dot(r_from, [[0], [corner_dist]])
+    corner1 = np.dot(rot_matrix(faf_angle), along) + faf
+    corner2 = np.dot(rot_matrix(-faf_angle), along) + faf
+    iaf = origin + np.dot(r_from, np.array([[0], [faf_threshold_distance + faf_iaf_distance]]))
+    phi_to = (phi_from_runway + 180) % 360
+    dir_rwy = np.dot(rot_matrix(phi_to), np.array([[0], [1]]))
+    return {
+        "x": float(x), "y": float(y), "h": float(h),
+        "phi_from_runway": float(phi_from_runway), "phi_to_runway": float(phi_to),
+        "faf": faf.ravel(), "iaf": iaf.ravel(), "corner1": corner1.ravel(), "corner2": corner2.ravel(),
+        "normal": normal.ravel(), "dir_rwy": dir_rwy.ravel(), "faf_angle": float(faf_angle),
+        "tri_h": close_ring([faf, corner1, corner2]),
+        "tri_1": close_ring([faf, corner1, iaf]),
+        "tri_2": close_ring([faf, corner2, iaf]),
+    }
+
+
+def _crossing_inside(x, y, ring):
+    """Host crossing-number test with the reference's inequality set (model.py:318-337); construction-time use
+    only (faf_mva, grid cell classification)."""
+    n = len(ring)
+    inside = False
+    p1x, p1y = ring[0]
+    for i in range(n + 1):
+        p2x, p2y = ring[i % n]
+        if y > min(p1y, p2y) and y <= max(p1y, p2y) and x <= max(p1x, p2x):
+            if p1y != p2y:
+                xints = (y - p1y) * (p2x - p1x) / (p2y - p1y) + p1x
+            if p1x == p2x or x <= xints:
+                inside = not inside
+        p1x, p1y = p2x, p2y
+    return inside
+
+
+def _first_polygon(x, y, rings, bounds):
+    for i, (ring, b) in enumerate(zip(rings, bounds)):
+        if b[0] <= x <= b[2] and b[1] <= y <= b[3] and _crossing_inside(x, y, ring):
+            return i
+    return -1
+
+
+def _seg_dist2_to_box(p, q, bx0, by0, bx1, by1):
+    """True if segment p-q comes within the (already inflated) box — conservative: segment bbox overlap + separating
+    axis along the segment normal."""
+    if max(p[0], q[0]) < bx0 or min(p[0], q[0]) > bx1 or max(p[1], q[1]) < by0 or min(p[1], q[1]) > by1:
+        return False
+    dx, dy = q[0] - p[0], q[1] - p[1]
+    if dx == 0.0 and dy == 0.0:
+        return True
+    # signed distances of the 4 box corners to the segment's supporting line: all on one side -> no intersection
+    s = [(cx - p[0]) * dy - (cy - p[1]) * dx for cx in (bx0, bx1) for cy in (by0, by1)]
+    return not (min(s) > 0.0 or max(s) < 0.0)
+
+
+def build_grid(rings, bounds, bbox, cell, guard=None):
+    """Uniform grid over the world bbox.  A cell is CLEAN when no edge of any MVA polygon comes within `guard`
+    of it; then every point of the cell has the same ordered-scan answer as its centre (evaluated here with the
+    reference's rule) — robustly so in fp32, because no point of the cell is within `guard` of an edge.  Otherwise the
+    cell stores the bitmask of candidate polygons (those with an edge near the cell or containing its centre); the
+    device then runs the exact ordered test over the candidates only."""
+    if guard is None:
+        guard = 1e-3
+    npoly = len(rings)
+    assert npoly <= 23, "grid bitmask supports at most 23 polygons"
+    x0, y0, x1, y1 = bbox
+    # one ring of padding cells so that points on/near the bbox border index safely
+    gx0 = x0 - cell
+    gy0 = y0 - cell
+    nx = int(math.ceil((x1 - gx0) / cell)) + 2
+    ny = int(math.ceil((y1 - gy0) / cell)) + 2
+    inv = 1.0 / cell
+    cells = np.zeros((ny, nx), dtype=np.float64)
+    near = np.zeros((ny, nx), dtype=np.int64)
+    # the device computes the cell index in fp32 from (x - gx0) * inv; inflate by an fp32 indexing slack as well
+    slack = guard + 1e-4 * max(1.0, abs(x1), abs(y1)) * 2.0 ** -10
+    for pi, ring in enumerate(rings):
+        for k in range(len(ring) - 1):
+            p, q = ring[k], ring[k + 1]
+            i0 = max(0, int(math.floor((min(p[0], q[0]) - slack - gx0) * inv)) - 1)
+            i1 = min(nx - 1, int(math.floor((max(p[0], q[0]) + slack - gx0) * inv)) + 1)
+            j0 = max(0, int(math.floor((min(p[1], q[1]) - slack - gy0) * inv)) - 1)
+            j1 = min(ny - 1, int(math.floor((max(p[1], q[1]) + slack - gy0) * inv)) + 1)
+            for j in range(j0, j1 + 1):
+                cy0 = gy0 + j * cell - slack
+                cy1 = gy0 + (j + 1) * cell + slack
+                for i in range(i0, i1 + 1):
+                    cx0 = gx0 + i * cell - slack
+                    cx1 = gx0 + (i + 1) * cell + slack
+                    if _seg_dist2_to_box(p, q, cx0, cy0, cx1, cy1):
+                        near[j, i] |= (1 << pi)
+    for j in range(ny):
+        cy = gy0 + (j + 0.5) * cell
+        for i in range(nx):
+            cx = gx0 + (i + 0.5) * cell
+            if near[j, i] == 0:
+                cells[j, i] = _first_polygon(cx, cy, rings, bounds) + 1
+            else:
+                mask = int(near[j, i])
+                # polygons that contain the whole cell without an edge nearby must stay candidates too
+                for pi, (ring, b) in enumerate(zip(rings, bounds)):
+                    if not (mask >> pi) & 1:
+                        if b[0] <= cx <= b[2] and b[1] <= cy <= b[3] and _crossing_inside(cx, cy, ring):
+                            mask |= (1 << pi)
+                cells[j, i] = L.GRID_MASK_BASE + mask
+    hdr = np.zeros(L.G_HDR, dtype=np.float64)
+    hdr[L.G_X0], hdr[L.G_Y0], hdr[L.G_INV], hdr[L.G_NX], hdr[L.G_NY] = gx0, gy0, inv, nx, ny
+    return np.concatenate([hdr, cells.ravel()])
+
+
+class CompiledSector:
+    """Result of compile_sector: `.blob64` (float64 master), `.blob32` (device copy) and the derived constants."""
+
+    def __init__(self, blob64, meta):
+        self.blob64 = np.ascontiguousarray(blob64, dtype=np.float64)
+        self.blob32 = np.ascontiguousarray(blob64.astype(np.float32))
+        self.meta = meta
+
+    def __getattr__(self, name):
+        try:
+            return self.__dict__["meta"][name]
+        except KeyError:
+            raise AttributeError(name)
+
+
+def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_guard=None):
+    """mvas: [(points, height_ft)], runway: (x, y, h, phi_from_runway), entrypoints: [(x, y, phi, [levels])],
+    noise: [(points, ceiling_ft, penalty_per_step)].  Returns CompiledSector."""
+    mva_rings = [close_ring(p) for p, _ in mvas]
+    mva_heights = [float(hh) for _, hh in mvas]
+    noise_rings = [close_ring(p) for p, _, _ in noise]
+    rings = mva_rings + noise_rings
+    heights = mva_heights + [float(c) for _, c, _ in noise]
+    penalties = [0.0] * len(mva_rings) + [float(pen) for _, _, pen in noise]
+    bounds = [(r[:, 0].min(), r[:, 1].min(), r[:, 0].max(), r[:, 1].max()) for r in rings]
+    cg = corridor_geometry(*runway)
+
+    if mva_rings:
+        mb = bounds[:len(mva_rings)]
+        bbox = (min(b[0] for b in mb), min(b[1] for b in mb), max(b[2] for b in mb), max(b[3] for b in mb))
+    else:
+        bbox = (0.0, 0.0, 1.0, 1.0)
+    x_len = bbox[2] - bbox[0]
+    y_len = bbox[3] - bbox[1]
+    world_diag = float(np.hypot(x_len, y_len))
+    fi = _first_polygon(cg["faf"][0], cg["faf"][1], mva_rings, bounds[:len(mva_rings)]) if mva_rings else -1
+    faf_mva = mva_heights[fi] if fi >= 0 else 0.0
+
+    v_min, v_max, h_min, h_max = 100.0, 300.0, 0.0, 38000.0
+    norm_min = np.array([bbox[0], bbox[1], 0, 0, v_min, 0, 0, 0, -180, -180], dtype=np.float32)
+    norm_max = np.array([x_len, y_len, h_max, 360, v_max - v_min, h_max, h_max, world_diag, 360, 360], dtype=np.float32)
+
+    n_poly = len(rings)
+    off_poly = L.C_END
+    off_vert = off_poly + n_poly * L.P_WORDS
+    n_vertw = 2 * sum(len(r) for r in rings)
+    off_entry = off_vert + n_vertw
+    n_entry = len(entrypoints)
+    end = off_entry + n_entry * L.E_WORDS
+    grid = None
+    off_grid = 0
+    if grid_cell is not None and mva_rings:
+        grid = build_grid(mva_rings, bounds[:len(mva_rings)], bbox, float(grid_cell), grid_guard)
+        off_grid = end
+        end += len(grid)
+
+    b = np.zeros(end, dtype=np.float64)
+    b[L.H_VERSION] = L.BLOB_VERSION
+    b[L.H_NWORDS] = end
+    b[L.H_N_MVA] = len(mva_rings)
+    b[L.H_N_NOISE] = len(noise_rings)
+    b[L.H_N_ENTRY] = n_entry
+    b[L.H_OFF_POLY], b[L.H_OFF_VERT], b[L.H_OFF_ENTRY], b[L.H_OFF_GRID] = off_poly, off_vert, off_entry, off_grid
+    b[L.H_N_VERTW] = n_vertw
+    b[L.C_RWY_X], b[L.C_RWY_Y], b[L.C_RWY_H] = cg["x"], cg["y"], cg["h"]
+    b[L.C_PHI_TO_RWY] = cg["phi_to_runway"]
+    b[L.C_FAF_X], b[L.C_FAF_Y] = cg["faf"]
+    b[L.C_NRM_X], b[L.C_NRM_Y] = cg["normal"]
+    b[L.C_FAF_ANGLE] = cg["faf_angle"]
+    b[L.C_GS_TAN] = math.tan(3 * math.pi / 180)
+    b[L.C_FAF_MVA] = faf_mva
+    b[L.C_WORLD_DIAG] = world_diag
+    b[L.C_NM_TO_FT] = 6076
+    b[L.C_V_MIN], b[L.C_V_MAX], b[L.C_H_MIN], b[L.C_H_MAX] = v_min, v_max, h_min, h_max
+    b[L.C_A_MIN], b[L.C_A_MAX], b[L.C_HDOT_MIN], b[L.C_HDOT_MAX] = -5, 5, -41, 15
+    b[L.C_PHIDOT_MIN], b[L.C_PHIDOT_MAX], b[L.C_V_INIT] = -3, 3, 250
+    b[L.C_TRI_H:L.C_TRI_H + 8] = cg["tri_h"].ravel()
+    b[L.C_TRI_1:L.C_TRI_1 + 8] = cg["tri_1"].ravel()
+    b[L.C_TRI_2:L.C_TRI_2 + 8] = cg["tri_2"].ravel()
+    b[L.C_NORM_MIN:L.C_NORM_MIN + 10] = norm_min.astype(np.float64)
+    b[L.C_NORM_MAX:L.C_NORM_MAX + 10] = norm_max.astype(np.float64)
+    b[L.C_ACT_DISCR:L.C_ACT_DISCR + 3] = (5, 50, 0.5)
+    b[L.C_BBOX:L.C_BBOX + 4] = bbox
+    b[L.C_DIR_RWY_X], b[L.C_DIR_RWY_Y] = cg["dir_rwy"]
+    # knife-edge of the reference's angle window for a heading exactly equal to the runway heading (model.py:216-229):
+    # min_angle = 45 - (45 - arccos(dir . dir)) must be <= relative_angle == 0.  Evaluated with numpy like the reference.
+    d = np.dot(rot_matrix(cg["phi_to_runway"]), np.array([[0], [1]]))
+    min_angle = cg["faf_angle"] - (cg["faf_angle"] - np.arccos(np.dot(np.transpose(d), d))[0][0])
+    b[L.C_ALIGNED_OK] = 1.0 if min_angle <= 0.0 else 0.0
+    voff = off_vert
+    for i, ring in enumerate(rings):
+        rec = off_poly + i * L.P_WORDS
+        b[rec + L.P_MINX:rec + L.P_MINX + 4] = bounds[i]
+        b[rec + L.P_HEIGHT] = heights[i]
+        b[rec + L.P_VOFF] = voff
+        b[rec + L.P_NVERT] = len(ring)
+        b[rec + L.P_PENALTY] = penalties[i]
+        b[voff:voff + 2 * len(ring)] = ring.ravel()
+        voff += 2 * len(ring)
+    for i, (ex, ey, ephi, levels) in enumerate(entrypoints):
+        assert 1 <= len(levels) <= L.E_MAXLEV, "1..8 levels per entry point"
+        rec = off_entry + i * L.E_WORDS
+        b[rec + L.E_X], b[rec + L.E_Y], b[rec + L.E_PHI], b[rec + L.E_NLEV] = ex, ey, ephi, len(levels)
+        b[rec + L.E_LEV0:rec + L.E_LEV0 + len(levels)] = levels
+    if grid is not None:
+        b[off_grid:off_grid + len(grid)] = grid
+    assert end < 2 ** 24, "blob offsets must stay exactly representable in fp32"
+
+    meta = dict(
+        mva_rings=mva_rings, mva_heights=mva_heights, mva_bounds=bounds[:len(mva_rings)], noise_rings=noise_rings,
+        bbox=bbox, world_diag=world_diag, faf_mva=faf_mva, corridor=cg, norm_min=norm_min, norm_max=norm_max,
+        entrypoints=[(float(a), float(b_), float(c), [int(l) for l in lv]) for a, b_, c, lv in entrypoints],
+        n_mva=len(mva_rings), n_noise=len(noise_rings), n_entry=n_entry, has_grid=grid is not None,
+        v_min=v_min, v_max=v_max, h_min=h_min, h_max=h_max,
+    )
+    return CompiledSector(b, meta)

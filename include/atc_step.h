@@ -1,0 +1,210 @@
+/*
+ * atc_step.h — C-ABI of libatcstep.so, the MI355X (gfx950) implementation of the batched
+ * AtcGym.step() hot path of fvalka/atc-reinforcement-learning.
+ *
+ * The reference has no FFI (pure Python).  Each entry point below replaces a Python call site of the
+ * reference (cited as path:line relative to the reference tree) and is what a ctypes binding on the
+ * reference side would load (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  No exceptions, no Python/torch objects cross the boundary.
+ *   - every int-returning function: 0 = ok, ATC_ERR_* (<0) otherwise; atc_last_error() gives a
+ *     thread-local message.
+ *   - every buffer is a BORROWED device pointer (e.g. torch tensor .data_ptr()); the library owns only
+ *     the opaque scenario handle.
+ *   - all launches are asynchronous on the caller's HIP stream (`stream` = hipStream_t, e.g.
+ *     torch.cuda.current_stream().cuda_stream); the caller synchronises.
+ *   - aircraft arrays are SoA, index = env * N + k   (k = aircraft slot in the env, N <= 64).
+ *   - re-entrant: no global mutable state besides the thread-local error string.
+ */
+#ifndef ATC_STEP_H
+#define ATC_STEP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ATC_ABI_VERSION 3
+
+/* ---------------------------------------------------------------------------------------------
+ * Scenario blob: one flat array of 32-bit floats (device copy) compiled on the host from the sector
+ * description (reference: envs/atc/scenarios.py:14-207, envs/atc/model.py:148-186,260-306,
+ * envs/atc/atc_gym.py:45-58,88-110).  Integer fields are stored as exactly representable floats.
+ * The float64 master (used by the f64 oracle) has the identical word layout.
+ * ------------------------------------------------------------------------------------------- */
+#define ATC_BLOB_VERSION 1003.0f
+enum {
+    ATC_H_VERSION = 0,   /* ATC_BLOB_VERSION */
+    ATC_H_NWORDS = 1,    /* total words */
+    ATC_H_N_MVA = 2,     /* number of MVA polygons (list order = lookup priority, model.py:283) */
+    ATC_H_N_NOISE = 3,   /* number of noise-abatement polygons (extension; 0 for reference scenarios) */
+    ATC_H_N_ENTRY = 4,   /* number of entry points (scenarios.py:192-207) */
+    ATC_H_OFF_POLY = 5,  /* word offset of polygon table: MVA polygons first, then noise polygons */
+    ATC_H_OFF_VERT = 6,  /* word offset of vertex pool (x,y interleaved; rings closed: first == last) */
+    ATC_H_OFF_ENTRY = 7, /* word offset of entry-point table */
+    ATC_H_OFF_GRID = 8,  /* word offset of the MVA lookup grid (0 = absent) */
+    ATC_H_N_VERTW = 9,   /* words in the vertex pool */
+    /* constants block */
+    ATC_C_RWY_X = 16, ATC_C_RWY_Y = 17, ATC_C_RWY_H = 18,
+    ATC_C_PHI_TO_RWY = 19,                /* (phi_from_runway + 180) % 360, model.py:163,245 */
+    ATC_C_FAF_X = 20, ATC_C_FAF_Y = 21,   /* model.py:171-172 */
+    ATC_C_NRM_X = 22, ATC_C_NRM_Y = 23,   /* _faf_iaf_normal, model.py:164 */
+    ATC_C_FAF_ANGLE = 24,                 /* 45, model.py:167 */
+    ATC_C_GS_TAN = 25,                    /* tan(3*pi/180), model.py:204 */
+    ATC_C_FAF_MVA = 26,                   /* atc_gym.py:49 */
+    ATC_C_WORLD_DIAG = 27,                /* atc_gym.py:58 */
+    ATC_C_NM_TO_FT = 28,                  /* 6076, model.py:10 */
+    ATC_C_V_MIN = 29, ATC_C_V_MAX = 30, ATC_C_H_MIN = 31, ATC_C_H_MAX = 32,          /* model.py:13 */
+    ATC_C_A_MIN = 33, ATC_C_A_MAX = 34, ATC_C_HDOT_MIN = 35, ATC_C_HDOT_MAX = 36,     /* model.py:45-48 */
+    ATC_C_PHIDOT_MIN = 37, ATC_C_PHIDOT_MAX = 38, ATC_C_V_INIT = 39,                  /* model.py:49-50; atc_gym.py:348 */
+    ATC_C_TRI_H = 40,   /* corridor_horizontal ring [faf, corner1, corner2, faf], 8 words, model.py:177 */
+    ATC_C_TRI_1 = 48,   /* corridor1 ring [faf, corner1, iaf, faf], model.py:180 */
+    ATC_C_TRI_2 = 56,   /* corridor2 ring [faf, corner2, iaf, faf], model.py:181 */
+    ATC_C_NORM_MIN = 64,  /* 10 words, atc_gym.py:88-98 */
+    ATC_C_NORM_MAX = 74,  /* 10 words, atc_gym.py:99-110 */
+    ATC_C_ACT_DISCR = 84, /* 3 words (5, 50, 0.5), atc_gym.py:84 */
+    ATC_C_BBOX = 87,      /* x0,y0,x1,y1, model.py:294-301 */
+    ATC_C_DIR_RWY_X = 91, ATC_C_DIR_RWY_Y = 92, /* rot_matrix(phi_to_runway) . [0,1], model.py:219 */
+    ATC_C_ALIGNED_OK = 93, /* 1 if the reference's angle window (model.py:216-229) accepts phi == phi_to_runway exactly,
+                              evaluated on the host with the reference's own expression (np.dot / arccos) */
+    ATC_C_END = 96
+};
+/* polygon table record (8 words) */
+enum { ATC_P_MINX = 0, ATC_P_MINY = 1, ATC_P_MAXX = 2, ATC_P_MAXY = 3,
+       ATC_P_HEIGHT = 4,  /* MVA height [ft] (model.py:265) or noise-area ceiling [ft] */
+       ATC_P_VOFF = 5,    /* word offset of first vertex */
+       ATC_P_NVERT = 6,   /* number of vertices in the closed ring (= len(area_as_list)) */
+       ATC_P_PENALTY = 7, /* noise-area per-step penalty (0 for MVA polygons) */
+       ATC_P_WORDS = 8 };
+/* entry-point record (12 words): x, y, phi, n_levels, levels[8] (flight levels, x100 ft; model.py:309-315) */
+enum { ATC_E_X = 0, ATC_E_Y = 1, ATC_E_PHI = 2, ATC_E_NLEV = 3, ATC_E_LEV0 = 4, ATC_E_WORDS = 12, ATC_E_MAXLEV = 8 };
+/* lookup grid (optional acceleration structure for Airspace.find_mva; results identical by construction):
+ *   header 8 words: x0, y0, inv_cell, nx, ny, reserved x3 ; then nx*ny cell words.
+ *   cell word (integer-valued float, < 2^24):
+ *     value <  ATC_GRID_MASK_BASE : cell is "clean" (no polygon edge within the guard band) -> value = poly index + 1,
+ *                                   or 0 = outside every polygon
+ *     value >= ATC_GRID_MASK_BASE : value - BASE = bitmask of candidate polygons (only when n_mva <= 23)   */
+enum { ATC_G_X0 = 0, ATC_G_Y0 = 1, ATC_G_INV = 2, ATC_G_NX = 3, ATC_G_NY = 4, ATC_G_HDR = 8 };
+#define ATC_GRID_MASK_BASE 8388608.0f /* 2^23 */
+
+#define ATC_MAX_AIRCRAFT 64
+#define ATC_OBS_DIM 10 /* atc_gym.py:262-277 */
+#define ATC_ACT_DIM 3  /* v, h, phi  (atc_gym.py:70,79) */
+
+/* per-aircraft flag word (outputs `flags`) */
+enum {
+    ATC_F_BELOW_MVA = 1u << 0, /* atc_gym.py:149-153 */
+    ATC_F_OUTSIDE = 1u << 1,   /* atc_gym.py:156-161 */
+    ATC_F_WON = 1u << 2,       /* atc_gym.py:163-169 */
+    ATC_F_TIMEOUT = 1u << 3,   /* atc_gym.py:171-173 */
+    ATC_F_INVALID_V = 1u << 4, /* atc_gym.py:312-315 via model.py:69-72 */
+    ATC_F_INVALID_H = 1u << 5, /* atc_gym.py:312-315 via model.py:91-94 */
+    ATC_F_CONFLICT = 1u << 6,  /* extension: 3 nm / 1000 ft separation lost (README.md:51) */
+    ATC_F_NOISE = 1u << 7,     /* extension: inside a noise-abatement area below its ceiling (README.md:62) */
+    ATC_F_INACTIVE = 1u << 8   /* extension: aircraft already handed over (won earlier in this episode) */
+};
+
+/* params.mode bits */
+enum {
+    ATC_M_REWARD_SHAPING = 1u << 0,  /* SimParameters.reward_shaping, model.py:143 */
+    ATC_M_NORMALIZE = 1u << 1,       /* SimParameters.normalize_state, model.py:144 */
+    ATC_M_DISCRETE = 1u << 2,        /* SimParameters.discrete_action_space, model.py:145 */
+    ATC_M_AUTO_RESET = 1u << 3,      /* VecEnv semantics: done envs are reset inside the step, obs := raw reset obs */
+    ATC_M_RANDOM_ENTRY = 1u << 4     /* reset draws (entry, level) from the counter-based RNG; else slot lattice */
+};
+
+typedef struct atc_params {
+    float dt;               /* SimParameters.timestep [s], model.py:141 */
+    int32_t timestep_limit; /* 6000, atc_gym.py:40 */
+    uint32_t mode;          /* ATC_M_* */
+    uint32_t reserved0;
+    uint64_t seed;          /* RNG key for ATC_M_RANDOM_ENTRY */
+    float sep_nm;           /* 3.0  (extension) */
+    float sep_ft;           /* 1000 (extension) */
+    float conflict_reward;  /* -200 (extension) */
+    float reserved1;
+} atc_params_t;
+
+/* Persistent environment state (all device pointers). */
+typedef struct atc_state {
+    /* per aircraft [B*N] */
+    double* x;       /* nm   model.py:33 — positions are accumulated in float64: fp32 accumulation drifts by up to */
+    double* y;       /* nm   model.py:34   0.5 ulp/step on straight legs (1e-4 nm after 100 steps), beyond the 1e-5 bar */
+    float* h;        /* ft   model.py:35 */
+    float* phi;      /* deg, never wrapped (model.py:113-120) */
+    float* v;        /* kt   model.py:38 */
+    float* last_act; /* [3][B*N] last accepted denormalised action v,h,phi (atc_gym.py:86,309); plane-major */
+    /* per env [B] */
+    int32_t* timesteps;     /* atc_gym.py:39 */
+    int32_t* actions_taken; /* atc_gym.py:31 */
+    float* total_reward;    /* atc_gym.py:30 */
+    uint64_t* active_mask;  /* bit k = aircraft k still under control (extension; N=1: always 1) */
+    uint32_t* win_bits;     /* last 10 episode outcomes, bit0 = most recent (atc_gym.py:36-37,359-363) */
+    int32_t* episodes;      /* atc_gym.py:33 (_episodes_run) */
+    float* ep_return;       /* return of the last finished episode (Monitor 'r') */
+    int32_t* ep_length;     /* length of the last finished episode (Monitor 'l') */
+} atc_state_t;
+
+/* Per-step outputs (device pointers; nullable ones may be NULL). */
+typedef struct atc_out {
+    float* obs;        /* [B*N*10] what step() returns (normalised iff ATC_M_NORMALIZE), atc_gym.py:187-192 */
+    float* raw_obs;    /* nullable [B*N*10] info["original_state"], atc_gym.py:192 */
+    float* reward;     /* [B] env reward = sum over aircraft */
+    float* ac_reward;  /* nullable [B*N] per-aircraft reward */
+    uint8_t* done;     /* [B] */
+    uint32_t* flags;   /* [B*N] ATC_F_* */
+    float* min_sep;    /* nullable [B] minimum horizontal separation among active pairs [nm] (diagnostic) */
+    float* term_obs;   /* nullable [B*N*10] terminal observation of envs that were auto-reset this step */
+} atc_out_t;
+
+/* Opaque device-resident scenario (owned by the library). */
+typedef struct atc_scenario atc_scenario_t;
+
+/* -- lifecycle -------------------------------------------------------------------------------- */
+int atc_abi_version(void);
+const char* atc_last_error(void);
+
+/* Uploads a compiled scenario blob (host pointer, n_words floats) to `device`.
+ * Replaces: AtcGym.__init__ scenario unpacking, atc_gym.py:45-58. */
+int atc_scenario_create(const float* blob_host, size_t n_words, int device, atc_scenario_t** out);
+int atc_scenario_destroy(atc_scenario_t* s);
+
+/* -- batched queries (same device functions as the step kernel) -------------------------------- */
+/* Airspace.get_mva_height, model.py:282-292.  out_h[i] = MVA height [ft] or -1 (outside airspace).
+ * use_grid != 0 uses the lookup grid if the blob has one. */
+int atc_query_mva(const atc_scenario_t* s, int n, const float* x, const float* y, int32_t* out_h, int use_grid,
+                  void* stream);
+/* Runway.inside_corridor, model.py:248-257,188-231.  angle_only != 0 evaluates Corridor._inside_corridor_angle
+ * (model.py:212-231) alone.  out[i] = 0/1. */
+int atc_query_corridor(const atc_scenario_t* s, int n, const float* x, const float* y, const float* h,
+                       const float* phi, int angle_only, uint8_t* out, void* stream);
+/* Shaping rewards, atc_gym.py:199-260: out3[3*i+0..2] = (_reward_approach_position, _reward_approach_angle,
+ * _reward_glideslope) for inputs (d_faf, phi_rel_faf, phi_plane, h, on_gp_altitude). */
+int atc_query_shaping(const atc_scenario_t* s, int n, const float* d_faf, const float* phi_rel_faf,
+                      const float* phi_plane, const float* h, const float* on_gp, float* out3, void* stream);
+
+/* -- environment ------------------------------------------------------------------------------- */
+/* AtcGym.reset, atc_gym.py:337-365, for every env whose mask byte is non-zero (mask == NULL: all envs).
+ * Writes the RAW reset observation (mva = 0, quirk atc_gym.py:351,365) to `obs` for reset envs only.
+ * first != 0 additionally clears last_act / win_bits / episodes (what AtcGym.__init__ does, atc_gym.py:29-41,86). */
+int atc_reset(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const uint8_t* mask, float* obs,
+              const atc_params_t* p, int first, void* stream);
+
+/* AtcGym.step, atc_gym.py:128-192, for B envs x N aircraft.  actions: [B*N*3] (v,h,phi per aircraft),
+ * continuous in [-1,1] or discrete indices stored as floats (atc_gym.py:318-335). */
+int atc_step(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const float* actions,
+             const atc_out_t* out, const atc_params_t* p, void* stream);
+
+/* T consecutive steps in ONE launch with aircraft state held in registers.  actions: [T][B*N*3];
+ * outputs are [T][...] versions of atc_out_t (each pointer strides by its per-step size).
+ * Requires ATC_M_AUTO_RESET semantics to be meaningful for T > episode length. */
+int atc_rollout(const atc_scenario_t* s, int B, int N, int T, const atc_state_t* st, const float* actions,
+                const atc_out_t* out, const atc_params_t* p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATC_STEP_H */

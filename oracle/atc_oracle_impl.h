@@ -1,0 +1,514 @@
+/*
+ * atc_oracle_impl.h — CPU restatement of the reference's AtcGym.step() hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle (checker) for the HIP product path.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  It is never imported by the product package.
+ *
+ * Included twice by atc_oracle.c with REAL = double (suffix _f64; pinned against the golden vectors captured from the
+ * reference, tests/golden/) and REAL = float (suffix _f32; the fp32 restatement the HIP kernel's integer outputs must
+ * match bit-for-bit).  Scalar, same operation order as the reference, compiled with -ffp-contract=off.
+ *
+ * Pinned by: tests/golden/{g1..g7,model_test_known_answers} (see tests/test_oracle_golden.py).
+ * The multi-aircraft separation scan and noise-abatement areas have NO reference implementation
+ * (README.md:51,60,62 are prose only): for those paths parity is UNPINNED and this file is the definition.
+ *
+ * Citations are path:line in the reference tree (fvalka/atc-reinforcement-learning).
+ */
+
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+#define FN(name) CAT(name, SUFFIX)
+
+/* ---- elementary helpers --------------------------------------------------------------------------------------- */
+
+/* Python float modulo: result takes the sign of the divisor (used by relative_angle, model.py:340-342). */
+static REAL FN(py_mod)(REAL a, REAL b) {
+    REAL r = R_FMOD(a, b);
+    if (r != (REAL)0 && ((r < (REAL)0) != (b < (REAL)0))) r += b;
+    return r;
+}
+
+/* model.py:340-342  relative_angle(angle1, angle2) = (angle2 - angle1 + 180) % 360 - 180 */
+static REAL FN(relative_angle)(REAL a1, REAL a2) {
+    return FN(py_mod)(a2 - a1 + (REAL)180, (REAL)360) - (REAL)180;
+}
+
+/* math.radians: x * (pi / 180)  (CPython mathmodule.c degToRad) */
+static REAL FN(radians)(REAL x) { return x * (REAL)(3.14159265358979323846 / 180.0); }
+/* np.degrees: x * (180 / pi) */
+static REAL FN(degrees)(REAL x) { return x * (REAL)(180.0 / 3.14159265358979323846); }
+
+/* model.py:318-337  ray_tracing(x, y, poly): crossing number over n+1 edges with the reference's inequality set.
+ * ring = x,y interleaved, n vertices (closed ring: first == last). */
+static int FN(ray_tracing)(REAL x, REAL y, const REAL* ring, int n) {
+    int inside = 0;
+    REAL xints = (REAL)0;
+    REAL p1x = ring[0], p1y = ring[1];
+    for (int i = 0; i < n + 1; ++i) {
+        int k = i % n;
+        REAL p2x = ring[2 * k], p2y = ring[2 * k + 1];
+        if (y > R_MIN(p1y, p2y)) {
+            if (y <= R_MAX(p1y, p2y)) {
+                if (x <= R_MAX(p1x, p2x)) {
+                    if (p1y != p2y) xints = (y - p1y) * (p2x - p1x) / (p2y - p1y) + p1x;
+                    if (p1x == p2x || x <= xints) inside = !inside;
+                }
+            }
+        }
+        p1x = p2x;
+        p1y = p2y;
+    }
+    return inside;
+}
+
+/* model.py:282-292  Airspace.find_mva / get_mva_height: first polygon in list order whose (inclusive) bounds contain
+ * the point and whose ray_tracing is true.  Returns the polygon index or -1 ("Outside of airspace"). */
+static int FN(find_mva)(const REAL* S, REAL x, REAL y) {
+    int n_mva = (int)S[ATC_H_N_MVA];
+    int off = (int)S[ATC_H_OFF_POLY];
+    for (int p = 0; p < n_mva; ++p) {
+        const REAL* rec = S + off + p * ATC_P_WORDS;
+        if (rec[ATC_P_MINX] <= x && x <= rec[ATC_P_MAXX] && rec[ATC_P_MINY] <= y && y <= rec[ATC_P_MAXY]) {
+            if (FN(ray_tracing)(x, y, S + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT])) return p;
+        }
+    }
+    return -1;
+}
+
+/* model.py:212-231  Corridor._inside_corridor_angle.  NOTE: min_angle is in RADIANS (arccos) while relative_angle is in
+ * DEGREES — reproduced as is (survey quirk Q5).
+ * The arccos argument is evaluated in float64 in BOTH instantiations, as fma(c1, c2, s1 * s2): that is what the
+ * reference's np.dot (BLAS, FMA) computes, and it decides the knife-edge "heading exactly equals the runway heading"
+ * (dot == 1.0 -> arccos == 0 -> 0 <= 0 passes; measured: plain mul/add gives 0.9999999999999999 for 340 vs 700 deg where
+ * np.dot gives 1.0).  Keeping this one expression in float64 makes the fp32 instantiation agree with the reference for
+ * exactly aligned (e.g. integer, discrete-action) headings. */
+static int FN(inside_corridor_angle)(const REAL* S, REAL x, REAL y, REAL phi) {
+    REAL to_runway = S[ATC_C_PHI_TO_RWY];
+    REAL faf_angle = S[ATC_C_FAF_ANGLE];
+    /* rot_matrix(a) . [0,1] = (sin(rad a), cos(rad a)) */
+    double tr = (double)to_runway * (3.14159265358979323846 / 180.0);
+    double pr = (double)phi * (3.14159265358979323846 / 180.0);
+    double dot = fma(cos(tr), cos(pr), sin(tr) * sin(pr));
+    REAL beta = faf_angle - (REAL)acos(dot);
+    REAL min_angle = faf_angle - beta;
+    if (FN(ray_tracing)(x, y, S + ATC_C_TRI_1, 4)) {
+        REAL ra = FN(relative_angle)(to_runway, phi);
+        if (min_angle <= ra && ra <= faf_angle) return 1;
+        return 0; /* python `elif`: corridor2 is only evaluated when ray_tracing(corridor1) is false */
+    }
+    if (FN(ray_tracing)(x, y, S + ATC_C_TRI_2, 4)) {
+        REAL ra = FN(relative_angle)(phi, to_runway);
+        if (min_angle <= ra && ra <= faf_angle) return 1;
+    }
+    return 0;
+}
+
+/* model.py:188-210  Corridor.inside_corridor */
+static int FN(inside_corridor)(const REAL* S, REAL x, REAL y, REAL h, REAL phi) {
+    if (!FN(ray_tracing)(x, y, S + ATC_C_TRI_H, 4)) return 0;
+    REAL fx = S[ATC_C_FAF_X], fy = S[ATC_C_FAF_Y], nx = S[ATC_C_NRM_X], ny = S[ATC_C_NRM_Y];
+    REAL t = (x - fx) * nx + (y - fy) * ny;            /* np.dot(p - faf^T, normal) */
+    REAL px = fx + t * nx, py = fy + t * ny;           /* faf + t * normal */
+    REAL dx = px - S[ATC_C_RWY_X], dy = py - S[ATC_C_RWY_Y];
+    REAL nrm = R_SQRT(dx * dx + dy * dy);              /* np.linalg.norm */
+    REAL h_max = nrm * S[ATC_C_GS_TAN] * S[ATC_C_NM_TO_FT] + S[ATC_C_RWY_H];
+    if (!(h <= h_max)) return 0;
+    return FN(inside_corridor_angle)(S, x, y, phi);
+}
+
+/* atc_gym.py:17-19 */
+static REAL FN(sigmoid_distance)(REAL d, REAL d_max) {
+    return ((REAL)1.0 - R_TANH((REAL)4.0 * (d / d_max) - (REAL)2.0)) / (REAL)2.0;
+}
+
+/* atc_gym.py:199-222 */
+static REAL FN(reward_approach_position)(REAL d_faf, REAL phi_to_runway, REAL phi_rel_to_faf, REAL world_max_dist) {
+    REAL reward_faf = FN(sigmoid_distance)(d_faf, world_max_dist);
+    REAL reward_app_angle = R_POW(R_ABS(FN(relative_angle)(phi_to_runway, phi_rel_to_faf)) / (REAL)180.0, (REAL)1.5);
+    return reward_faf * reward_app_angle * (REAL)0.8;
+}
+
+/* atc_gym.py:224-237 */
+static REAL FN(reward_glideslope)(REAL h, REAL on_gp_altitude, REAL position_factor) {
+    REAL f = FN(sigmoid_distance)(R_ABS(h - on_gp_altitude), (REAL)36000);
+    return f * position_factor * (REAL)0.8;
+}
+
+/* atc_gym.py:239-260 */
+static REAL FN(reward_approach_angle)(REAL phi_to_runway, REAL phi_rel_to_faf, REAL phi_plane, REAL position_factor) {
+    REAL plane_to_runway = FN(relative_angle)(phi_to_runway, phi_plane);
+    REAL s = FN(relative_angle)(phi_to_runway, phi_rel_to_faf);
+    REAL side = (s > (REAL)0) ? (REAL)1 : ((s < (REAL)0) ? (REAL)-1 : (REAL)0); /* np.sign */
+    REAL angle = side * plane_to_runway;
+    REAL q = (angle - (REAL)22.5) / (REAL)202.0;
+    REAL model = R_POW(-R_POW(q, (REAL)2.0) + (REAL)1.0, (REAL)32.0);
+    return model * position_factor * (REAL)1.2;
+}
+
+/* ---- counter-based RNG for entry-point draws (build-defined; integer-only so every implementation agrees) -------- */
+static uint64_t FN(mix64)(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static uint64_t FN(draw)(uint64_t seed, uint32_t env, uint32_t episode, uint32_t slot) {
+    uint64_t z = FN(mix64)(seed ^ ((uint64_t)env << 32 | (uint64_t)episode));
+    return FN(mix64)(z ^ (uint64_t)slot);
+}
+
+/* ---- structures (host pointers; same field meaning as include/atc_step.h) ----------------------------------------- */
+typedef struct FN(orc_state) {
+    double *x, *y;             /* [B*N] positions are ALWAYS accumulated in float64 (fp32 accumulation drifts by up to
+                                  0.5 ulp per step on straight legs: 1e-4 nm after 100 steps, measured) */
+    REAL *h, *phi, *v;         /* [B*N] */
+    REAL* last_act;            /* [3][B*N] */
+    int32_t* timesteps;
+    int32_t* actions_taken;
+    REAL* total_reward;
+    uint64_t* active_mask;
+    uint32_t* win_bits;
+    int32_t* episodes;
+    REAL* ep_return;
+    int32_t* ep_length;
+} FN(orc_state_t);
+
+typedef struct FN(orc_out) {
+    float* obs;     /* [B*N*10] float32 like the reference (atc_gym.py:276) */
+    float* raw_obs; /* nullable */
+    REAL* reward;   /* [B] */
+    REAL* ac_reward;/* nullable [B*N] */
+    uint8_t* done;  /* [B] */
+    uint32_t* flags;/* [B*N] */
+    REAL* min_sep;  /* nullable [B] */
+    float* term_obs;/* nullable */
+    int32_t* mva;   /* nullable [B*N] MVA height used for the observation (-1 outside) — oracle-only diagnostic */
+} FN(orc_out_t);
+
+/* atc_gym.py:262-277 _get_state -> float32[10]; also returns the full-precision d_faf / phi_rel_faf / on_gp used by the
+ * shaping rewards (atc_gym.py:179-185 read self._d_faf etc., which are not rounded to float32). */
+static void FN(get_state)(const REAL* S, REAL x, REAL y, REAL h, REAL phi, REAL v, REAL mva, float* obs10, REAL* d_faf,
+                          REAL* phi_rel_faf, REAL* on_gp) {
+    REAL to_faf_x = S[ATC_C_FAF_X] - x;
+    REAL to_faf_y = S[ATC_C_FAF_Y] - y;
+    REAL phi_rel_runway = FN(relative_angle)(S[ATC_C_PHI_TO_RWY], phi); /* atc_gym.py:284-287 */
+    *d_faf = R_HYPOT(to_faf_x, to_faf_y);                               /* atc_gym.py:294-297 */
+    *phi_rel_faf = FN(degrees)(R_ATAN2(to_faf_y, to_faf_x));            /* atc_gym.py:289-292 */
+    *on_gp = (REAL)318.4 * (*d_faf) + S[ATC_C_FAF_MVA] - (REAL)200;     /* atc_gym.py:279-282 */
+    obs10[0] = (float)x;
+    obs10[1] = (float)y;
+    obs10[2] = (float)h;
+    obs10[3] = (float)phi;
+    obs10[4] = (float)v;
+    obs10[5] = (float)(h - mva);
+    obs10[6] = (float)*on_gp;
+    obs10[7] = (float)*d_faf;
+    obs10[8] = (float)*phi_rel_faf;
+    obs10[9] = (float)phi_rel_runway;
+}
+
+/* atc_gym.py:187-189: float32 arithmetic on float32 vectors: (state - min - 0.5*max) / (0.5*max) */
+static void FN(normalize)(const REAL* S, const float* raw, float* out) {
+    for (int i = 0; i < 10; ++i) {
+        float mn = (float)S[ATC_C_NORM_MIN + i];
+        float half = 0.5f * (float)S[ATC_C_NORM_MAX + i];
+        float t = raw[i] - mn;
+        t = t - half;
+        out[i] = t / half;
+    }
+}
+
+/* atc_gym.py:346-348 + model.py:13-52: place aircraft `k` of env `e` at an entry point. */
+static void FN(spawn)(const REAL* S, const atc_params_t* p, int e, int k, int episode, REAL* x, REAL* y, REAL* h,
+                      REAL* phi, REAL* v) {
+    int n_entry = (int)S[ATC_H_N_ENTRY];
+    int ei, li;
+    if (p->mode & ATC_M_RANDOM_ENTRY) {
+        uint64_t u = FN(draw)(p->seed, (uint32_t)e, (uint32_t)episode, (uint32_t)k);
+        ei = (int)((uint32_t)(u & 0xffffffffu) % (uint32_t)n_entry);
+        const REAL* rec0 = S + (int)S[ATC_H_OFF_ENTRY] + ei * ATC_E_WORDS;
+        li = (int)((uint32_t)(u >> 32) % (uint32_t)(int)rec0[ATC_E_NLEV]);
+    } else {
+        ei = k % n_entry;
+        const REAL* rec0 = S + (int)S[ATC_H_OFF_ENTRY] + ei * ATC_E_WORDS;
+        li = (k / n_entry) % (int)rec0[ATC_E_NLEV];
+    }
+    const REAL* rec = S + (int)S[ATC_H_OFF_ENTRY] + ei * ATC_E_WORDS;
+    *x = rec[ATC_E_X];
+    *y = rec[ATC_E_Y];
+    *phi = rec[ATC_E_PHI];
+    *h = rec[ATC_E_LEV0 + li] * (REAL)100;
+    *v = S[ATC_C_V_INIT];
+}
+
+/* AtcGym.reset (atc_gym.py:337-365) for env e; writes RAW obs computed with mva = 0 (atc_gym.py:351,365).
+ * last_action is NOT touched here: the reference sets it once in __init__ (atc_gym.py:86, quirk Q7). */
+static void FN(reset_env)(const REAL* S, int N, const FN(orc_state_t) * st, const atc_params_t* p, int e, float* obs,
+                          int first) {
+    if (first) {
+        st->win_bits[e] = 0;
+        st->episodes[e] = 0;
+        st->ep_return[e] = 0;
+        st->ep_length[e] = 0;
+    }
+    int episode = st->episodes[e];
+    for (int k = 0; k < N; ++k) {
+        int i = e * N + k;
+        REAL sx, sy;
+        FN(spawn)(S, p, e, k, episode, &sx, &sy, &st->h[i], &st->phi[i], &st->v[i]);
+        st->x[i] = (double)sx;
+        st->y[i] = (double)sy;
+        if (obs) {
+            REAL d, pr, gp;
+            FN(get_state)(S, (REAL)st->x[i], (REAL)st->y[i], st->h[i], st->phi[i], st->v[i], (REAL)0, obs + (size_t)i * 10, &d, &pr, &gp);
+        }
+    }
+    st->total_reward[e] = 0;
+    st->actions_taken[e] = 0;
+    st->timesteps[e] = 0;
+    st->episodes[e] = episode + 1;
+    st->active_mask[e] = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
+}
+
+int FN(atc_oracle_reset)(const REAL* S, int B, int N, const FN(orc_state_t) * st, const uint8_t* mask, float* obs,
+                         const atc_params_t* p, int first) {
+    if (!S || !st || !p || B < 0 || N < 1 || N > ATC_MAX_AIRCRAFT) return -1;
+    size_t BN = (size_t)B * N;
+    for (int e = 0; e < B; ++e) {
+        if (mask && !mask[e]) continue;
+        if (first)
+            for (int k = 0; k < N; ++k)
+                for (int c = 0; c < 3; ++c) st->last_act[(size_t)c * BN + (size_t)e * N + k] = 0;
+        FN(reset_env)(S, N, st, p, e, obs, first);
+    }
+    return 0;
+}
+
+/* AtcGym.step (atc_gym.py:128-192) for B envs x N aircraft. */
+int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st, const REAL* actions,
+                        const FN(orc_out_t) * out, const atc_params_t* p) {
+    if (!S || !st || !actions || !out || !p || B < 0 || N < 1 || N > ATC_MAX_AIRCRAFT) return -1;
+    const size_t BN = (size_t)B * N;
+    const REAL dt = (REAL)p->dt;
+    const int discrete = (p->mode & ATC_M_DISCRETE) != 0;
+    const REAL v_min = S[ATC_C_V_MIN], v_max = S[ATC_C_V_MAX], h_min = S[ATC_C_H_MIN], h_max = S[ATC_C_H_MAX];
+    /* atc_gym.py:64-78: offset = (v_min, 0, 0); factor = (10,100,1) discrete | (v_max - v_min, h_max, 360) continuous */
+    const REAL off[3] = {v_min, 0, 0};
+    const REAL fac[3] = {discrete ? (REAL)10 : v_max - v_min, discrete ? (REAL)100 : h_max, discrete ? (REAL)1 : (REAL)360};
+    const int n_mva = (int)S[ATC_H_N_MVA];
+    const int n_noise = (int)S[ATC_H_N_NOISE];
+    const int off_poly = (int)S[ATC_H_OFF_POLY];
+
+    for (int e = 0; e < B; ++e) {
+        st->timesteps[e] += 1; /* atc_gym.py:135 */
+        const int t = st->timesteps[e];
+        const uint64_t act0 = st->active_mask[e];
+        REAL r[ATC_MAX_AIRCRAFT];
+        uint32_t fl[ATC_MAX_AIRCRAFT];
+        REAL mva_h[ATC_MAX_AIRCRAFT];
+        int mva_i[ATC_MAX_AIRCRAFT];
+
+        /* pass 1: actions + kinematics for every active aircraft */
+        for (int k = 0; k < N; ++k) {
+            const size_t i = (size_t)e * N + k;
+            fl[k] = 0;
+            r[k] = 0;
+            if (!((act0 >> k) & 1ull)) {
+                fl[k] = ATC_F_INACTIVE;
+                continue;
+            }
+            REAL reward = (REAL)-0.05 * dt; /* atc_gym.py:137 */
+            for (int c = 0; c < 3; ++c) {   /* atc_gym.py:139-141 -> _action_with_reward :299-316 */
+                REAL a = actions[i * 3 + c];
+                REAL tgt;
+                if (discrete)
+                    tgt = a * fac[c] + off[c]; /* atc_gym.py:329-330 */
+                else
+                    tgt = a * fac[c] / (REAL)2 + fac[c] / (REAL)2 + off[c]; /* atc_gym.py:333-335 */
+                int valid = 1;
+                if (c == 0) { /* model.py:60-80 */
+                    if (tgt < v_min || tgt > v_max) valid = 0;
+                    else {
+                        REAL d = tgt - st->v[i];
+                        d = R_MIN(d, S[ATC_C_A_MAX] * dt);
+                        d = R_MAX(d, S[ATC_C_A_MIN] * dt);
+                        st->v[i] = st->v[i] + d;
+                    }
+                } else if (c == 1) { /* model.py:82-102 */
+                    if (tgt < h_min || tgt > h_max) valid = 0;
+                    else {
+                        REAL d = tgt - st->h[i];
+                        d = R_MIN(d, S[ATC_C_HDOT_MAX] * dt);
+                        d = R_MAX(d, S[ATC_C_HDOT_MIN] * dt);
+                        st->h[i] = st->h[i] + d;
+                    }
+                } else { /* model.py:104-120: no validation, no wrap */
+                    REAL d = tgt - st->phi[i];
+                    d = R_MIN(d, S[ATC_C_PHIDOT_MAX] * dt);
+                    d = R_MAX(d, S[ATC_C_PHIDOT_MIN] * dt);
+                    st->phi[i] = st->phi[i] + d;
+                }
+                if (valid) {
+                    REAL* la = &st->last_act[(size_t)c * BN + i];
+                    if (!(R_ABS(tgt - *la) < S[ATC_C_ACT_DISCR + c])) st->actions_taken[e] += 1; /* atc_gym.py:305-306 */
+                    *la = tgt;                                                                   /* atc_gym.py:311 */
+                } else {
+                    reward -= (REAL)1.0; /* atc_gym.py:312-315 */
+                    fl[k] |= (c == 0) ? ATC_F_INVALID_V : ATC_F_INVALID_H;
+                }
+            }
+            /* model.py:122-129 Airplane.step: rot_matrix(phi) . [0, (v/3600)*dt] */
+            REAL dist = (st->v[i] / (REAL)3600) * dt;
+            REAL pr = FN(radians)(st->phi[i]);
+            st->x[i] += (double)(R_SIN(pr) * dist); /* increment in REAL, accumulation in float64 */
+            st->y[i] += (double)(R_COS(pr) * dist);
+            r[k] = reward;
+        }
+
+        /* pass 2: MVA floor (atc_gym.py:146-161) */
+        int env_done = 0;
+        for (int k = 0; k < N; ++k) {
+            if (fl[k] & ATC_F_INACTIVE) continue;
+            const size_t i = (size_t)e * N + k;
+            int pi = FN(find_mva)(S, (REAL)st->x[i], (REAL)st->y[i]);
+            mva_i[k] = pi;
+            if (pi >= 0) {
+                REAL mva = S[off_poly + pi * ATC_P_WORDS + ATC_P_HEIGHT];
+                mva_h[k] = mva;
+                if (st->h[i] < mva) {
+                    r[k] = (REAL)-200;
+                    fl[k] |= ATC_F_BELOW_MVA;
+                }
+            } else {
+                r[k] = (REAL)-50;
+                fl[k] |= ATC_F_OUTSIDE;
+                mva_h[k] = 0; /* atc_gym.py:161 */
+            }
+        }
+
+        /* pass 3 (extension, no reference code): pairwise separation among aircraft active at step start */
+        REAL min_sep = (REAL)1e30;
+        for (int a = 0; a < N; ++a) {
+            if (fl[a] & ATC_F_INACTIVE) continue;
+            for (int b = a + 1; b < N; ++b) {
+                if (fl[b] & ATC_F_INACTIVE) continue;
+                const size_t ia = (size_t)e * N + a, ib = (size_t)e * N + b;
+                REAL dx = (REAL)st->x[ia] - (REAL)st->x[ib], dy = (REAL)st->y[ia] - (REAL)st->y[ib];
+                REAL d2 = dx * dx + dy * dy;
+                REAL dh = R_ABS(st->h[ia] - st->h[ib]);
+                REAL d = R_SQRT(d2);
+                if (d < min_sep) min_sep = d;
+                if (d2 < (REAL)p->sep_nm * (REAL)p->sep_nm && dh < (REAL)p->sep_ft) {
+                    fl[a] |= ATC_F_CONFLICT;
+                    fl[b] |= ATC_F_CONFLICT;
+                }
+            }
+        }
+        if (out->min_sep) out->min_sep[e] = min_sep;
+
+        /* pass 4: remaining override chain, observation, shaping (atc_gym.py:163-189) */
+        REAL env_reward = 0;
+        uint64_t act1 = act0;
+        for (int k = 0; k < N; ++k) {
+            const size_t i = (size_t)e * N + k;
+            float raw[10], nrm[10];
+            if (fl[k] & ATC_F_INACTIVE) {
+                for (int c = 0; c < 10; ++c) raw[c] = 0.f, nrm[c] = 0.f;
+                if (out->raw_obs) memcpy(out->raw_obs + i * 10, raw, sizeof raw);
+                memcpy(out->obs + i * 10, nrm, sizeof nrm);
+                out->flags[i] = fl[k];
+                if (out->ac_reward) out->ac_reward[i] = 0;
+                if (out->mva) out->mva[i] = 0;
+                continue;
+            }
+            if (fl[k] & ATC_F_CONFLICT) r[k] = (REAL)p->conflict_reward;
+            const REAL px = (REAL)st->x[i], py = (REAL)st->y[i];
+            if (FN(inside_corridor)(S, px, py, st->h[i], st->phi[i])) { /* atc_gym.py:163-169 */
+                int bonus = (p->timestep_limit - t) * 5;
+                if (bonus < 0) bonus = 0;
+                r[k] = (REAL)(10000 + bonus);
+                fl[k] |= ATC_F_WON;
+                act1 &= ~(1ull << k);
+            }
+            if (t > p->timestep_limit) { /* atc_gym.py:171-173 */
+                r[k] = (REAL)-200;
+                fl[k] |= ATC_F_TIMEOUT;
+            }
+            REAL d_faf, phi_rel_faf, on_gp;
+            FN(get_state)(S, px, py, st->h[i], st->phi[i], st->v[i], mva_h[k], raw, &d_faf, &phi_rel_faf, &on_gp);
+            if (p->mode & ATC_M_REWARD_SHAPING) { /* atc_gym.py:179-185 */
+                REAL pos = FN(reward_approach_position)(d_faf, S[ATC_C_PHI_TO_RWY], phi_rel_faf, S[ATC_C_WORLD_DIAG]);
+                r[k] += pos;
+                r[k] += FN(reward_approach_angle)(S[ATC_C_PHI_TO_RWY], phi_rel_faf, st->phi[i], pos);
+                r[k] += FN(reward_glideslope)(st->h[i], on_gp, pos);
+            }
+            /* extension: noise-abatement areas (no reference code): inside polygon and below its ceiling */
+            for (int q = 0; q < n_noise; ++q) {
+                const REAL* rec = S + off_poly + (n_mva + q) * ATC_P_WORDS;
+                if (rec[ATC_P_MINX] <= px && px <= rec[ATC_P_MAXX] && rec[ATC_P_MINY] <= py && py <= rec[ATC_P_MAXY] &&
+                    st->h[i] < rec[ATC_P_HEIGHT] &&
+                    FN(ray_tracing)(px, py, S + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT])) {
+                    r[k] -= rec[ATC_P_PENALTY];
+                    fl[k] |= ATC_F_NOISE;
+                }
+            }
+            if (p->mode & ATC_M_NORMALIZE) FN(normalize)(S, raw, nrm);
+            else memcpy(nrm, raw, sizeof raw);
+            if (out->raw_obs) memcpy(out->raw_obs + i * 10, raw, sizeof raw);
+            memcpy(out->obs + i * 10, nrm, sizeof nrm);
+            out->flags[i] = fl[k];
+            if (out->ac_reward) out->ac_reward[i] = r[k];
+            if (out->mva) out->mva[i] = (mva_i[k] >= 0) ? (int32_t)mva_h[k] : -1;
+            env_reward += r[k];
+            if (fl[k] & (ATC_F_BELOW_MVA | ATC_F_OUTSIDE | ATC_F_CONFLICT | ATC_F_TIMEOUT)) env_done = 1;
+        }
+        if (act1 == 0) env_done = 1; /* every aircraft handed over (N = 1: the reference's win, atc_gym.py:169) */
+        st->active_mask[e] = act1;
+        st->total_reward[e] += env_reward; /* atc_gym.py:194-197 */
+        out->reward[e] = env_reward;
+        out->done[e] = (uint8_t)env_done;
+
+        if (env_done && (p->mode & ATC_M_AUTO_RESET)) {
+            st->ep_return[e] = st->total_reward[e];
+            st->ep_length[e] = t;
+            int won_all = (act1 == 0); /* every aircraft reached the corridor (N = 1: win_buffer.append(1), atc_gym.py:165) */
+            st->win_bits[e] = ((st->win_bits[e] << 1) | (uint32_t)won_all) & 0x3ffu;
+            if (out->term_obs) memcpy(out->term_obs + (size_t)e * N * 10, out->obs + (size_t)e * N * 10, sizeof(float) * 10 * N);
+            FN(reset_env)(S, N, st, p, e, out->obs, 0);
+        }
+    }
+    return 0;
+}
+
+/* ---- batched queries (for golden lattices G3/G4/G5) ------------------------------------------------------------------ */
+int FN(atc_oracle_query_mva)(const REAL* S, int n, const REAL* x, const REAL* y, int32_t* out_h) {
+    int off_poly = (int)S[ATC_H_OFF_POLY];
+    for (int i = 0; i < n; ++i) {
+        int pi = FN(find_mva)(S, x[i], y[i]);
+        out_h[i] = pi >= 0 ? (int32_t)S[off_poly + pi * ATC_P_WORDS + ATC_P_HEIGHT] : -1;
+    }
+    return 0;
+}
+int FN(atc_oracle_query_corridor)(const REAL* S, int n, const REAL* x, const REAL* y, const REAL* h, const REAL* phi,
+                                  int angle_only, uint8_t* out) {
+    for (int i = 0; i < n; ++i)
+        out[i] = (uint8_t)(angle_only ? FN(inside_corridor_angle)(S, x[i], y[i], phi[i])
+                                      : FN(inside_corridor)(S, x[i], y[i], h[i], phi[i]));
+    return 0;
+}
+int FN(atc_oracle_query_shaping)(const REAL* S, int n, const REAL* d_faf, const REAL* phi_rel_faf, const REAL* phi_plane,
+                                 const REAL* h, const REAL* on_gp, REAL* out3) {
+    for (int i = 0; i < n; ++i) {
+        REAL pos = FN(reward_approach_position)(d_faf[i], S[ATC_C_PHI_TO_RWY], phi_rel_faf[i], S[ATC_C_WORLD_DIAG]);
+        out3[3 * i + 0] = pos;
+        out3[3 * i + 1] = FN(reward_approach_angle)(S[ATC_C_PHI_TO_RWY], phi_rel_faf[i], phi_plane[i], pos);
+        out3[3 * i + 2] = FN(reward_glideslope)(h[i], on_gp[i], pos);
+    }
+    return 0;
+}
+REAL FN(atc_oracle_relative_angle)(REAL a1, REAL a2) { return FN(relative_angle)(a1, a2); }
+REAL FN(atc_oracle_sigmoid)(REAL d, REAL dmax) { return FN(sigmoid_distance)(d, dmax); }
+
+#undef CAT_
+#undef CAT
+#undef FN

@@ -1,0 +1,155 @@
+"""ctypes wrapper of the CPU parity oracle (oracle/liboracle_atc.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; it is the checker, never
+the thing shipped or measured as the product.  See oracle/atc_oracle_impl.h for what it restates and how it is pinned.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle_atc.so")
+
+M_REWARD_SHAPING, M_NORMALIZE, M_DISCRETE, M_AUTO_RESET, M_RANDOM_ENTRY = 1, 2, 4, 8, 16
+
+
+class Params(C.Structure):
+    """Mirror of atc_params_t (include/atc_step.h)."""
+    _fields_ = [("dt", C.c_float), ("timestep_limit", C.c_int32), ("mode", C.c_uint32), ("reserved0", C.c_uint32),
+                ("seed", C.c_uint64), ("sep_nm", C.c_float), ("sep_ft", C.c_float), ("conflict_reward", C.c_float),
+                ("reserved1", C.c_float)]
+
+
+def make_params(dt=1.0, shaping=True, normalize=True, discrete=False, auto_reset=False, random_entry=False, seed=0,
+                timestep_limit=6000, sep_nm=3.0, sep_ft=1000.0, conflict_reward=-200.0):
+    mode = (M_REWARD_SHAPING if shaping else 0) | (M_NORMALIZE if normalize else 0) | (M_DISCRETE if discrete else 0) | \
+           (M_AUTO_RESET if auto_reset else 0) | (M_RANDOM_ENTRY if random_entry else 0)
+    return Params(dt, timestep_limit, mode, 0, seed, sep_nm, sep_ft, conflict_reward, 0.0)
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH) or any(
+            os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(LIB_PATH)
+            for f in ("atc_oracle.c", "atc_oracle_impl.h", "../include/atc_step.h")):
+        subprocess.check_call(["make", "-C", HERE, "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class OracleEnv:
+    """B envs x N aircraft on host arrays, stepping through atc_oracle_step_{f64,f32}."""
+
+    def __init__(self, compiled, B=1, N=1, params=None, dtype=np.float64):
+        self.dtype = np.dtype(dtype)
+        self.sfx = "_f64" if self.dtype == np.float64 else "_f32"
+        self.blob = np.ascontiguousarray(compiled.blob64 if self.dtype == np.float64 else compiled.blob32)
+        self.B, self.N = B, N
+        self.params = params or make_params()
+        r = self.dtype
+        BN = B * N
+        self.x, self.y = np.zeros(BN, np.float64), np.zeros(BN, np.float64)  # positions: always float64
+        self.h, self.phi, self.v = (np.zeros(BN, r) for _ in range(3))
+        self.last_act = np.zeros((3, BN), r)
+        self.timesteps = np.zeros(B, np.int32)
+        self.actions_taken = np.zeros(B, np.int32)
+        self.total_reward = np.zeros(B, r)
+        self.active_mask = np.zeros(B, np.uint64)
+        self.win_bits = np.zeros(B, np.uint32)
+        self.episodes = np.zeros(B, np.int32)
+        self.ep_return = np.zeros(B, r)
+        self.ep_length = np.zeros(B, np.int32)
+        self.obs = np.zeros((B, N, 10), np.float32)
+        self.raw_obs = np.zeros((B, N, 10), np.float32)
+        self.reward = np.zeros(B, r)
+        self.ac_reward = np.zeros((B, N), r)
+        self.done = np.zeros(B, np.uint8)
+        self.flags = np.zeros((B, N), np.uint32)
+        self.min_sep = np.zeros(B, r)
+        self.term_obs = np.zeros((B, N, 10), np.float32)
+        self.mva = np.zeros((B, N), np.int32)
+        self._st = (C.c_void_p * 14)(*[_ptr(a) for a in (
+            self.x, self.y, self.h, self.phi, self.v, self.last_act, self.timesteps, self.actions_taken,
+            self.total_reward, self.active_mask, self.win_bits, self.episodes, self.ep_return, self.ep_length)])
+        self._out = (C.c_void_p * 9)(*[_ptr(a) for a in (
+            self.obs, self.raw_obs, self.reward, self.ac_reward, self.done, self.flags, self.min_sep, self.term_obs,
+            self.mva)])
+        self.reset(first=True)
+
+    def reset(self, mask=None, first=False):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        fn = getattr(lib(), "atc_oracle_reset" + self.sfx)
+        rc = fn(_ptr(self.blob), self.B, self.N, self._st, _ptr(m), _ptr(self.obs), C.byref(self.params), int(first))
+        assert rc == 0
+        return self.obs.copy()
+
+    def set_state(self, e, k, x, y, h, phi, v):
+        i = e * self.N + k
+        self.x[i], self.y[i], self.h[i], self.phi[i], self.v[i] = x, y, h, phi, v
+
+    def step(self, actions):
+        a = np.ascontiguousarray(np.asarray(actions, dtype=self.dtype).reshape(self.B * self.N * 3))
+        fn = getattr(lib(), "atc_oracle_step" + self.sfx)
+        rc = fn(_ptr(self.blob), self.B, self.N, self._st, _ptr(a), self._out, C.byref(self.params))
+        assert rc == 0
+        return self.obs, self.reward, self.done, self.flags
+
+
+class OracleQueries:
+    def __init__(self, compiled, dtype=np.float64):
+        self.dtype = np.dtype(dtype)
+        self.sfx = "_f64" if self.dtype == np.float64 else "_f32"
+        self.blob = np.ascontiguousarray(compiled.blob64 if self.dtype == np.float64 else compiled.blob32)
+
+    def _a(self, v):
+        return np.ascontiguousarray(np.asarray(v, dtype=self.dtype).ravel())
+
+    def mva(self, x, y):
+        x, y = self._a(x), self._a(y)
+        out = np.zeros(len(x), np.int32)
+        getattr(lib(), "atc_oracle_query_mva" + self.sfx)(_ptr(self.blob), len(x), _ptr(x), _ptr(y), _ptr(out))
+        return out
+
+    def corridor(self, x, y, h, phi, angle_only=False):
+        x, y, h, phi = self._a(x), self._a(y), self._a(h), self._a(phi)
+        out = np.zeros(len(x), np.uint8)
+        getattr(lib(), "atc_oracle_query_corridor" + self.sfx)(_ptr(self.blob), len(x), _ptr(x), _ptr(y), _ptr(h),
+                                                                _ptr(phi), int(angle_only), _ptr(out))
+        return out
+
+    def shaping(self, d_faf, phi_rel_faf, phi_plane, h, on_gp):
+        args = [self._a(v) for v in (d_faf, phi_rel_faf, phi_plane, h, on_gp)]
+        out = np.zeros((len(args[0]), 3), self.dtype)
+        getattr(lib(), "atc_oracle_query_shaping" + self.sfx)(_ptr(self.blob), len(args[0]), *[_ptr(a) for a in args],
+                                                               _ptr(out))
+        return out
+
+    def relative_angle(self, a1, a2):
+        fn = getattr(lib(), "atc_oracle_relative_angle" + self.sfx)
+        ct = C.c_double if self.dtype == np.float64 else C.c_float
+        fn.restype = ct
+        fn.argtypes = [ct, ct]
+        return np.array([fn(float(a), float(b)) for a, b in zip(np.ravel(a1), np.ravel(a2))])
+
+    def sigmoid(self, d, dmax):
+        fn = getattr(lib(), "atc_oracle_sigmoid" + self.sfx)
+        ct = C.c_double if self.dtype == np.float64 else C.c_float
+        fn.restype = ct
+        fn.argtypes = [ct, ct]
+        return np.array([fn(float(a), float(dmax)) for a in np.ravel(d)])

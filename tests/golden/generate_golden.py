@@ -1,0 +1,545 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (runs ONLY in the build container; the outputs are committed).
+
+Imports the read-only reference at /root/reference through the stand-in modules in
+tests/oracle_shims/ (numba/gym/shapely/pyglet are not installed here; see that README) and records
+inputs + expected outputs of the AtcGym.step() hot path as small fixtures:
+
+  g1_constants.json   derived scenario constants (bbox, FAF/IAF/corners, normal, faf_mva, norm vectors, rings)
+  g2_scripted.npz     scripted fixed-action trajectories + dt/discrete/shaping/normalise variants + invalid action
+  g3_mva.npz          Airspace.get_mva_height over lattices, polygon vertices and edge midpoints (tie-breaks)
+  g4_corridor.npz     Runway.inside_corridor truth tables
+  g5_shaping.npz      shaping-reward functions, sigmoid_distance_func, relative_angle on grids
+  g6_rollouts.npz     seeded random-action rollouts (continuous + discrete, random entry points, injected
+                      win / timeout cases)
+  g7_metrics.json     reset / metrics sequence over consecutive episodes
+  model_test_known_answers.json  the 8 known answers of the reference's own envs/atc/model_test.py
+
+Usage:
+  PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/generate_golden.py
+Nothing here is imported by the product; the GPU box never sees /root/reference.
+"""
+import json
+import os
+import random
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SHIMS = os.path.join(os.path.dirname(HERE), "oracle_shims")
+REF = os.environ.get("ATC_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, SHIMS)
+
+import numpy as np  # noqa: E402
+
+import envs.atc.atc_gym as ref_gym  # noqa: E402
+import envs.atc.model as ref_model  # noqa: E402
+import envs.atc.scenarios as ref_scen  # noqa: E402
+import shapely.geometry as shape  # noqa: E402
+
+F_BELOW_MVA, F_OUTSIDE, F_WON, F_TIMEOUT, F_INVALID_V, F_INVALID_H = 1, 2, 4, 8, 16, 32
+
+
+def unit_test_world():
+    """The fixture world of envs/atc/model_test.py:94-113 (same data as SimpleScenario, runway phi=180)."""
+    mvas = [
+        ref_model.MinimumVectoringAltitude(shape.Polygon([(15, 0), (35, 0), (35, 26)]), 3500),
+        ref_model.MinimumVectoringAltitude(shape.Polygon([(15, 0), (35, 26), (35, 30), (15, 30), (15, 27.8)]), 2400),
+        ref_model.MinimumVectoringAltitude(shape.Polygon([(15, 30), (35, 30), (35, 40), (15, 40)]), 4000),
+        ref_model.MinimumVectoringAltitude(shape.Polygon([(0, 10), (15, 0), (15, 28.7), (0, 17)]), 8000),
+        ref_model.MinimumVectoringAltitude(shape.Polygon([(0, 17), (15, 28.7), (15, 40), (0, 32)]), 6500),
+    ]
+    runway = ref_model.Runway(20, 20, 0, 180)
+    return mvas, runway, ref_model.Airspace(mvas, runway)
+
+
+class UnitTestScenario(ref_scen.Scenario):
+    def __init__(self):
+        self.mvas, self.runway, self.airspace = unit_test_world()
+        self.entrypoints = [ref_model.EntryPoint(5, 35, 90, [150])]
+
+
+SCENARIOS = {
+    "LOWW": lambda: ref_scen.LOWW(),
+    "LOWW_random": lambda: ref_scen.LOWW(random_entrypoints=True),
+    "Simple": lambda: ref_scen.SimpleScenario(),
+    "UnitTest": lambda: UnitTestScenario(),
+}
+
+
+def make_env(scen="LOWW", dt=1, shaping=True, normalize=True, discrete=False):
+    sp = ref_model.SimParameters(dt, reward_shaping=shaping, normalize_state=normalize, discrete_action_space=discrete)
+    return ref_gym.AtcGym(sim_parameters=sp, scenario=SCENARIOS[scen]())
+
+
+def mva_or_neg(airspace, x, y):
+    try:
+        return int(airspace.get_mva_height(x, y))
+    except ValueError:
+        return -1
+
+
+# ----------------------------------------------------------------------------------------------- G1
+def gen_g1():
+    out = {}
+    for name in SCENARIOS:
+        env = make_env(name)
+        c = env._runway.corridor
+        d = {
+            "mva_rings": [np.asarray(m.area_as_list).tolist() for m in env._mvas],
+            "mva_heights": [int(m.height) for m in env._mvas],
+            "mva_bounds": [list(map(float, m.outer_bounds)) for m in env._mvas],
+            "bbox": list(map(float, env._airspace.get_bounding_box())),
+            "world_max_distance": float(env._world_max_distance),
+            "runway": [float(env._runway.x), float(env._runway.y), float(env._runway.h),
+                       float(env._runway.phi_from_runway), float(env._runway.phi_to_runway)],
+            "faf": c.faf.ravel().tolist(), "iaf": c.iaf.ravel().tolist(),
+            "corner1": c.corner1.ravel().tolist(), "corner2": c.corner2.ravel().tolist(),
+            "faf_iaf_normal": c._faf_iaf_normal.ravel().tolist(),
+            "corridor_horizontal": c.corridor_horizontal_list.tolist(),
+            "corridor1": c.corridor1_list.tolist(), "corridor2": c.corridor2_list.tolist(),
+            "faf_angle": float(c.faf_angle),
+            "faf_mva": int(env._faf_mva),
+            "norm_min": env.normalization_state_min.astype(np.float64).tolist(),
+            "norm_max": env.normalization_state_max.astype(np.float64).tolist(),
+            "action_factor_continuous": [float(v) for v in env.normalization_action_factor],
+            "action_offset": [float(v) for v in env.normalization_action_offset],
+            "entrypoints": [[float(e.x), float(e.y), float(e.phi)] + [int(l) for l in e.levels]
+                            for e in env._scenario.entrypoints],
+            "reset_state": env.reset().astype(np.float64).tolist() if name != "LOWW_random" else None,
+        }
+        envd = make_env(name, discrete=True)
+        d["action_factor_discrete"] = [float(v) for v in envd.normalization_action_factor]
+        d["action_space_discrete_nvec"] = [int(v) for v in envd.action_space.nvec]
+        out[name] = d
+    with open(os.path.join(HERE, "g1_constants.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    return out
+
+
+# ------------------------------------------------------------------------------------ trajectory recorder
+class Recorder:
+    """Collects per-step records for a list of episodes (each episode has its own config/initial state)."""
+
+    def __init__(self):
+        self.ep = []  # dicts
+        self.rows = {k: [] for k in ("action", "state", "obs", "raw", "reward", "done", "flags", "mva",
+                                     "timesteps", "actions_taken", "total_reward")}
+
+    def run(self, env, actions, scen, dt, shaping, normalize, discrete, init_state=None, init_timesteps=None,
+            stop_on_done=True, last_action=None):
+        """Resets env, optionally injects a state (attribute pokes on the reference objects), steps through
+        `actions` (array [T,3]) and records.  Returns number of steps taken."""
+        reset_obs = env.reset()
+        ap = env._airplane
+        if init_state is not None:
+            ap.x, ap.y, ap.h, ap.phi, ap.v = [float(v) for v in init_state]
+        if init_timesteps is not None:
+            env.timesteps = int(init_timesteps)
+        if last_action is not None:
+            env.last_action = [float(v) for v in last_action]
+        start = len(self.rows["reward"])
+        ep = dict(scen=scen, dt=float(dt), shaping=bool(shaping), normalize=bool(normalize), discrete=bool(discrete),
+                  init_state=[float(ap.x), float(ap.y), float(ap.h), float(ap.phi), float(ap.v)],
+                  init_timesteps=int(env.timesteps), init_last_action=[float(v) for v in env.last_action],
+                  reset_obs=reset_obs.astype(np.float64).tolist(), start=start)
+        n = 0
+        for a in actions:
+            a64 = np.asarray(a, dtype=np.float64)
+            den = [env._denormalized_action(float(a64[i]), i) for i in range(3)]
+            flags = 0
+            if den[0] < ap.v_min or den[0] > ap.v_max:
+                flags |= F_INVALID_V
+            if den[1] < ap.h_min or den[1] > ap.h_max:
+                flags |= F_INVALID_H
+            obs, rew, done, info = env.step(a64)
+            m = mva_or_neg(env._airspace, ap.x, ap.y)
+            if m < 0:
+                flags |= F_OUTSIDE
+            elif ap.h < m:
+                flags |= F_BELOW_MVA
+            if env._runway.inside_corridor(ap.x, ap.y, ap.h, ap.phi):
+                flags |= F_WON
+            if env.timesteps > env.timestep_limit:
+                flags |= F_TIMEOUT
+            assert bool(flags & (F_OUTSIDE | F_BELOW_MVA | F_WON | F_TIMEOUT)) == bool(done)
+            r = self.rows
+            r["action"].append(a64.copy())
+            r["state"].append([ap.x, ap.y, ap.h, ap.phi, ap.v])
+            r["obs"].append(np.asarray(obs, dtype=np.float32))
+            r["raw"].append(np.asarray(info["original_state"], dtype=np.float32))
+            r["reward"].append(float(rew))
+            r["done"].append(int(done))
+            r["flags"].append(flags)
+            r["mva"].append(m)
+            r["timesteps"].append(int(env.timesteps))
+            r["actions_taken"].append(int(env.actions_taken))
+            r["total_reward"].append(float(env.total_reward))
+            n += 1
+            if done and stop_on_done:
+                break
+        ep["steps"] = n
+        self.ep.append(ep)
+        return n
+
+    def save(self, path):
+        r = self.rows
+        np.savez_compressed(
+            path,
+            episodes=json.dumps(self.ep),
+            action=np.asarray(r["action"], dtype=np.float64),
+            state=np.asarray(r["state"], dtype=np.float64),
+            obs=np.asarray(r["obs"], dtype=np.float32),
+            raw=np.asarray(r["raw"], dtype=np.float32),
+            reward=np.asarray(r["reward"], dtype=np.float64),
+            done=np.asarray(r["done"], dtype=np.uint8),
+            flags=np.asarray(r["flags"], dtype=np.uint32),
+            mva=np.asarray(r["mva"], dtype=np.int32),
+            timesteps=np.asarray(r["timesteps"], dtype=np.int32),
+            actions_taken=np.asarray(r["actions_taken"], dtype=np.int32),
+            total_reward=np.asarray(r["total_reward"], dtype=np.float64),
+        )
+
+
+def f32(a):
+    """Round actions to float32-representable values so the fp32 device path sees identical inputs."""
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+# ----------------------------------------------------------------------------------------------- G2
+def gen_g2():
+    rec = Recorder()
+    fixed = [[0, 0, 0], [0, -1, -0.5], [0, 0, 0.5], [0, 15000 / 19000 - 1, -0.5]]
+    for a in fixed:
+        env = make_env()
+        rec.run(env, np.tile(f32(a), (7000, 1)), "LOWW", 1, True, True, False)
+    # dt = 5, shaping off, normalise off
+    rec.run(make_env(dt=5), np.tile(f32([0, 0, 0]), (2000, 1)), "LOWW", 5, True, True, False)
+    rec.run(make_env(shaping=False), np.tile(f32([0, -1, -0.5]), (2000, 1)), "LOWW", 1, False, True, False)
+    rec.run(make_env(normalize=False), np.tile(f32([0, 0, 0.5]), (2000, 1)), "LOWW", 1, True, False, False)
+    # discrete action space: (v idx, h idx, phi idx)
+    rec.run(make_env(discrete=True), np.tile(np.array([15.0, 30.0, 135.0]), (4000, 1)), "LOWW", 1, True, True, True)
+    rec.run(make_env(discrete=True), np.tile(np.array([3.0, 120.0, 20.0]), (4000, 1)), "LOWW", 1, True, True, True)
+    # invalid (out of range) action, then valid ones (quirk Q6)
+    acts = np.concatenate([np.tile(f32([1.5, -1.2, 3.0]), (3, 1)), np.tile(f32([0.2, -0.3, 0.1]), (30, 1)),
+                           np.tile(f32([-1.01, 1.01, -1.0]), (3, 1)), np.tile(f32([1.0, 1.0, 1.0]), (30, 1))])
+    rec.run(make_env(), acts, "LOWW", 1, True, True, False)
+    # SimpleScenario
+    # SimpleScenario: its own entry point (5,35) lies outside the airspace (episode ends on step 1); the other
+    # episodes start from injected states inside it
+    rec.run(make_env("Simple"), np.tile(f32([0, -0.5, 0.0]), (3000, 1)), "Simple", 1, True, True, False)
+    rec.run(make_env("Simple"), np.tile(f32([0, -0.5, 0.0]), (3000, 1)), "Simple", 1, True, True, False,
+            init_state=(5.0, 30.0, 9000.0, 90.0, 250.0))
+    rec.run(make_env("Simple"), np.tile(f32([-0.5, -0.8, -0.2]), (3000, 1)), "Simple", 1, True, True, False,
+            init_state=(30.0, 35.0, 7000.0, 200.0, 220.0))
+    rec.run(make_env("Simple"), np.tile(f32([-0.5, -0.9, -0.7]), (3000, 1)), "Simple", 1, True, True, False,
+            init_state=(25.0, 5.0, 6000.0, 20.0, 220.0))
+    # stepping past done without reset (compute-performance protocol, quirk Q9): 40 extra steps
+    env = make_env()
+    rec.run(env, np.tile(f32([0, 0, 0.5]), (146 + 40, 1)), "LOWW", 1, True, True, False, stop_on_done=False)
+    rec.save(os.path.join(HERE, "g2_scripted.npz"))
+    return rec
+
+
+# ----------------------------------------------------------------------------------------------- G3
+def gen_g3():
+    out = {}
+    for name in ("LOWW", "Simple"):
+        env = make_env(name)
+        asp = env._airspace
+        x0, y0, x1, y1 = asp.get_bounding_box()
+        step = 0.25
+        # lattice slightly larger than the bbox so that "outside" is covered on every side
+        xs = np.arange(np.floor(x0) - 1.0, np.ceil(x1) + 1.0 + 1e-9, step)
+        ys = np.arange(np.floor(y0) - 1.0, np.ceil(y1) + 1.0 + 1e-9, step)
+        # offset lattice (avoids exact integer coordinates) in float32-representable form
+        xs = f32(xs + 0.0625)
+        ys = f32(ys + 0.03125)
+        lat = np.empty((len(ys), len(xs)), dtype=np.int32)
+        for j, y in enumerate(ys):
+            for i, x in enumerate(xs):
+                lat[j, i] = mva_or_neg(asp, float(x), float(y))
+        # exact polygon vertices and edge midpoints: tie-break cases (float64 inputs; see tests for fp32 handling)
+        pts = []
+        for m in env._mvas:
+            ring = np.asarray(m.area_as_list)
+            for k in range(len(ring) - 1):
+                pts.append(ring[k])
+                pts.append(0.5 * (ring[k] + ring[k + 1]))
+        # a few exactly representable integer / half-integer points
+        for x in np.arange(np.floor(x0), np.ceil(x1) + 1, 2.0):
+            for y in np.arange(np.floor(y0), np.ceil(y1) + 1, 2.5):
+                pts.append([x, y])
+        pts = np.asarray(pts, dtype=np.float64)
+        ph = np.array([mva_or_neg(asp, float(p[0]), float(p[1])) for p in pts], dtype=np.int32)
+        # the same special points rounded to float32 first (what an fp32 path can represent)
+        pts32 = f32(pts)
+        ph32 = np.array([mva_or_neg(asp, float(p[0]), float(p[1])) for p in pts32], dtype=np.int32)
+        out[name + "_xs"] = xs
+        out[name + "_ys"] = ys
+        out[name + "_lattice"] = lat
+        out[name + "_pts"] = pts
+        out[name + "_pts_h"] = ph
+        out[name + "_pts32"] = pts32
+        out[name + "_pts32_h"] = ph32
+    np.savez_compressed(os.path.join(HERE, "g3_mva.npz"), **out)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- G4
+def gen_g4():
+    out = {}
+    for name in ("LOWW", "UnitTest", "Simple"):
+        env = make_env(name)
+        rw = env._runway
+        fx, fy = rw.corridor.faf.ravel()
+        xs = f32(np.arange(-5.0, 5.0 + 1e-9, 0.25) + fx + 0.013)
+        ys = f32(np.arange(-5.0, 5.0 + 1e-9, 0.25) + fy - 0.007)
+        hs = np.array([2000.0, 3000.0, 3400.0, 3500.0, 4000.0]) if name == "LOWW" else \
+            np.array([0.0, 1000.0, 2400.0, 2700.0, 4000.0])
+        phis = np.arange(0.0, 360.0, 5.0)
+        full = np.zeros((len(ys), len(xs), len(hs), len(phis)), dtype=np.uint8)
+        ang = np.zeros((len(ys), len(xs), len(phis)), dtype=np.uint8)
+        for j, y in enumerate(ys):
+            for i, x in enumerate(xs):
+                for p, phi in enumerate(phis):
+                    ang[j, i, p] = rw.corridor._inside_corridor_angle(float(x), float(y), float(phi))
+                    for k, h in enumerate(hs):
+                        full[j, i, k, p] = rw.inside_corridor(float(x), float(y), float(h), float(phi))
+        out[name + "_xs"], out[name + "_ys"], out[name + "_hs"], out[name + "_phis"] = xs, ys, hs, phis
+        out[name + "_inside"] = np.packbits(full.ravel())
+        out[name + "_inside_shape"] = np.array(full.shape)
+        out[name + "_angle"] = np.packbits(ang.ravel())
+        out[name + "_angle_shape"] = np.array(ang.shape)
+        # unwrapped / negative headings also occur on the hot path (heading is never wrapped, quirk Q4)
+        phis2 = np.array([-725.0, -380.0, -20.0, -0.5, 359.5, 700.0, 1060.0, 335.0 + 360.0, 340.0 - 720.0])
+        ex = np.zeros((len(ys), len(xs), len(phis2)), dtype=np.uint8)
+        for j, y in enumerate(ys):
+            for i, x in enumerate(xs):
+                for p, phi in enumerate(phis2):
+                    ex[j, i, p] = rw.inside_corridor(float(x), float(y), float(hs[1]), float(phi))
+        out[name + "_phis_unwrapped"] = phis2
+        out[name + "_inside_unwrapped"] = ex
+    np.savez_compressed(os.path.join(HERE, "g4_corridor.npz"), **out)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- G5
+def gen_g5():
+    G = ref_gym.AtcGym
+    rng = np.random.default_rng(5)
+    n = 4000
+    d_faf = f32(rng.uniform(0, 110, n))
+    phi_rel_faf = f32(rng.uniform(-180, 180, n))
+    phi_plane = f32(rng.uniform(-400, 760, n))
+    h = f32(rng.uniform(0, 38000, n))
+    on_gp = f32(rng.uniform(2000, 36000, n))
+    phi_to_rwy = 340.0
+    diag = 102.46251265706887
+    pos = np.array([G._reward_approach_position(float(a), phi_to_rwy, float(b), diag) for a, b in zip(d_faf, phi_rel_faf)])
+    ang = np.array([G._reward_approach_angle(phi_to_rwy, float(b), float(c), float(p))
+                    for b, c, p in zip(phi_rel_faf, phi_plane, pos)])
+    gs = np.array([G._reward_glideslope(float(a), float(b), float(p)) for a, b, p in zip(h, on_gp, pos)])
+    sig = np.array([ref_gym.sigmoid_distance_func(float(a), diag) for a in d_faf])
+    a1 = f32(rng.uniform(-720, 720, n))
+    a2 = f32(rng.uniform(-720, 720, n))
+    rel = np.array([ref_model.relative_angle(float(a), float(b)) for a, b in zip(a1, a2)])
+    # exact multiples (modulo edge cases)
+    e1 = np.array([0.0, 340.0, 340.0, 340.0, 160.0, 0.0, 360.0, -360.0, 180.0, 90.0])
+    e2 = np.array([0.0, 160.0, 520.0, -20.0, 340.0, 180.0, 0.0, 0.0, 0.0, -90.0])
+    erel = np.array([ref_model.relative_angle(float(a), float(b)) for a, b in zip(e1, e2)])
+    np.savez_compressed(os.path.join(HERE, "g5_shaping.npz"), d_faf=d_faf, phi_rel_faf=phi_rel_faf,
+                        phi_plane=phi_plane, h=h, on_gp=on_gp, phi_to_rwy=phi_to_rwy, diag=diag, pos=pos, ang=ang,
+                        gs=gs, sig=sig, a1=a1, a2=a2, rel=rel, e1=e1, e2=e2, erel=erel)
+
+
+# ----------------------------------------------------------------------------------------------- G6
+def hold_actions(rng, n_steps, hold, discrete, nvec=None):
+    acts = []
+    cur = None
+    for t in range(n_steps):
+        if t % hold == 0:
+            if discrete:
+                cur = np.floor(rng.uniform(0, 1, 3) * nvec).astype(np.float64)
+            else:
+                cur = f32(rng.uniform(-1, 1, 3))
+        acts.append(cur)
+    return np.asarray(acts)
+
+
+def gen_g6():
+    rec = Recorder()
+    # continuous, default LOWW, actions resampled every 20 steps (atc-gym-demo.py:18-19 protocol)
+    env = make_env()
+    for seed in range(40):
+        rng = np.random.default_rng(1000 + seed)
+        rec.run(env, hold_actions(rng, 6100, 20, False), "LOWW", 1, True, True, False)
+    # per-step resampled actions (short horizon) — exercises the rate limiters and actions_taken
+    for seed in range(4):
+        rng = np.random.default_rng(2000 + seed)
+        rec.run(env, hold_actions(rng, 400, 1, False), "LOWW", 1, True, True, False)
+    # low-altitude biased targets -> below-MVA terminals; slightly out-of-range components -> invalid actions
+    for seed in range(16):
+        rng = np.random.default_rng(2500 + seed)
+        acts = hold_actions(rng, 6100, 20, False)
+        acts[:, 1] = f32(-1.0 + 0.12 * (acts[:, 1] + 1.0) * 0.5)
+        rec.run(env, acts, "LOWW", 1, True, True, False)
+    for seed in range(8):
+        rng = np.random.default_rng(2600 + seed)
+        acts = f32(hold_actions(rng, 6100, 20, False) * 1.08)
+        rec.run(env, acts, "LOWW", 1, True, True, False)
+    # discrete
+    envd = make_env(discrete=True)
+    nvec = np.array([20, 380, 360])
+    for seed in range(12):
+        rng = np.random.default_rng(3000 + seed)
+        rec.run(envd, hold_actions(rng, 6100, 20, True, nvec), "LOWW", 1, True, True, True)
+    # random entry points (the drawn entry/level is recoverable from init_state)
+    random.seed(7)
+    envr = make_env("LOWW_random")
+    for seed in range(24):
+        rng = np.random.default_rng(4000 + seed)
+        rec.run(envr, hold_actions(rng, 6100, 20, False), "LOWW_random", 1, True, True, False)
+    # dt = 2 with random entries
+    envr2 = make_env("LOWW_random", dt=2)
+    for seed in range(6):
+        rng = np.random.default_rng(5000 + seed)
+        rec.run(envr2, hold_actions(rng, 3100, 10, False), "LOWW_random", 2, True, True, False)
+    # injected wins: aircraft placed on the intercept, descending through the glide path (LOWW FAF 47.69,36.31)
+    env = make_env()
+    win_inits = [
+        # x, y, h, phi, v
+        (48.9, 31.9, 3300.0, 345.0, 200.0),
+        (47.0, 32.0, 3400.0, 10.0, 220.0),
+        (50.6, 33.2, 3200.0, 310.0, 180.0),
+        (49.2, 30.5, 5000.0, 340.0, 250.0),
+        (46.2, 31.8, 3600.0, 20.0, 250.0),
+        (51.3, 33.0, 2900.0, 300.0, 160.0),
+    ]
+    for k, st in enumerate(win_inits):
+        # hold heading, descend to 2700 ft, slow down
+        a_h = 2.0 * 2700.0 / 38000.0 - 1.0
+        a_phi = 2.0 * st[3] / 360.0 - 1.0
+        a_v = 2.0 * (st[4] - 100.0) / 200.0 - 1.0
+        acts = np.tile(f32([a_v, a_h, a_phi]), (600, 1))
+        rec.run(env, acts, "LOWW", 1, True, True, False, init_state=st, init_timesteps=100 * k)
+    # win with the time bonus exhausted (timesteps near the limit) and win on the timeout step (timeout overrides)
+    a = f32([0.0, 2.0 * 2700.0 / 38000.0 - 1.0, 2.0 * 345.0 / 360.0 - 1.0])
+    rec.run(env, np.tile(a, (600, 1)), "LOWW", 1, True, True, False, init_state=win_inits[0], init_timesteps=5900)
+    rec.run(env, np.tile(a, (600, 1)), "LOWW", 1, True, True, False, init_state=win_inits[0], init_timesteps=5990)
+    # corridor entry exactly on step 6001: timeout overrides the win (both flags set)
+    rec.run(env, np.tile(a, (600, 1)), "LOWW", 1, True, True, False, init_state=win_inits[0], init_timesteps=5972)
+    rec.run(env, np.tile(a, (600, 1)), "LOWW", 1, True, True, False, init_state=win_inits[0], init_timesteps=5971)
+    # timeouts: start at 5990 far from everything
+    for seed in range(3):
+        rng = np.random.default_rng(6000 + seed)
+        rec.run(env, hold_actions(rng, 40, 5, False), "LOWW", 1, True, True, False, init_timesteps=5990 - seed)
+    rec.save(os.path.join(HERE, "g6_rollouts.npz"))
+    return rec
+
+
+# ----------------------------------------------------------------------------------------------- G7
+def gen_g7():
+    """Reset/metrics sequence: winning_ratio, _win_buffer, actions_per_timestep over consecutive episodes."""
+    env = make_env()
+    win_state = (48.9, 31.9, 3300.0, 345.0, 200.0)
+    a_win = f32([0.0, 2.0 * 2700.0 / 38000.0 - 1.0, 2.0 * 345.0 / 360.0 - 1.0])
+    plan = ["lose", "win", "win", "lose", "win", "timeout", "win", "lose", "lose", "win", "win", "win", "lose", "win",
+            "lose", "lose"]
+    episodes = []
+    rng = np.random.default_rng(77)
+    for kind in plan:
+        env.reset()
+        ep = {"kind": kind, "after_reset": {"winning_ratio": float(env.winning_ratio),
+                                            "win_buffer": [int(v) for v in env._win_buffer],
+                                            "episodes_run": int(env._episodes_run)}}
+        if kind == "win":
+            ap = env._airplane
+            ap.x, ap.y, ap.h, ap.phi, ap.v = win_state
+            acts = np.tile(a_win, (600, 1))
+        elif kind == "timeout":
+            env.timesteps = 5980
+            acts = hold_actions(rng, 60, 7, False)
+        else:
+            acts = hold_actions(rng, 6100, 20, False)
+        ep["init_state"] = [float(v) for v in (env._airplane.x, env._airplane.y, env._airplane.h, env._airplane.phi,
+                                                env._airplane.v)]
+        ep["init_timesteps"] = int(env.timesteps)
+        used = []
+        apt = []
+        for a in acts:
+            _, r, done, _ = env.step(np.asarray(a, dtype=np.float64))
+            used.append([float(v) for v in a])
+            apt.append(float(env.actions_per_timestep))
+            if done:
+                break
+        ep["actions"] = used
+        ep["actions_per_timestep"] = apt
+        ep["final"] = {"total_reward": float(env.total_reward), "last_reward": float(env.last_reward),
+                       "timesteps": int(env.timesteps), "actions_taken": int(env.actions_taken),
+                       "win_buffer": [int(v) for v in env._win_buffer], "winning_ratio": float(env.winning_ratio)}
+        episodes.append(ep)
+    env.reset()
+    tail = {"winning_ratio": float(env.winning_ratio), "win_buffer": [int(v) for v in env._win_buffer],
+            "episodes_run": int(env._episodes_run)}
+    with open(os.path.join(HERE, "g7_metrics.json"), "w") as f:
+        json.dump({"episodes": episodes, "after_last_reset": tail}, f)
+
+
+# ------------------------------------------------------------------------- reference unit-test known answers
+def gen_model_test():
+    """Inputs and expected outputs of envs/atc/model_test.py:10-92, re-evaluated here against the reference."""
+    mvas, rw, asp = unit_test_world()
+    faf = rw.corridor.faf
+    mva_faf = asp.get_mva_height(faf[0][0], faf[1][0])
+    cases = {
+        "world": "UnitTest",
+        "mva_at_faf": int(mva_faf),
+        "get_mva_height": [{"x": 34, "y": 1, "expect": int(asp.get_mva_height(34, 1))}],
+        "inside_corridor": [
+            {"x": 19, "y": 10, "h": mva_faf + 300, "phi": 30, "expect": bool(rw.inside_corridor(19, 10, mva_faf + 300, 30))},
+            {"x": 19, "y": 10, "h": mva_faf, "phi": 330, "expect": bool(rw.inside_corridor(19, 10, mva_faf, 330))},
+        ],
+        "inside_corridor_angle": [
+            {"x": 21, "y": 10, "phi": 30, "expect": bool(rw.corridor._inside_corridor_angle(21, 10, 30))},
+            {"x": 19, "y": 10, "phi": 340, "expect": bool(rw.corridor._inside_corridor_angle(19, 10, 340))},
+            {"x": 19, "y": 10, "phi": 190, "expect": bool(rw.corridor._inside_corridor_angle(19, 10, 190))},
+            {"x": 21, "y": 10, "phi": 340, "expect": bool(rw.corridor._inside_corridor_angle(21, 10, 340))},
+        ],
+        "bounding_box": [float(v) for v in asp.get_bounding_box()],
+    }
+    # expected values as written in the reference test file (model_test.py:16,27,38,49,59,69,79,89-92)
+    assert cases["get_mva_height"][0]["expect"] == 3500
+    assert [c["expect"] for c in cases["inside_corridor"]] == [True, False]
+    assert [c["expect"] for c in cases["inside_corridor_angle"]] == [False, False, False, True]
+    assert cases["bounding_box"] == [0.0, 0.0, 35.0, 40.0]
+    with open(os.path.join(HERE, "model_test_known_answers.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "mt"]
+    if "g1" in which:
+        gen_g1()
+    if "mt" in which:
+        gen_model_test()
+    if "g5" in which:
+        gen_g5()
+    if "g2" in which:
+        r = gen_g2()
+        print("g2 episodes", [(e["steps"]) for e in r.ep])
+    if "g3" in which:
+        gen_g3()
+    if "g4" in which:
+        gen_g4()
+    if "g6" in which:
+        r = gen_g6()
+        print("g6 episodes", len(r.ep), "steps", len(r.rows["reward"]))
+        fl = np.asarray(r.rows["flags"])
+        dn = np.asarray(r.rows["done"])
+        for name, bit in (("below", 1), ("outside", 2), ("won", 4), ("timeout", 8), ("inv_v", 16), ("inv_h", 32)):
+            print(name, int(((fl & bit) != 0).sum()), "terminal:", int((((fl & bit) != 0) & (dn != 0)).sum()))
+    if "g7" in which:
+        gen_g7()
+    print("done")

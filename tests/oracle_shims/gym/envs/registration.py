@@ -1,0 +1,5 @@
+registry = {}
+
+
+def register(id, entry_point, **kwargs):
+    registry[id] = entry_point
