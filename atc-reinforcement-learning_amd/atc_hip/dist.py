@@ -1,0 +1,76 @@
+"""Multi-GPU: env instances never interact, so the batch shards by contiguous env-index range, one process per GPU,
+with NO collective on the step path.  The only exchange is an all-gather of per-env episode statistics (returns,
+lengths) once per report interval — `torch.distributed` backend "nccl" (= RCCL over xGMI on ROCm); 256 KiB per rank at
+65 536 envs, i.e. latency-bound, so it is issued once per rollout, never per step.  (The reference's counterpart is
+SubprocVecEnv's pipe per worker + Monitor CSVs, learning/atc-gym-stable-baselines.py:69-80.)
+
+Works on CPU tensors with the gloo backend too (tests/test_dist_gloo.py, world_size 2)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    """(rank, world_size, local_rank) from the torchrun environment (1-process defaults)."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None):
+    """Initialises the default process group when WORLD_SIZE > 1 (nccl on GPU, gloo otherwise)."""
+    rank, ws, local = world()
+    if ws > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+    return rank, ws, local
+
+
+def shard_range(total_envs, rank, world_size):
+    """Contiguous env-index range [lo, hi) owned by `rank`; remainders go to the lowest ranks."""
+    base, rem = divmod(int(total_envs), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def rank_seed(seed, rank):
+    """Distinct RNG key per rank for the entry draws (envs are indexed locally on each GPU)."""
+    return (int(seed) + 0x9E3779B97F4A7C15 * (rank + 1)) & (2 ** 64 - 1) if rank else int(seed)
+
+
+def all_gather_stats(*tensors):
+    """All-gathers equally-shaped per-env tensors from every rank into [world, ...] tensors (one collective each).
+    Identity (with a leading axis of 1) when not distributed."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [t.unsqueeze(0) for t in tensors]
+    ws = dist.get_world_size()
+    out = []
+    for t in tensors:
+        t = t.contiguous()
+        g = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(g, t)  # concatenation along dim 0 (the layout both nccl/RCCL and gloo accept)
+        out.append(g.view((ws,) + tuple(t.shape)))
+    return out
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

@@ -1,0 +1,209 @@
+"""AtcVecEnv — B envs x N aircraft of the AtcGym.step() path, all state in device tensors, stepped by libatcstep.so.
+
+Build-own batched surface (the reference has only the single-env AtcGym, atc_gym.py:22-365, and reaches parallelism
+through stable-baselines' SubprocVecEnv x8, learning/atc-gym-stable-baselines.py:76-78).  Method names follow the
+stable-baselines VecEnv protocol (reset / step / get_attr / seed / close) so that a PPO loop can consume it directly;
+tensors stay on the device.  `auto_reset=True` gives VecEnv semantics: a finished env restarts inside the step and the
+returned observation is the RAW reset observation (quirk of atc_gym.py:351,365 that SubprocVecEnv workers expose too).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import layout as L
+from . import lib as _lib
+
+
+class AtcVecEnv:
+    def __init__(self, num_envs, num_aircraft=1, sim_parameters=None, scenario=None, device=0, auto_reset=True,
+                 spawn="auto", seed=0, grid_cell=0.5, want_raw_obs=False, want_ac_reward=False, want_min_sep=False,
+                 want_term_obs=False, timestep_limit=6000, sep_nm=3.0, sep_ft=1000.0, conflict_reward=-200.0):
+        torch = _lib._torch_cuda()
+        self.torch = torch
+        from envs.atc import model, scenarios
+        self.sim_parameters = sim_parameters if sim_parameters is not None else model.SimParameters(1)
+        self.scenario_obj = scenario if scenario is not None else scenarios.LOWW()
+        if not 1 <= num_aircraft <= L.MAX_AIRCRAFT:
+            raise ValueError("1 <= num_aircraft <= %d" % L.MAX_AIRCRAFT)
+        self.B, self.N = int(num_envs), int(num_aircraft)
+        self.num_envs = self.B
+        self.compiled = scenarios.compile_scenario(self.scenario_obj, grid_cell=grid_cell)
+        self.sector = _lib.Scenario(self.compiled, device)
+        self.device = self.sector.device
+        n_entry = self.compiled.n_entry
+        if n_entry < 1:
+            raise ValueError("scenario has no entry point")
+        if spawn == "auto":
+            spawn = "random" if (self.N == 1 and n_entry > 1) else "lattice"
+        if spawn not in ("random", "lattice"):
+            raise ValueError("spawn must be 'auto', 'random' or 'lattice'")
+        sp = self.sim_parameters
+        self.params = _lib.make_params(dt=sp.timestep, shaping=sp.reward_shaping, normalize=sp.normalize_state,
+                                       discrete=sp.discrete_action_space, auto_reset=auto_reset,
+                                       random_entry=(spawn == "random"), seed=seed, timestep_limit=timestep_limit,
+                                       sep_nm=sep_nm, sep_ft=sep_ft, conflict_reward=conflict_reward)
+        self.timestep_limit = timestep_limit
+        B, N, BN, dev = self.B, self.N, self.B * self.N, self.device
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+        f32, f64, i32 = torch.float32, torch.float64, torch.int32
+        # persistent state (atc_state_t)
+        self.x, self.y = z(BN, f64), z(BN, f64)
+        self.h, self.phi, self.v = z(BN, f32), z(BN, f32), z(BN, f32)
+        self.last_act = z((3, BN), f32)
+        self.timesteps, self.actions_taken = z(B, i32), z(B, i32)
+        self.total_reward = z(B, f32)
+        self.active_mask = z(B, torch.int64)
+        self.win_bits = z(B, i32)
+        self.episodes = z(B, i32)
+        self.ep_return, self.ep_length = z(B, f32), z(B, i32)
+        self._state = _lib.AtcState(*[getattr(self, n).data_ptr() for n in _lib.STATE_FIELDS])
+        # per-step outputs (atc_out_t)
+        self.obs = z((B, N * L.OBS_DIM), f32)
+        self.raw_obs = z((B, N * L.OBS_DIM), f32) if want_raw_obs else None
+        self.reward = z(B, f32)
+        self.ac_reward = z((B, N), f32) if want_ac_reward else None
+        self.done = z(B, torch.uint8)
+        self.flags = z((B, N), i32)
+        self.min_sep = z(B, f32) if want_min_sep else None
+        self.term_obs = z((B, N * L.OBS_DIM), f32) if want_term_obs else None
+        self._out = self._make_out(self.obs, self.raw_obs, self.reward, self.ac_reward, self.done, self.flags,
+                                   self.min_sep, self.term_obs)
+        self._lib = _lib.load()
+        self.reset(first=True)
+
+    # ------------------------------------------------------------------------------------------------ plumbing
+    @staticmethod
+    def _make_out(*tensors):
+        return _lib.AtcOut(*[(t.data_ptr() if t is not None else None) for t in tensors])
+
+    def _stream(self):
+        return _lib.current_stream_ptr(self.device)
+
+    @property
+    def action_dim(self):
+        return self.N * L.ACT_DIM
+
+    @property
+    def obs_dim(self):
+        return self.N * L.OBS_DIM
+
+    # ------------------------------------------------------------------------------------------------ VecEnv surface
+    def seed(self, seed=None):
+        self.params.seed = int(seed or 0) & (2 ** 64 - 1)
+        return [seed] * self.B
+
+    def reset(self, mask=None, first=False):
+        """AtcGym.reset (atc_gym.py:337-365) for all envs (or those with mask != 0); returns RAW obs [B, N*10]."""
+        torch = self.torch
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.atc_reset(self.sector.handle, self.B, self.N, C.byref(self._state),
+                                           m.data_ptr() if m is not None else None, self.obs.data_ptr(),
+                                           C.byref(self.params), int(first), self._stream()))
+        return self.obs
+
+    def observe(self, mask=None):
+        """Raw observation (mva = 0) of the current state, like the tail of AtcGym.reset (atc_gym.py:351,365)."""
+        torch = self.torch
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.atc_observe(self.sector.handle, self.B, self.N, C.byref(self._state),
+                                             m.data_ptr() if m is not None else None, self.obs.data_ptr(),
+                                             C.byref(self.params), self._stream()))
+        return self.obs
+
+    def _as_actions(self, actions, lead=()):
+        torch = self.torch
+        a = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions, dtype=np.float32))
+        a = a.to(device=self.device, dtype=torch.float32).contiguous()
+        want = int(np.prod(lead, dtype=np.int64)) * self.B * self.N * L.ACT_DIM if lead else self.B * self.N * L.ACT_DIM
+        if a.numel() != want:
+            raise ValueError("actions must have %d elements, got %d" % (want, a.numel()))
+        return a
+
+    def step(self, actions):
+        """AtcGym.step (atc_gym.py:128-192) for every env.  actions: [B, N, 3] (or [B, N*3]) float tensor / array:
+        continuous in [-1, 1] or discrete indices (atc_gym.py:318-335).  Returns (obs [B,N*10], reward [B], done [B]
+        uint8, info) — device tensors that are overwritten by the next step."""
+        a = self._as_actions(actions)
+        with self.torch.cuda.device(self.device):
+            _lib.check(self._lib.atc_step(self.sector.handle, self.B, self.N, C.byref(self._state), a.data_ptr(),
+                                          C.byref(self._out), C.byref(self.params), self._stream()))
+        self._keep = a
+        return self.obs, self.reward, self.done, self._info()
+
+    def step_async(self, actions):
+        self._pending = actions
+
+    def step_wait(self):
+        return self.step(self._pending)
+
+    def _info(self):
+        info = {"flags": self.flags, "ep_return": self.ep_return, "ep_length": self.ep_length}
+        if self.raw_obs is not None:
+            info["original_state"] = self.raw_obs
+        if self.ac_reward is not None:
+            info["aircraft_reward"] = self.ac_reward
+        if self.min_sep is not None:
+            info["min_separation"] = self.min_sep
+        if self.term_obs is not None:
+            info["terminal_observation"] = self.term_obs
+        return info
+
+    def rollout(self, actions, out=None):
+        """T consecutive steps in one launch (state stays in registers).  actions: [T, B, N, 3].  Returns a dict of
+        [T, ...] device tensors (obs, reward, done, flags [+ optional outputs when `out` provides them])."""
+        torch = self.torch
+        T = int(actions.shape[0])
+        a = self._as_actions(actions, lead=(T,))
+        B, N, dev = self.B, self.N, self.device
+        if out is None:
+            out = {
+                "obs": torch.empty((T, B, N * L.OBS_DIM), dtype=torch.float32, device=dev),
+                "reward": torch.empty((T, B), dtype=torch.float32, device=dev),
+                "done": torch.empty((T, B), dtype=torch.uint8, device=dev),
+                "flags": torch.empty((T, B, N), dtype=torch.int32, device=dev),
+            }
+        o = self._make_out(out["obs"], out.get("raw_obs"), out["reward"], out.get("ac_reward"), out["done"],
+                           out["flags"], out.get("min_sep"), out.get("term_obs"))
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.atc_rollout(self.sector.handle, B, N, T, C.byref(self._state), a.data_ptr(),
+                                             C.byref(o), C.byref(self.params), self._stream()))
+        self._keep = a
+        return out
+
+    def get_attr(self, name, indices=None):
+        """VecEnv.get_attr for the attributes the reference's trainer reads (learning/atc-gym-stable-baselines.py:34,36)
+        and the episode counters."""
+        torch = self.torch
+        if name == "actions_per_timestep":  # atc_gym.py:197
+            t = self.actions_taken.to(torch.float64) / self.timesteps.clamp(min=1).to(torch.float64)
+        elif name == "winning_ratio":  # atc_gym.py:362-363: mean of the last 10 episode outcomes
+            bits = self.win_bits.to(torch.int64)
+            t = sum(((bits >> k) & 1) for k in range(10)).to(torch.float64) / 10.0
+        elif name in ("timesteps", "actions_taken", "total_reward", "episodes", "ep_return", "ep_length"):
+            t = getattr(self, name)
+        else:
+            raise AttributeError(name)
+        vals = t.cpu().tolist()
+        if indices is not None:
+            vals = [vals[i] for i in indices]
+        return vals
+
+    def set_state(self, env, slot, x, y, h, phi, v):
+        i = env * self.N + slot
+        self.x[i], self.y[i], self.h[i], self.phi[i], self.v[i] = float(x), float(y), float(h), float(phi), float(v)
+
+    def get_state(self, env, slot):
+        i = env * self.N + slot
+        return [float(t[i]) for t in (self.x, self.y, self.h, self.phi, self.v)]
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)
+
+    def close(self):
+        self.sector.close()

@@ -1,0 +1,41 @@
+"""Builds libatcstep.so (the HIP kernels + C-ABI) for gfx950, in-tree, with hipcc.
+
+    python atc-reinforcement-learning_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off: the integer outputs (done/flags/counters) must match the fp32
+oracle bit-for-bit, so the compiler may not fuse a*b+c on its own (explicit fmaf is used where exactness is argued).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "atc_step.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "atc_device.h"), os.path.join(os.path.dirname(HERE), "include", "atc_step.h")]
+OUT = os.path.join(HERE, "atc_hip", "libatcstep.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
+         "-Wno-unused-function"]
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build_lib(force=False, verbose=False, extra=()):
+    if not force and not needs_build():
+        return OUT
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-o", OUT, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build_lib(force="--force" in sys.argv, verbose=True,
+              extra=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else ())
+    print(OUT)

@@ -1,0 +1,659 @@
+// atc_step.hip — libatcstep.so: hand-written gfx950 (CDNA4, MI355X) kernels + C-ABI of the batched AtcGym.step() path.
+//
+// Work decomposition (one wavefront = 64 lanes):
+//   lane  = one aircraft slot;  W = next_pow2(N) consecutive lanes = one env;  64/W envs per wavefront
+//   (N = 64: one wavefront per env, N = 16: 4 envs per wavefront, N = 1: 64 envs per wavefront).
+//   Aircraft state is SoA in HBM (index env*N + k) so that the 64 lanes of a wavefront read consecutive words.
+//   The sector (polygons, corridor, constants: ~2 KB) is staged once per workgroup in LDS; the optional MVA lookup grid
+//   stays in global memory (L2 resident, one 4-byte gather per aircraft).
+//   The O(N^2) separation scan stages (x, y, h, active) of the wavefront's aircraft in LDS; every lane walks its env's
+//   W partners (LDS broadcast reads), and the per-env minimum separation / conflict / reward / done are reduced with
+//   wavefront xor-shuffles and a ballot — no block barrier, no atomics, no MFMA (there is no dense contraction here).
+//   Workgroup = 256 threads, grid-stride over env slots with a grid of at most 8 workgroups per CU.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared   (see build.py)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "atc_device.h"
+
+using namespace atc;
+
+struct atc_scenario {
+    float* d_blob;   // device copy of the whole blob (constants + polygons + entries [+ grid])
+    int n_words;
+    int lds_words;   // words staged into LDS (everything before the grid)
+    int off_grid;    // 0 = no grid
+    int device;
+    int n_cu;
+};
+
+static thread_local char g_err[512] = "";
+
+#define ATC_OK 0
+#define ATC_ERR_ARG (-1)
+#define ATC_ERR_HIP (-2)
+
+static int fail_arg(const char* msg) {
+    snprintf(g_err, sizeof g_err, "bad argument: %s", msg);
+    return ATC_ERR_ARG;
+}
+static int fail_hip(hipError_t e, const char* what) {
+    snprintf(g_err, sizeof g_err, "HIP error in %s: %s", what, hipGetErrorString(e));
+    return ATC_ERR_HIP;
+}
+#define HIP_TRY(expr)                                    \
+    do {                                                 \
+        hipError_t _e = (expr);                          \
+        if (_e != hipSuccess) return fail_hip(_e, #expr); \
+    } while (0)
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------------------------------------------
+// wavefront-group helpers (groups of W consecutive lanes, W a power of two <= 64)
+// ---------------------------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int W>
+__device__ __forceinline__ int group_sum_i(int v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int W>
+__device__ __forceinline__ float group_min(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+template <int W>
+__device__ __forceinline__ uint64_t group_ballot(bool pred, int lane) {
+    const uint64_t b = __ballot(pred);
+    if (W == 64) return b;
+    const int base = lane & ~(W - 1);
+    return (b >> base) & ((1ull << W) - 1ull);
+}
+
+__device__ __forceinline__ void stage_sector(float* S, const float* __restrict__ blob, int lds_words) {
+    for (int i = threadIdx.x; i < lds_words; i += kBlock) S[i] = blob[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void store_obs(float* __restrict__ dst, const float* o) {
+    // 10 floats = 40 B per aircraft: 8-byte aligned -> five 8-byte stores
+    float2* d = reinterpret_cast<float2*>(dst);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) d[c] = make_float2(o[2 * c], o[2 * c + 1]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// step / rollout kernel
+// ---------------------------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(kBlock)
+k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N, int T, atc_state_t st,
+       const float* __restrict__ actions, atc_out_t out, atc_params_t p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* S = smem;
+    float4* pos = reinterpret_cast<float4*>(smem + ((lds_words + 3) & ~3));  // [kBlock] pair-scan staging
+    stage_sector(S, blob, lds_words);
+    const float* grid = off_grid ? blob + off_grid : nullptr;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const long long BN = (long long)B * N;
+    const long long slots = (long long)B * W;
+    const float dt = p.dt;
+    const bool discrete = (p.mode & ATC_M_DISCRETE) != 0;
+    const float v_min = S[ATC_C_V_MIN], v_max = S[ATC_C_V_MAX], h_min = S[ATC_C_H_MIN], h_max = S[ATC_C_H_MAX];
+    // atc_gym.py:64-78
+    const float fac_v = discrete ? 10.0f : v_max - v_min;
+    const float fac_h = discrete ? 100.0f : h_max;
+    const float fac_p = discrete ? 1.0f : 360.0f;
+    const float off_v = v_min;
+    const float sep2 = p.sep_nm * p.sep_nm;
+    const uint64_t full_mask = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
+    const int n_mva = (int)S[ATC_H_N_MVA];
+    const int n_noise = (int)S[ATC_H_N_NOISE];
+    const float* polytab = S + (int)S[ATC_H_OFF_POLY];
+
+    for (long long slot0 = (long long)blockIdx.x * kBlock; slot0 < slots; slot0 += (long long)gridDim.x * kBlock) {
+        const long long slot = slot0 + tid;
+        const int e = (int)(slot / W);
+        const int k = (int)(slot % W);
+        const bool env_valid = slot < slots;
+        const bool lane_valid = env_valid && k < N;
+        const long long i = (long long)e * N + k;
+
+        // ---- load persistent state -------------------------------------------------------------------------------
+        int t = 0, n_actions = 0, episode = 0;
+        float total_reward = 0.0f;
+        uint64_t amask = 0;
+        if (env_valid) {
+            t = st.timesteps[e];
+            n_actions = st.actions_taken[e];
+            total_reward = st.total_reward[e];
+            amask = st.active_mask[e];
+            episode = st.episodes[e];
+        }
+        Aircraft a = {0.0, 0.0, 0.0f, 0.0f, 0.0f};
+        float la_v = 0.0f, la_h = 0.0f, la_p = 0.0f;
+        if (lane_valid) {
+            a.x = st.x[i];
+            a.y = st.y[i];
+            a.h = st.h[i];
+            a.phi = st.phi[i];
+            a.v = st.v[i];
+            la_v = st.last_act[i];
+            la_h = st.last_act[BN + i];
+            la_p = st.last_act[2 * BN + i];
+        }
+
+        for (int step = 0; step < T; ++step) {
+            const float* act_t = actions + (long long)step * BN * 3;
+            float* obs_t = out.obs + (long long)step * BN * ATC_OBS_DIM;
+            t += 1;  // atc_gym.py:135
+            const bool active = lane_valid && ((amask >> k) & 1ull);
+            uint32_t fl = lane_valid ? (active ? 0u : (uint32_t)ATC_F_INACTIVE) : 0u;
+            float r = 0.0f;
+            int acts = 0;
+            float mva = 0.0f;
+            float x32 = 0.0f, y32 = 0.0f;
+
+            if (active) {
+                const float a_v = act_t[i * 3 + 0], a_h = act_t[i * 3 + 1], a_p = act_t[i * 3 + 2];
+                r = -0.05f * dt;  // atc_gym.py:137
+                // ---- _action_with_reward x3 (atc_gym.py:139-141,299-335) -> Airplane.action_* (model.py:60-120) ----
+                const float tv = discrete ? a_v * fac_v + off_v : a_v * fac_v / 2.0f + fac_v / 2.0f + off_v;
+                const float th = discrete ? a_h * fac_h + 0.0f : a_h * fac_h / 2.0f + fac_h / 2.0f + 0.0f;
+                const float tp = discrete ? a_p * fac_p + 0.0f : a_p * fac_p / 2.0f + fac_p / 2.0f + 0.0f;
+                if (tv < v_min || tv > v_max) {
+                    r -= 1.0f;
+                    fl |= ATC_F_INVALID_V;
+                } else {
+                    float d = tv - a.v;
+                    d = fminf(d, S[ATC_C_A_MAX] * dt);
+                    d = fmaxf(d, S[ATC_C_A_MIN] * dt);
+                    a.v = a.v + d;
+                    if (!(fabsf(tv - la_v) < S[ATC_C_ACT_DISCR + 0])) acts += 1;
+                    la_v = tv;
+                }
+                if (th < h_min || th > h_max) {
+                    r -= 1.0f;
+                    fl |= ATC_F_INVALID_H;
+                } else {
+                    float d = th - a.h;
+                    d = fminf(d, S[ATC_C_HDOT_MAX] * dt);
+                    d = fmaxf(d, S[ATC_C_HDOT_MIN] * dt);
+                    a.h = a.h + d;
+                    if (!(fabsf(th - la_h) < S[ATC_C_ACT_DISCR + 1])) acts += 1;
+                    la_h = th;
+                }
+                {
+                    float d = tp - a.phi;
+                    d = fminf(d, S[ATC_C_PHIDOT_MAX] * dt);
+                    d = fmaxf(d, S[ATC_C_PHIDOT_MIN] * dt);
+                    a.phi = a.phi + d;
+                    if (!(fabsf(tp - la_p) < S[ATC_C_ACT_DISCR + 2])) acts += 1;
+                    la_p = tp;
+                }
+                // ---- Airplane.step (model.py:122-129): rot_matrix(phi) . [0, (v/3600) dt] ----------------------------
+                const float dist = (a.v / 3600.0f) * dt;
+                float sn, cs;
+                sincosf(a.phi * kDegToRad, &sn, &cs);
+                a.x += (double)(sn * dist);
+                a.y += (double)(cs * dist);
+                x32 = (float)a.x;
+                y32 = (float)a.y;
+                // ---- MVA floor (atc_gym.py:146-161) ------------------------------------------------------------------
+                const int pi = find_mva(S, grid, x32, y32);
+                if (pi >= 0) {
+                    mva = polytab[pi * ATC_P_WORDS + ATC_P_HEIGHT];
+                    if (a.h < mva) {
+                        r = -200.0f;
+                        fl |= ATC_F_BELOW_MVA;
+                    }
+                } else {
+                    r = -50.0f;
+                    fl |= ATC_F_OUTSIDE;
+                    mva = 0.0f;
+                }
+            }
+
+            // ---- separation scan (extension; README.md:51): 3 nm / 1000 ft among aircraft active at step start ------
+            float min_d2 = 1e30f;
+            if (W > 1) {
+                pos[tid] = make_float4(x32, y32, a.h, active ? 1.0f : 0.0f);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int gbase = tid & ~(W - 1);
+                bool conflict = false;
+#pragma unroll 4
+                for (int j = 0; j < W; ++j) {
+                    const float4 q = pos[gbase + j];
+                    const float dx = x32 - q.x, dy = y32 - q.y;
+                    const float d2 = dx * dx + dy * dy;
+                    const bool other = (j != k) && (q.w != 0.0f);
+                    if (other) {
+                        min_d2 = fminf(min_d2, d2);
+                        if (d2 < sep2 && fabsf(a.h - q.z) < p.sep_ft) conflict = true;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (active && conflict) {
+                    r = p.conflict_reward;
+                    fl |= ATC_F_CONFLICT;
+                }
+                if (!active) min_d2 = 1e30f;
+            }
+
+            // ---- win / timeout overrides, observation, shaping (atc_gym.py:163-189) ---------------------------------
+            float o[ATC_OBS_DIM];
+#pragma unroll
+            for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = 0.0f;
+            float raw[ATC_OBS_DIM];
+#pragma unroll
+            for (int c = 0; c < ATC_OBS_DIM; ++c) raw[c] = 0.0f;
+            if (active) {
+                if (inside_corridor(S, x32, y32, a.h, a.phi)) {
+                    int bonus = (p.timestep_limit - t) * 5;
+                    bonus = bonus < 0 ? 0 : bonus;
+                    r = (float)(10000 + bonus);
+                    fl |= ATC_F_WON;
+                }
+                if (t > p.timestep_limit) {
+                    r = -200.0f;
+                    fl |= ATC_F_TIMEOUT;
+                }
+                const Obs ob = get_state(S, x32, y32, a.h, a.phi, a.v, mva);
+                if (p.mode & ATC_M_REWARD_SHAPING) {
+                    const Shaping sh = shaping_rewards(S, ob.d_faf, ob.phi_rel_faf, a.phi, a.h, ob.on_gp);
+                    r += sh.pos;
+                    r += sh.ang;
+                    r += sh.gs;
+                }
+                for (int q = 0; q < n_noise; ++q) {  // extension (README.md:62): noise-abatement areas
+                    const float* rec = polytab + (n_mva + q) * ATC_P_WORDS;
+                    if (rec[ATC_P_MINX] <= x32 && x32 <= rec[ATC_P_MAXX] && rec[ATC_P_MINY] <= y32 &&
+                        y32 <= rec[ATC_P_MAXY] && a.h < rec[ATC_P_HEIGHT] &&
+                        ray_tracing(x32, y32, S + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT])) {
+                        r -= rec[ATC_P_PENALTY];
+                        fl |= ATC_F_NOISE;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < ATC_OBS_DIM; ++c) raw[c] = ob.o[c];
+                if (p.mode & ATC_M_NORMALIZE) {  // atc_gym.py:187-189
+#pragma unroll
+                    for (int c = 0; c < ATC_OBS_DIM; ++c) {
+                        const float half = 0.5f * S[ATC_C_NORM_MAX + c];
+                        o[c] = ((raw[c] - S[ATC_C_NORM_MIN + c]) - half) / half;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = raw[c];
+                }
+            }
+
+            // ---- per-env reductions over the W lanes of the group ----------------------------------------------------
+            const float env_r = group_sum<W>(r);
+            const int env_acts = group_sum_i<W>(acts);
+            const uint64_t won = group_ballot<W>((fl & ATC_F_WON) != 0, lane);
+            const uint64_t term = group_ballot<W>(
+                (fl & (ATC_F_BELOW_MVA | ATC_F_OUTSIDE | ATC_F_CONFLICT | ATC_F_TIMEOUT)) != 0, lane);
+            const uint64_t amask1 = amask & ~won;
+            const bool done = env_valid && (term != 0 || amask1 == 0);
+            total_reward += env_r;  // atc_gym.py:194-197
+            n_actions += env_acts;
+            amask = amask1;
+
+            if (lane_valid) {
+                out.flags[(long long)step * BN + i] = fl;
+                if (out.ac_reward) out.ac_reward[(long long)step * BN + i] = r;
+                if (out.raw_obs) store_obs(out.raw_obs + ((long long)step * BN + i) * ATC_OBS_DIM, raw);
+            }
+            if (env_valid && k == 0) {
+                out.reward[(long long)step * B + e] = env_r;
+                out.done[(long long)step * B + e] = done ? 1 : 0;
+            }
+            if (W > 1) {
+                const float m2 = group_min<W>(min_d2);
+                const float ms = (m2 >= 1e30f) ? 1e30f : sqrtf(m2);
+                if (out.min_sep && env_valid && k == 0) out.min_sep[(long long)step * B + e] = ms;
+            } else if (out.min_sep && env_valid) {
+                out.min_sep[(long long)step * B + e] = 1e30f;
+            }
+
+            if (done && (p.mode & ATC_M_AUTO_RESET)) {
+                // VecEnv semantics: the env restarts inside the step; the returned obs is the RAW reset state
+                // (atc_gym.py:351,365: reset() returns the un-normalised state computed with mva = 0).
+                if (k == 0) {
+                    st.ep_return[e] = total_reward;
+                    st.ep_length[e] = t;
+                    st.win_bits[e] = ((st.win_bits[e] << 1) | (amask == 0 ? 1u : 0u)) & 0x3ffu;
+                }
+                if (lane_valid) {
+                    if (out.term_obs) store_obs(out.term_obs + ((long long)step * BN + i) * ATC_OBS_DIM, o);
+                    a = spawn(S, p, e, k, episode);
+                    const Obs ob = get_state(S, (float)a.x, (float)a.y, a.h, a.phi, a.v, 0.0f);
+#pragma unroll
+                    for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = ob.o[c];
+                }
+                total_reward = 0.0f;
+                n_actions = 0;
+                t = 0;
+                episode += 1;
+                amask = full_mask;
+            }
+            if (lane_valid) store_obs(obs_t + i * ATC_OBS_DIM, o);
+        }
+
+        // ---- write back persistent state -------------------------------------------------------------------------------
+        if (lane_valid) {
+            st.x[i] = a.x;
+            st.y[i] = a.y;
+            st.h[i] = a.h;
+            st.phi[i] = a.phi;
+            st.v[i] = a.v;
+            st.last_act[i] = la_v;
+            st.last_act[BN + i] = la_h;
+            st.last_act[2 * BN + i] = la_p;
+        }
+        if (env_valid && k == 0) {
+            st.timesteps[e] = t;
+            st.actions_taken[e] = n_actions;
+            st.total_reward[e] = total_reward;
+            st.active_mask[e] = amask;
+            st.episodes[e] = episode;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// reset kernel (AtcGym.reset, atc_gym.py:337-365)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_reset(const float* __restrict__ blob, int lds_words, int B, int N, atc_state_t st, const uint8_t* __restrict__ mask,
+        float* __restrict__ obs, atc_params_t p, int first) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* S = smem;
+    stage_sector(S, blob, lds_words);
+    const long long BN = (long long)B * N;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < BN; i += (long long)gridDim.x * kBlock) {
+        const int e = (int)(i / N), k = (int)(i % N);
+        if (mask && !mask[e]) continue;
+        const int episode = first ? 0 : st.episodes[e];
+        const Aircraft a = spawn(S, p, e, k, episode);
+        st.x[i] = a.x;
+        st.y[i] = a.y;
+        st.h[i] = a.h;
+        st.phi[i] = a.phi;
+        st.v[i] = a.v;
+        if (first) {  // atc_gym.py:86: last_action = [0,0,0] once, in __init__ — never on reset (quirk Q7)
+            st.last_act[i] = 0.0f;
+            st.last_act[BN + i] = 0.0f;
+            st.last_act[2 * BN + i] = 0.0f;
+        }
+        if (obs) {
+            const Obs ob = get_state(S, (float)a.x, (float)a.y, a.h, a.phi, a.v, 0.0f);  // mva = 0, atc_gym.py:351
+            store_obs(obs + i * ATC_OBS_DIM, ob.o);
+        }
+    }
+}
+// _get_state(0) of the current state (atc_gym.py:351)
+__global__ void __launch_bounds__(kBlock)
+k_observe(const float* __restrict__ blob, int lds_words, int B, int N, atc_state_t st, const uint8_t* __restrict__ mask,
+          float* __restrict__ obs) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* S = smem;
+    stage_sector(S, blob, lds_words);
+    const long long BN = (long long)B * N;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < BN; i += (long long)gridDim.x * kBlock) {
+        const int e = (int)(i / N);
+        if (mask && !mask[e]) continue;
+        const Obs ob = get_state(S, (float)st.x[i], (float)st.y[i], st.h[i], st.phi[i], st.v[i], 0.0f);
+        store_obs(obs + i * ATC_OBS_DIM, ob.o);
+    }
+}
+// env-level part of reset runs after k_reset (episodes[] is read by k_reset's spawn)
+__global__ void __launch_bounds__(kBlock)
+k_reset_env(int B, int N, atc_state_t st, const uint8_t* __restrict__ mask, int first) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= B) return;
+    if (mask && !mask[e]) return;
+    if (first) {
+        st.win_bits[e] = 0;
+        st.episodes[e] = 0;
+        st.ep_return[e] = 0.0f;
+        st.ep_length[e] = 0;
+    }
+    st.total_reward[e] = 0.0f;
+    st.actions_taken[e] = 0;
+    st.timesteps[e] = 0;
+    st.episodes[e] = st.episodes[e] + 1;
+    st.active_mask[e] = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// query kernels
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_query_mva(const float* __restrict__ blob, int lds_words, int off_grid, int n, const float* __restrict__ x,
+            const float* __restrict__ y, int32_t* __restrict__ out_h, int32_t* __restrict__ out_idx) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    stage_sector(smem, blob, lds_words);
+    const float* S = smem;
+    const float* grid = off_grid ? blob + off_grid : nullptr;
+    const float* polytab = S + (int)S[ATC_H_OFF_POLY];
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const int pi = find_mva(S, grid, x[i], y[i]);
+        if (out_h) out_h[i] = pi >= 0 ? (int32_t)polytab[pi * ATC_P_WORDS + ATC_P_HEIGHT] : -1;
+        if (out_idx) out_idx[i] = pi;
+    }
+}
+__global__ void __launch_bounds__(kBlock)
+k_query_corridor(const float* __restrict__ blob, int lds_words, int n, const float* __restrict__ x,
+                 const float* __restrict__ y, const float* __restrict__ h, const float* __restrict__ phi, int angle_only,
+                 uint8_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    stage_sector(smem, blob, lds_words);
+    const float* S = smem;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        out[i] = angle_only ? inside_corridor_angle(S, x[i], y[i], phi[i]) : inside_corridor(S, x[i], y[i], h[i], phi[i]);
+}
+__global__ void __launch_bounds__(kBlock)
+k_query_shaping(const float* __restrict__ blob, int lds_words, int n, const float* __restrict__ d_faf,
+                const float* __restrict__ phi_rel_faf, const float* __restrict__ phi_plane, const float* __restrict__ h,
+                const float* __restrict__ on_gp, float* __restrict__ out3) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    stage_sector(smem, blob, lds_words);
+    const float* S = smem;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const Shaping s = shaping_rewards(S, d_faf[i], phi_rel_faf[i], phi_plane[i], h[i], on_gp[i]);
+        out3[3 * i + 0] = s.pos;
+        out3[3 * i + 1] = s.ang;
+        out3[3 * i + 2] = s.gs;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side of the C-ABI
+// ---------------------------------------------------------------------------------------------------------------
+static int grid_for(const atc_scenario* s, long long threads) {
+    long long blocks = (threads + kBlock - 1) / kBlock;
+    const long long cap = (long long)s->n_cu * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+static size_t lds_bytes(const atc_scenario* s, bool pair_scan) {
+    size_t w = (size_t)((s->lds_words + 3) & ~3);
+    if (pair_scan) w += (size_t)kBlock * 4;
+    return w * sizeof(float);
+}
+
+template <int W>
+static int launch_step(const atc_scenario* s, int B, int N, int T, const atc_state_t* st, const float* actions,
+                       const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
+    const size_t lds = lds_bytes(s, W > 1);
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<W>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+    const int grid = grid_for(s, (long long)B * W);
+    hipLaunchKernelGGL(k_step<W>, dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->lds_words, s->off_grid, B, N, T, *st,
+                       actions, *out, *p);
+    HIP_TRY(hipGetLastError());
+    return ATC_OK;
+}
+
+static int step_common(const atc_scenario_t* s, int B, int N, int T, const atc_state_t* st, const float* actions,
+                       const atc_out_t* out, const atc_params_t* p, void* stream) {
+    if (!s || !st || !actions || !out || !p) return fail_arg("null pointer");
+    if (B < 1 || N < 1 || N > ATC_MAX_AIRCRAFT || T < 1) return fail_arg("need B >= 1, 1 <= N <= 64, T >= 1");
+    if (!st->x || !st->y || !st->h || !st->phi || !st->v || !st->last_act || !st->timesteps || !st->actions_taken ||
+        !st->total_reward || !st->active_mask || !st->win_bits || !st->episodes || !st->ep_return || !st->ep_length)
+        return fail_arg("atc_state_t has a null field");
+    if (!out->obs || !out->reward || !out->done || !out->flags) return fail_arg("obs/reward/done/flags are required");
+    if (!(p->dt > 0.0f)) return fail_arg("dt must be > 0");
+    hipStream_t q = (hipStream_t)stream;
+    if (N == 1) return launch_step<1>(s, B, N, T, st, actions, out, p, q);
+    if (N == 2) return launch_step<2>(s, B, N, T, st, actions, out, p, q);
+    if (N <= 4) return launch_step<4>(s, B, N, T, st, actions, out, p, q);
+    if (N <= 8) return launch_step<8>(s, B, N, T, st, actions, out, p, q);
+    if (N <= 16) return launch_step<16>(s, B, N, T, st, actions, out, p, q);
+    if (N <= 32) return launch_step<32>(s, B, N, T, st, actions, out, p, q);
+    return launch_step<64>(s, B, N, T, st, actions, out, p, q);
+}
+
+extern "C" {
+
+int atc_abi_version(void) { return ATC_ABI_VERSION; }
+const char* atc_last_error(void) { return g_err; }
+
+int atc_scenario_create(const float* blob_host, size_t n_words, int device, atc_scenario_t** out) {
+    if (!blob_host || !out) return fail_arg("null pointer");
+    if (n_words < ATC_C_END || blob_host[ATC_H_VERSION] != ATC_BLOB_VERSION || (size_t)blob_host[ATC_H_NWORDS] != n_words)
+        return fail_arg("not a scenario blob of this ABI version");
+    if ((int)blob_host[ATC_H_N_MVA] > 32) return fail_arg("at most 32 MVA polygons");
+    HIP_TRY(hipSetDevice(device));
+    atc_scenario* s = new atc_scenario();
+    s->n_words = (int)n_words;
+    s->off_grid = (int)blob_host[ATC_H_OFF_GRID];
+    s->lds_words = s->off_grid ? s->off_grid : (int)n_words;
+    s->device = device;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        delete s;
+        return fail_hip(e, "hipGetDeviceProperties");
+    }
+    s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((size_t)s->lds_words * 4 + kBlock * 16 > 160 * 1024) {
+        delete s;
+        return fail_arg("sector does not fit the 160 KB LDS");
+    }
+    e = hipMalloc(&s->d_blob, n_words * sizeof(float));
+    if (e != hipSuccess) {
+        delete s;
+        return fail_hip(e, "hipMalloc");
+    }
+    e = hipMemcpy(s->d_blob, blob_host, n_words * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(s->d_blob);
+        delete s;
+        return fail_hip(e, "hipMemcpy");
+    }
+    *out = s;
+    return ATC_OK;
+}
+
+int atc_scenario_destroy(atc_scenario_t* s) {
+    if (!s) return ATC_OK;
+    (void)hipFree(s->d_blob);
+    delete s;
+    return ATC_OK;
+}
+
+int atc_query_mva(const atc_scenario_t* s, int n, const float* x, const float* y, int32_t* out_h, int use_grid,
+                  void* stream) {
+    if (!s || !x || !y || !out_h || n < 0) return fail_arg("null pointer / negative n");
+    if (n == 0) return ATC_OK;
+    hipLaunchKernelGGL(k_query_mva, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false), (hipStream_t)stream, s->d_blob,
+                       s->lds_words, use_grid ? s->off_grid : 0, n, x, y, out_h, (int32_t*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return ATC_OK;
+}
+// index variant used by the host mirror's Airspace.find_mva (returns the polygon index, -1 outside)
+int atc_query_mva_index(const atc_scenario_t* s, int n, const float* x, const float* y, int32_t* out_idx, int use_grid,
+                        void* stream) {
+    if (!s || !x || !y || !out_idx || n < 0) return fail_arg("null pointer / negative n");
+    if (n == 0) return ATC_OK;
+    hipLaunchKernelGGL(k_query_mva, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false), (hipStream_t)stream, s->d_blob,
+                       s->lds_words, use_grid ? s->off_grid : 0, n, x, y, (int32_t*)nullptr, out_idx);
+    HIP_TRY(hipGetLastError());
+    return ATC_OK;
+}
+
+int atc_query_corridor(const atc_scenario_t* s, int n, const float* x, const float* y, const float* h, const float* phi,
+                       int angle_only, uint8_t* out, void* stream) {
+    if (!s || !x || !y || !h || !phi || !out || n < 0) return fail_arg("null pointer / negative n");
+    if (n == 0) return ATC_OK;
+    hipLaunchKernelGGL(k_query_corridor, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false), (hipStream_t)stream,
+                       s->d_blob, s->lds_words, n, x, y, h, phi, angle_only, out);
+    HIP_TRY(hipGetLastError());
+    return ATC_OK;
+}
+
+int atc_query_shaping(const atc_scenario_t* s, int n, const float* d_faf, const float* phi_rel_faf, const float* phi_plane,
+                      const float* h, const float* on_gp, float* out3, void* stream) {
+    if (!s || !d_faf || !phi_rel_faf || !phi_plane || !h || !on_gp || !out3 || n < 0)
+        return fail_arg("null pointer / negative n");
+    if (n == 0) return ATC_OK;
+    hipLaunchKernelGGL(k_query_shaping, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false), (hipStream_t)stream,
+                       s->d_blob, s->lds_words, n, d_faf, phi_rel_faf, phi_plane, h, on_gp, out3);
+    HIP_TRY(hipGetLastError());
+    return ATC_OK;
+}
+
+int atc_reset(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const uint8_t* mask, float* obs,
+              const atc_params_t* p, int first, void* stream) {
+    if (!s || !st || !p) return fail_arg("null pointer");
+    if (B < 1 || N < 1 || N > ATC_MAX_AIRCRAFT) return fail_arg("need B >= 1, 1 <= N <= 64");
+    hipStream_t q = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_reset, dim3(grid_for(s, (long long)B * N)), dim3(kBlock), lds_bytes(s, false), q, s->d_blob,
+                       s->lds_words, B, N, *st, mask, obs, *p, first);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_reset_env, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, q, B, N, *st, mask, first);
+    HIP_TRY(hipGetLastError());
+    return ATC_OK;
+}
+
+int atc_observe(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const uint8_t* mask, float* obs,
+                const atc_params_t* p, void* stream) {
+    if (!s || !st || !obs || !p) return fail_arg("null pointer");
+    if (B < 1 || N < 1 || N > ATC_MAX_AIRCRAFT) return fail_arg("need B >= 1, 1 <= N <= 64");
+    hipLaunchKernelGGL(k_observe, dim3(grid_for(s, (long long)B * N)), dim3(kBlock), lds_bytes(s, false),
+                       (hipStream_t)stream, s->d_blob, s->lds_words, B, N, *st, mask, obs);
+    HIP_TRY(hipGetLastError());
+    return ATC_OK;
+}
+
+int atc_step(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const float* actions, const atc_out_t* out,
+             const atc_params_t* p, void* stream) {
+    return step_common(s, B, N, 1, st, actions, out, p, stream);
+}
+
+int atc_rollout(const atc_scenario_t* s, int B, int N, int T, const atc_state_t* st, const float* actions,
+                const atc_out_t* out, const atc_params_t* p, void* stream) {
+    return step_common(s, B, N, T, st, actions, out, p, stream);
+}
+
+}  // extern "C"

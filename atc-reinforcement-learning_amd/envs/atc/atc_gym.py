@@ -1,0 +1,210 @@
+"""AtcGym — single-environment gym.Env surface of the reference (envs/atc/atc_gym.py:22-365), backed by the HIP step
+kernels (one env x one aircraft on the GPU; there is no CPU step path).
+
+Everything the reference's callers touch is kept: ctor signature, seed/reset/step/render/close, action_space,
+observation_space, reward_range, metadata, the metric attributes read through VecEnv.get_attr
+(actions_per_timestep, winning_ratio; learning/atc-gym-stable-baselines.py:34,36) and info["original_state"]
+(:101-103).  The arithmetic of step() runs in libatcstep.so; this class only does the episode bookkeeping the
+reference does in Python (win ring buffer, counters), in the same order, including its quirks:
+  * reset() returns the RAW state, step() the normalised one (atc_gym.py:365 vs :187-192)
+  * last_action is initialised once in __init__ and never reset (atc_gym.py:86)
+  * no auto-reset, stepping a finished episode keeps counting (learning/atc-gym-compute-performance.py relies on it)
+  * the win buffer gets one append per terminal CAUSE (atc_gym.py:151,158,165) and reset() pops exactly one (:359-363)
+"""
+import random
+
+import numpy as np
+
+from atc_hip import layout as L
+from . import model
+from . import scenarios
+from ._spaces import Box, Env, MultiDiscrete
+
+
+class _AirplaneView:
+    """`env._airplane` of the reference (model.py:13-52) as a live view of the device state."""
+    h_min, h_max, v_min, v_max = 0, 38000, 100, 300
+    h_dot_min, h_dot_max, a_max, a_min, phi_dot_max, phi_dot_min = -41, 15, 5, -5, 3, -3
+
+    def __init__(self, vec, name="FLT01"):
+        object.__setattr__(self, "_vec", vec)
+        object.__setattr__(self, "name", name)
+        object.__setattr__(self, "id", 0)
+
+    def __getattr__(self, key):
+        if key in ("x", "y", "h", "phi", "v"):
+            return float(getattr(self._vec, key)[0])
+        raise AttributeError(key)
+
+    def __setattr__(self, key, value):
+        if key in ("x", "y", "h", "phi", "v"):
+            getattr(self._vec, key)[0] = float(value)
+        else:
+            object.__setattr__(self, key, value)
+
+
+class AtcGym(Env):
+    metadata = {
+        'render.modes': ['human', 'rgb_array'],
+        'video.frames_per_second': 50
+    }
+
+    def __init__(self, sim_parameters=None, scenario=None, device=0):
+        # the reference evaluates its defaults once at import (atc_gym.py:28): SimParameters(1), LOWW()
+        sim_parameters = sim_parameters if sim_parameters is not None else model.SimParameters(1)
+        scenario = scenario if scenario is not None else scenarios.LOWW()
+        self.last_reward = 0
+        self.total_reward = 0
+        self.actions_taken = 0
+        self._episodes_run = 0
+        self._actions_ignoring_resets = 0
+        self._won_simulations_ignoring_resets = 0
+        self._win_buffer_size = 10
+        self._win_buffer = [0] * self._win_buffer_size
+        self.actions_per_timestep = 0
+        self.timesteps = 0
+        self.timestep_limit = 6000
+        self.winning_ratio = 0
+        self._sim_parameters = sim_parameters
+        self._scenario = scenario
+        self._mvas = scenario.mvas
+        self._runway = scenario.runway
+        self._airspace = scenario.airspace
+
+        self._vec = self._make_backend(sim_parameters, scenario, device)
+        comp = self._vec.compiled
+        self._faf_mva = int(comp.faf_mva)
+        self._world_x_min, self._world_y_min, self._world_x_max, self._world_y_max = comp.bbox
+        self._world_max_distance = comp.world_diag
+        self._airplane = _AirplaneView(self._vec)
+
+        self.done = True
+        self.reset()
+        self.viewer = None
+
+        self.normalization_action_offset = np.array([self._airplane.v_min, 0, 0])
+        if sim_parameters.discrete_action_space:
+            self.normalization_action_factor = np.array([10, 100, 1])
+            self.action_space = MultiDiscrete([int((self._airplane.v_max - self._airplane.v_min) / 10),
+                                               int(self._airplane.h_max / 100), 360])
+        else:
+            self.normalization_action_factor = np.array([self._airplane.v_max - self._airplane.v_min,
+                                                         self._airplane.h_max, 360])
+            self.action_space = Box(low=np.array([-1, -1, -1]), high=np.array([1, 1, 1]))
+        self._action_discriminator = [5, 50, 0.5]
+        self.normalization_state_min = comp.norm_min.copy()
+        self.normalization_state_max = comp.norm_max.copy()
+        self.observation_space = Box(low=-1.0, high=1.0, shape=(10,))
+        self.reward_range = (-3000.0, 23000.0)  # as declared by the reference (atc_gym.py:115)
+
+    # -- backend ---------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _make_backend(sim_parameters, scenario, device):
+        from atc_hip.vec_env import AtcVecEnv
+        return AtcVecEnv(1, 1, sim_parameters=sim_parameters, scenario=scenario, device=device, auto_reset=False,
+                         spawn="lattice", want_raw_obs=True)
+
+    @property
+    def last_action(self):
+        """atc_gym.py:86,311 — lives on the device next to the aircraft state."""
+        return [float(v) for v in self._vec.last_act[:, 0].cpu()]
+
+    @last_action.setter
+    def last_action(self, value):
+        for c in range(3):
+            self._vec.last_act[c, 0] = float(value[c])
+
+    # -- gym.Env ----------------------------------------------------------------------------------------------------
+    def seed(self, seed=None):
+        """atc_gym.py:117-126"""
+        if seed is None:
+            seed = int(np.random.SeedSequence().entropy % (2 ** 31))
+        self.np_random = np.random.RandomState(seed % (2 ** 32))
+        random.seed(seed)
+        return [seed]
+
+    def step(self, action):
+        """atc_gym.py:128-192 — one launch of the HIP step kernel + the reference's Python-side bookkeeping."""
+        vec = self._vec
+        a = np.asarray(action, dtype=np.float32).reshape(1, 1, 3)
+        obs, reward, done, info = vec.step(a)
+        host = self._fetch(obs, info["original_state"], reward, done, info["flags"], vec.timesteps, vec.actions_taken)
+        state_out, raw, rew, dn, flags, self.timesteps, self.actions_taken = host
+        self.done = False
+        # one append per terminal cause, in the reference's order (atc_gym.py:151,158,165)
+        if flags & (L.F_BELOW_MVA | L.F_OUTSIDE):
+            self._win_buffer.append(0)
+            self.done = True
+        if flags & L.F_WON:
+            self._win_buffer.append(1)
+            self.done = True
+        if flags & L.F_TIMEOUT:
+            self.done = True
+        if flags & (L.F_INVALID_V | L.F_INVALID_H):  # atc_gym.py:314
+            for bit, idx in ((L.F_INVALID_V, 0), (L.F_INVALID_H, 1)):
+                if flags & bit:
+                    print("Warning invalid action: %d for index: %d" % (self._denormalized_action(a[0, 0, idx], idx), idx))
+        assert self.done == bool(dn)
+        self.state = raw
+        self._update_metrics(rew)
+        return state_out, rew, self.done, {"original_state": self.state}
+
+    def _fetch(self, obs, raw, reward, done, flags, timesteps, actions_taken):
+        """Single device->host hop for everything step() returns."""
+        torch = self._vec.torch
+        pack = torch.cat([obs.reshape(-1), raw.reshape(-1), reward.reshape(-1),
+                          done.reshape(-1).to(torch.float32),
+                          flags.reshape(-1).to(torch.float32), timesteps.to(torch.float32),
+                          actions_taken.to(torch.float32)]).cpu().numpy()
+        return (pack[0:10].astype(np.float32), pack[10:20].astype(np.float32), float(pack[20]), bool(pack[21]),
+                int(pack[22]), int(pack[23]), int(pack[24]))
+
+    def _update_metrics(self, reward):
+        """atc_gym.py:194-197"""
+        self.last_reward = reward
+        self.total_reward += reward
+        self.actions_per_timestep = self.actions_taken / self.timesteps
+
+    def _denormalized_action(self, action, index):
+        """atc_gym.py:318-335 (host copy used only for the warning text; the kernel applies its own)."""
+        f, o = self.normalization_action_factor, self.normalization_action_offset
+        if self._sim_parameters.discrete_action_space:
+            return action * f[index] + o[index]
+        return action * f[index] / 2 + f[index] / 2 + o[index]
+
+    def reset(self):
+        """atc_gym.py:337-365.  Draws the entry point with Python's `random` in the reference's order (choice, choice,
+        randint: atc_gym.py:346-348, model.py:52) so a seeded run picks the same entries, then places the aircraft on the
+        device."""
+        self.done = False
+        vec = self._vec
+        entry_point = random.choice(self._scenario.entrypoints)
+        level = random.choice(entry_point.levels)
+        plane_id = random.randint(0, 32767)
+        vec.reset()
+        vec.set_state(0, 0, entry_point.x, entry_point.y, level * 100, entry_point.phi, 250)
+        self._airplane.id = plane_id
+        self.state = vec.observe().reshape(-1).cpu().numpy().astype(np.float32)
+        self.total_reward = 0
+        self.last_reward = 0
+        self._actions_ignoring_resets += self.actions_taken
+        self.actions_taken = 0
+        self.timesteps = 0
+        self._episodes_run += 1
+        if len(self._win_buffer) < self._win_buffer_size:
+            self._win_buffer.append(0)
+        self.winning_ratio = self.winning_ratio + 1 / self._win_buffer_size * \
+            (self._win_buffer[-1] - self._win_buffer.pop(0))
+        return self.state
+
+    def render(self, mode='human'):
+        """The pyglet viewer of the reference (atc_gym.py:367-552) is out of scope; `rgb_array` gives a
+        blank frame so recorders keep working."""
+        if mode == 'rgb_array':
+            return np.zeros((800, 800, 3), dtype=np.uint8)
+        return None
+
+    def close(self):
+        if getattr(self, "_vec", None) is not None:
+            self._vec.close()
+            self._vec = None

@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the batched AtcGym.step() hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: run under torch.distributed.run, one rank per GPU)
+
+One "step" = one pass of the hot path (one atc_step launch) over this GPU's batch: 65 536 envs x 16 aircraft, the
+configuration BASELINE.json's metric is quoted on ("env-steps/sec aggregate @16 aircraft/env, 64k envs").  Weak scaling:
+every rank owns 65 536 envs (8 ranks = config C5, 524 288 envs); no collective on the step path, one RCCL all-gather of the
+per-env episode returns at the end of the timed rollout.  Inputs (sector, state, a ring of pre-sampled action tensors:
+U(-1,1) fp32, re-sampled every 20 steps like learning/atc-gym-demo.py:18-19) are resident in HBM before the timed region;
+envs auto-reset on done.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "atc-reinforcement-learning_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+ENVS_PER_GPU = 65536
+AIRCRAFT = 16
+HOLD = 20            # action re-sampling interval [steps]
+HBM_PEAK_GBS = 8000  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_env_step(n):
+    """SURVEY.md §8(d) / BASELINE.md §3: 96 B per aircraft (32 read: state 20 + action 12; 64 write: state 20 + obs 40 +
+    reward 4) + 13 B per env (timesteps r/w 8, done 1, flags 4)."""
+    return 96 * n + 13
+
+
+def cpu_baseline(n_aircraft, seconds_target=15.0):
+    """The fp32 CPU oracle (a scalar C port of the reference's step, oracle/) timed on ONE host core on a bounded sample of
+    the same workload (same sector, spawn lattice, action protocol, auto-reset)."""
+    import numpy as np
+    from envs.atc import scenarios
+    from oracle import oracle as O
+    scn = scenarios.LOWW(random_entrypoints=True)
+    comp = scenarios.compile_scenario(scn)
+    B = 2048
+    env = O.OracleEnv(comp, B, n_aircraft, O.make_params(auto_reset=True, seed=0), np.float32)
+    rng = np.random.default_rng(0)
+    acts = [rng.uniform(-1, 1, (B, n_aircraft, 3)).astype(np.float32) for _ in range(4)]
+    for t in range(5):
+        env.step(acts[0])
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        env.step(acts[(steps // HOLD) % 4])
+        steps += 1
+        if steps % 10 == 0 and time.perf_counter() - t0 > seconds_target:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": B * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d envs x %d aircraft x %d steps (%.1f s) of the same workload through oracle/ (fp32 C port of the "
+                      "reference step, gcc -O2, 1 thread); host has %d cores" % (B, n_aircraft, steps, dt, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU")
+    ap.add_argument("--aircraft", type=int, default=AIRCRAFT)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rollout", type=int, default=0, help="fuse this many steps per launch (0 = one launch per step)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)]
+        cmd += sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import torch
+    from atc_hip import dist as D
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+
+    rank, ws, local = D.init()
+    assert ws == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (ws, args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs the GPU (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B, N, K, W = args.envs, args.aircraft, args.steps, args.warmup
+
+    scn = scenarios.LOWWDense() if N > 16 else scenarios.LOWW(random_entrypoints=N > 1)
+    env = AtcVecEnv(B, N, scenario=scn, device=local, auto_reset=True, seed=D.rank_seed(0, rank), grid_cell=0.5)
+
+    # action ring resident in HBM before timing (Philox, seed 0 + rank)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    n_ring = max(2, min(64, (K + W) // HOLD + 1))
+    ring = [torch.rand((B, N, 3), generator=g, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(n_ring)]
+
+    def run(n_steps, t_base):
+        if args.rollout:
+            T = args.rollout
+            assert n_steps % T == 0 and HOLD % T == 0 or T % HOLD == 0
+            for s in range(0, n_steps, T):
+                a = torch.stack([ring[((t_base + s + c) // HOLD) % n_ring] for c in range(T)])
+                env.rollout(a, out=roll_out)
+        else:
+            for s in range(n_steps):
+                env.step(ring[((t_base + s) // HOLD) % n_ring])
+
+    roll_out = None
+    if args.rollout:
+        T = args.rollout
+        roll_out = {"obs": torch.empty((T, B, N * 10), dtype=torch.float32, device=dev),
+                    "reward": torch.empty((T, B), dtype=torch.float32, device=dev),
+                    "done": torch.empty((T, B), dtype=torch.uint8, device=dev),
+                    "flags": torch.empty((T, B, N), dtype=torch.int32, device=dev)}
+
+    run(W, 0)
+    torch.cuda.synchronize(dev)
+    D.barrier()
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()               # torch's current stream == the stream atc_step is launched on
+    run(K, W)
+    ev1.record()
+    returns, lengths = D.all_gather_stats(env.ep_return, env.ep_length)  # the path's only exchange (RCCL, N > 1)
+    torch.cuda.synchronize(dev)
+    D.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms_total = ev0.elapsed_time(ev1)
+    elapsed = D.max_over_ranks(elapsed, dev)
+    T = args.rollout or 1
+    n_launches = K // T
+    launch_ms = D.max_over_ranks(kernel_ms_total, dev) / n_launches   # average launch duration (HIP events)
+
+    episodes = D.sum_over_ranks(float(env.episodes.sum().item()) - B, dev)
+    value = ws * B * K / elapsed
+    bytes_launch = algorithmic_bytes_per_env_step(N) * B * T
+    achieved = bytes_launch / (launch_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("envs") == B and tj.get("aircraft") == N:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        line = {
+            "metric": "env-steps/sec aggregate @16 aircraft/env, 64k envs" if (N == 16 and B == 65536) else "env-steps/sec",
+            "value": value, "unit": "env-steps/s", "n_gpus": ws, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d envs x %d aircraft per GPU (%d envs total), sector %s, dt=1 s, reward shaping + "
+                                   "normalisation on, continuous actions U(-1,1) re-sampled every %d steps, auto-reset, "
+                                   "O(N^2) separation scan, MVA lookup grid 0.5 nm" % (B, N, B * ws, type(scn).__name__, HOLD),
+                       "envs_per_gpu": B, "aircraft_per_env": N, "launch": "rollout T=%d" % args.rollout if args.rollout
+                       else "one atc_step launch per step", "parallelism": "env-sharded x%d, no step-path collective, "
+                       "1 all-gather of episode returns per rollout" % ws,
+                       "episodes_finished": int(episodes), "positions": "f64 accumulators"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_step<%d>" % (1 << max(0, (N - 1).bit_length())),
+                         "avg_launch_ms": launch_ms, "algorithmic_bytes_per_launch": bytes_launch,
+                         "note": "HIP events on the launch stream around the %d timed launches (includes inter-launch "
+                                 "gaps)" % n_launches},
+        }
+        if ws == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(N)
+        print(json.dumps(line))
+    env.close()
+    if ws > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -177,6 +177,9 @@ int atc_scenario_destroy(atc_scenario_t* s);
  * use_grid != 0 uses the lookup grid if the blob has one. */
 int atc_query_mva(const atc_scenario_t* s, int n, const float* x, const float* y, int32_t* out_h, int use_grid,
                   void* stream);
+/* Airspace.find_mva, model.py:282-289: out_idx[i] = index of the MVA polygon in list order, or -1. */
+int atc_query_mva_index(const atc_scenario_t* s, int n, const float* x, const float* y, int32_t* out_idx, int use_grid,
+                        void* stream);
 /* Runway.inside_corridor, model.py:248-257,188-231.  angle_only != 0 evaluates Corridor._inside_corridor_angle
  * (model.py:212-231) alone.  out[i] = 0/1. */
 int atc_query_corridor(const atc_scenario_t* s, int n, const float* x, const float* y, const float* h,
@@ -192,6 +195,12 @@ int atc_query_shaping(const atc_scenario_t* s, int n, const float* d_faf, const 
  * first != 0 additionally clears last_act / win_bits / episodes (what AtcGym.__init__ does, atc_gym.py:29-41,86). */
 int atc_reset(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const uint8_t* mask, float* obs,
               const atc_params_t* p, int first, void* stream);
+
+/* AtcGym._get_state(0), atc_gym.py:262-277,351: RAW observation (mva = 0) of the CURRENT aircraft state of every masked
+ * env (mask == NULL: all) — used after the host places aircraft explicitly (e.g. to replay the reference's
+ * random.choice entry draws, atc_gym.py:346-348). */
+int atc_observe(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const uint8_t* mask, float* obs,
+                const atc_params_t* p, void* stream);
 
 /* AtcGym.step, atc_gym.py:128-192, for B envs x N aircraft.  actions: [B*N*3] (v,h,phi per aircraft),
  * continuous in [-1,1] or discrete indices stored as floats (atc_gym.py:318-335). */

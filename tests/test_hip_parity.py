@@ -1,0 +1,580 @@
+"""GPU parity tests: the HIP path (through the C-ABI of libatcstep.so) against
+  (a) the golden vectors captured from the reference (tests/golden/), and
+  (b) the fp32 CPU oracle on identical seeded inputs (integer outputs bit-exact, fp32 values within 1e-5).
+Run on the MI355X box with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TERMINAL = H.F_BELOW_MVA | H.F_OUTSIDE | H.F_TIMEOUT | H.F_CONFLICT
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _sector(name, grid_cell=None):
+    from atc_hip import lib
+    return lib.Scenario(H.compiled(name, grid_cell=grid_cell))
+
+
+# ------------------------------------------------------------------------------------------------ reference's own tests
+class TestReferenceModelTests:
+    """The 8 cases of the reference's envs/atc/model_test.py, written against the mirrored classes (which evaluate on
+    the GPU)."""
+
+    def setup_method(self):
+        from envs.atc import model
+        self.model = model
+        self.mvas = [
+            model.MinimumVectoringAltitude([(15, 0), (35, 0), (35, 26)], 3500),
+            model.MinimumVectoringAltitude([(15, 0), (35, 26), (35, 30), (15, 30), (15, 27.8)], 2400),
+            model.MinimumVectoringAltitude([(15, 30), (35, 30), (35, 40), (15, 40)], 4000),
+            model.MinimumVectoringAltitude([(0, 10), (15, 0), (15, 28.7), (0, 17)], 8000),
+            model.MinimumVectoringAltitude([(0, 17), (15, 28.7), (15, 40), (0, 32)], 6500),
+        ]
+        self.runway = model.Runway(20, 20, 0, 180)
+        self.airspace = model.Airspace(self.mvas, self.runway)
+
+    def test_airspace_get_mvas(self):
+        assert self.airspace.get_mva_height(34, 1) == 3500
+
+    def test_inside_corridor_true_when_on_correct_side(self):
+        mva = self.airspace.get_mva_height(self.runway.corridor.faf[0][0], self.runway.corridor.faf[1][0])
+        assert self.runway.inside_corridor(19, 10, mva + 300, 30) is True
+
+    def test_inside_corridor_false_when_right_position_with_wrong_heading(self):
+        mva = self.airspace.get_mva_height(self.runway.corridor.faf[0][0], self.runway.corridor.faf[1][0])
+        assert self.runway.inside_corridor(19, 10, mva, 330) is False
+
+    def test_inside_corridor_angle_cases(self):
+        c = self.runway.corridor
+        assert c._inside_corridor_angle(21, 10, 30) is False
+        assert c._inside_corridor_angle(19, 10, 340) is False
+        assert c._inside_corridor_angle(19, 10, 190) is False
+        assert c._inside_corridor_angle(21, 10, 340) is True
+
+    def test_bounding_box_airspace_multiple_mva(self):
+        assert self.airspace.get_bounding_box() == (0.0, 0.0, 35.0, 40.0)
+
+    def test_outside_raises(self):
+        with pytest.raises(ValueError):
+            self.airspace.get_mva_height(-5, -5)
+
+    def test_ray_tracing_function(self):
+        assert self.model.ray_tracing(20, 10, [(15, 0), (35, 0), (35, 26)]) is True
+        assert self.model.ray_tracing(16, 20, [(15, 0), (35, 0), (35, 26)]) is False
+
+
+# ------------------------------------------------------------------------------------------------ G3 / G4 / G5 lattices
+@pytest.mark.parametrize("grid_cell", [None, 0.5, 1.0])
+@pytest.mark.parametrize("scen", ["LOWW", "Simple"])
+def test_mva_lattice_golden(scen, grid_cell):
+    g = H.golden_npz("g3_mva.npz")
+    s = _sector(scen, grid_cell)
+    xs, ys = g[scen + "_xs"], g[scen + "_ys"]
+    X, Y = np.meshgrid(xs, ys)
+    got = s.query_mva(X.ravel(), Y.ravel(), use_grid=grid_cell is not None).reshape(len(ys), len(xs))
+    assert np.array_equal(got, g[scen + "_lattice"])
+
+
+@pytest.mark.parametrize("grid_cell", [None, 0.25, 0.5, 2.0])
+@pytest.mark.parametrize("scen", ["LOWW", "Simple"])
+def test_mva_bitexact_vs_oracle_dense_and_edges(scen, grid_cell):
+    """1.5 M random points + points hugging every polygon edge/vertex (within a few fp32 ulps): the polygon index must be
+    identical to the fp32 oracle's ordered scan, with and without the lookup grid."""
+    from oracle import oracle as O
+    comp = H.compiled(scen, grid_cell)
+    s = _sector(scen, grid_cell)
+    rng = np.random.default_rng(3)
+    b = comp.bbox
+    pts = [np.stack([rng.uniform(b[0] - 2, b[2] + 2, 1500000), rng.uniform(b[1] - 2, b[3] + 2, 1500000)], 1)]
+    for ring in comp.mva_rings:
+        for k in range(len(ring) - 1):
+            t = rng.uniform(0, 1, 400)[:, None]
+            p = ring[k][None, :] * (1 - t) + ring[k + 1][None, :] * t
+            jitter = rng.integers(-3, 4, p.shape) * np.spacing(np.abs(p).astype(np.float32)).astype(np.float64)
+            pts.append(p + jitter)
+            pts.append(np.repeat(ring[k][None, :], 49, 0) + np.stack(np.meshgrid(np.arange(-3, 4), np.arange(-3, 4)), -1)
+                       .reshape(-1, 2) * np.spacing(np.abs(ring[k]).astype(np.float32)).astype(np.float64))
+    pts = np.concatenate(pts).astype(np.float32)
+    q = O.OracleQueries(comp, np.float32)
+    exp = q.mva(pts[:, 0], pts[:, 1])
+    got = s.query_mva(pts[:, 0], pts[:, 1], use_grid=grid_cell is not None)
+    assert np.array_equal(got, exp)
+    assert (exp >= 0).sum() > 100000 and (exp < 0).sum() > 1000
+
+
+@pytest.mark.parametrize("scen", ["LOWW", "UnitTest", "Simple"])
+def test_corridor_tables_golden(scen):
+    g = H.golden_npz("g4_corridor.npz")
+    s = _sector(scen)
+    xs, ys, hs, phis = (g[scen + k] for k in ("_xs", "_ys", "_hs", "_phis"))
+    shape = tuple(g[scen + "_inside_shape"])
+    exp = np.unpackbits(g[scen + "_inside"])[:int(np.prod(shape))].reshape(shape)
+    Y, X, Hh, P = np.meshgrid(ys, xs, hs, phis, indexing="ij")
+    got = s.query_corridor(X.ravel(), Y.ravel(), Hh.ravel(), P.ravel()).reshape(shape)
+    assert np.array_equal(got, exp)
+    ashape = tuple(g[scen + "_angle_shape"])
+    aexp = np.unpackbits(g[scen + "_angle"])[:int(np.prod(ashape))].reshape(ashape)
+    Y, X, P = np.meshgrid(ys, xs, phis, indexing="ij")
+    agot = s.query_corridor(X.ravel(), Y.ravel(), np.zeros(X.size), P.ravel(), angle_only=True).reshape(ashape)
+    assert np.array_equal(agot, aexp)
+    p2 = g[scen + "_phis_unwrapped"]
+    Y, X, P = np.meshgrid(ys, xs, p2, indexing="ij")
+    ugot = s.query_corridor(X.ravel(), Y.ravel(), np.full(X.size, hs[1]), P.ravel()).reshape(Y.shape)
+    assert np.array_equal(ugot, g[scen + "_inside_unwrapped"])
+
+
+def test_corridor_random_vs_oracle():
+    from oracle import oracle as O
+    comp = H.compiled("LOWW")
+    s = _sector("LOWW")
+    rng = np.random.default_rng(11)
+    n = 400000
+    fx, fy = comp.corridor["faf"]
+    x = (fx + rng.uniform(-5, 5, n)).astype(np.float32)
+    y = (fy + rng.uniform(-6, 3, n)).astype(np.float32)
+    h = rng.uniform(2000, 5000, n).astype(np.float32)
+    phi = np.where(rng.random(n) < 0.3, np.round(rng.uniform(-400, 800, n)), rng.uniform(-400, 800, n)).astype(np.float32)
+    exp = O.OracleQueries(comp, np.float32).corridor(x, y, h, phi)
+    got = s.query_corridor(x, y, h, phi)
+    assert np.array_equal(got, exp)
+    assert exp.sum() > 1000
+
+
+def test_shaping_golden():
+    g = H.golden_npz("g5_shaping.npz")
+    s = _sector("LOWW")
+    out = s.query_shaping(g["d_faf"], g["phi_rel_faf"], g["phi_plane"], g["h"], g["on_gp"])
+    assert np.max(np.abs(out[:, 0] - g["pos"])) <= 1e-5
+    assert np.max(np.abs(out[:, 1] - g["ang"])) <= 1e-5
+    assert np.max(np.abs(out[:, 2] - g["gs"])) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ trajectories (G2, G6)
+class HipGymAdapter:
+    """Replays golden episodes through the single-env AtcGym mirror (what a user of the reference would call)."""
+
+    def __init__(self):
+        self.env = None
+        self.key = None
+
+    def configure(self, scen, dt, shaping, normalize, discrete):
+        from envs.atc import atc_gym, model
+        key = (scen, dt, shaping, normalize, discrete)
+        if key != self.key:
+            if self.env is not None:
+                self.env.close()
+            sp = model.SimParameters(dt, reward_shaping=shaping, normalize_state=normalize,
+                                     discrete_action_space=discrete)
+            self.env = atc_gym.AtcGym(sim_parameters=sp, scenario=H.make_scenario(scen))
+            self.key = key
+
+    def reset(self):
+        return self.env.reset()
+
+    def set_state(self, x, y, h, phi, v):
+        ap = self.env._airplane
+        ap.x, ap.y, ap.h, ap.phi, ap.v = x, y, h, phi, v
+
+    def set_counters(self, timesteps, last_action):
+        self.env._vec.timesteps[0] = int(timesteps)
+        self.env.timesteps = int(timesteps)
+        self.env.last_action = last_action
+
+    def step(self, action):
+        e = self.env
+        obs, rew, done, info = e.step(action)
+        r = H.StepRecord()
+        r.obs, r.raw = np.asarray(obs), np.asarray(info["original_state"])
+        r.reward, r.done = float(rew), int(done)
+        r.flags = int(e._vec.flags[0, 0])
+        r.timesteps, r.actions_taken, r.total_reward = e.timesteps, e.actions_taken, float(e.total_reward)
+        r.state = np.array(e._vec.get_state(0, 0))
+        return r
+
+
+def _hip_check(npz, ep, stats):
+    half_range = 0.5 * H.compiled(ep["scen"]).norm_max.astype(np.float64)
+
+    def check(t, row, rec):
+        assert rec.flags == int(npz["flags"][row]), (t, rec.flags, int(npz["flags"][row]))
+        assert rec.done == int(npz["done"][row])
+        assert rec.timesteps == int(npz["timesteps"][row])
+        assert rec.actions_taken == int(npz["actions_taken"][row])
+        go, gr = npz["obs"][row].astype(np.float64), npz["raw"][row].astype(np.float64)
+        if ep["normalize"]:
+            assert np.all(np.abs(rec.obs - go) <= 1e-5), (t, rec.obs, go)
+        else:
+            assert np.all(np.abs(rec.obs - go) <= 1e-5 * half_range), (t, rec.obs, go)
+        assert np.all(np.abs(rec.raw - gr) <= 1e-5 * half_range), (t, rec.raw, gr)
+        gw = float(npz["reward"][row])
+        assert abs(rec.reward - gw) <= 1e-5 * max(1.0, abs(gw)), (t, rec.reward, gw)
+        stats["steps"] += 1
+
+    return check
+
+
+def test_scripted_trajectories_through_atcgym():
+    npz = H.golden_npz("g2_scripted.npz")
+    stats = {"steps": 0}
+    ad = HipGymAdapter()
+    for ep in H.episodes_of(npz):
+        H.replay_episode(ad, npz, ep, _hip_check(npz, ep, stats))
+    assert stats["steps"] == len(npz["reward"])
+
+
+def _group_key(ep):
+    return (ep["scen"], ep["dt"], ep["shaping"], ep["normalize"], ep["discrete"])
+
+
+@pytest.mark.parametrize("fixture", ["g6_rollouts.npz", "g2_scripted.npz"])
+def test_golden_rollouts_batched(fixture):
+    """All golden episodes of one configuration run side by side as the envs of ONE AtcVecEnv (each env fed its own
+    recorded actions) — the batched kernel must reproduce every per-step record of the reference."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import model
+    npz = H.golden_npz(fixture)
+    eps = H.episodes_of(npz)
+    groups = {}
+    for ep in eps:
+        groups.setdefault(_group_key(ep), []).append(ep)
+    total = 0
+    for (scen, dt, shaping, normalize, discrete), geps in groups.items():
+        B = len(geps)
+        sp = model.SimParameters(dt, reward_shaping=shaping, normalize_state=normalize, discrete_action_space=discrete)
+        env = AtcVecEnv(B, 1, sim_parameters=sp, scenario=H.make_scenario(scen), auto_reset=False, spawn="lattice",
+                        want_raw_obs=True)
+        half_range = torch.as_tensor(0.5 * H.compiled(scen).norm_max.astype(np.float64))
+        for b, ep in enumerate(geps):
+            env.set_state(b, 0, *ep["init_state"])
+            env.timesteps[b] = ep["init_timesteps"]
+            for c in range(3):
+                env.last_act[c, b] = ep["init_last_action"][c]
+        T = max(ep["steps"] for ep in geps)
+        steps = np.array([ep["steps"] for ep in geps])
+        starts = np.array([ep["start"] for ep in geps])
+        for t in range(T):
+            live = t < steps
+            rows = np.where(live, starts + t, starts)  # finished envs just replay a harmless action
+            act = npz["action"][rows].astype(np.float32).reshape(B, 1, 3)
+            obs, rew, done, info = env.step(act)
+            obs_c, raw_c = obs.cpu().double(), info["original_state"].cpu().double()
+            rew_c, done_c, fl_c = rew.cpu().double().numpy(), done.cpu().numpy(), info["flags"].cpu().numpy()[:, 0]
+            ts_c, at_c = env.timesteps.cpu().numpy(), env.actions_taken.cpu().numpy()
+            lr = rows[live]
+            assert np.array_equal(fl_c[live], npz["flags"][lr].astype(np.int32)), t
+            assert np.array_equal(done_c[live], npz["done"][lr]), t
+            assert np.array_equal(ts_c[live], npz["timesteps"][lr]), t
+            assert np.array_equal(at_c[live], npz["actions_taken"][lr]), t
+            go = torch.as_tensor(npz["obs"][lr].astype(np.float64))
+            gr = torch.as_tensor(npz["raw"][lr].astype(np.float64))
+            lt = torch.as_tensor(live)
+            tol_o = 1e-5 if normalize else 1e-5 * half_range
+            assert bool(((obs_c[lt] - go).abs() <= tol_o).all()), t
+            assert bool(((raw_c[lt] - gr).abs() <= 1e-5 * half_range).all()), t
+            gw = npz["reward"][lr]
+            assert np.all(np.abs(rew_c[live] - gw) <= 1e-5 * np.maximum(1.0, np.abs(gw))), t
+            total += int(live.sum())
+        env.close()
+    assert total == len(npz["reward"])
+
+
+# ------------------------------------------------------------------------------------------------ batched vs fp32 oracle
+def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, spawn="lattice", hold=20, grid_cell=0.5,
+                   use_rollout=0, timestep_limit=6000):
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import model
+    from oracle import oracle as O
+    sp = model.SimParameters(dt, discrete_action_space=discrete)
+    env = AtcVecEnv(B, N, sim_parameters=sp, scenario=scen_obj, auto_reset=True, spawn=spawn, seed=seed,
+                    grid_cell=grid_cell, want_raw_obs=True, want_ac_reward=True, want_min_sep=True, want_term_obs=True,
+                    timestep_limit=timestep_limit)
+    p = O.make_params(dt=dt, discrete=discrete, auto_reset=True, random_entry=(spawn == "random"), seed=seed,
+                      timestep_limit=timestep_limit)
+    orc = O.OracleEnv(comp, B, N, p, np.float32)
+    o0 = env.obs.cpu().numpy().reshape(B, N, 10)
+    assert np.all(np.abs(o0 - orc.obs) <= 1e-5 * np.maximum(1.0, np.abs(orc.obs)))
+    rng = np.random.default_rng(seed)
+    n_done = 0
+    seen = 0
+    act = None
+    if use_rollout:
+        assert steps % use_rollout == 0
+    t = 0
+    while t < steps:
+        chunk = use_rollout or 1
+        acts = []
+        for c in range(chunk):
+            if (t + c) % hold == 0 or act is None:
+                if discrete:
+                    act = np.floor(rng.uniform(0, 1, (B, N, 3)) * np.array([20, 380, 360])).astype(np.float32)
+                else:
+                    act = rng.uniform(-1.05, 1.05, (B, N, 3)).astype(np.float32)
+            acts.append(act)
+        if use_rollout:
+            out = env.rollout(torch.as_tensor(np.stack(acts)))
+            res = [(out["obs"][c], out["reward"][c], out["done"][c], out["flags"][c]) for c in range(chunk)]
+        else:
+            o, r, d, info = env.step(acts[0])
+            res = [(o, r, d, info["flags"])]
+        for c in range(chunk):
+            orc.step(acts[c])
+            o, r, d, fl = res[c]
+            fl = fl.cpu().numpy().astype(np.uint32)
+            assert np.array_equal(fl, orc.flags), ("flags", t + c, np.argwhere(fl != orc.flags)[:5])
+            assert np.array_equal(d.cpu().numpy(), orc.done), ("done", t + c)
+            on = o.cpu().numpy().reshape(B, N, 10)
+            # envs that were auto-reset return RAW obs (large values): compare relative to magnitude
+            assert np.all(np.abs(on - orc.obs) <= 1e-5 * np.maximum(1.0, np.abs(orc.obs))), ("obs", t + c)
+            rr = r.cpu().numpy()
+            assert np.all(np.abs(rr - orc.reward) <= 1e-5 * np.maximum(1.0, np.abs(orc.reward)) * max(1, N // 4)), ("rew", t + c)
+            n_done += int(orc.done.sum())
+            seen |= int(np.bitwise_or.reduce(orc.flags.ravel()))
+        if not use_rollout:
+            # optional outputs and persistent state
+            assert np.all(np.abs(info["original_state"].cpu().numpy().reshape(B, N, 10) - orc.raw_obs)
+                          <= 1e-5 * np.maximum(1.0, np.abs(orc.raw_obs))), t
+            assert np.all(np.abs(info["aircraft_reward"].cpu().numpy() - orc.ac_reward)
+                          <= 1e-5 * np.maximum(1.0, np.abs(orc.ac_reward))), t
+            ms, oms = info["min_separation"].cpu().numpy(), orc.min_sep
+            assert np.all(np.abs(ms - oms) <= 1e-5 * np.maximum(1.0, np.abs(oms))), t
+            dn = orc.done.astype(bool)
+            if dn.any():
+                tob = info["terminal_observation"].cpu().numpy().reshape(B, N, 10)
+                assert np.all(np.abs(tob[dn] - orc.term_obs[dn]) <= 1e-5 * np.maximum(1.0, np.abs(orc.term_obs[dn]))), t
+        t += chunk
+    # persistent state after the run: integer state exact, float state within tolerance
+    assert np.array_equal(env.timesteps.cpu().numpy(), orc.timesteps)
+    assert np.array_equal(env.actions_taken.cpu().numpy(), orc.actions_taken)
+    assert np.array_equal(env.episodes.cpu().numpy(), orc.episodes)
+    assert np.array_equal(env.win_bits.cpu().numpy().astype(np.uint32), orc.win_bits)
+    assert np.array_equal(env.active_mask.cpu().numpy().astype(np.uint64), orc.active_mask)
+    assert np.array_equal(env.ep_length.cpu().numpy(), orc.ep_length)
+    assert np.allclose(env.x.cpu().numpy(), orc.x, rtol=0, atol=2e-5)
+    assert np.allclose(env.h.cpu().numpy(), orc.h, rtol=1e-6, atol=1e-3)
+    assert np.allclose(env.ep_return.cpu().numpy(), orc.ep_return, rtol=2e-5, atol=1e-3)
+    env.close()
+    return n_done, seen
+
+
+def test_batched_n1_vs_oracle():
+    from envs.atc import scenarios
+    n_done, seen = _run_vs_oracle(scenarios.LOWW(), H.compiled("LOWW", 0.5), B=2048, N=1, steps=600, seed=5)
+    assert n_done > 100 and (seen & H.F_OUTSIDE) and (seen & (H.F_INVALID_V | H.F_INVALID_H))
+
+
+def test_batched_n1_random_entries_discrete_vs_oracle():
+    from envs.atc import scenarios
+    n_done, seen = _run_vs_oracle(scenarios.LOWW(random_entrypoints=True), H.compiled("LOWW_random", 0.5), B=1024, N=1,
+                                  steps=400, seed=9, discrete=True, spawn="random", dt=2.0)
+    assert n_done > 20
+
+
+def test_batched_n16_vs_oracle():
+    from envs.atc import scenarios
+    scn = scenarios.LOWW(random_entrypoints=True)
+    n_done, seen = _run_vs_oracle(scn, scenarios.compile_scenario(scn, grid_cell=0.5), B=512, N=16, steps=400, seed=21)
+    assert n_done > 50 and (seen & H.F_CONFLICT)
+
+
+def test_batched_n64_noise_vs_oracle():
+    from envs.atc import scenarios
+    scn = scenarios.LOWWDense()
+    n_done, seen = _run_vs_oracle(scn, scenarios.compile_scenario(scn, grid_cell=0.5), B=128, N=64, steps=240, seed=33)
+    assert n_done > 20 and (seen & H.F_CONFLICT)
+
+
+def test_batched_odd_n_and_short_timeout_vs_oracle():
+    """N that is not a power of two (idle lanes in the group), tiny timestep limit so that timeouts and win-less
+    resets happen often, no lookup grid."""
+    from envs.atc import scenarios
+    scn = scenarios.LOWW(random_entrypoints=True)
+    n_done, seen = _run_vs_oracle(scn, scenarios.compile_scenario(scn), B=300, N=5, steps=200, seed=4, grid_cell=None,
+                                  timestep_limit=37)
+    assert seen & H.F_TIMEOUT
+
+
+def test_rollout_equals_single_steps_vs_oracle():
+    from envs.atc import scenarios
+    scn = scenarios.LOWW(random_entrypoints=True)
+    _run_vs_oracle(scn, scenarios.compile_scenario(scn, grid_cell=0.5), B=256, N=16, steps=120, seed=8, use_rollout=24)
+    _run_vs_oracle(scenarios.LOWW(), H.compiled("LOWW", 0.5), B=1000, N=1, steps=250, seed=2, use_rollout=50)
+
+
+# ------------------------------------------------------------------------------------------------ extension known answers
+def test_separation_known_answers():
+    """Two aircraft at 2.99 / 3.00 / 3.01 nm x 999 / 1000 / 1001 ft: conflict iff d < 3 nm and dh < 1000 ft."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+    cases = [(d, dh) for d in (2.99, 3.0, 3.01) for dh in (999.0, 1000.0, 1001.0)]
+    env = AtcVecEnv(len(cases), 2, scenario=scenarios.LOWW(random_entrypoints=True), auto_reset=False, want_min_sep=True)
+    for b, (d, dh) in enumerate(cases):
+        # both fly north at the same speed so the horizontal distance is unchanged by the step
+        env.set_state(b, 0, 30.0, 60.0, 15000.0, 0.0, 250.0)
+        env.set_state(b, 1, 30.0 + d, 60.0, 15000.0 + dh, 0.0, 250.0)
+    hold = np.zeros((len(cases), 2, 3), np.float32)
+    hold[:, :, 0] = 0.5      # v target 250
+    hold[:, 0, 1] = 2 * 15000.0 / 38000.0 - 1
+    for b, (d, dh) in enumerate(cases):
+        hold[b, 1, 1] = 2 * (15000.0 + dh) / 38000.0 - 1
+    hold[:, :, 2] = -1.0     # heading target 0
+    obs, rew, done, info = env.step(hold)
+    fl = info["flags"].cpu().numpy()
+    for b, (d, dh) in enumerate(cases):
+        expect = d < 3.0 and dh < 1000.0
+        assert bool(fl[b, 0] & H.F_CONFLICT) == expect and bool(fl[b, 1] & H.F_CONFLICT) == expect, (d, dh)
+        assert bool(done[b]) == expect
+        assert abs(float(info["min_separation"][b]) - d) < 1e-4
+        if expect:
+            assert float(rew[b]) < -390.0  # 2 x (-200 + shaping)
+    env.close()
+
+
+def test_noise_abatement_area_penalty():
+    """Aircraft inside a noise polygon below its ceiling pays the per-step penalty and is flagged; above the ceiling or
+    outside the polygon it is not (extension; checked against the oracle's definition)."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+    from oracle import oracle as O
+    scn = scenarios.LOWWDense()
+    comp = scenarios.compile_scenario(scn, grid_cell=0.5)
+    env = AtcVecEnv(3, 1, scenario=scn, auto_reset=False, spawn="lattice", want_ac_reward=True)
+    orc = O.OracleEnv(comp, 3, 1, O.make_params(), np.float32)
+    states = [(43.0, 38.0, 5000.0, 90.0, 200.0), (43.0, 38.0, 9000.0, 90.0, 200.0), (20.0, 60.0, 5000.0, 90.0, 200.0)]
+    for b, st in enumerate(states):
+        env.set_state(b, 0, *st)
+        orc.set_state(b, 0, *st)
+    a = np.zeros((3, 1, 3), np.float32)
+    a[:, 0, 0] = 0.0
+    a[:, 0, 1] = [2 * 5000 / 38000 - 1, 2 * 9000 / 38000 - 1, 2 * 5000 / 38000 - 1]
+    a[:, 0, 2] = -0.5
+    obs, rew, done, info = env.step(a)
+    orc.step(a)
+    fl = info["flags"].cpu().numpy()[:, 0]
+    assert [bool(f & H.F_NOISE) for f in fl] == [True, False, False]
+    assert np.array_equal(fl.astype(np.uint32), orc.flags[:, 0])
+    assert np.allclose(rew.cpu().numpy(), orc.reward, atol=1e-5)
+    env.close()
+
+
+def test_win_hands_aircraft_over_and_env_continues():
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+    env = AtcVecEnv(1, 2, scenario=scenarios.LOWW(random_entrypoints=True), auto_reset=False)
+    env.set_state(0, 0, 48.9, 31.9, 3300.0, 345.0, 200.0)       # on the intercept (golden win case)
+    env.set_state(0, 1, 20.0, 60.0, 15000.0, 90.0, 250.0)       # far away
+    a = np.zeros((1, 2, 3), np.float32)
+    a[0, 0] = [0.0, 2 * 2700.0 / 38000.0 - 1, 2 * 345.0 / 360.0 - 1]
+    won_at = None
+    for t in range(60):
+        obs, rew, done, info = env.step(a)
+        fl = info["flags"].cpu().numpy()[0]
+        if fl[0] & H.F_WON:
+            won_at = t
+            assert not bool(done[0])            # the other aircraft is still under control
+            assert float(rew[0]) > 10000
+            break
+    assert won_at is not None
+    obs, rew, done, info = env.step(a)
+    fl = info["flags"].cpu().numpy()[0]
+    assert fl[0] == H.F_INACTIVE and int(env.active_mask[0]) == 2
+    assert np.all(obs.cpu().numpy()[0, :10] == 0)
+    env.close()
+
+
+# ------------------------------------------------------------------------------------------------ metrics (G7)
+def test_metrics_sequence_g7():
+    from envs.atc import atc_gym
+    g = H.golden_json("g7_metrics.json")
+    env = atc_gym.AtcGym()
+    for ep in g["episodes"]:
+        env.reset()
+        assert abs(env.winning_ratio - ep["after_reset"]["winning_ratio"]) < 1e-9
+        assert env._win_buffer == ep["after_reset"]["win_buffer"]
+        assert env._episodes_run == ep["after_reset"]["episodes_run"]
+        ap = env._airplane
+        ap.x, ap.y, ap.h, ap.phi, ap.v = ep["init_state"]
+        env._vec.timesteps[0] = ep["init_timesteps"]
+        env.timesteps = ep["init_timesteps"]
+        for k, a in enumerate(ep["actions"]):
+            _, r, done, _ = env.step(np.asarray(a))
+            assert abs(env.actions_per_timestep - ep["actions_per_timestep"][k]) < 1e-12
+        assert done
+        f = ep["final"]
+        assert env.timesteps == f["timesteps"] and env.actions_taken == f["actions_taken"]
+        assert env._win_buffer == f["win_buffer"]
+        assert abs(env.total_reward - f["total_reward"]) <= 2e-5 * max(1.0, abs(f["total_reward"]))
+        assert abs(env.last_reward - f["last_reward"]) <= 1e-5 * max(1.0, abs(f["last_reward"]))
+    env.reset()
+    assert abs(env.winning_ratio - g["after_last_reset"]["winning_ratio"]) < 1e-9
+    assert env._win_buffer == g["after_last_reset"]["win_buffer"]
+    env.close()
+
+
+def test_seeded_random_entry_draws_match_reference():
+    """random.seed(7) + LOWW(random_entrypoints=True): the reference's first aircraft is (53, 60, 16000 ft, 260 deg, 250 kt),
+    id 25875; AtcGym.reset consumes Python's RNG in the same order."""
+    import random
+    from envs.atc import atc_gym, scenarios
+    random.seed(7)
+    env = atc_gym.AtcGym(scenario=scenarios.LOWW(random_entrypoints=True))
+    s = env.state
+    assert list(s[:5]) == [53.0, 60.0, 16000.0, 260.0, 250.0] and env._airplane.id == 25875
+    g6 = H.golden_npz("g6_rollouts.npz")
+    eps = [e for e in H.episodes_of(g6) if e["scen"] == "LOWW_random" and e["dt"] == 1.0]
+    assert eps[0]["init_state"] == [53.0, 60.0, 16000.0, 260.0, 250.0]
+    env.close()
+
+
+# ------------------------------------------------------------------------------------------------ full-size properties
+@pytest.mark.parametrize("B,N", [(65536, 1), (8192, 16), (65536, 16), (4096, 64)])
+def test_full_size_properties(B, N):
+    """At BASELINE.json's sizes the oracle is too slow for a full comparison; check size-independent properties:
+    (1) determinism, (2) a prefix of the big batch equals the same envs run as a small batch (envs are independent),
+    (3) done <=> a terminal flag or every aircraft handed over, (4) the first 256 envs match the oracle."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+    from oracle import oracle as O
+    scn = scenarios.LOWWDense() if N == 64 else scenarios.LOWW(random_entrypoints=N > 1)
+    steps, small = 60, 256
+    g = torch.Generator(device="cpu").manual_seed(B + N)
+    acts = [(torch.rand((B, N, 3), generator=g) * 2 - 1).cuda() for _ in range(3)]
+
+    def run(nb):
+        env = AtcVecEnv(nb, N, scenario=scn, auto_reset=True, seed=1)
+        outs = []
+        for t in range(steps):
+            a = acts[(t // 20) % 3][:nb]
+            o, r, d, info = env.step(a)
+            outs.append((o.clone(), r.clone(), d.clone(), info["flags"].clone()))
+        env.close()
+        return outs
+
+    big, big2, sm = run(B), run(B), run(small)
+    comp = scenarios.compile_scenario(scn, grid_cell=0.5)
+    orc = O.OracleEnv(comp, small, N, O.make_params(auto_reset=True, seed=1), np.float32)
+    for t in range(steps):
+        o, r, d, fl = big[t]
+        assert torch.equal(o, big2[t][0]) and torch.equal(r, big2[t][1]) and torch.equal(fl, big2[t][3])
+        assert torch.equal(o[:small], sm[t][0]) and torch.equal(fl[:small], sm[t][3]) and torch.equal(d[:small], sm[t][2])
+        term = ((fl & TERMINAL) != 0).any(dim=1)
+        assert bool((term <= (d != 0)).all())
+        assert bool(torch.isfinite(o).all()) and bool(torch.isfinite(r).all())
+        orc.step(acts[(t // 20) % 3][:small].cpu().numpy())
+        assert np.array_equal(fl[:small].cpu().numpy().astype(np.uint32), orc.flags)
+        assert np.array_equal(d[:small].cpu().numpy(), orc.done)
+        on = o[:small].cpu().numpy().reshape(small, N, 10)
+        assert np.all(np.abs(on - orc.obs) <= 1e-5 * np.maximum(1.0, np.abs(orc.obs)))
