@@ -2,8 +2,8 @@
 
 tests/test_abi.py parses the header and checks that every constant here matches it.
 """
-ABI_VERSION = 3
-BLOB_VERSION = 1003.0
+ABI_VERSION = 4
+BLOB_VERSION = 1004.0
 
 H_VERSION, H_NWORDS, H_N_MVA, H_N_NOISE, H_N_ENTRY, H_OFF_POLY, H_OFF_VERT, H_OFF_ENTRY, H_OFF_GRID, H_N_VERTW = range(10)
 C_RWY_X, C_RWY_Y, C_RWY_H, C_PHI_TO_RWY, C_FAF_X, C_FAF_Y, C_NRM_X, C_NRM_Y = range(16, 24)
@@ -19,9 +19,9 @@ C_END = 96
 P_MINX, P_MINY, P_MAXX, P_MAXY, P_HEIGHT, P_VOFF, P_NVERT, P_PENALTY, P_WORDS = range(9)
 E_X, E_Y, E_PHI, E_NLEV, E_LEV0 = range(5)
 E_WORDS, E_MAXLEV = 12, 8
-G_X0, G_Y0, G_INV, G_NX, G_NY = range(5)
+G_X0, G_Y0, G_INV, G_NX, G_NY, G_OFF_POOL, G_NREC = range(7)
 G_HDR = 8
-GRID_MASK_BASE = 8388608.0
+GE_WORDS = 8
 
 MAX_AIRCRAFT = 64
 OBS_DIM = 10
@@ -32,3 +32,7 @@ F_INVALID_V, F_INVALID_H, F_CONFLICT, F_NOISE, F_INACTIVE = 16, 32, 64, 128, 256
 F_TERMINAL = F_BELOW_MVA | F_OUTSIDE | F_TIMEOUT | F_CONFLICT  # episode-ending on their own (WON: when all handed over)
 
 M_REWARD_SHAPING, M_NORMALIZE, M_DISCRETE, M_AUTO_RESET, M_RANDOM_ENTRY = 1, 2, 4, 8, 16
+
+# per-env record (atc_state_t.env): 12 x 32-bit words, float fields by bit pattern
+ENV_TIMESTEPS, ENV_ACTIONS_TAKEN, ENV_EPISODES, ENV_EP_LENGTH, ENV_TOTAL_REWARD, ENV_EP_RETURN, ENV_WIN_BITS = range(7)
+ENV_MASK_LO, ENV_MASK_HI, ENV_WORDS = 8, 9, 12

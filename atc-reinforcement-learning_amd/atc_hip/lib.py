@@ -8,7 +8,8 @@ import numpy as np
 from . import layout as L
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libatcstep.so")
+# ATC_LIBATCSTEP: developer override used only to A/B kernel build variants (tools/); default is the in-tree build
+LIB_PATH = os.environ.get("ATC_LIBATCSTEP") or os.path.join(HERE, "libatcstep.so")
 
 
 class AtcParams(C.Structure):
@@ -18,8 +19,7 @@ class AtcParams(C.Structure):
                 ("reserved1", C.c_float)]
 
 
-STATE_FIELDS = ("x", "y", "h", "phi", "v", "last_act", "timesteps", "actions_taken", "total_reward", "active_mask",
-                "win_bits", "episodes", "ep_return", "ep_length")
+STATE_FIELDS = ("pos", "kin", "last_vh", "env")
 OUT_FIELDS = ("obs", "raw_obs", "reward", "ac_reward", "done", "flags", "min_sep", "term_obs")
 
 

@@ -85,41 +85,61 @@ def _first_polygon(x, y, rings, bounds):
     return -1
 
 
-def _seg_dist2_to_box(p, q, bx0, by0, bx1, by1):
-    """True if segment p-q comes within the (already inflated) box — conservative: segment bbox overlap + separating
-    axis along the segment normal."""
+def _seg_near_box(p, q, bx0, by0, bx1, by1):
+    """True if segment p-q may touch the (already inflated) box — conservative: segment bbox overlap + separating axis
+    along the segment normal."""
     if max(p[0], q[0]) < bx0 or min(p[0], q[0]) > bx1 or max(p[1], q[1]) < by0 or min(p[1], q[1]) > by1:
         return False
     dx, dy = q[0] - p[0], q[1] - p[1]
     if dx == 0.0 and dy == 0.0:
         return True
-    # signed distances of the 4 box corners to the segment's supporting line: all on one side -> no intersection
     s = [(cx - p[0]) * dy - (cy - p[1]) * dx for cx in (bx0, bx1) for cy in (by0, by1)]
     return not (min(s) > 0.0 or max(s) < 0.0)
 
 
+def _ring_edges(ring):
+    """Edges the reference's ray_tracing visits (model.py:324-335): consecutive vertex pairs plus the wrap edge
+    ring[n-1] -> ring[0]; zero-height edges can never be counted (y > min and y <= max) and are dropped."""
+    n = len(ring)
+    e = [(ring[k - 1], ring[k]) for k in range(1, n)] + [(ring[n - 1], ring[0])]
+    return np.array([[a[0], a[1], b[0], b[1]] for a, b in e if a[1] != b[1]], dtype=np.float64).reshape(-1, 4)
+
+
+GRID_EDGE_WORDS = 8      # p1x, p1y, p2x, p2y, polygon index, flags, 0, 0
+GRID_F_LAST = 1.0        # last edge record of its polygon: evaluate the parity now
+GRID_F_CERTAIN = 2.0     # every point of the cell lies left of this edge: crossing needs no intersection test
+
+
 def build_grid(rings, bounds, bbox, cell, guard=None):
-    """Uniform grid over the world bbox.  A cell is CLEAN when no edge of any MVA polygon comes within `guard`
-    of it; then every point of the cell has the same ordered-scan answer as its centre (evaluated here with the
-    reference's rule) — robustly so in fp32, because no point of the cell is within `guard` of an edge.  Otherwise the
-    cell stores the bitmask of candidate polygons (those with an edge near the cell or containing its centre); the
-    device then runs the exact ordered test over the candidates only."""
+    """Uniform lookup grid for Airspace.find_mva (model.py:282-289) with IDENTICAL results to the ordered polygon scan.
+
+    * CLEAN cell: no edge of any MVA polygon comes within `guard` of it, so every point of the cell gets the answer of its
+      centre (evaluated here with the reference's rule); stored directly.
+    * DIRTY cell: an edge list.  The crossing test of the reference (y > min(p1y,p2y), y <= max(p1y,p2y),
+      x <= max(p1x,p2x), then x <= x-intersection) can only count an edge whose y-span meets the cell's y-span and whose
+      x-max is not left of the cell; all other edges contribute nothing for ANY point of the cell, so dropping them leaves
+      every crossing count — hence the result of ray_tracing — unchanged.  The device walks the listed edges polygon by
+      polygon (list order = priority) with the reference's own formula and bbox test.  Edges that lie entirely to the
+      right of the cell by more than 1e-3 nm are marked CERTAIN: x <= xints holds for every point of the cell whatever the
+      rounding of xints (which stays within a few ulps of [min(p1x,p2x), max(p1x,p2x)]), so the division is skipped.
+    Cell bounds are inflated by `slack` (guard + fp32 indexing error) so that a point the device bins into a neighbouring
+    cell because of fp32 rounding is still covered.
+
+    Layout (words): header[8] = x0, y0, inv_cell, nx, ny, offset of the edge pool (from grid start), n_records, 0;
+    cells[ny*nx][2] = (n_records, first_record) for dirty cells, (0, polygon+1 | 0) for clean ones; pool of 8-word edge
+    records."""
     if guard is None:
         guard = 1e-3
-    npoly = len(rings)
-    assert npoly <= 23, "grid bitmask supports at most 23 polygons"
     x0, y0, x1, y1 = bbox
-    # one ring of padding cells so that points on/near the bbox border index safely
     gx0 = x0 - cell
     gy0 = y0 - cell
     nx = int(math.ceil((x1 - gx0) / cell)) + 2
     ny = int(math.ceil((y1 - gy0) / cell)) + 2
     inv = 1.0 / cell
-    cells = np.zeros((ny, nx), dtype=np.float64)
-    near = np.zeros((ny, nx), dtype=np.int64)
-    # the device computes the cell index in fp32 from (x - gx0) * inv; inflate by an fp32 indexing slack as well
     slack = guard + 1e-4 * max(1.0, abs(x1), abs(y1)) * 2.0 ** -10
-    for pi, ring in enumerate(rings):
+    edges = [_ring_edges(r) for r in rings]
+    near = np.zeros((ny, nx), dtype=bool)
+    for ring in rings:
         for k in range(len(ring) - 1):
             p, q = ring[k], ring[k + 1]
             i0 = max(0, int(math.floor((min(p[0], q[0]) - slack - gx0) * inv)) - 1)
@@ -130,27 +150,51 @@ def build_grid(rings, bounds, bbox, cell, guard=None):
                 cy0 = gy0 + j * cell - slack
                 cy1 = gy0 + (j + 1) * cell + slack
                 for i in range(i0, i1 + 1):
-                    cx0 = gx0 + i * cell - slack
-                    cx1 = gx0 + (i + 1) * cell + slack
-                    if _seg_dist2_to_box(p, q, cx0, cy0, cx1, cy1):
-                        near[j, i] |= (1 << pi)
+                    if not near[j, i] and _seg_near_box(p, q, gx0 + i * cell - slack, cy0, gx0 + (i + 1) * cell + slack, cy1):
+                        near[j, i] = True
+    cells = np.zeros((ny, nx, 2), dtype=np.float64)
+    pool = []
+    n_rec = 0
     for j in range(ny):
-        cy = gy0 + (j + 0.5) * cell
+        cy0s = gy0 + j * cell - slack
+        cy1s = gy0 + (j + 1) * cell + slack
         for i in range(nx):
-            cx = gx0 + (i + 0.5) * cell
-            if near[j, i] == 0:
-                cells[j, i] = _first_polygon(cx, cy, rings, bounds) + 1
-            else:
-                mask = int(near[j, i])
-                # polygons that contain the whole cell without an edge nearby must stay candidates too
-                for pi, (ring, b) in enumerate(zip(rings, bounds)):
-                    if not (mask >> pi) & 1:
-                        if b[0] <= cx <= b[2] and b[1] <= cy <= b[3] and _crossing_inside(cx, cy, ring):
-                            mask |= (1 << pi)
-                cells[j, i] = L.GRID_MASK_BASE + mask
+            if not near[j, i]:
+                cells[j, i, 1] = _first_polygon(gx0 + (i + 0.5) * cell, gy0 + (j + 0.5) * cell, rings, bounds) + 1
+                continue
+            cx0s = gx0 + i * cell - slack
+            cx1s = gx0 + (i + 1) * cell + slack
+            first = n_rec
+            for pi, (e, b) in enumerate(zip(edges, bounds)):
+                if b[2] < cx0s or b[0] > cx1s or b[3] < cy0s or b[1] > cy1s:
+                    continue  # the (inclusive) bounds test of model.py:286 rejects every point of the cell
+                ymin = np.minimum(e[:, 1], e[:, 3])
+                ymax = np.maximum(e[:, 1], e[:, 3])
+                xmin = np.minimum(e[:, 0], e[:, 2])
+                xmax = np.maximum(e[:, 0], e[:, 2])
+                rel = (cy1s > ymin) & (cy0s <= ymax) & (cx0s <= xmax)
+                idx = np.nonzero(rel)[0]
+                if len(idx) == 0:
+                    continue
+                certain = cx1s < xmin[idx] - 1e-3
+                order = np.argsort(certain, kind="stable")  # intersection-test edges first: lanes diverge less
+                for n_, k in enumerate(order):
+                    flags = (GRID_F_LAST if n_ == len(order) - 1 else 0.0) + (GRID_F_CERTAIN if certain[k] else 0.0)
+                    pool.append([e[idx[k], 0], e[idx[k], 1], e[idx[k], 2], e[idx[k], 3], float(pi), flags, 0.0, 0.0])
+                    n_rec += 1
+            cells[j, i, 0] = n_rec - first
+            cells[j, i, 1] = first
+            if n_rec == first:  # near an edge of a polygon whose bounds exclude the cell: nothing can match
+                cells[j, i, 1] = 0.0
     hdr = np.zeros(L.G_HDR, dtype=np.float64)
     hdr[L.G_X0], hdr[L.G_Y0], hdr[L.G_INV], hdr[L.G_NX], hdr[L.G_NY] = gx0, gy0, inv, nx, ny
-    return np.concatenate([hdr, cells.ravel()])
+    off_pool = (L.G_HDR + cells.size + 3) & ~3  # edge records are read as 16-byte vectors
+    hdr[L.G_OFF_POOL] = off_pool
+    hdr[L.G_NREC] = n_rec
+    assert n_rec < 2 ** 21 and off_pool + n_rec * GRID_EDGE_WORDS < 2 ** 24
+    pool_arr = np.asarray(pool, dtype=np.float64).reshape(-1, GRID_EDGE_WORDS)
+    pad = np.zeros(off_pool - L.G_HDR - cells.size)
+    return np.concatenate([hdr, cells.ravel(), pad, pool_arr.ravel()])
 
 
 class CompiledSector:
@@ -206,8 +250,8 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
     off_grid = 0
     if grid_cell is not None and mva_rings:
         grid = build_grid(mva_rings, bounds[:len(mva_rings)], bbox, float(grid_cell), grid_guard)
-        off_grid = end
-        end += len(grid)
+        off_grid = (end + 3) & ~3  # 16-byte aligned: cells are read as 8-byte pairs, edge records as 16-byte vectors
+        end = off_grid + len(grid)
 
     b = np.zeros(end, dtype=np.float64)
     b[L.H_VERSION] = L.BLOB_VERSION

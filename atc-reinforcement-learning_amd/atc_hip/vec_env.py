@@ -46,17 +46,22 @@ class AtcVecEnv:
         B, N, BN, dev = self.B, self.N, self.B * self.N, self.device
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
         f32, f64, i32 = torch.float32, torch.float64, torch.int32
-        # persistent state (atc_state_t)
-        self.x, self.y = z(BN, f64), z(BN, f64)
-        self.h, self.phi, self.v = z(BN, f32), z(BN, f32), z(BN, f32)
-        self.last_act = z((3, BN), f32)
-        self.timesteps, self.actions_taken = z(B, i32), z(B, i32)
-        self.total_reward = z(B, f32)
-        self.active_mask = z(B, torch.int64)
-        self.win_bits = z(B, i32)
-        self.episodes = z(B, i32)
-        self.ep_return, self.ep_length = z(B, f32), z(B, i32)
+        # persistent state (atc_state_t): packed records, see include/atc_step.h
+        self.pos = z((BN, 2), f64)            # x, y
+        self.kin = z((BN, 4), f32)            # h, phi, v, last accepted phi target
+        self.last_vh = z((BN, 2), f32)        # last accepted v / h targets
+        self.env = z((B, L.ENV_WORDS), i32)   # per-env record
         self._state = _lib.AtcState(*[getattr(self, n).data_ptr() for n in _lib.STATE_FIELDS])
+        # named views into the records (live device memory, usable for reads and in-place writes)
+        self.x, self.y = self.pos[:, 0], self.pos[:, 1]
+        self.h, self.phi, self.v = self.kin[:, 0], self.kin[:, 1], self.kin[:, 2]
+        self.timesteps = self.env[:, L.ENV_TIMESTEPS]
+        self.actions_taken = self.env[:, L.ENV_ACTIONS_TAKEN]
+        self.episodes = self.env[:, L.ENV_EPISODES]
+        self.ep_length = self.env[:, L.ENV_EP_LENGTH]
+        self.total_reward = self.env[:, L.ENV_TOTAL_REWARD:L.ENV_TOTAL_REWARD + 1].view(f32).squeeze(1)
+        self.ep_return = self.env[:, L.ENV_EP_RETURN:L.ENV_EP_RETURN + 1].view(f32).squeeze(1)
+        self.win_bits = self.env[:, L.ENV_WIN_BITS]
         # per-step outputs (atc_out_t)
         self.obs = z((B, N * L.OBS_DIM), f32)
         self.raw_obs = z((B, N * L.OBS_DIM), f32) if want_raw_obs else None
@@ -194,9 +199,25 @@ class AtcVecEnv:
             vals = [vals[i] for i in indices]
         return vals
 
+    @property
+    def active_mask(self):
+        """u64 mask per env (bit k = aircraft k still under control) as an int64 tensor."""
+        lo = self.env[:, L.ENV_MASK_LO].to(self.torch.int64) & 0xffffffff
+        hi = self.env[:, L.ENV_MASK_HI].to(self.torch.int64) & 0xffffffff
+        return lo | (hi << 32)
+
     def set_state(self, env, slot, x, y, h, phi, v):
         i = env * self.N + slot
         self.x[i], self.y[i], self.h[i], self.phi[i], self.v[i] = float(x), float(y), float(h), float(phi), float(v)
+
+    def get_last_action(self, env, slot):
+        """AtcGym.last_action (atc_gym.py:86,311) of one aircraft: [v, h, phi] targets last accepted."""
+        i = env * self.N + slot
+        return [float(self.last_vh[i, 0]), float(self.last_vh[i, 1]), float(self.kin[i, 3])]
+
+    def set_last_action(self, env, slot, value):
+        i = env * self.N + slot
+        self.last_vh[i, 0], self.last_vh[i, 1], self.kin[i, 3] = float(value[0]), float(value[1]), float(value[2])
 
     def get_state(self, env, slot):
         i = env * self.N + slot

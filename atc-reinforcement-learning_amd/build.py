@@ -28,7 +28,8 @@ def needs_build():
 def build_lib(force=False, verbose=False, extra=()):
     if not force and not needs_build():
         return OUT
-    cmd = [HIPCC] + FLAGS + list(extra) + ["-o", OUT, SRC]
+    extra = list(extra) + os.environ.get("ATC_HIPCC_EXTRA", "").split()
+    cmd = [HIPCC] + FLAGS + extra + ["-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -16,14 +16,66 @@ constexpr float kPi = 3.14159265358979323846f;
 constexpr float kDegToRad = (float)(3.14159265358979323846 / 180.0);
 constexpr float kRadToDeg = (float)(180.0 / 3.14159265358979323846);
 
-// Python float modulo by 360 (sign of the divisor), as used by relative_angle (model.py:340-342).
-// a - 360*floor(a/360) evaluated with one fma is the exactly rounded value of (fmod(a,360) [+360]), i.e. what
-// CPython computes; the quotient can only be off by +1 when a/360 rounds up to an integer, fixed by the r < 0 branch
-// (then r is exact and r + 360 rounds once, like CPython's `r += b`).
+// ---- value-only fast math (results feed observations / shaping rewards, tolerance 1e-5; never a flag) ---------------
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32, 1 ulp
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }  // v_sqrt_f32, 1 ulp
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
+// sin/cos of a heading in DEGREES.  The reduction is exact: k = rint(phi/90), t = phi - 90 k is computed by one fma and is
+// exactly representable (|t| <= 45 + slop, a multiple of ulp(phi)); the polynomials (fitted on |t| <= 46.4 deg) have
+// 8.5e-8 / 8.3e-8 max abs error in fp32 — the accuracy class of libm's sinf/cosf, at ~1/4 of the instructions of a generic
+// radian sincosf (no Payne-Hanek path, no division).  Used for the kinematics (model.py:122-129, 345-348).
+__device__ __forceinline__ void sincos_deg(float phi, float* sn, float* cs) {
+    const float k = rintf(phi * (1.0f / 90.0f));
+    const float t = fmaf(-90.0f, k, phi);
+    const float r = t * kDegToRad;
+    const float r2 = r * r;
+    const float sp = fmaf(fmaf(fmaf(-0.00019439239986240864f, r2, 0.008331366814672947f), r2, -0.16666631400585175f), r2, 1.0f);
+    const float s = sp * r;
+    const float c = fmaf(fmaf(fmaf(fmaf(2.436429167573806e-05f, r2, -0.001388648059219122f), r2, 0.04166661575436592f), r2,
+                              -0.5f), r2, 1.0f);
+    const int q = (int)k & 3;
+    const float s1 = (q & 1) ? c : s;
+    const float c1 = (q & 1) ? s : c;
+    *sn = (q & 2) ? -s1 : s1;
+    *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
+// atan2 in DEGREES (np.degrees(np.arctan2(y, x)), atc_gym.py:289-292) — value-only: octant reduction to a = min/max in
+// [0,1], 8-term odd polynomial (1.5e-7 rad max error), reciprocal instead of a division.
+__device__ __forceinline__ float atan2_deg(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = (mx > 0.0f) ? mn * fast_rcp(mx) : 0.0f;
+    const float s = a * a;
+    float p = -0.004054565913975239f;
+    p = fmaf(p, s, 0.021862955763936043f);
+    p = fmaf(p, s, -0.0559123270213604f);
+    p = fmaf(p, s, 0.0964219719171524f);
+    p = fmaf(p, s, -0.1390862911939621f);
+    p = fmaf(p, s, 0.19946566224098206f);
+    p = fmaf(p, s, -0.33329859375953674f);
+    p = fmaf(p, s, 0.9999993443489075f);
+    float r = p * a;                                   // atan(min/max) in [0, pi/4]
+    r = (ay > ax) ? (0.5f * kPi - r) : r;              // first quadrant
+    r = (x < 0.0f) ? (kPi - r) : r;
+    r = (y < 0.0f) ? -r : r;
+    return r * kRadToDeg;
+}
+
+// Python float modulo by 360 (sign of the divisor), as used by relative_angle (model.py:340-342):  CPython computes
+// r = fmod(a, 360) exactly and, if r has the wrong sign, r += 360 (one rounding).
+// Here: q = floor(a * (1/360)) estimates the quotient (off by at most one either way), and r = fma(-360, q, a) is the
+// EXACT value a - 360 q rounded once (a and 360 q are both multiples of ulp(a) below 2^24 ulp(a)).
+//   * q exact        -> r is what CPython returns, including the a = -tiny case that rounds to 360.0
+//   * q one too big  -> r is exact and negative; r + 360 rounds once, like CPython's `r += b`
+//   * q one too small-> r in [360, 720) exactly, detected by a >= 360 (q + 1) (integers below 2^24: exact); r - 360 exact.
+// No IEEE division (bit-identical to the fmodf-based oracle on every input, checked in tests/test_hip_parity.py).
 __device__ __forceinline__ float py_mod360(float a) {
-    float q = floorf(a / 360.0f);
+    const float q = floorf(a * (1.0f / 360.0f));
     float r = fmaf(-360.0f, q, a);
     if (r < 0.0f) r += 360.0f;
+    else if (a >= (q + 1.0f) * 360.0f) r -= 360.0f;
     return r;
 }
 
@@ -52,29 +104,51 @@ __device__ __forceinline__ bool ray_tracing(float x, float y, const float* ring,
 }
 
 // model.py:282-292 Airspace.find_mva: first polygon in list order whose inclusive bounds contain the point and whose
-// ray_tracing is true; -1 = "Outside of airspace".  With a lookup grid (global memory, L2-resident) clean cells answer
-// directly and dirty cells restrict the ordered scan to their candidate polygons (identical results by construction,
-// see atc_hip/scenario.py:build_grid).
+// ray_tracing is true; -1 = "Outside of airspace".
+//
+// With the lookup grid (global memory, L2-resident; atc_hip/scenario.py:build_grid) a CLEAN cell answers directly and a
+// DIRTY cell lists, polygon by polygon in priority order, exactly those edges the reference's crossing test could count
+// for some point of the cell; every other edge fails one of `y > min`, `y <= max`, `x <= max` for the whole cell, so
+// walking the list with the reference's formula yields the same crossing parity as ray_tracing over the full ring.
+// CERTAIN edges lie > 1e-3 nm to the right of the whole cell: x <= xints holds whatever the rounding of xints.
+__device__ __forceinline__ bool in_bounds(const float* rec, float x, float y) {
+    return rec[ATC_P_MINX] <= x && x <= rec[ATC_P_MAXX] && rec[ATC_P_MINY] <= y && y <= rec[ATC_P_MAXY];
+}
 __device__ __forceinline__ int find_mva(const float* S, const float* __restrict__ grid, float x, float y) {
-    const int n_mva = (int)S[ATC_H_N_MVA];
-    uint32_t cand = (n_mva >= 32) ? 0xffffffffu : ((1u << n_mva) - 1u);
+    const float* tab = S + (int)S[ATC_H_OFF_POLY];
     if (grid) {
         const float fx = (x - grid[ATC_G_X0]) * grid[ATC_G_INV];
         const float fy = (y - grid[ATC_G_Y0]) * grid[ATC_G_INV];
         const float nx = grid[ATC_G_NX], ny = grid[ATC_G_NY];
         if (!(fx >= 0.0f && fx < nx && fy >= 0.0f && fy < ny)) return -1;  // beyond the padded bbox (also NaN)
-        const float c = grid[ATC_G_HDR + (int)fy * (int)nx + (int)fx];
-        if (c < ATC_GRID_MASK_BASE) return (int)c - 1;
-        cand = (uint32_t)(c - ATC_GRID_MASK_BASE);
-    }
-    const float* tab = S + (int)S[ATC_H_OFF_POLY];
-    while (cand) {
-        const int p = __builtin_ctz(cand);
-        cand &= cand - 1u;
-        const float* rec = tab + p * ATC_P_WORDS;
-        if (rec[ATC_P_MINX] <= x && x <= rec[ATC_P_MAXX] && rec[ATC_P_MINY] <= y && y <= rec[ATC_P_MAXY]) {
-            if (ray_tracing(x, y, S + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT])) return p;
+        const float2 cell = *reinterpret_cast<const float2*>(grid + ATC_G_HDR + 2 * ((int)fy * (int)nx + (int)fx));
+        const int n = (int)cell.x;
+        if (n == 0) return (int)cell.y - 1;
+        const float4* rec = reinterpret_cast<const float4*>(grid + (int)grid[ATC_G_OFF_POOL]) + 2 * (int)cell.y;
+        bool inside = false;
+        for (int e = 0; e < n; ++e) {
+            const float4 g = rec[2 * e];      // p1x, p1y, p2x, p2y
+            const float4 m = rec[2 * e + 1];  // polygon index, flags
+            const int fl = (int)m.y;
+            if (y > fminf(g.y, g.w) && y <= fmaxf(g.y, g.w) && x <= fmaxf(g.x, g.z)) {
+                bool cross = (fl & ATC_GE_CERTAIN) != 0;
+                if (!cross) {
+                    const float xints = (y - g.y) * (g.z - g.x) / (g.w - g.y) + g.x;
+                    cross = (g.x == g.z) || x <= xints;
+                }
+                inside = inside != cross;
+            }
+            if (fl & ATC_GE_LAST) {
+                if (inside && in_bounds(tab + (int)m.x * ATC_P_WORDS, x, y)) return (int)m.x;
+                inside = false;
+            }
         }
+        return -1;
+    }
+    const int n_mva = (int)S[ATC_H_N_MVA];
+    for (int p = 0; p < n_mva; ++p) {
+        const float* rec = tab + p * ATC_P_WORDS;
+        if (in_bounds(rec, x, y) && ray_tracing(x, y, S + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT])) return p;
     }
     return -1;
 }
@@ -101,6 +175,12 @@ __device__ __forceinline__ bool inside_corridor_angle(const float* S, float x, f
 
 // model.py:188-210 Corridor.inside_corridor
 __device__ __forceinline__ bool inside_corridor(const float* S, float x, float y, float h, float phi) {
+    {   // exact early-out: a point the crossing test accepts lies within the ring's bounds
+        const float* t = S + ATC_C_TRI_H;
+        const float bx0 = fminf(fminf(t[0], t[2]), t[4]), bx1 = fmaxf(fmaxf(t[0], t[2]), t[4]);
+        const float by0 = fminf(fminf(t[1], t[3]), t[5]), by1 = fmaxf(fmaxf(t[1], t[3]), t[5]);
+        if (!(x >= bx0 && x <= bx1 && y >= by0 && y <= by1)) return false;
+    }
     if (!ray_tracing(x, y, S + ATC_C_TRI_H, 4)) return false;
     const float fx = S[ATC_C_FAF_X], fy = S[ATC_C_FAF_Y], nx = S[ATC_C_NRM_X], ny = S[ATC_C_NRM_Y];
     const float t = (x - fx) * nx + (y - fy) * ny;
@@ -113,25 +193,25 @@ __device__ __forceinline__ bool inside_corridor(const float* S, float x, float y
 }
 
 // atc_gym.py:17-19  (1 - tanh(4 d/dmax - 2)) / 2  ==  1 / (1 + exp(2 (4 d/dmax - 2)))   [exact identity]
-__device__ __forceinline__ float sigmoid_distance(float d, float d_max) {
-    const float z = 4.0f * (d / d_max) - 2.0f;
-    return 1.0f / (1.0f + __expf(2.0f * z));
+__device__ __forceinline__ float sigmoid_distance(float d, float inv_d_max) {
+    const float z2 = fmaf(8.0f * inv_d_max, d, -4.0f);  // 2 * (4 d/dmax - 2)
+    return fast_rcp(1.0f + fast_exp(z2));
 }
 
 struct Shaping {
     float pos, ang, gs;
 };
 // atc_gym.py:199-260: _reward_approach_position, _reward_approach_angle, _reward_glideslope
-__device__ __forceinline__ Shaping shaping_rewards(const float* S, float d_faf, float phi_rel_faf, float phi_plane, float h,
-                                                   float on_gp) {
+__device__ __forceinline__ Shaping shaping_rewards(const float* S, float d_faf, float phi_rel_faf, float plane_to_runway,
+                                                   float h, float on_gp) {
+    // plane_to_runway = relative_angle(phi_to_runway, phi_plane): the caller already has it as obs[9]
     const float to_rwy = S[ATC_C_PHI_TO_RWY];
     Shaping r;
     const float rel_faf = relative_angle(to_rwy, phi_rel_faf);
-    const float u = fabsf(rel_faf) / 180.0f;
-    r.pos = sigmoid_distance(d_faf, S[ATC_C_WORLD_DIAG]) * (u * sqrtf(u)) * 0.8f;  // u ** 1.5
-    const float plane_to_runway = relative_angle(to_rwy, phi_plane);
+    const float u = fabsf(rel_faf) * (1.0f / 180.0f);
+    r.pos = sigmoid_distance(d_faf, fast_rcp(S[ATC_C_WORLD_DIAG])) * (u * fast_sqrt(u)) * 0.8f;  // u ** 1.5
     const float side = (rel_faf > 0.0f) ? 1.0f : ((rel_faf < 0.0f) ? -1.0f : 0.0f);  // np.sign
-    const float q = (side * plane_to_runway - 22.5f) / 202.0f;
+    const float q = (side * plane_to_runway - 22.5f) * (1.0f / 202.0f);
     float m = -(q * q) + 1.0f;  // (-(q ** 2.0) + 1.0) ** 32.0 by five squarings (even power: sign-safe)
     m = m * m;
     m = m * m;
@@ -139,7 +219,7 @@ __device__ __forceinline__ Shaping shaping_rewards(const float* S, float d_faf, 
     m = m * m;
     m = m * m;
     r.ang = m * r.pos * 1.2f;
-    r.gs = sigmoid_distance(fabsf(h - on_gp), 36000.0f) * r.pos * 0.8f;
+    r.gs = sigmoid_distance(fabsf(h - on_gp), 1.0f / 36000.0f) * r.pos * 0.8f;
     return r;
 }
 
@@ -192,8 +272,8 @@ __device__ __forceinline__ Obs get_state(const float* S, float x, float y, float
     Obs r;
     const float to_faf_x = S[ATC_C_FAF_X] - x;
     const float to_faf_y = S[ATC_C_FAF_Y] - y;
-    r.d_faf = sqrtf(to_faf_x * to_faf_x + to_faf_y * to_faf_y);           // np.hypot
-    r.phi_rel_faf = atan2f(to_faf_y, to_faf_x) * kRadToDeg;               // np.degrees(np.arctan2)
+    r.d_faf = fast_sqrt(fmaf(to_faf_x, to_faf_x, to_faf_y * to_faf_y));   // np.hypot (value-only)
+    r.phi_rel_faf = atan2_deg(to_faf_y, to_faf_x);                        // np.degrees(np.arctan2) (value-only)
     r.on_gp = 318.4f * r.d_faf + S[ATC_C_FAF_MVA] - 200.0f;
     r.o[0] = x;
     r.o[1] = y;

@@ -3,7 +3,10 @@
 // Work decomposition (one wavefront = 64 lanes):
 //   lane  = one aircraft slot;  W = next_pow2(N) consecutive lanes = one env;  64/W envs per wavefront
 //   (N = 64: one wavefront per env, N = 16: 4 envs per wavefront, N = 1: 64 envs per wavefront).
-//   Aircraft state is SoA in HBM (index env*N + k) so that the 64 lanes of a wavefront read consecutive words.
+//   Aircraft state lives in HBM as packed records indexed env*N + k: pos = double2 (x, y), kin = float4 (h, phi, v, last
+//   phi target), last_vh = float2 — a wavefront moves each array with ONE 16-byte (8-byte) access per lane, consecutive
+//   lanes on consecutive records (1 KiB per wave-instruction); the per-env record (12 words) is read with three 16-byte
+//   loads that the W lanes of an env share.  All per-lane indices are 32-bit offsets from uniform base pointers.
 //   The sector (polygons, corridor, constants: ~2 KB) is staged once per workgroup in LDS; the optional MVA lookup grid
 //   stays in global memory (L2 resident, one 4-byte gather per aircraft).
 //   The O(N^2) separation scan stages (x, y, h, active) of the wavefront's aircraft in LDS; every lane walks its env's
@@ -51,6 +54,15 @@ static int fail_hip(hipError_t e, const char* what) {
     } while (0)
 
 constexpr int kBlock = 256;
+#ifndef ATC_ABLATE
+#define ATC_ABLATE 0  // developer-only timing ablations (tools/ablate.sh); the shipped build always uses 0
+#endif
+#ifndef ATC_GRID_CAP
+#define ATC_GRID_CAP 8   // workgroups per CU before the kernels grid-stride
+#endif
+#ifndef ATC_MIN_WAVES
+#define ATC_MIN_WAVES 4  // waves per SIMD the step kernel is register-budgeted for (<= 128 VGPRs)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // wavefront-group helpers (groups of W consecutive lanes, W a power of two <= 64)
@@ -97,19 +109,29 @@ __device__ __forceinline__ void store_obs(float* __restrict__ dst, const float* 
 // step / rollout kernel
 // ---------------------------------------------------------------------------------------------------------------
 template <int W>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, ATC_MIN_WAVES)
 k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N, int T, atc_state_t st,
        const float* __restrict__ actions, atc_out_t out, atc_params_t p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* S = smem;
-    float4* pos = reinterpret_cast<float4*>(smem + ((lds_words + 3) & ~3));  // [kBlock] pair-scan staging
+    const int w0 = (lds_words + 3) & ~3;
+    float* normA = smem + w0;        // [10] 1 / (0.5 max)                       (atc_gym.py:187-189 as one fma)
+    float* normB = smem + w0 + 12;   // [10] -(min + 0.5 max) / (0.5 max)
+    float4* pos = reinterpret_cast<float4*>(smem + w0 + 24);                 // [kBlock] pair-scan staging
+    float* obs_stage = smem + w0 + 24 + (W > 1 ? kBlock * 4 : 0);             // [4 waves][64 x 10] obs transpose
     stage_sector(S, blob, lds_words);
+    if (threadIdx.x < ATC_OBS_DIM) {
+        const float half = 0.5f * S[ATC_C_NORM_MAX + threadIdx.x];
+        normA[threadIdx.x] = 1.0f / half;
+        normB[threadIdx.x] = -(S[ATC_C_NORM_MIN + threadIdx.x] + half) / half;
+    }
+    __syncthreads();
     const float* grid = off_grid ? blob + off_grid : nullptr;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const long long BN = (long long)B * N;
-    const long long slots = (long long)B * W;
+    const uint32_t BN = (uint32_t)B * (uint32_t)N;      // host guarantees B*N*40 bytes < 4 GiB: 32-bit lane offsets
+    const uint32_t slots = (uint32_t)B * (uint32_t)W;
     const float dt = p.dt;
     const bool discrete = (p.mode & ATC_M_DISCRETE) != 0;
     const float v_min = S[ATC_C_V_MIN], v_max = S[ATC_C_V_MAX], h_min = S[ATC_C_H_MIN], h_max = S[ATC_C_H_MAX];
@@ -124,41 +146,52 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
     const int n_noise = (int)S[ATC_H_N_NOISE];
     const float* polytab = S + (int)S[ATC_H_OFF_POLY];
 
-    for (long long slot0 = (long long)blockIdx.x * kBlock; slot0 < slots; slot0 += (long long)gridDim.x * kBlock) {
-        const long long slot = slot0 + tid;
+    for (uint32_t slot0 = blockIdx.x * kBlock; slot0 < slots; slot0 += gridDim.x * kBlock) {
+        const uint32_t slot = slot0 + tid;
         const int e = (int)(slot / W);
         const int k = (int)(slot % W);
         const bool env_valid = slot < slots;
         const bool lane_valid = env_valid && k < N;
-        const long long i = (long long)e * N + k;
+        const uint32_t i = (uint32_t)e * (uint32_t)N + (uint32_t)k;
 
-        // ---- load persistent state -------------------------------------------------------------------------------
-        int t = 0, n_actions = 0, episode = 0;
-        float total_reward = 0.0f;
+        // ---- load persistent state (16-byte records; the W lanes of an env share the env record) ---------------------
+        int t = 0, n_actions = 0, episode = 0, ep_length = 0;
+        float total_reward = 0.0f, ep_return = 0.0f;
+        uint32_t win_bits = 0;
         uint64_t amask = 0;
         if (env_valid) {
-            t = st.timesteps[e];
-            n_actions = st.actions_taken[e];
-            total_reward = st.total_reward[e];
-            amask = st.active_mask[e];
-            episode = st.episodes[e];
+            const int4* er = reinterpret_cast<const int4*>(st.env) + (uint32_t)e * (ATC_ENV_WORDS / 4);
+            const int4 e0 = er[0], e1 = er[1], e2 = er[2];
+            t = e0.x;
+            n_actions = e0.y;
+            episode = e0.z;
+            ep_length = e0.w;
+            total_reward = __int_as_float(e1.x);
+            ep_return = __int_as_float(e1.y);
+            win_bits = (uint32_t)e1.z;
+            amask = (uint64_t)(uint32_t)e2.x | ((uint64_t)(uint32_t)e2.y << 32);
         }
         Aircraft a = {0.0, 0.0, 0.0f, 0.0f, 0.0f};
         float la_v = 0.0f, la_h = 0.0f, la_p = 0.0f;
+        float la_v0 = 0.0f, la_h0 = 0.0f;
         if (lane_valid) {
-            a.x = st.x[i];
-            a.y = st.y[i];
-            a.h = st.h[i];
-            a.phi = st.phi[i];
-            a.v = st.v[i];
-            la_v = st.last_act[i];
-            la_h = st.last_act[BN + i];
-            la_p = st.last_act[2 * BN + i];
+            const double2 ps = reinterpret_cast<const double2*>(st.pos)[i];
+            const float4 kn = reinterpret_cast<const float4*>(st.kin)[i];
+            const float2 lv = reinterpret_cast<const float2*>(st.last_vh)[i];
+            a.x = ps.x;
+            a.y = ps.y;
+            a.h = kn.x;
+            a.phi = kn.y;
+            a.v = kn.z;
+            la_p = kn.w;
+            la_v = la_v0 = lv.x;
+            la_h = la_h0 = lv.y;
         }
 
         for (int step = 0; step < T; ++step) {
-            const float* act_t = actions + (long long)step * BN * 3;
-            float* obs_t = out.obs + (long long)step * BN * ATC_OBS_DIM;
+            const size_t sBN = (size_t)step * BN, sB = (size_t)step * (uint32_t)B;  // uniform (scalar) per-step bases
+            const float* act_t = actions + sBN * 3;
+            float* obs_t = out.obs + sBN * ATC_OBS_DIM;
             t += 1;  // atc_gym.py:135
             const bool active = lane_valid && ((amask >> k) & 1ull);
             uint32_t fl = lane_valid ? (active ? 0u : (uint32_t)ATC_F_INACTIVE) : 0u;
@@ -168,7 +201,7 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
             float x32 = 0.0f, y32 = 0.0f;
 
             if (active) {
-                const float a_v = act_t[i * 3 + 0], a_h = act_t[i * 3 + 1], a_p = act_t[i * 3 + 2];
+                const float a_v = act_t[i * 3u + 0u], a_h = act_t[i * 3u + 1u], a_p = act_t[i * 3u + 2u];
                 r = -0.05f * dt;  // atc_gym.py:137
                 // ---- _action_with_reward x3 (atc_gym.py:139-141,299-335) -> Airplane.action_* (model.py:60-120) ----
                 const float tv = discrete ? a_v * fac_v + off_v : a_v * fac_v / 2.0f + fac_v / 2.0f + off_v;
@@ -207,13 +240,13 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
                 // ---- Airplane.step (model.py:122-129): rot_matrix(phi) . [0, (v/3600) dt] ----------------------------
                 const float dist = (a.v / 3600.0f) * dt;
                 float sn, cs;
-                sincosf(a.phi * kDegToRad, &sn, &cs);
+                if (ATC_ABLATE & 32) { sn = 0.6f; cs = 0.8f; } else sincos_deg(a.phi, &sn, &cs);
                 a.x += (double)(sn * dist);
                 a.y += (double)(cs * dist);
                 x32 = (float)a.x;
                 y32 = (float)a.y;
                 // ---- MVA floor (atc_gym.py:146-161) ------------------------------------------------------------------
-                const int pi = find_mva(S, grid, x32, y32);
+                const int pi = (ATC_ABLATE & 1) ? 0 : find_mva(S, grid, x32, y32);
                 if (pi >= 0) {
                     mva = polytab[pi * ATC_P_WORDS + ATC_P_HEIGHT];
                     if (a.h < mva) {
@@ -229,7 +262,7 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
 
             // ---- separation scan (extension; README.md:51): 3 nm / 1000 ft among aircraft active at step start ------
             float min_d2 = 1e30f;
-            if (W > 1) {
+            if (W > 1 && !(ATC_ABLATE & 2)) {
                 pos[tid] = make_float4(x32, y32, a.h, active ? 1.0f : 0.0f);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -259,11 +292,8 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
             float o[ATC_OBS_DIM];
 #pragma unroll
             for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = 0.0f;
-            float raw[ATC_OBS_DIM];
-#pragma unroll
-            for (int c = 0; c < ATC_OBS_DIM; ++c) raw[c] = 0.0f;
             if (active) {
-                if (inside_corridor(S, x32, y32, a.h, a.phi)) {
+                if (!(ATC_ABLATE & 4) && inside_corridor(S, x32, y32, a.h, a.phi)) {
                     int bonus = (p.timestep_limit - t) * 5;
                     bonus = bonus < 0 ? 0 : bonus;
                     r = (float)(10000 + bonus);
@@ -273,9 +303,16 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
                     r = -200.0f;
                     fl |= ATC_F_TIMEOUT;
                 }
-                const Obs ob = get_state(S, x32, y32, a.h, a.phi, a.v, mva);
-                if (p.mode & ATC_M_REWARD_SHAPING) {
-                    const Shaping sh = shaping_rewards(S, ob.d_faf, ob.phi_rel_faf, a.phi, a.h, ob.on_gp);
+                Obs ob;
+                if (ATC_ABLATE & 8) {
+#pragma unroll
+                    for (int c = 0; c < ATC_OBS_DIM; ++c) ob.o[c] = x32;
+                    ob.d_faf = ob.phi_rel_faf = ob.on_gp = y32;
+                } else {
+                    ob = get_state(S, x32, y32, a.h, a.phi, a.v, mva);
+                }
+                if ((p.mode & ATC_M_REWARD_SHAPING) && !(ATC_ABLATE & 8)) {
+                    const Shaping sh = shaping_rewards(S, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp);
                     r += sh.pos;
                     r += sh.ang;
                     r += sh.gs;
@@ -289,18 +326,16 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
                         fl |= ATC_F_NOISE;
                     }
                 }
+                if (out.raw_obs) store_obs(out.raw_obs + sBN * ATC_OBS_DIM + i * ATC_OBS_DIM, ob.o);
+                if (p.mode & ATC_M_NORMALIZE) {  // atc_gym.py:187-189: (s - min - max/2) / (max/2) as one fma
 #pragma unroll
-                for (int c = 0; c < ATC_OBS_DIM; ++c) raw[c] = ob.o[c];
-                if (p.mode & ATC_M_NORMALIZE) {  // atc_gym.py:187-189
-#pragma unroll
-                    for (int c = 0; c < ATC_OBS_DIM; ++c) {
-                        const float half = 0.5f * S[ATC_C_NORM_MAX + c];
-                        o[c] = ((raw[c] - S[ATC_C_NORM_MIN + c]) - half) / half;
-                    }
+                    for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = fmaf(ob.o[c], normA[c], normB[c]);
                 } else {
 #pragma unroll
-                    for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = raw[c];
+                    for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = ob.o[c];
                 }
+            } else if (lane_valid && out.raw_obs) {
+                store_obs(out.raw_obs + sBN * ATC_OBS_DIM + i * ATC_OBS_DIM, o);  // zeros for handed-over aircraft
             }
 
             // ---- per-env reductions over the W lanes of the group ----------------------------------------------------
@@ -316,32 +351,29 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
             amask = amask1;
 
             if (lane_valid) {
-                out.flags[(long long)step * BN + i] = fl;
-                if (out.ac_reward) out.ac_reward[(long long)step * BN + i] = r;
-                if (out.raw_obs) store_obs(out.raw_obs + ((long long)step * BN + i) * ATC_OBS_DIM, raw);
+                (out.flags + sBN)[i] = fl;
+                if (out.ac_reward) (out.ac_reward + sBN)[i] = r;
             }
             if (env_valid && k == 0) {
-                out.reward[(long long)step * B + e] = env_r;
-                out.done[(long long)step * B + e] = done ? 1 : 0;
+                (out.reward + sB)[e] = env_r;
+                (out.done + sB)[e] = done ? 1 : 0;
             }
             if (W > 1) {
                 const float m2 = group_min<W>(min_d2);
                 const float ms = (m2 >= 1e30f) ? 1e30f : sqrtf(m2);
-                if (out.min_sep && env_valid && k == 0) out.min_sep[(long long)step * B + e] = ms;
+                if (out.min_sep && env_valid && k == 0) (out.min_sep + sB)[e] = ms;
             } else if (out.min_sep && env_valid) {
-                out.min_sep[(long long)step * B + e] = 1e30f;
+                (out.min_sep + sB)[e] = 1e30f;
             }
 
             if (done && (p.mode & ATC_M_AUTO_RESET)) {
                 // VecEnv semantics: the env restarts inside the step; the returned obs is the RAW reset state
                 // (atc_gym.py:351,365: reset() returns the un-normalised state computed with mva = 0).
-                if (k == 0) {
-                    st.ep_return[e] = total_reward;
-                    st.ep_length[e] = t;
-                    st.win_bits[e] = ((st.win_bits[e] << 1) | (amask == 0 ? 1u : 0u)) & 0x3ffu;
-                }
+                ep_return = total_reward;
+                ep_length = t;
+                win_bits = ((win_bits << 1) | (amask == 0 ? 1u : 0u)) & 0x3ffu;
                 if (lane_valid) {
-                    if (out.term_obs) store_obs(out.term_obs + ((long long)step * BN + i) * ATC_OBS_DIM, o);
+                    if (out.term_obs) store_obs(out.term_obs + sBN * ATC_OBS_DIM + i * ATC_OBS_DIM, o);
                     a = spawn(S, p, e, k, episode);
                     const Obs ob = get_state(S, (float)a.x, (float)a.y, a.h, a.phi, a.v, 0.0f);
 #pragma unroll
@@ -353,26 +385,44 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
                 episode += 1;
                 amask = full_mask;
             }
-            if (lane_valid) store_obs(obs_t + i * ATC_OBS_DIM, o);
+            // ---- observation store: [aircraft][10] rows are 40 B apart, so per-lane stores would scatter 8-byte pieces
+            //      over 20 cache lines per instruction; a full wavefront instead transposes its 64 x 10 block through LDS
+            //      and writes 2 560 contiguous bytes as 16-byte stores.
+            const bool wave_full = (N == W) && (slot0 + (uint32_t)(tid | 63) < slots);
+            if (ATC_ABLATE & 16) {
+                if (lane_valid && o[0] == 12345.678f) obs_t[i] = o[1];
+            } else if (wave_full) {
+                float* tb = obs_stage + (tid >> 6) * (64 * ATC_OBS_DIM);
+#pragma unroll
+                for (int c = 0; c < ATC_OBS_DIM; ++c) tb[lane * ATC_OBS_DIM + c] = o[c];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                float4* dst = reinterpret_cast<float4*>(obs_t + (size_t)(slot0 + (uint32_t)(tid & ~63)) * ATC_OBS_DIM);
+                const float4* src = reinterpret_cast<const float4*>(tb);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int idx = j * 64 + lane;
+                    if (idx < 64 * ATC_OBS_DIM / 4) dst[idx] = src[idx];
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else if (lane_valid) {
+                store_obs(obs_t + i * ATC_OBS_DIM, o);
+            }
         }
 
         // ---- write back persistent state -------------------------------------------------------------------------------
         if (lane_valid) {
-            st.x[i] = a.x;
-            st.y[i] = a.y;
-            st.h[i] = a.h;
-            st.phi[i] = a.phi;
-            st.v[i] = a.v;
-            st.last_act[i] = la_v;
-            st.last_act[BN + i] = la_h;
-            st.last_act[2 * BN + i] = la_p;
+            reinterpret_cast<double2*>(st.pos)[i] = make_double2(a.x, a.y);
+            reinterpret_cast<float4*>(st.kin)[i] = make_float4(a.h, a.phi, a.v, la_p);
+            // actions are typically held for many steps: write last v/h targets back only where they changed
+            if (la_v != la_v0 || la_h != la_h0) reinterpret_cast<float2*>(st.last_vh)[i] = make_float2(la_v, la_h);
         }
         if (env_valid && k == 0) {
-            st.timesteps[e] = t;
-            st.actions_taken[e] = n_actions;
-            st.total_reward[e] = total_reward;
-            st.active_mask[e] = amask;
-            st.episodes[e] = episode;
+            int4* er = reinterpret_cast<int4*>(st.env) + (uint32_t)e * (ATC_ENV_WORDS / 4);
+            er[0] = make_int4(t, n_actions, episode, ep_length);
+            er[1] = make_int4(__float_as_int(total_reward), __float_as_int(ep_return), (int)win_bits, 0);
+            er[2] = make_int4((int)(uint32_t)(amask & 0xffffffffu), (int)(uint32_t)(amask >> 32), 0, 0);
         }
     }
 }
@@ -386,25 +436,20 @@ k_reset(const float* __restrict__ blob, int lds_words, int B, int N, atc_state_t
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* S = smem;
     stage_sector(S, blob, lds_words);
-    const long long BN = (long long)B * N;
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < BN; i += (long long)gridDim.x * kBlock) {
-        const int e = (int)(i / N), k = (int)(i % N);
+    const uint32_t BN = (uint32_t)B * (uint32_t)N;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < BN; i += gridDim.x * kBlock) {
+        const int e = (int)(i / (uint32_t)N), k = (int)(i % (uint32_t)N);
         if (mask && !mask[e]) continue;
-        const int episode = first ? 0 : st.episodes[e];
+        const int episode = first ? 0 : st.env[(size_t)e * ATC_ENV_WORDS + ATC_ENV_EPISODES];
         const Aircraft a = spawn(S, p, e, k, episode);
-        st.x[i] = a.x;
-        st.y[i] = a.y;
-        st.h[i] = a.h;
-        st.phi[i] = a.phi;
-        st.v[i] = a.v;
-        if (first) {  // atc_gym.py:86: last_action = [0,0,0] once, in __init__ — never on reset (quirk Q7)
-            st.last_act[i] = 0.0f;
-            st.last_act[BN + i] = 0.0f;
-            st.last_act[2 * BN + i] = 0.0f;
-        }
+        reinterpret_cast<double2*>(st.pos)[i] = make_double2(a.x, a.y);
+        // atc_gym.py:86: last_action = [0,0,0] once, in __init__ — never on reset (quirk Q7)
+        const float la_p = first ? 0.0f : st.kin[(size_t)i * 4 + 3];
+        reinterpret_cast<float4*>(st.kin)[i] = make_float4(a.h, a.phi, a.v, la_p);
+        if (first) reinterpret_cast<float2*>(st.last_vh)[i] = make_float2(0.0f, 0.0f);
         if (obs) {
             const Obs ob = get_state(S, (float)a.x, (float)a.y, a.h, a.phi, a.v, 0.0f);  // mva = 0, atc_gym.py:351
-            store_obs(obs + i * ATC_OBS_DIM, ob.o);
+            store_obs(obs + (size_t)i * ATC_OBS_DIM, ob.o);
         }
     }
 }
@@ -415,31 +460,37 @@ k_observe(const float* __restrict__ blob, int lds_words, int B, int N, atc_state
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* S = smem;
     stage_sector(S, blob, lds_words);
-    const long long BN = (long long)B * N;
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < BN; i += (long long)gridDim.x * kBlock) {
-        const int e = (int)(i / N);
+    const uint32_t BN = (uint32_t)B * (uint32_t)N;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < BN; i += gridDim.x * kBlock) {
+        const int e = (int)(i / (uint32_t)N);
         if (mask && !mask[e]) continue;
-        const Obs ob = get_state(S, (float)st.x[i], (float)st.y[i], st.h[i], st.phi[i], st.v[i], 0.0f);
-        store_obs(obs + i * ATC_OBS_DIM, ob.o);
+        const double2 ps = reinterpret_cast<const double2*>(st.pos)[i];
+        const float4 kn = reinterpret_cast<const float4*>(st.kin)[i];
+        const Obs ob = get_state(S, (float)ps.x, (float)ps.y, kn.x, kn.y, kn.z, 0.0f);
+        store_obs(obs + (size_t)i * ATC_OBS_DIM, ob.o);
     }
 }
-// env-level part of reset runs after k_reset (episodes[] is read by k_reset's spawn)
+// env-level part of reset runs after k_reset (the episode counter is read by k_reset's spawn)
 __global__ void __launch_bounds__(kBlock)
 k_reset_env(int B, int N, atc_state_t st, const uint8_t* __restrict__ mask, int first) {
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= B) return;
     if (mask && !mask[e]) return;
+    int32_t* er = st.env + (size_t)e * ATC_ENV_WORDS;
     if (first) {
-        st.win_bits[e] = 0;
-        st.episodes[e] = 0;
-        st.ep_return[e] = 0.0f;
-        st.ep_length[e] = 0;
+        er[ATC_ENV_WIN_BITS] = 0;
+        er[ATC_ENV_EPISODES] = 0;
+        er[ATC_ENV_EP_RETURN] = __float_as_int(0.0f);
+        er[ATC_ENV_EP_LENGTH] = 0;
+        er[7] = er[10] = er[11] = 0;
     }
-    st.total_reward[e] = 0.0f;
-    st.actions_taken[e] = 0;
-    st.timesteps[e] = 0;
-    st.episodes[e] = st.episodes[e] + 1;
-    st.active_mask[e] = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
+    er[ATC_ENV_TOTAL_REWARD] = __float_as_int(0.0f);
+    er[ATC_ENV_ACTIONS_TAKEN] = 0;
+    er[ATC_ENV_TIMESTEPS] = 0;
+    er[ATC_ENV_EPISODES] = er[ATC_ENV_EPISODES] + 1;
+    const uint64_t full = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
+    er[ATC_ENV_MASK_LO] = (int)(uint32_t)(full & 0xffffffffu);
+    er[ATC_ENV_MASK_HI] = (int)(uint32_t)(full >> 32);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -477,7 +528,8 @@ k_query_shaping(const float* __restrict__ blob, int lds_words, int n, const floa
     stage_sector(smem, blob, lds_words);
     const float* S = smem;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const Shaping s = shaping_rewards(S, d_faf[i], phi_rel_faf[i], phi_plane[i], h[i], on_gp[i]);
+        const Shaping s = shaping_rewards(S, d_faf[i], phi_rel_faf[i], relative_angle(S[ATC_C_PHI_TO_RWY], phi_plane[i]),
+                                          h[i], on_gp[i]);
         out3[3 * i + 0] = s.pos;
         out3[3 * i + 1] = s.ang;
         out3[3 * i + 2] = s.gs;
@@ -489,13 +541,14 @@ k_query_shaping(const float* __restrict__ blob, int lds_words, int n, const floa
 // ---------------------------------------------------------------------------------------------------------------
 static int grid_for(const atc_scenario* s, long long threads) {
     long long blocks = (threads + kBlock - 1) / kBlock;
-    const long long cap = (long long)s->n_cu * 8;
+    const long long cap = (long long)s->n_cu * ATC_GRID_CAP;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
-static size_t lds_bytes(const atc_scenario* s, bool pair_scan) {
+static size_t lds_bytes(const atc_scenario* s, bool pair_scan, bool step_kernel = false) {
     size_t w = (size_t)((s->lds_words + 3) & ~3);
+    if (step_kernel) w += 24 + (size_t)(kBlock / 64) * 64 * ATC_OBS_DIM;  // norm scale/shift + obs transpose stage
     if (pair_scan) w += (size_t)kBlock * 4;
     return w * sizeof(float);
 }
@@ -503,7 +556,7 @@ static size_t lds_bytes(const atc_scenario* s, bool pair_scan) {
 template <int W>
 static int launch_step(const atc_scenario* s, int B, int N, int T, const atc_state_t* st, const float* actions,
                        const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
-    const size_t lds = lds_bytes(s, W > 1);
+    const size_t lds = lds_bytes(s, W > 1, true);
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<W>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
@@ -518,9 +571,9 @@ static int step_common(const atc_scenario_t* s, int B, int N, int T, const atc_s
                        const atc_out_t* out, const atc_params_t* p, void* stream) {
     if (!s || !st || !actions || !out || !p) return fail_arg("null pointer");
     if (B < 1 || N < 1 || N > ATC_MAX_AIRCRAFT || T < 1) return fail_arg("need B >= 1, 1 <= N <= 64, T >= 1");
-    if (!st->x || !st->y || !st->h || !st->phi || !st->v || !st->last_act || !st->timesteps || !st->actions_taken ||
-        !st->total_reward || !st->active_mask || !st->win_bits || !st->episodes || !st->ep_return || !st->ep_length)
-        return fail_arg("atc_state_t has a null field");
+    if (!st->pos || !st->kin || !st->last_vh || !st->env) return fail_arg("atc_state_t has a null field");
+    if ((unsigned long long)B * N * ATC_OBS_DIM * 4ull >= (1ull << 32) || (unsigned long long)B * 64ull >= (1ull << 32))
+        return fail_arg("B*N too large for one launch (B*N*40 bytes must stay below 4 GiB): split the batch");
     if (!out->obs || !out->reward || !out->done || !out->flags) return fail_arg("obs/reward/done/flags are required");
     if (!(p->dt > 0.0f)) return fail_arg("dt must be > 0");
     hipStream_t q = (hipStream_t)stream;
@@ -556,7 +609,7 @@ int atc_scenario_create(const float* blob_host, size_t n_words, int device, atc_
         return fail_hip(e, "hipGetDeviceProperties");
     }
     s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if ((size_t)s->lds_words * 4 + kBlock * 16 > 160 * 1024) {
+    if ((size_t)s->lds_words * 4 + kBlock * 16 + 24 * 4 + 4 * 64 * ATC_OBS_DIM * 4 + 64 > 160 * 1024) {
         delete s;
         return fail_arg("sector does not fit the 160 KB LDS");
     }
@@ -627,6 +680,8 @@ int atc_reset(const atc_scenario_t* s, int B, int N, const atc_state_t* st, cons
               const atc_params_t* p, int first, void* stream) {
     if (!s || !st || !p) return fail_arg("null pointer");
     if (B < 1 || N < 1 || N > ATC_MAX_AIRCRAFT) return fail_arg("need B >= 1, 1 <= N <= 64");
+    if (!st->pos || !st->kin || !st->last_vh || !st->env) return fail_arg("atc_state_t has a null field");
+    if ((unsigned long long)B * N * ATC_OBS_DIM * 4ull >= (1ull << 32)) return fail_arg("B*N too large for one launch");
     hipStream_t q = (hipStream_t)stream;
     hipLaunchKernelGGL(k_reset, dim3(grid_for(s, (long long)B * N)), dim3(kBlock), lds_bytes(s, false), q, s->d_blob,
                        s->lds_words, B, N, *st, mask, obs, *p, first);

@@ -107,12 +107,11 @@ class AtcGym(Env):
     @property
     def last_action(self):
         """atc_gym.py:86,311 — lives on the device next to the aircraft state."""
-        return [float(v) for v in self._vec.last_act[:, 0].cpu()]
+        return self._vec.get_last_action(0, 0)
 
     @last_action.setter
     def last_action(self, value):
-        for c in range(3):
-            self._vec.last_act[c, 0] = float(value[c])
+        self._vec.set_last_action(0, 0, value)
 
     # -- gym.Env ----------------------------------------------------------------------------------------------------
     def seed(self, seed=None):

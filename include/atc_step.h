@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ATC_ABI_VERSION 3
+#define ATC_ABI_VERSION 4
 
 /* ---------------------------------------------------------------------------------------------
  * Scenario blob: one flat array of 32-bit floats (device copy) compiled on the host from the sector
@@ -35,7 +35,7 @@ extern "C" {
  * envs/atc/atc_gym.py:45-58,88-110).  Integer fields are stored as exactly representable floats.
  * The float64 master (used by the f64 oracle) has the identical word layout.
  * ------------------------------------------------------------------------------------------- */
-#define ATC_BLOB_VERSION 1003.0f
+#define ATC_BLOB_VERSION 1004.0f
 enum {
     ATC_H_VERSION = 0,   /* ATC_BLOB_VERSION */
     ATC_H_NWORDS = 1,    /* total words */
@@ -81,14 +81,16 @@ enum { ATC_P_MINX = 0, ATC_P_MINY = 1, ATC_P_MAXX = 2, ATC_P_MAXY = 3,
        ATC_P_WORDS = 8 };
 /* entry-point record (12 words): x, y, phi, n_levels, levels[8] (flight levels, x100 ft; model.py:309-315) */
 enum { ATC_E_X = 0, ATC_E_Y = 1, ATC_E_PHI = 2, ATC_E_NLEV = 3, ATC_E_LEV0 = 4, ATC_E_WORDS = 12, ATC_E_MAXLEV = 8 };
-/* lookup grid (optional acceleration structure for Airspace.find_mva; results identical by construction):
- *   header 8 words: x0, y0, inv_cell, nx, ny, reserved x3 ; then nx*ny cell words.
- *   cell word (integer-valued float, < 2^24):
- *     value <  ATC_GRID_MASK_BASE : cell is "clean" (no polygon edge within the guard band) -> value = poly index + 1,
- *                                   or 0 = outside every polygon
- *     value >= ATC_GRID_MASK_BASE : value - BASE = bitmask of candidate polygons (only when n_mva <= 23)   */
-enum { ATC_G_X0 = 0, ATC_G_Y0 = 1, ATC_G_INV = 2, ATC_G_NX = 3, ATC_G_NY = 4, ATC_G_HDR = 8 };
-#define ATC_GRID_MASK_BASE 8388608.0f /* 2^23 */
+/* lookup grid (optional acceleration structure for Airspace.find_mva, model.py:282-289; results identical to the
+ * ordered polygon scan by construction — see atc_hip/scenario.py:build_grid).  16-byte aligned in the blob.
+ *   header 8 words : x0, y0, 1/cell, nx, ny, offset of the edge pool (from grid start), number of edge records, 0
+ *   cells  ny*nx*2 : (n_records, first_record) -> dirty cell: walk that many edge records
+ *                    (0, polygon index + 1)    -> clean cell: every point has this answer (0 = outside the airspace)
+ *   pool           : 8-word edge records  p1x, p1y, p2x, p2y, polygon index, flags, 0, 0                              */
+enum { ATC_G_X0 = 0, ATC_G_Y0 = 1, ATC_G_INV = 2, ATC_G_NX = 3, ATC_G_NY = 4, ATC_G_OFF_POOL = 5, ATC_G_NREC = 6,
+       ATC_G_HDR = 8, ATC_GE_WORDS = 8 };
+#define ATC_GE_LAST 1    /* last edge record of its polygon: evaluate parity (+ bounds test) now */
+#define ATC_GE_CERTAIN 2 /* the cell lies entirely left of this edge: crossing iff the y test passes */
 
 #define ATC_MAX_AIRCRAFT 64
 #define ATC_OBS_DIM 10 /* atc_gym.py:262-277 */
@@ -128,25 +130,28 @@ typedef struct atc_params {
     float reserved1;
 } atc_params_t;
 
-/* Persistent environment state (all device pointers). */
+/* Persistent environment state (all device pointers).  Aircraft arrays are indexed env * N + k and packed so that a
+ * wavefront moves them with 16-byte (pos, kin) / 8-byte (last_vh) accesses, fully coalesced. */
 typedef struct atc_state {
-    /* per aircraft [B*N] */
-    double* x;       /* nm   model.py:33 — positions are accumulated in float64: fp32 accumulation drifts by up to */
-    double* y;       /* nm   model.py:34   0.5 ulp/step on straight legs (1e-4 nm after 100 steps), beyond the 1e-5 bar */
-    float* h;        /* ft   model.py:35 */
-    float* phi;      /* deg, never wrapped (model.py:113-120) */
-    float* v;        /* kt   model.py:38 */
-    float* last_act; /* [3][B*N] last accepted denormalised action v,h,phi (atc_gym.py:86,309); plane-major */
-    /* per env [B] */
-    int32_t* timesteps;     /* atc_gym.py:39 */
-    int32_t* actions_taken; /* atc_gym.py:31 */
-    float* total_reward;    /* atc_gym.py:30 */
-    uint64_t* active_mask;  /* bit k = aircraft k still under control (extension; N=1: always 1) */
-    uint32_t* win_bits;     /* last 10 episode outcomes, bit0 = most recent (atc_gym.py:36-37,359-363) */
-    int32_t* episodes;      /* atc_gym.py:33 (_episodes_run) */
-    float* ep_return;       /* return of the last finished episode (Monitor 'r') */
-    int32_t* ep_length;     /* length of the last finished episode (Monitor 'l') */
+    double* pos;      /* [B*N][2]  x, y [nm] (model.py:33-34).  float64 accumulators: fp32 accumulation drifts by up to
+                         0.5 ulp/step on straight legs (1e-4 nm after 100 steps), beyond the 1e-5 bar */
+    float* kin;       /* [B*N][4]  h [ft], phi [deg, never wrapped], v [kt] (model.py:35-38), last accepted phi target */
+    float* last_vh;   /* [B*N][2]  last accepted v and h targets; with kin[3] = AtcGym.last_action (atc_gym.py:86,311) */
+    int32_t* env;     /* [B][ATC_ENV_WORDS] per-env record, see ATC_ENV_* */
 } atc_state_t;
+/* per-env record (12 x 32-bit words; float fields are stored by bit pattern) */
+enum {
+    ATC_ENV_TIMESTEPS = 0,     /* i32  atc_gym.py:39 */
+    ATC_ENV_ACTIONS_TAKEN = 1, /* i32  atc_gym.py:31 */
+    ATC_ENV_EPISODES = 2,      /* i32  atc_gym.py:33 (_episodes_run) */
+    ATC_ENV_EP_LENGTH = 3,     /* i32  length of the last finished episode (Monitor 'l') */
+    ATC_ENV_TOTAL_REWARD = 4,  /* f32  atc_gym.py:30 */
+    ATC_ENV_EP_RETURN = 5,     /* f32  return of the last finished episode (Monitor 'r') */
+    ATC_ENV_WIN_BITS = 6,      /* u32  last 10 episode outcomes, bit0 = most recent (atc_gym.py:36-37,359-363) */
+    ATC_ENV_MASK_LO = 8,       /* u32  active mask bits 0..31: bit k = aircraft k still under control (extension) */
+    ATC_ENV_MASK_HI = 9,       /* u32  active mask bits 32..63 */
+    ATC_ENV_WORDS = 12
+};
 
 /* Per-step outputs (device pointers; nullable ones may be NULL). */
 typedef struct atc_out {
@@ -192,7 +197,8 @@ int atc_query_shaping(const atc_scenario_t* s, int n, const float* d_faf, const 
 /* -- environment ------------------------------------------------------------------------------- */
 /* AtcGym.reset, atc_gym.py:337-365, for every env whose mask byte is non-zero (mask == NULL: all envs).
  * Writes the RAW reset observation (mva = 0, quirk atc_gym.py:351,365) to `obs` for reset envs only.
- * first != 0 additionally clears last_act / win_bits / episodes (what AtcGym.__init__ does, atc_gym.py:29-41,86). */
+ * first != 0 additionally clears the last-action fields / win_bits / episodes (what AtcGym.__init__ does,
+ * atc_gym.py:29-41,86). */
 int atc_reset(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const uint8_t* mask, float* obs,
               const atc_params_t* p, int first, void* stream);
 

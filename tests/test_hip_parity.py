@@ -256,8 +256,7 @@ def test_golden_rollouts_batched(fixture):
         for b, ep in enumerate(geps):
             env.set_state(b, 0, *ep["init_state"])
             env.timesteps[b] = ep["init_timesteps"]
-            for c in range(3):
-                env.last_act[c, b] = ep["init_last_action"][c]
+            env.set_last_action(b, 0, ep["init_last_action"])
         T = max(ep["steps"] for ep in geps)
         steps = np.array([ep["steps"] for ep in geps])
         starts = np.array([ep["start"] for ep in geps])
@@ -342,6 +341,10 @@ def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, sp
             seen |= int(np.bitwise_or.reduce(orc.flags.ravel()))
         if not use_rollout:
             # optional outputs and persistent state
+            # heading arithmetic is exact in both implementations -> relative_angle (raw[9]) must be bit-identical
+            # (checks the division-free Python-modulo of csrc/atc_device.h against the fmodf-based oracle)
+            assert np.array_equal(info["original_state"].cpu().numpy().reshape(B, N, 10)[..., 9], orc.raw_obs[..., 9]), t
+            assert np.array_equal(info["original_state"].cpu().numpy().reshape(B, N, 10)[..., 3], orc.raw_obs[..., 3]), t
             # raw (un-normalised) values: 1e-5 of each component's normalisation half-range (= 1e-5 in obs units)
             assert np.all(np.abs(info["original_state"].cpu().numpy().reshape(B, N, 10) - orc.raw_obs)
                           <= 1e-5 * half_range), t
