@@ -2,8 +2,8 @@
 
 tests/test_abi.py parses the header and checks that every constant here matches it.
 """
-ABI_VERSION = 4
-BLOB_VERSION = 1004.0
+ABI_VERSION = 5
+BLOB_VERSION = 1005.0
 
 H_VERSION, H_NWORDS, H_N_MVA, H_N_NOISE, H_N_ENTRY, H_OFF_POLY, H_OFF_VERT, H_OFF_ENTRY, H_OFF_GRID, H_N_VERTW = range(10)
 C_RWY_X, C_RWY_Y, C_RWY_H, C_PHI_TO_RWY, C_FAF_X, C_FAF_Y, C_NRM_X, C_NRM_Y = range(16, 24)
@@ -14,7 +14,8 @@ C_TRI_H, C_TRI_1, C_TRI_2 = 40, 48, 56
 C_NORM_MIN, C_NORM_MAX, C_ACT_DISCR, C_BBOX = 64, 74, 84, 87
 C_DIR_RWY_X, C_DIR_RWY_Y = 91, 92
 C_ALIGNED_OK = 93
-C_END = 96
+C_TRI_BBOX = 96
+C_END = 104
 
 P_MINX, P_MINY, P_MAXX, P_MAXY, P_HEIGHT, P_VOFF, P_NVERT, P_PENALTY, P_WORDS = range(9)
 E_X, E_Y, E_PHI, E_NLEV, E_LEV0 = range(5)

@@ -105,7 +105,7 @@ def _ring_edges(ring):
     return np.array([[a[0], a[1], b[0], b[1]] for a, b in e if a[1] != b[1]], dtype=np.float64).reshape(-1, 4)
 
 
-GRID_EDGE_WORDS = 8      # p1x, p1y, p2x, p2y, polygon index, flags, 0, 0
+GRID_EDGE_WORDS = 8      # p1x, p1y, p2x, p2y, min(p1y,p2y), max(p1y,p2y), max(p1x,p2x), 4 * polygon index + flags
 GRID_F_LAST = 1.0        # last edge record of its polygon: evaluate the parity now
 GRID_F_CERTAIN = 2.0     # every point of the cell lies left of this edge: crossing needs no intersection test
 
@@ -180,7 +180,9 @@ def build_grid(rings, bounds, bbox, cell, guard=None):
                 order = np.argsort(certain, kind="stable")  # intersection-test edges first: lanes diverge less
                 for n_, k in enumerate(order):
                     flags = (GRID_F_LAST if n_ == len(order) - 1 else 0.0) + (GRID_F_CERTAIN if certain[k] else 0.0)
-                    pool.append([e[idx[k], 0], e[idx[k], 1], e[idx[k], 2], e[idx[k], 3], float(pi), flags, 0.0, 0.0])
+                    ek = e[idx[k]]
+                    pool.append([ek[0], ek[1], ek[2], ek[3], min(ek[1], ek[3]), max(ek[1], ek[3]), max(ek[0], ek[2]),
+                                 4.0 * pi + flags])
                     n_rec += 1
             cells[j, i, 0] = n_rec - first
             cells[j, i, 1] = first
@@ -281,6 +283,8 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
     b[L.C_ACT_DISCR:L.C_ACT_DISCR + 3] = (5, 50, 0.5)
     b[L.C_BBOX:L.C_BBOX + 4] = bbox
     b[L.C_DIR_RWY_X], b[L.C_DIR_RWY_Y] = cg["dir_rwy"]
+    th = cg["tri_h"]
+    b[L.C_TRI_BBOX:L.C_TRI_BBOX + 4] = (th[:, 0].min(), th[:, 1].min(), th[:, 0].max(), th[:, 1].max())
     # knife-edge of the reference's angle window for a heading exactly equal to the runway heading (model.py:216-229):
     # min_angle = 45 - (45 - arccos(dir . dir)) must be <= relative_angle == 0.  Evaluated with numpy like the reference.
     d = np.dot(rot_matrix(cg["phi_to_runway"]), np.array([[0], [1]]))

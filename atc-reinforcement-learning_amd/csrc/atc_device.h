@@ -114,38 +114,42 @@ __device__ __forceinline__ bool ray_tracing(float x, float y, const float* ring,
 __device__ __forceinline__ bool in_bounds(const float* rec, float x, float y) {
     return rec[ATC_P_MINX] <= x && x <= rec[ATC_P_MAXX] && rec[ATC_P_MINY] <= y && y <= rec[ATC_P_MAXY];
 }
-__device__ __forceinline__ int find_mva(const float* S, const float* __restrict__ grid, float x, float y) {
-    const float* tab = S + (int)S[ATC_H_OFF_POLY];
+// `gh` = the 8-word grid header (staged in LDS by the caller), `grid` = the grid in global memory.
+// K = sector constants read with UNIFORM indices from global memory (scalar loads -> SGPRs, no VGPR cost);
+// S = the LDS copy, used where lanes index differently (polygon records, ring vertices, entry table).
+__device__ __forceinline__ int find_mva(const float* __restrict__ K, const float* S, const float* gh,
+                                        const float* __restrict__ grid, float x, float y) {
+    const float* tab = S + (int)K[ATC_H_OFF_POLY];
     if (grid) {
-        const float fx = (x - grid[ATC_G_X0]) * grid[ATC_G_INV];
-        const float fy = (y - grid[ATC_G_Y0]) * grid[ATC_G_INV];
-        const float nx = grid[ATC_G_NX], ny = grid[ATC_G_NY];
+        const float fx = (x - gh[ATC_G_X0]) * gh[ATC_G_INV];
+        const float fy = (y - gh[ATC_G_Y0]) * gh[ATC_G_INV];
+        const float nx = gh[ATC_G_NX], ny = gh[ATC_G_NY];
         if (!(fx >= 0.0f && fx < nx && fy >= 0.0f && fy < ny)) return -1;  // beyond the padded bbox (also NaN)
         const float2 cell = *reinterpret_cast<const float2*>(grid + ATC_G_HDR + 2 * ((int)fy * (int)nx + (int)fx));
         const int n = (int)cell.x;
         if (n == 0) return (int)cell.y - 1;
-        const float4* rec = reinterpret_cast<const float4*>(grid + (int)grid[ATC_G_OFF_POOL]) + 2 * (int)cell.y;
+        const float4* rec = reinterpret_cast<const float4*>(grid + (int)gh[ATC_G_OFF_POOL]) + 2 * (int)cell.y;
         bool inside = false;
         for (int e = 0; e < n; ++e) {
             const float4 g = rec[2 * e];      // p1x, p1y, p2x, p2y
-            const float4 m = rec[2 * e + 1];  // polygon index, flags
-            const int fl = (int)m.y;
-            if (y > fminf(g.y, g.w) && y <= fmaxf(g.y, g.w) && x <= fmaxf(g.x, g.z)) {
-                bool cross = (fl & ATC_GE_CERTAIN) != 0;
+            const float4 m = rec[2 * e + 1];  // min(p1y,p2y), max(p1y,p2y), max(p1x,p2x), 4 * polygon + flags
+            const int code = (int)m.w;
+            if (y > m.x && y <= m.y && x <= m.z) {  // the three cheap tests of model.py:328-330
+                bool cross = (code & ATC_GE_CERTAIN) != 0;
                 if (!cross) {
                     const float xints = (y - g.y) * (g.z - g.x) / (g.w - g.y) + g.x;
                     cross = (g.x == g.z) || x <= xints;
                 }
                 inside = inside != cross;
             }
-            if (fl & ATC_GE_LAST) {
-                if (inside && in_bounds(tab + (int)m.x * ATC_P_WORDS, x, y)) return (int)m.x;
+            if (code & ATC_GE_LAST) {
+                if (inside && in_bounds(tab + (code >> 2) * ATC_P_WORDS, x, y)) return code >> 2;
                 inside = false;
             }
         }
         return -1;
     }
-    const int n_mva = (int)S[ATC_H_N_MVA];
+    const int n_mva = (int)K[ATC_H_N_MVA];
     for (int p = 0; p < n_mva; ++p) {
         const float* rec = tab + p * ATC_P_WORDS;
         if (in_bounds(rec, x, y) && ray_tracing(x, y, S + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT])) return p;
@@ -163,33 +167,30 @@ __device__ __forceinline__ int find_mva(const float* S, const float* __restrict_
 //              the host with the reference's expression (ATC_C_ALIGNED_OK).
 // This drops sin/cos/acos from the path and removes the fp32 noise band (|rel| < 3.5e-4 deg) a literal fp32
 // transcription would have; it differs from the float64 reference only for 0 < rel < ~1e-6 deg.
-__device__ __forceinline__ bool angle_window(const float* S, float rel) {
-    return (rel > 0.0f && rel <= S[ATC_C_FAF_ANGLE]) || (rel == 0.0f && S[ATC_C_ALIGNED_OK] != 0.0f);
+__device__ __forceinline__ bool angle_window(const float* __restrict__ K, float rel) {
+    return (rel > 0.0f && rel <= K[ATC_C_FAF_ANGLE]) || (rel == 0.0f && K[ATC_C_ALIGNED_OK] != 0.0f);
 }
-__device__ __forceinline__ bool inside_corridor_angle(const float* S, float x, float y, float phi) {
-    const float to_runway = S[ATC_C_PHI_TO_RWY];
-    if (ray_tracing(x, y, S + ATC_C_TRI_1, 4)) return angle_window(S, relative_angle(to_runway, phi));
-    if (ray_tracing(x, y, S + ATC_C_TRI_2, 4)) return angle_window(S, relative_angle(phi, to_runway));
+__device__ __forceinline__ bool inside_corridor_angle(const float* __restrict__ K, float x, float y, float phi) {
+    const float to_runway = K[ATC_C_PHI_TO_RWY];
+    if (ray_tracing(x, y, K + ATC_C_TRI_1, 4)) return angle_window(K, relative_angle(to_runway, phi));
+    if (ray_tracing(x, y, K + ATC_C_TRI_2, 4)) return angle_window(K, relative_angle(phi, to_runway));
     return false;
 }
 
 // model.py:188-210 Corridor.inside_corridor
-__device__ __forceinline__ bool inside_corridor(const float* S, float x, float y, float h, float phi) {
-    {   // exact early-out: a point the crossing test accepts lies within the ring's bounds
-        const float* t = S + ATC_C_TRI_H;
-        const float bx0 = fminf(fminf(t[0], t[2]), t[4]), bx1 = fmaxf(fmaxf(t[0], t[2]), t[4]);
-        const float by0 = fminf(fminf(t[1], t[3]), t[5]), by1 = fmaxf(fmaxf(t[1], t[3]), t[5]);
-        if (!(x >= bx0 && x <= bx1 && y >= by0 && y <= by1)) return false;
-    }
-    if (!ray_tracing(x, y, S + ATC_C_TRI_H, 4)) return false;
-    const float fx = S[ATC_C_FAF_X], fy = S[ATC_C_FAF_Y], nx = S[ATC_C_NRM_X], ny = S[ATC_C_NRM_Y];
+__device__ __forceinline__ bool inside_corridor(const float* __restrict__ K, float x, float y, float h, float phi) {
+    // exact early-out: a point the crossing test accepts lies within the ring's bounds (precomputed on the host)
+    if (!(x >= K[ATC_C_TRI_BBOX] && x <= K[ATC_C_TRI_BBOX + 2] && y >= K[ATC_C_TRI_BBOX + 1] && y <= K[ATC_C_TRI_BBOX + 3]))
+        return false;
+    if (!ray_tracing(x, y, K + ATC_C_TRI_H, 4)) return false;
+    const float fx = K[ATC_C_FAF_X], fy = K[ATC_C_FAF_Y], nx = K[ATC_C_NRM_X], ny = K[ATC_C_NRM_Y];
     const float t = (x - fx) * nx + (y - fy) * ny;
     const float px = fx + t * nx, py = fy + t * ny;
-    const float dx = px - S[ATC_C_RWY_X], dy = py - S[ATC_C_RWY_Y];
+    const float dx = px - K[ATC_C_RWY_X], dy = py - K[ATC_C_RWY_Y];
     const float nrm = sqrtf(dx * dx + dy * dy);
-    const float h_max = nrm * S[ATC_C_GS_TAN] * S[ATC_C_NM_TO_FT] + S[ATC_C_RWY_H];
+    const float h_max = nrm * K[ATC_C_GS_TAN] * K[ATC_C_NM_TO_FT] + K[ATC_C_RWY_H];
     if (!(h <= h_max)) return false;
-    return inside_corridor_angle(S, x, y, phi);
+    return inside_corridor_angle(K, x, y, phi);
 }
 
 // atc_gym.py:17-19  (1 - tanh(4 d/dmax - 2)) / 2  ==  1 / (1 + exp(2 (4 d/dmax - 2)))   [exact identity]
@@ -202,14 +203,14 @@ struct Shaping {
     float pos, ang, gs;
 };
 // atc_gym.py:199-260: _reward_approach_position, _reward_approach_angle, _reward_glideslope
-__device__ __forceinline__ Shaping shaping_rewards(const float* S, float d_faf, float phi_rel_faf, float plane_to_runway,
+__device__ __forceinline__ Shaping shaping_rewards(const float* __restrict__ K, float d_faf, float phi_rel_faf, float plane_to_runway,
                                                    float h, float on_gp) {
     // plane_to_runway = relative_angle(phi_to_runway, phi_plane): the caller already has it as obs[9]
-    const float to_rwy = S[ATC_C_PHI_TO_RWY];
+    const float to_rwy = K[ATC_C_PHI_TO_RWY];
     Shaping r;
     const float rel_faf = relative_angle(to_rwy, phi_rel_faf);
     const float u = fabsf(rel_faf) * (1.0f / 180.0f);
-    r.pos = sigmoid_distance(d_faf, fast_rcp(S[ATC_C_WORLD_DIAG])) * (u * fast_sqrt(u)) * 0.8f;  // u ** 1.5
+    r.pos = sigmoid_distance(d_faf, fast_rcp(K[ATC_C_WORLD_DIAG])) * (u * fast_sqrt(u)) * 0.8f;  // u ** 1.5
     const float side = (rel_faf > 0.0f) ? 1.0f : ((rel_faf < 0.0f) ? -1.0f : 0.0f);  // np.sign
     const float q = (side * plane_to_runway - 22.5f) * (1.0f / 202.0f);
     float m = -(q * q) + 1.0f;  // (-(q ** 2.0) + 1.0) ** 32.0 by five squarings (even power: sign-safe)
@@ -241,9 +242,10 @@ struct Aircraft {
 };
 
 // atc_gym.py:346-348 + model.py:13-52: aircraft k of env e enters at an entry point.
-__device__ __forceinline__ Aircraft spawn(const float* S, const atc_params_t& p, int e, int k, int episode) {
-    const int n_entry = (int)S[ATC_H_N_ENTRY];
-    const float* tab = S + (int)S[ATC_H_OFF_ENTRY];
+__device__ __forceinline__ Aircraft spawn(const float* __restrict__ K, const float* S, const atc_params_t& p, int e, int k,
+                                          int episode) {
+    const int n_entry = (int)K[ATC_H_N_ENTRY];
+    const float* tab = S + (int)K[ATC_H_OFF_ENTRY];
     int ei, li;
     if (p.mode & ATC_M_RANDOM_ENTRY) {
         const uint64_t u = draw(p.seed, (uint32_t)e, (uint32_t)episode, (uint32_t)k);
@@ -259,7 +261,7 @@ __device__ __forceinline__ Aircraft spawn(const float* S, const atc_params_t& p,
     a.y = (double)rec[ATC_E_Y];
     a.phi = rec[ATC_E_PHI];
     a.h = rec[ATC_E_LEV0 + li] * 100.0f;
-    a.v = S[ATC_C_V_INIT];
+    a.v = K[ATC_C_V_INIT];
     return a;
 }
 
@@ -268,13 +270,13 @@ struct Obs {
     float d_faf, phi_rel_faf, on_gp;
 };
 // atc_gym.py:262-297 _get_state
-__device__ __forceinline__ Obs get_state(const float* S, float x, float y, float h, float phi, float v, float mva) {
+__device__ __forceinline__ Obs get_state(const float* __restrict__ K, float x, float y, float h, float phi, float v, float mva) {
     Obs r;
-    const float to_faf_x = S[ATC_C_FAF_X] - x;
-    const float to_faf_y = S[ATC_C_FAF_Y] - y;
+    const float to_faf_x = K[ATC_C_FAF_X] - x;
+    const float to_faf_y = K[ATC_C_FAF_Y] - y;
     r.d_faf = fast_sqrt(fmaf(to_faf_x, to_faf_x, to_faf_y * to_faf_y));   // np.hypot (value-only)
     r.phi_rel_faf = atan2_deg(to_faf_y, to_faf_x);                        // np.degrees(np.arctan2) (value-only)
-    r.on_gp = 318.4f * r.d_faf + S[ATC_C_FAF_MVA] - 200.0f;
+    r.on_gp = 318.4f * r.d_faf + K[ATC_C_FAF_MVA] - 200.0f;
     r.o[0] = x;
     r.o[1] = y;
     r.o[2] = h;
@@ -284,7 +286,7 @@ __device__ __forceinline__ Obs get_state(const float* S, float x, float y, float
     r.o[6] = r.on_gp;
     r.o[7] = r.d_faf;
     r.o[8] = r.phi_rel_faf;
-    r.o[9] = relative_angle(S[ATC_C_PHI_TO_RWY], phi);
+    r.o[9] = relative_angle(K[ATC_C_PHI_TO_RWY], phi);
     return r;
 }
 

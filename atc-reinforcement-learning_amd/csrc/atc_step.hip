@@ -54,6 +54,7 @@ static int fail_hip(hipError_t e, const char* what) {
     } while (0)
 
 constexpr int kBlock = 256;
+constexpr int kStepExtraWords = 32;  // LDS words after the sector in k_step: norm scale/shift (2 x 12) + grid header (8)
 #ifndef ATC_ABLATE
 #define ATC_ABLATE 0  // developer-only timing ablations (tools/ablate.sh); the shipped build always uses 0
 #endif
@@ -93,6 +94,28 @@ __device__ __forceinline__ uint64_t group_ballot(bool pred, int lane) {
     return (b >> base) & ((1ull << W) - 1ull);
 }
 
+// Separation scan for N = 16: one env = one DPP row (16 lanes).  Partner state arrives by row rotation (v_*_dpp
+// row_ror:D, D = 1..15 visits every other lane of the row exactly once) — no LDS, no waits, no branches.
+template <int D>
+__device__ __forceinline__ float row_ror(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + D, 0xf, 0xf, false));
+}
+template <int D>
+struct PairScan16 {
+    static __device__ __forceinline__ void run(float xs, float y, float h, float sep2, float sep_ft, float& min_d2,
+                                               int& conflict) {
+        const float dx = xs - row_ror<D>(xs), dy = y - row_ror<D>(y), dh = h - row_ror<D>(h);
+        const float d2 = fmaf(dx, dx, dy * dy);
+        min_d2 = fminf(min_d2, d2);
+        conflict |= (int)(d2 < sep2) & (int)(fabsf(dh) < sep_ft);
+        PairScan16<D + 1>::run(xs, y, h, sep2, sep_ft, min_d2, conflict);
+    }
+};
+template <>
+struct PairScan16<16> {
+    static __device__ __forceinline__ void run(float, float, float, float, float, float&, int&) {}
+};
+
 __device__ __forceinline__ void stage_sector(float* S, const float* __restrict__ blob, int lds_words) {
     for (int i = threadIdx.x; i < lds_words; i += kBlock) S[i] = blob[i];
     __syncthreads();
@@ -107,8 +130,14 @@ __device__ __forceinline__ void store_obs(float* __restrict__ dst, const float* 
 
 // ---------------------------------------------------------------------------------------------------------------
 // step / rollout kernel
+//   FULL = false : the fast variant — obs, reward, done, flags only (what step() returns); the optional outputs
+//                  (raw_obs, ac_reward, min_sep, term_obs) and their pointers are compiled out.
+//   One workgroup handles 256 consecutive slots (no grid-stride loop: with a loop the compiler hoists the uniform loads
+//   out of it and spills the scalar registers that then stay live across the whole body).
+//   The body is straight-line for every lane: lanes whose aircraft is not under control compute on their frozen state and
+//   the results are discarded by selects; only the rare paths (dirty grid cells, corridor interior, auto-reset) branch.
 // ---------------------------------------------------------------------------------------------------------------
-template <int W>
+template <int W, bool FULL>
 __global__ void __launch_bounds__(kBlock, ATC_MIN_WAVES)
 k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N, int T, atc_state_t st,
        const float* __restrict__ actions, atc_out_t out, atc_params_t p) {
@@ -117,13 +146,17 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
     const int w0 = (lds_words + 3) & ~3;
     float* normA = smem + w0;        // [10] 1 / (0.5 max)                       (atc_gym.py:187-189 as one fma)
     float* normB = smem + w0 + 12;   // [10] -(min + 0.5 max) / (0.5 max)
-    float4* pos = reinterpret_cast<float4*>(smem + w0 + 24);                 // [kBlock] pair-scan staging
-    float* obs_stage = smem + w0 + 24 + (W > 1 ? kBlock * 4 : 0);             // [4 waves][64 x 10] obs transpose
+    float* gh = smem + w0 + 24;      // [8]  lookup-grid header
+    float4* pos = reinterpret_cast<float4*>(smem + w0 + kStepExtraWords);    // [kBlock] pair-scan staging (W != 16)
+    float* obs_stage = smem + w0 + kStepExtraWords + (W > 1 ? kBlock * 4 : 0);  // [4 waves][64 x 10] obs transpose
+    const float* __restrict__ K = blob;  // uniform-index constant reads -> scalar loads
     stage_sector(S, blob, lds_words);
     if (threadIdx.x < ATC_OBS_DIM) {
         const float half = 0.5f * S[ATC_C_NORM_MAX + threadIdx.x];
         normA[threadIdx.x] = 1.0f / half;
         normB[threadIdx.x] = -(S[ATC_C_NORM_MIN + threadIdx.x] + half) / half;
+    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + ATC_G_HDR) {
+        gh[threadIdx.x - 64] = off_grid ? blob[off_grid + threadIdx.x - 64] : 0.0f;
     }
     __syncthreads();
     const float* grid = off_grid ? blob + off_grid : nullptr;
@@ -132,298 +165,286 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
     const int lane = tid & 63;
     const uint32_t BN = (uint32_t)B * (uint32_t)N;      // host guarantees B*N*40 bytes < 4 GiB: 32-bit lane offsets
     const uint32_t slots = (uint32_t)B * (uint32_t)W;
+    const uint32_t slot0 = blockIdx.x * kBlock;
+    const uint32_t slot = slot0 + tid;
+    const bool env_valid = slot < slots;
+    const int e = env_valid ? (int)(slot / W) : B - 1;  // clamped: loads stay in bounds, results are never stored
+    const int k = (int)(slot % W);
+    const bool lane_valid = env_valid && k < N;
+    const uint32_t i = lane_valid ? (uint32_t)e * (uint32_t)N + (uint32_t)k : BN - 1u;
+
+    // ---- load persistent state (16-byte records; the W lanes of an env share the env record) -------------------------
+    const int4* erp = reinterpret_cast<const int4*>(st.env) + (uint32_t)e * (ATC_ENV_WORDS / 4);
+    const int4 e0 = erp[0], e1 = erp[1], e2 = erp[2];
+    int t = e0.x, n_actions = e0.y, episode = e0.z, ep_length = e0.w;
+    float total_reward = __int_as_float(e1.x), ep_return = __int_as_float(e1.y);
+    uint32_t win_bits = (uint32_t)e1.z;
+    uint64_t amask = (uint64_t)(uint32_t)e2.x | ((uint64_t)(uint32_t)e2.y << 32);
+    const double2 ps = reinterpret_cast<const double2*>(st.pos)[i];
+    const float4 kn = reinterpret_cast<const float4*>(st.kin)[i];
+    const float2 lv = reinterpret_cast<const float2*>(st.last_vh)[i];
+    Aircraft a = {ps.x, ps.y, kn.x, kn.y, kn.z};
+    float la_p = kn.w, la_v = lv.x, la_h = lv.y;
+    bool la_changed = false;
+
     const float dt = p.dt;
     const bool discrete = (p.mode & ATC_M_DISCRETE) != 0;
-    const float v_min = S[ATC_C_V_MIN], v_max = S[ATC_C_V_MAX], h_min = S[ATC_C_H_MIN], h_max = S[ATC_C_H_MAX];
-    // atc_gym.py:64-78
-    const float fac_v = discrete ? 10.0f : v_max - v_min;
-    const float fac_h = discrete ? 100.0f : h_max;
-    const float fac_p = discrete ? 1.0f : 360.0f;
-    const float off_v = v_min;
-    const float sep2 = p.sep_nm * p.sep_nm;
     const uint64_t full_mask = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
-    const int n_mva = (int)S[ATC_H_N_MVA];
-    const int n_noise = (int)S[ATC_H_N_NOISE];
-    const float* polytab = S + (int)S[ATC_H_OFF_POLY];
 
-    for (uint32_t slot0 = blockIdx.x * kBlock; slot0 < slots; slot0 += gridDim.x * kBlock) {
-        const uint32_t slot = slot0 + tid;
-        const int e = (int)(slot / W);
-        const int k = (int)(slot % W);
-        const bool env_valid = slot < slots;
-        const bool lane_valid = env_valid && k < N;
-        const uint32_t i = (uint32_t)e * (uint32_t)N + (uint32_t)k;
+    for (int step = 0; step < T; ++step) {
+        const size_t sBN = (size_t)step * BN, sB = (size_t)step * (uint32_t)B;  // uniform (scalar) per-step bases
+        const float* act_t = actions + sBN * 3;
+        float* obs_t = out.obs + sBN * ATC_OBS_DIM;
+        t += 1;  // atc_gym.py:135
+        const bool active = lane_valid && ((amask >> k) & 1ull);
+        uint32_t fl = 0;
+        float r = -0.05f * dt;  // atc_gym.py:137
+        int acts = 0;
 
-        // ---- load persistent state (16-byte records; the W lanes of an env share the env record) ---------------------
-        int t = 0, n_actions = 0, episode = 0, ep_length = 0;
-        float total_reward = 0.0f, ep_return = 0.0f;
-        uint32_t win_bits = 0;
-        uint64_t amask = 0;
-        if (env_valid) {
-            const int4* er = reinterpret_cast<const int4*>(st.env) + (uint32_t)e * (ATC_ENV_WORDS / 4);
-            const int4 e0 = er[0], e1 = er[1], e2 = er[2];
-            t = e0.x;
-            n_actions = e0.y;
-            episode = e0.z;
-            ep_length = e0.w;
-            total_reward = __int_as_float(e1.x);
-            ep_return = __int_as_float(e1.y);
-            win_bits = (uint32_t)e1.z;
-            amask = (uint64_t)(uint32_t)e2.x | ((uint64_t)(uint32_t)e2.y << 32);
-        }
-        Aircraft a = {0.0, 0.0, 0.0f, 0.0f, 0.0f};
-        float la_v = 0.0f, la_h = 0.0f, la_p = 0.0f;
-        float la_v0 = 0.0f, la_h0 = 0.0f;
-        if (lane_valid) {
-            const double2 ps = reinterpret_cast<const double2*>(st.pos)[i];
-            const float4 kn = reinterpret_cast<const float4*>(st.kin)[i];
-            const float2 lv = reinterpret_cast<const float2*>(st.last_vh)[i];
-            a.x = ps.x;
-            a.y = ps.y;
-            a.h = kn.x;
-            a.phi = kn.y;
-            a.v = kn.z;
-            la_p = kn.w;
-            la_v = la_v0 = lv.x;
-            la_h = la_h0 = lv.y;
-        }
-
-        for (int step = 0; step < T; ++step) {
-            const size_t sBN = (size_t)step * BN, sB = (size_t)step * (uint32_t)B;  // uniform (scalar) per-step bases
-            const float* act_t = actions + sBN * 3;
-            float* obs_t = out.obs + sBN * ATC_OBS_DIM;
-            t += 1;  // atc_gym.py:135
-            const bool active = lane_valid && ((amask >> k) & 1ull);
-            uint32_t fl = lane_valid ? (active ? 0u : (uint32_t)ATC_F_INACTIVE) : 0u;
-            float r = 0.0f;
-            int acts = 0;
-            float mva = 0.0f;
-            float x32 = 0.0f, y32 = 0.0f;
-
-            if (active) {
-                const float a_v = act_t[i * 3u + 0u], a_h = act_t[i * 3u + 1u], a_p = act_t[i * 3u + 2u];
-                r = -0.05f * dt;  // atc_gym.py:137
-                // ---- _action_with_reward x3 (atc_gym.py:139-141,299-335) -> Airplane.action_* (model.py:60-120) ----
-                const float tv = discrete ? a_v * fac_v + off_v : a_v * fac_v / 2.0f + fac_v / 2.0f + off_v;
-                const float th = discrete ? a_h * fac_h + 0.0f : a_h * fac_h / 2.0f + fac_h / 2.0f + 0.0f;
-                const float tp = discrete ? a_p * fac_p + 0.0f : a_p * fac_p / 2.0f + fac_p / 2.0f + 0.0f;
-                if (tv < v_min || tv > v_max) {
-                    r -= 1.0f;
-                    fl |= ATC_F_INVALID_V;
-                } else {
-                    float d = tv - a.v;
-                    d = fminf(d, S[ATC_C_A_MAX] * dt);
-                    d = fmaxf(d, S[ATC_C_A_MIN] * dt);
-                    a.v = a.v + d;
-                    if (!(fabsf(tv - la_v) < S[ATC_C_ACT_DISCR + 0])) acts += 1;
-                    la_v = tv;
-                }
-                if (th < h_min || th > h_max) {
-                    r -= 1.0f;
-                    fl |= ATC_F_INVALID_H;
-                } else {
-                    float d = th - a.h;
-                    d = fminf(d, S[ATC_C_HDOT_MAX] * dt);
-                    d = fmaxf(d, S[ATC_C_HDOT_MIN] * dt);
-                    a.h = a.h + d;
-                    if (!(fabsf(th - la_h) < S[ATC_C_ACT_DISCR + 1])) acts += 1;
-                    la_h = th;
-                }
-                {
-                    float d = tp - a.phi;
-                    d = fminf(d, S[ATC_C_PHIDOT_MAX] * dt);
-                    d = fmaxf(d, S[ATC_C_PHIDOT_MIN] * dt);
-                    a.phi = a.phi + d;
-                    if (!(fabsf(tp - la_p) < S[ATC_C_ACT_DISCR + 2])) acts += 1;
-                    la_p = tp;
-                }
-                // ---- Airplane.step (model.py:122-129): rot_matrix(phi) . [0, (v/3600) dt] ----------------------------
-                const float dist = (a.v / 3600.0f) * dt;
-                float sn, cs;
-                if (ATC_ABLATE & 32) { sn = 0.6f; cs = 0.8f; } else sincos_deg(a.phi, &sn, &cs);
-                a.x += (double)(sn * dist);
-                a.y += (double)(cs * dist);
-                x32 = (float)a.x;
-                y32 = (float)a.y;
-                // ---- MVA floor (atc_gym.py:146-161) ------------------------------------------------------------------
-                const int pi = (ATC_ABLATE & 1) ? 0 : find_mva(S, grid, x32, y32);
-                if (pi >= 0) {
-                    mva = polytab[pi * ATC_P_WORDS + ATC_P_HEIGHT];
-                    if (a.h < mva) {
-                        r = -200.0f;
-                        fl |= ATC_F_BELOW_MVA;
-                    }
-                } else {
-                    r = -50.0f;
-                    fl |= ATC_F_OUTSIDE;
-                    mva = 0.0f;
-                }
+        // ---- _action_with_reward x3 (atc_gym.py:139-141,299-335) -> Airplane.action_* (model.py:60-120) --------------
+        // branch-free form of: invalid target -> ValueError -> -1 reward, nothing applied, last_action kept
+        // (atc_gym.py:303-315); valid -> rate-limited move, actions_taken++ unless |target - last| < discriminator
+        {
+            const float a_v = act_t[i * 3u + 0u], a_h = act_t[i * 3u + 1u], a_p = act_t[i * 3u + 2u];
+            const float v_min = K[ATC_C_V_MIN], v_max = K[ATC_C_V_MAX], h_min = K[ATC_C_H_MIN], h_max = K[ATC_C_H_MAX];
+            // atc_gym.py:64-78: offset (v_min,0,0); factor (10,100,1) discrete | (v_max-v_min, h_max, 360) continuous
+            const float fac_v = discrete ? 10.0f : v_max - v_min;
+            const float fac_h = discrete ? 100.0f : h_max;
+            const float fac_p = discrete ? 1.0f : 360.0f;
+            const float tv = discrete ? a_v * fac_v + v_min : a_v * fac_v / 2.0f + fac_v / 2.0f + v_min;
+            const float th = discrete ? a_h * fac_h + 0.0f : a_h * fac_h / 2.0f + fac_h / 2.0f + 0.0f;
+            const float tp = discrete ? a_p * fac_p + 0.0f : a_p * fac_p / 2.0f + fac_p / 2.0f + 0.0f;
+            {
+                const bool valid = !(tv < v_min || tv > v_max);
+                const bool ok = valid && active;
+                float d = tv - a.v;
+                d = fminf(d, K[ATC_C_A_MAX] * dt);
+                d = fmaxf(d, K[ATC_C_A_MIN] * dt);
+                a.v = ok ? a.v + d : a.v;
+                acts += (ok && !(fabsf(tv - la_v) < K[ATC_C_ACT_DISCR + 0])) ? 1 : 0;
+                la_changed = la_changed || (ok && tv != la_v);
+                la_v = ok ? tv : la_v;
+                r = valid ? r : r - 1.0f;
+                fl |= valid ? 0u : (uint32_t)ATC_F_INVALID_V;
             }
+            {
+                const bool valid = !(th < h_min || th > h_max);
+                const bool ok = valid && active;
+                float d = th - a.h;
+                d = fminf(d, K[ATC_C_HDOT_MAX] * dt);
+                d = fmaxf(d, K[ATC_C_HDOT_MIN] * dt);
+                a.h = ok ? a.h + d : a.h;
+                acts += (ok && !(fabsf(th - la_h) < K[ATC_C_ACT_DISCR + 1])) ? 1 : 0;
+                la_changed = la_changed || (ok && th != la_h);
+                la_h = ok ? th : la_h;
+                r = valid ? r : r - 1.0f;
+                fl |= valid ? 0u : (uint32_t)ATC_F_INVALID_H;
+            }
+            {
+                float d = tp - a.phi;
+                d = fminf(d, K[ATC_C_PHIDOT_MAX] * dt);
+                d = fmaxf(d, K[ATC_C_PHIDOT_MIN] * dt);
+                a.phi = active ? a.phi + d : a.phi;
+                acts += (active && !(fabsf(tp - la_p) < K[ATC_C_ACT_DISCR + 2])) ? 1 : 0;
+                la_p = active ? tp : la_p;
+            }
+        }
+        // ---- Airplane.step (model.py:122-129): rot_matrix(phi) . [0, (v/3600) dt] ------------------------------------
+        {
+            const float dist = active ? (a.v / 3600.0f) * dt : 0.0f;
+            float sn, cs;
+            if (ATC_ABLATE & 32) { sn = 0.6f; cs = 0.8f; } else sincos_deg(a.phi, &sn, &cs);
+            a.x += (double)(sn * dist);
+            a.y += (double)(cs * dist);
+        }
+        const float x32 = (float)a.x, y32 = (float)a.y;
+        // ---- MVA floor (atc_gym.py:146-161) ----------------------------------------------------------------------------
+        float mva = 0.0f;
+        {
+            const int pi = (ATC_ABLATE & 1) ? 0 : find_mva(K, S, gh, grid, x32, y32);
+            const float hgt = S[(int)K[ATC_H_OFF_POLY] + (pi < 0 ? 0 : pi) * ATC_P_WORDS + ATC_P_HEIGHT];
+            mva = pi >= 0 ? hgt : 0.0f;                    // atc_gym.py:161: mva = 0 outside
+            const bool below = pi >= 0 && a.h < mva;
+            r = pi < 0 ? -50.0f : (below ? -200.0f : r);
+            fl |= pi < 0 ? (uint32_t)ATC_F_OUTSIDE : (below ? (uint32_t)ATC_F_BELOW_MVA : 0u);
+        }
 
-            // ---- separation scan (extension; README.md:51): 3 nm / 1000 ft among aircraft active at step start ------
-            float min_d2 = 1e30f;
-            if (W > 1 && !(ATC_ABLATE & 2)) {
-                pos[tid] = make_float4(x32, y32, a.h, active ? 1.0f : 0.0f);
+        // ---- separation scan (extension; README.md:51): 3 nm / 1000 ft among aircraft active at step start -----------
+        // Every lane visits its env's other W-1 slots (never itself); aircraft that are not under control are staged
+        // at x = 1e18 so that they neither conflict nor enter the minimum — branch-free.
+        float min_d2 = 1e30f;
+        if (W > 1 && !(ATC_ABLATE & 2)) {
+            const float xs = active ? x32 : 1e18f;
+            const float sep2 = p.sep_nm * p.sep_nm;
+            int conflict = 0;
+            if (W == 16) {
+                PairScan16<1>::run(xs, y32, a.h, sep2, p.sep_ft, min_d2, conflict);
+            } else {
+                pos[tid] = make_float4(xs, y32, a.h, 0.0f);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const int gbase = tid & ~(W - 1);
-                bool conflict = false;
-#pragma unroll 4
-                for (int j = 0; j < W; ++j) {
-                    const float4 q = pos[gbase + j];
-                    const float dx = x32 - q.x, dy = y32 - q.y;
-                    const float d2 = dx * dx + dy * dy;
-                    const bool other = (j != k) && (q.w != 0.0f);
-                    if (other) {
+                constexpr int U = (W >= 32) ? 3 : (W >= 8 ? 7 : (W > 1 ? W - 1 : 1));  // per batch: 63 = 21x3, 31 = 10x3+1
+#pragma unroll 1
+                for (int d0 = 1; d0 < W; d0 += U) {
+                    float4 q[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) q[u] = pos[gbase + ((k + d0 + u) & (W - 1))];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const float dx = xs - q[u].x, dy = y32 - q[u].y;
+                        const float d2 = (d0 + u < W) ? fmaf(dx, dx, dy * dy) : 1e36f;  // tail of the last batch
                         min_d2 = fminf(min_d2, d2);
-                        if (d2 < sep2 && fabsf(a.h - q.z) < p.sep_ft) conflict = true;
+                        conflict |= (int)(d2 < sep2) & (int)(fabsf(a.h - q[u].z) < p.sep_ft);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (active && conflict) {
-                    r = p.conflict_reward;
-                    fl |= ATC_F_CONFLICT;
-                }
-                if (!active) min_d2 = 1e30f;
             }
-
-            // ---- win / timeout overrides, observation, shaping (atc_gym.py:163-189) ---------------------------------
-            float o[ATC_OBS_DIM];
-#pragma unroll
-            for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = 0.0f;
-            if (active) {
-                if (!(ATC_ABLATE & 4) && inside_corridor(S, x32, y32, a.h, a.phi)) {
-                    int bonus = (p.timestep_limit - t) * 5;
-                    bonus = bonus < 0 ? 0 : bonus;
-                    r = (float)(10000 + bonus);
-                    fl |= ATC_F_WON;
-                }
-                if (t > p.timestep_limit) {
-                    r = -200.0f;
-                    fl |= ATC_F_TIMEOUT;
-                }
-                Obs ob;
-                if (ATC_ABLATE & 8) {
-#pragma unroll
-                    for (int c = 0; c < ATC_OBS_DIM; ++c) ob.o[c] = x32;
-                    ob.d_faf = ob.phi_rel_faf = ob.on_gp = y32;
-                } else {
-                    ob = get_state(S, x32, y32, a.h, a.phi, a.v, mva);
-                }
-                if ((p.mode & ATC_M_REWARD_SHAPING) && !(ATC_ABLATE & 8)) {
-                    const Shaping sh = shaping_rewards(S, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp);
-                    r += sh.pos;
-                    r += sh.ang;
-                    r += sh.gs;
-                }
-                for (int q = 0; q < n_noise; ++q) {  // extension (README.md:62): noise-abatement areas
-                    const float* rec = polytab + (n_mva + q) * ATC_P_WORDS;
-                    if (rec[ATC_P_MINX] <= x32 && x32 <= rec[ATC_P_MAXX] && rec[ATC_P_MINY] <= y32 &&
-                        y32 <= rec[ATC_P_MAXY] && a.h < rec[ATC_P_HEIGHT] &&
-                        ray_tracing(x32, y32, S + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT])) {
-                        r -= rec[ATC_P_PENALTY];
-                        fl |= ATC_F_NOISE;
-                    }
-                }
-                if (out.raw_obs) store_obs(out.raw_obs + sBN * ATC_OBS_DIM + i * ATC_OBS_DIM, ob.o);
-                if (p.mode & ATC_M_NORMALIZE) {  // atc_gym.py:187-189: (s - min - max/2) / (max/2) as one fma
-#pragma unroll
-                    for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = fmaf(ob.o[c], normA[c], normB[c]);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = ob.o[c];
-                }
-            } else if (lane_valid && out.raw_obs) {
-                store_obs(out.raw_obs + sBN * ATC_OBS_DIM + i * ATC_OBS_DIM, o);  // zeros for handed-over aircraft
-            }
-
-            // ---- per-env reductions over the W lanes of the group ----------------------------------------------------
-            const float env_r = group_sum<W>(r);
-            const int env_acts = group_sum_i<W>(acts);
-            const uint64_t won = group_ballot<W>((fl & ATC_F_WON) != 0, lane);
-            const uint64_t term = group_ballot<W>(
-                (fl & (ATC_F_BELOW_MVA | ATC_F_OUTSIDE | ATC_F_CONFLICT | ATC_F_TIMEOUT)) != 0, lane);
-            const uint64_t amask1 = amask & ~won;
-            const bool done = env_valid && (term != 0 || amask1 == 0);
-            total_reward += env_r;  // atc_gym.py:194-197
-            n_actions += env_acts;
-            amask = amask1;
-
-            if (lane_valid) {
-                (out.flags + sBN)[i] = fl;
-                if (out.ac_reward) (out.ac_reward + sBN)[i] = r;
-            }
-            if (env_valid && k == 0) {
-                (out.reward + sB)[e] = env_r;
-                (out.done + sB)[e] = done ? 1 : 0;
-            }
-            if (W > 1) {
-                const float m2 = group_min<W>(min_d2);
-                const float ms = (m2 >= 1e30f) ? 1e30f : sqrtf(m2);
-                if (out.min_sep && env_valid && k == 0) (out.min_sep + sB)[e] = ms;
-            } else if (out.min_sep && env_valid) {
-                (out.min_sep + sB)[e] = 1e30f;
-            }
-
-            if (done && (p.mode & ATC_M_AUTO_RESET)) {
-                // VecEnv semantics: the env restarts inside the step; the returned obs is the RAW reset state
-                // (atc_gym.py:351,365: reset() returns the un-normalised state computed with mva = 0).
-                ep_return = total_reward;
-                ep_length = t;
-                win_bits = ((win_bits << 1) | (amask == 0 ? 1u : 0u)) & 0x3ffu;
-                if (lane_valid) {
-                    if (out.term_obs) store_obs(out.term_obs + sBN * ATC_OBS_DIM + i * ATC_OBS_DIM, o);
-                    a = spawn(S, p, e, k, episode);
-                    const Obs ob = get_state(S, (float)a.x, (float)a.y, a.h, a.phi, a.v, 0.0f);
-#pragma unroll
-                    for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = ob.o[c];
-                }
-                total_reward = 0.0f;
-                n_actions = 0;
-                t = 0;
-                episode += 1;
-                amask = full_mask;
-            }
-            // ---- observation store: [aircraft][10] rows are 40 B apart, so per-lane stores would scatter 8-byte pieces
-            //      over 20 cache lines per instruction; a full wavefront instead transposes its 64 x 10 block through LDS
-            //      and writes 2 560 contiguous bytes as 16-byte stores.
-            const bool wave_full = (N == W) && (slot0 + (uint32_t)(tid | 63) < slots);
-            if (ATC_ABLATE & 16) {
-                if (lane_valid && o[0] == 12345.678f) obs_t[i] = o[1];
-            } else if (wave_full) {
-                float* tb = obs_stage + (tid >> 6) * (64 * ATC_OBS_DIM);
-#pragma unroll
-                for (int c = 0; c < ATC_OBS_DIM; ++c) tb[lane * ATC_OBS_DIM + c] = o[c];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                float4* dst = reinterpret_cast<float4*>(obs_t + (size_t)(slot0 + (uint32_t)(tid & ~63)) * ATC_OBS_DIM);
-                const float4* src = reinterpret_cast<const float4*>(tb);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int idx = j * 64 + lane;
-                    if (idx < 64 * ATC_OBS_DIM / 4) dst[idx] = src[idx];
-                }
-                __builtin_amdgcn_wave_barrier();
-            } else if (lane_valid) {
-                store_obs(obs_t + i * ATC_OBS_DIM, o);
-            }
+            r = conflict ? p.conflict_reward : r;
+            fl |= conflict ? (uint32_t)ATC_F_CONFLICT : 0u;
         }
 
-        // ---- write back persistent state -------------------------------------------------------------------------------
+        // ---- win / timeout overrides (atc_gym.py:163-173) ---------------------------------------------------------------
+        if (!(ATC_ABLATE & 4) && inside_corridor(K, x32, y32, a.h, a.phi)) {
+            int bonus = (p.timestep_limit - t) * 5;
+            bonus = bonus < 0 ? 0 : bonus;
+            r = (float)(10000 + bonus);
+            fl |= ATC_F_WON;
+        }
+        {
+            const bool timeout = t > p.timestep_limit;
+            r = timeout ? -200.0f : r;
+            fl |= timeout ? (uint32_t)ATC_F_TIMEOUT : 0u;
+        }
+        // ---- observation, shaping, noise areas, normalisation (atc_gym.py:175-189) --------------------------------------
+        float o[ATC_OBS_DIM];
+        {
+            Obs ob;
+            if (ATC_ABLATE & 8) {
+#pragma unroll
+                for (int c = 0; c < ATC_OBS_DIM; ++c) ob.o[c] = x32;
+                ob.d_faf = ob.phi_rel_faf = ob.on_gp = y32;
+            } else {
+                ob = get_state(K, x32, y32, a.h, a.phi, a.v, mva);
+            }
+            if ((p.mode & ATC_M_REWARD_SHAPING) && !(ATC_ABLATE & 8)) {
+                const Shaping sh = shaping_rewards(K, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp);
+                r += sh.pos;
+                r += sh.ang;
+                r += sh.gs;
+            }
+            const int n_noise = (int)K[ATC_H_N_NOISE];
+            for (int q = 0; q < n_noise; ++q) {  // extension (README.md:62): noise-abatement areas
+                const float* rec = S + (int)K[ATC_H_OFF_POLY] + ((int)K[ATC_H_N_MVA] + q) * ATC_P_WORDS;
+                if (in_bounds(rec, x32, y32) && a.h < rec[ATC_P_HEIGHT] &&
+                    ray_tracing(x32, y32, S + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT])) {
+                    r -= rec[ATC_P_PENALTY];
+                    fl |= ATC_F_NOISE;
+                }
+            }
+            if (FULL && out.raw_obs && lane_valid) {
+                float z[ATC_OBS_DIM];
+#pragma unroll
+                for (int c = 0; c < ATC_OBS_DIM; ++c) z[c] = active ? ob.o[c] : 0.0f;  // zeros for handed-over aircraft
+                store_obs(out.raw_obs + sBN * ATC_OBS_DIM + i * ATC_OBS_DIM, z);
+            }
+            if (p.mode & ATC_M_NORMALIZE) {  // atc_gym.py:187-189: (s - min - max/2) / (max/2) as one fma
+#pragma unroll
+                for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = active ? fmaf(ob.o[c], normA[c], normB[c]) : 0.0f;
+            } else {
+#pragma unroll
+                for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = active ? ob.o[c] : 0.0f;
+            }
+        }
+        // lanes without an aircraft under control: nothing happened
+        r = active ? r : 0.0f;
+        acts = active ? acts : 0;
+        fl = active ? fl : (lane_valid ? (uint32_t)ATC_F_INACTIVE : 0u);
+        if (!active) min_d2 = 1e30f;
+
+        // ---- per-env reductions over the W lanes of the group ------------------------------------------------------------
+        const float env_r = group_sum<W>(r);
+        const int env_acts = group_sum_i<W>(acts);
+        const uint64_t won = group_ballot<W>((fl & ATC_F_WON) != 0, lane);
+        const uint64_t term = group_ballot<W>(
+            (fl & (ATC_F_BELOW_MVA | ATC_F_OUTSIDE | ATC_F_CONFLICT | ATC_F_TIMEOUT)) != 0, lane);
+        amask &= ~won;
+        const bool done = env_valid && (term != 0 || amask == 0);
+        total_reward += env_r;  // atc_gym.py:194-197
+        n_actions += env_acts;
+
         if (lane_valid) {
-            reinterpret_cast<double2*>(st.pos)[i] = make_double2(a.x, a.y);
-            reinterpret_cast<float4*>(st.kin)[i] = make_float4(a.h, a.phi, a.v, la_p);
-            // actions are typically held for many steps: write last v/h targets back only where they changed
-            if (la_v != la_v0 || la_h != la_h0) reinterpret_cast<float2*>(st.last_vh)[i] = make_float2(la_v, la_h);
+            (out.flags + sBN)[i] = fl;
+            if (FULL && out.ac_reward) (out.ac_reward + sBN)[i] = r;
         }
         if (env_valid && k == 0) {
-            int4* er = reinterpret_cast<int4*>(st.env) + (uint32_t)e * (ATC_ENV_WORDS / 4);
-            er[0] = make_int4(t, n_actions, episode, ep_length);
-            er[1] = make_int4(__float_as_int(total_reward), __float_as_int(ep_return), (int)win_bits, 0);
-            er[2] = make_int4((int)(uint32_t)(amask & 0xffffffffu), (int)(uint32_t)(amask >> 32), 0, 0);
+            (out.reward + sB)[e] = env_r;
+            (out.done + sB)[e] = done ? 1 : 0;
         }
+        if (FULL && out.min_sep) {
+            const float m2 = (W > 1) ? group_min<W>(min_d2) : 1e30f;
+            if (env_valid && k == 0) (out.min_sep + sB)[e] = (m2 >= 1e30f) ? 1e30f : sqrtf(m2);
+        }
+
+        if (done && (p.mode & ATC_M_AUTO_RESET)) {
+            // VecEnv semantics: the env restarts inside the step; the returned obs is the RAW reset state
+            // (atc_gym.py:351,365: reset() returns the un-normalised state computed with mva = 0).
+            ep_return = total_reward;
+            ep_length = t;
+            win_bits = ((win_bits << 1) | (amask == 0 ? 1u : 0u)) & 0x3ffu;
+            if (lane_valid) {
+                if (FULL && out.term_obs) store_obs(out.term_obs + sBN * ATC_OBS_DIM + i * ATC_OBS_DIM, o);
+                a = spawn(K, S, p, e, k, episode);
+                const Obs ob = get_state(K, (float)a.x, (float)a.y, a.h, a.phi, a.v, 0.0f);
+#pragma unroll
+                for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = ob.o[c];
+            }
+            total_reward = 0.0f;
+            n_actions = 0;
+            t = 0;
+            episode += 1;
+            amask = full_mask;
+        }
+
+        // ---- observation store: [aircraft][10] rows are 40 B apart, so per-lane stores would scatter 8-byte pieces over
+        //      20 cache lines per instruction; a full wavefront instead transposes its 64 x 10 block through LDS and writes
+        //      2 560 contiguous bytes as 16-byte stores.
+        const bool wave_full = (N == W) && (slot0 + (uint32_t)(tid | 63) < slots);
+        if (ATC_ABLATE & 16) {
+            if (lane_valid && o[0] == 12345.678f) obs_t[i] = o[1];
+        } else if (wave_full) {
+            float* tb = obs_stage + (tid >> 6) * (64 * ATC_OBS_DIM);
+#pragma unroll
+            for (int c = 0; c < ATC_OBS_DIM; ++c) tb[lane * ATC_OBS_DIM + c] = o[c];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float4* dst = reinterpret_cast<float4*>(obs_t + (size_t)(slot0 + (uint32_t)(tid & ~63)) * ATC_OBS_DIM);
+            const float4* src = reinterpret_cast<const float4*>(tb);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int idx = j * 64 + lane;
+                if (idx < 64 * ATC_OBS_DIM / 4) dst[idx] = src[idx];
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else if (lane_valid) {
+            store_obs(obs_t + i * ATC_OBS_DIM, o);
+        }
+    }
+
+    // ---- write back persistent state ---------------------------------------------------------------------------------------
+    if (lane_valid) {
+        reinterpret_cast<double2*>(st.pos)[i] = make_double2(a.x, a.y);
+        reinterpret_cast<float4*>(st.kin)[i] = make_float4(a.h, a.phi, a.v, la_p);
+        // actions are typically held for many steps: write last v/h targets back only where they changed
+        if (la_changed) reinterpret_cast<float2*>(st.last_vh)[i] = make_float2(la_v, la_h);
+    }
+    if (env_valid && k == 0) {
+        int4* er = reinterpret_cast<int4*>(st.env) + (uint32_t)e * (ATC_ENV_WORDS / 4);
+        er[0] = make_int4(t, n_actions, episode, ep_length);
+        er[1] = make_int4(__float_as_int(total_reward), __float_as_int(ep_return), (int)win_bits, 0);
+        er[2] = make_int4((int)(uint32_t)(amask & 0xffffffffu), (int)(uint32_t)(amask >> 32), 0, 0);
     }
 }
 
@@ -441,14 +462,14 @@ k_reset(const float* __restrict__ blob, int lds_words, int B, int N, atc_state_t
         const int e = (int)(i / (uint32_t)N), k = (int)(i % (uint32_t)N);
         if (mask && !mask[e]) continue;
         const int episode = first ? 0 : st.env[(size_t)e * ATC_ENV_WORDS + ATC_ENV_EPISODES];
-        const Aircraft a = spawn(S, p, e, k, episode);
+        const Aircraft a = spawn(blob, S, p, e, k, episode);
         reinterpret_cast<double2*>(st.pos)[i] = make_double2(a.x, a.y);
         // atc_gym.py:86: last_action = [0,0,0] once, in __init__ — never on reset (quirk Q7)
         const float la_p = first ? 0.0f : st.kin[(size_t)i * 4 + 3];
         reinterpret_cast<float4*>(st.kin)[i] = make_float4(a.h, a.phi, a.v, la_p);
         if (first) reinterpret_cast<float2*>(st.last_vh)[i] = make_float2(0.0f, 0.0f);
         if (obs) {
-            const Obs ob = get_state(S, (float)a.x, (float)a.y, a.h, a.phi, a.v, 0.0f);  // mva = 0, atc_gym.py:351
+            const Obs ob = get_state(blob, (float)a.x, (float)a.y, a.h, a.phi, a.v, 0.0f);  // mva = 0, atc_gym.py:351
             store_obs(obs + (size_t)i * ATC_OBS_DIM, ob.o);
         }
     }
@@ -466,7 +487,7 @@ k_observe(const float* __restrict__ blob, int lds_words, int B, int N, atc_state
         if (mask && !mask[e]) continue;
         const double2 ps = reinterpret_cast<const double2*>(st.pos)[i];
         const float4 kn = reinterpret_cast<const float4*>(st.kin)[i];
-        const Obs ob = get_state(S, (float)ps.x, (float)ps.y, kn.x, kn.y, kn.z, 0.0f);
+        const Obs ob = get_state(blob, (float)ps.x, (float)ps.y, kn.x, kn.y, kn.z, 0.0f);
         store_obs(obs + (size_t)i * ATC_OBS_DIM, ob.o);
     }
 }
@@ -500,12 +521,14 @@ __global__ void __launch_bounds__(kBlock)
 k_query_mva(const float* __restrict__ blob, int lds_words, int off_grid, int n, const float* __restrict__ x,
             const float* __restrict__ y, int32_t* __restrict__ out_h, int32_t* __restrict__ out_idx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* gh = smem + ((lds_words + 3) & ~3);
+    if (threadIdx.x < ATC_G_HDR) gh[threadIdx.x] = off_grid ? blob[off_grid + threadIdx.x] : 0.0f;
     stage_sector(smem, blob, lds_words);
     const float* S = smem;
     const float* grid = off_grid ? blob + off_grid : nullptr;
     const float* polytab = S + (int)S[ATC_H_OFF_POLY];
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const int pi = find_mva(S, grid, x[i], y[i]);
+        const int pi = find_mva(blob, S, gh, grid, x[i], y[i]);
         if (out_h) out_h[i] = pi >= 0 ? (int32_t)polytab[pi * ATC_P_WORDS + ATC_P_HEIGHT] : -1;
         if (out_idx) out_idx[i] = pi;
     }
@@ -518,7 +541,8 @@ k_query_corridor(const float* __restrict__ blob, int lds_words, int n, const flo
     stage_sector(smem, blob, lds_words);
     const float* S = smem;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
-        out[i] = angle_only ? inside_corridor_angle(S, x[i], y[i], phi[i]) : inside_corridor(S, x[i], y[i], h[i], phi[i]);
+        out[i] = angle_only ? inside_corridor_angle(blob, x[i], y[i], phi[i])
+                            : inside_corridor(blob, x[i], y[i], h[i], phi[i]);
 }
 __global__ void __launch_bounds__(kBlock)
 k_query_shaping(const float* __restrict__ blob, int lds_words, int n, const float* __restrict__ d_faf,
@@ -528,7 +552,7 @@ k_query_shaping(const float* __restrict__ blob, int lds_words, int n, const floa
     stage_sector(smem, blob, lds_words);
     const float* S = smem;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const Shaping s = shaping_rewards(S, d_faf[i], phi_rel_faf[i], relative_angle(S[ATC_C_PHI_TO_RWY], phi_plane[i]),
+        const Shaping s = shaping_rewards(blob, d_faf[i], phi_rel_faf[i], relative_angle(blob[ATC_C_PHI_TO_RWY], phi_plane[i]),
                                           h[i], on_gp[i]);
         out3[3 * i + 0] = s.pos;
         out3[3 * i + 1] = s.ang;
@@ -548,23 +572,31 @@ static int grid_for(const atc_scenario* s, long long threads) {
 }
 static size_t lds_bytes(const atc_scenario* s, bool pair_scan, bool step_kernel = false) {
     size_t w = (size_t)((s->lds_words + 3) & ~3);
-    if (step_kernel) w += 24 + (size_t)(kBlock / 64) * 64 * ATC_OBS_DIM;  // norm scale/shift + obs transpose stage
+    if (step_kernel) w += kStepExtraWords + (size_t)(kBlock / 64) * 64 * ATC_OBS_DIM;  // + obs transpose stage
     if (pair_scan) w += (size_t)kBlock * 4;
     return w * sizeof(float);
 }
 
+template <int W, bool FULL>
+static int launch_step2(const atc_scenario* s, int B, int N, int T, const atc_state_t* st, const float* actions,
+                        const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
+    const size_t lds = lds_bytes(s, W > 1, true);
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<W, FULL>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long long slots = (long long)B * W;
+    const int grid = (int)((slots + kBlock - 1) / kBlock);  // one workgroup per 256 slots, no grid-stride loop
+    hipLaunchKernelGGL((k_step<W, FULL>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->lds_words, s->off_grid, B, N,
+                       T, *st, actions, *out, *p);
+    HIP_TRY(hipGetLastError());
+    return ATC_OK;
+}
 template <int W>
 static int launch_step(const atc_scenario* s, int B, int N, int T, const atc_state_t* st, const float* actions,
                        const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
-    const size_t lds = lds_bytes(s, W > 1, true);
-    if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<W>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
-    const int grid = grid_for(s, (long long)B * W);
-    hipLaunchKernelGGL(k_step<W>, dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->lds_words, s->off_grid, B, N, T, *st,
-                       actions, *out, *p);
-    HIP_TRY(hipGetLastError());
-    return ATC_OK;
+    const bool full = out->raw_obs || out->ac_reward || out->min_sep || out->term_obs;
+    return full ? launch_step2<W, true>(s, B, N, T, st, actions, out, p, stream)
+                : launch_step2<W, false>(s, B, N, T, st, actions, out, p, stream);
 }
 
 static int step_common(const atc_scenario_t* s, int B, int N, int T, const atc_state_t* st, const float* actions,
@@ -609,7 +641,7 @@ int atc_scenario_create(const float* blob_host, size_t n_words, int device, atc_
         return fail_hip(e, "hipGetDeviceProperties");
     }
     s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if ((size_t)s->lds_words * 4 + kBlock * 16 + 24 * 4 + 4 * 64 * ATC_OBS_DIM * 4 + 64 > 160 * 1024) {
+    if ((size_t)s->lds_words * 4 + kBlock * 16 + kStepExtraWords * 4 + 4 * 64 * ATC_OBS_DIM * 4 + 64 > 160 * 1024) {
         delete s;
         return fail_arg("sector does not fit the 160 KB LDS");
     }
@@ -639,8 +671,8 @@ int atc_query_mva(const atc_scenario_t* s, int n, const float* x, const float* y
                   void* stream) {
     if (!s || !x || !y || !out_h || n < 0) return fail_arg("null pointer / negative n");
     if (n == 0) return ATC_OK;
-    hipLaunchKernelGGL(k_query_mva, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false), (hipStream_t)stream, s->d_blob,
-                       s->lds_words, use_grid ? s->off_grid : 0, n, x, y, out_h, (int32_t*)nullptr);
+    hipLaunchKernelGGL(k_query_mva, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false) + 64, (hipStream_t)stream,
+                       s->d_blob, s->lds_words, use_grid ? s->off_grid : 0, n, x, y, out_h, (int32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     return ATC_OK;
 }
@@ -649,8 +681,8 @@ int atc_query_mva_index(const atc_scenario_t* s, int n, const float* x, const fl
                         void* stream) {
     if (!s || !x || !y || !out_idx || n < 0) return fail_arg("null pointer / negative n");
     if (n == 0) return ATC_OK;
-    hipLaunchKernelGGL(k_query_mva, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false), (hipStream_t)stream, s->d_blob,
-                       s->lds_words, use_grid ? s->off_grid : 0, n, x, y, (int32_t*)nullptr, out_idx);
+    hipLaunchKernelGGL(k_query_mva, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false) + 64, (hipStream_t)stream,
+                       s->d_blob, s->lds_words, use_grid ? s->off_grid : 0, n, x, y, (int32_t*)nullptr, out_idx);
     HIP_TRY(hipGetLastError());
     return ATC_OK;
 }

@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--aircraft", type=int, default=AIRCRAFT)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollout", type=int, default=0, help="fuse this many steps per launch (0 = one launch per step)")
+    ap.add_argument("--sep-nm", type=float, default=3.0, help="developer knob: separation minimum (0 disables conflicts)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -91,7 +92,8 @@ def main():
     B, N, K, W = args.envs, args.aircraft, args.steps, args.warmup
 
     scn = scenarios.LOWWDense() if N > 16 else scenarios.LOWW(random_entrypoints=N > 1)
-    env = AtcVecEnv(B, N, scenario=scn, device=local, auto_reset=True, seed=D.rank_seed(0, rank), grid_cell=0.5)
+    env = AtcVecEnv(B, N, scenario=scn, device=local, auto_reset=True, seed=D.rank_seed(0, rank), grid_cell=0.5,
+                    sep_nm=args.sep_nm)
 
     # action ring resident in HBM before timing (Philox, seed 0 + rank)
     g = torch.Generator(device=dev)

@@ -12,6 +12,7 @@
 #define REAL double
 #define SUFFIX _f64
 #define R_FMOD fmod
+#define R_FMA fma
 #define R_SIN sin
 #define R_COS cos
 #define R_ACOS acos
@@ -27,6 +28,7 @@
 #undef REAL
 #undef SUFFIX
 #undef R_FMOD
+#undef R_FMA
 #undef R_SIN
 #undef R_COS
 #undef R_ACOS
@@ -40,6 +42,7 @@
 #define REAL float
 #define SUFFIX _f32
 #define R_FMOD fmodf
+#define R_FMA fmaf
 #define R_SIN sinf
 #define R_COS cosf
 #define R_ACOS acosf

@@ -394,7 +394,7 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
                 if (fl[b] & ATC_F_INACTIVE) continue;
                 const size_t ia = (size_t)e * N + a, ib = (size_t)e * N + b;
                 REAL dx = (REAL)st->x[ia] - (REAL)st->x[ib], dy = (REAL)st->y[ia] - (REAL)st->y[ib];
-                REAL d2 = dx * dx + dy * dy;
+                REAL d2 = R_FMA(dx, dx, dy * dy); /* fused: the definition shared with the device kernel */
                 REAL dh = R_ABS(st->h[ia] - st->h[ib]);
                 REAL d = R_SQRT(d2);
                 if (d < min_sep) min_sep = d;

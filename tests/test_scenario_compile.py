@@ -79,8 +79,9 @@ def _walk_grid(b, g, tabs, x, y):
     inside = False
     for e in range(n):
         r = b[pool + (v + e) * L.GE_WORDS: pool + (v + e + 1) * L.GE_WORDS]
-        p1x, p1y, p2x, p2y, pi, fl = r[0], r[1], r[2], r[3], int(r[4]), int(r[5])
-        if y > min(p1y, p2y) and y <= max(p1y, p2y) and x <= max(p1x, p2x):
+        p1x, p1y, p2x, p2y, pi, fl = r[0], r[1], r[2], r[3], int(r[7]) // 4, int(r[7]) % 4
+        assert (r[4], r[5], r[6]) == (min(p1y, p2y), max(p1y, p2y), max(p1x, p2x))
+        if y > r[4] and y <= r[5] and x <= r[6]:
             cross = bool(fl & 2)
             if not cross:
                 xints = (y - p1y) * (p2x - p1x) / (p2y - p1y) + p1x
