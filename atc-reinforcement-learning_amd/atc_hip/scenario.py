@@ -110,7 +110,7 @@ GRID_F_LAST = 1.0        # last edge record of its polygon: evaluate the parity 
 GRID_F_CERTAIN = 2.0     # every point of the cell lies left of this edge: crossing needs no intersection test
 
 
-def build_grid(rings, bounds, bbox, cell, guard=None):
+def build_grid(rings, bounds, heights, bbox, cell, guard=None):
     """Uniform lookup grid for Airspace.find_mva (model.py:282-289) with IDENTICAL results to the ordered polygon scan.
 
     * CLEAN cell: no edge of any MVA polygon comes within `guard` of it, so every point of the cell gets the answer of its
@@ -126,8 +126,8 @@ def build_grid(rings, bounds, bbox, cell, guard=None):
     cell because of fp32 rounding is still covered.
 
     Layout (words): header[8] = x0, y0, inv_cell, nx, ny, offset of the edge pool (from grid start), n_records, 0;
-    cells[ny*nx][2] = (n_records, first_record) for dirty cells, (0, polygon+1 | 0) for clean ones; pool of 8-word edge
-    records."""
+    cells[ny*nx][2] = (n_records, first_record) for dirty cells, (-(polygon+1), MVA height) or (0, 0) for clean ones; pool of
+    8-word edge records."""
     if guard is None:
         guard = 1e-3
     x0, y0, x1, y1 = bbox
@@ -160,7 +160,10 @@ def build_grid(rings, bounds, bbox, cell, guard=None):
         cy1s = gy0 + (j + 1) * cell + slack
         for i in range(nx):
             if not near[j, i]:
-                cells[j, i, 1] = _first_polygon(gx0 + (i + 0.5) * cell, gy0 + (j + 0.5) * cell, rings, bounds) + 1
+                pi = _first_polygon(gx0 + (i + 0.5) * cell, gy0 + (j + 0.5) * cell, rings, bounds)
+                if pi >= 0:
+                    cells[j, i, 0] = -(pi + 1.0)
+                    cells[j, i, 1] = heights[pi]
                 continue
             cx0s = gx0 + i * cell - slack
             cx1s = gx0 + (i + 1) * cell + slack
@@ -251,7 +254,7 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
     grid = None
     off_grid = 0
     if grid_cell is not None and mva_rings:
-        grid = build_grid(mva_rings, bounds[:len(mva_rings)], bbox, float(grid_cell), grid_guard)
+        grid = build_grid(mva_rings, bounds[:len(mva_rings)], mva_heights, bbox, float(grid_cell), grid_guard)
         off_grid = (end + 3) & ~3  # 16-byte aligned: cells are read as 8-byte pairs, edge records as 16-byte vectors
         end = off_grid + len(grid)
 
@@ -280,6 +283,9 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
     b[L.C_TRI_2:L.C_TRI_2 + 8] = cg["tri_2"].ravel()
     b[L.C_NORM_MIN:L.C_NORM_MIN + 10] = norm_min.astype(np.float64)
     b[L.C_NORM_MAX:L.C_NORM_MAX + 10] = norm_max.astype(np.float64)
+    half = np.float32(0.5) * norm_max                       # float32 arithmetic, like the reference's numpy vectors
+    b[L.C_NORM_A:L.C_NORM_A + 10] = (np.float32(1.0) / half).astype(np.float64)
+    b[L.C_NORM_B:L.C_NORM_B + 10] = (-(norm_min + half) / half).astype(np.float64)
     b[L.C_ACT_DISCR:L.C_ACT_DISCR + 3] = (5, 50, 0.5)
     b[L.C_BBOX:L.C_BBOX + 4] = bbox
     b[L.C_DIR_RWY_X], b[L.C_DIR_RWY_Y] = cg["dir_rwy"]

@@ -104,31 +104,36 @@ __device__ __forceinline__ bool ray_tracing(float x, float y, const float* ring,
 }
 
 // model.py:282-292 Airspace.find_mva: first polygon in list order whose inclusive bounds contain the point and whose
-// ray_tracing is true; -1 = "Outside of airspace".
+// ray_tracing is true; returns its index (-1 = "Outside of airspace") and its height through *height.
 //
-// With the lookup grid (global memory, L2-resident; atc_hip/scenario.py:build_grid) a CLEAN cell answers directly and a
-// DIRTY cell lists, polygon by polygon in priority order, exactly those edges the reference's crossing test could count
+// K = the sector blob in global memory.  Uniform-index reads of it become scalar loads (SGPRs); the per-lane reads
+// below (polygon records, edge records) are L2/L1-resident gathers and sit on rare paths only.
+//
+// With the lookup grid (atc_hip/scenario.py:build_grid) a CLEAN cell answers directly (index + height in the cell) and
+// a DIRTY cell lists, polygon by polygon in priority order, exactly those edges the reference's crossing test could count
 // for some point of the cell; every other edge fails one of `y > min`, `y <= max`, `x <= max` for the whole cell, so
 // walking the list with the reference's formula yields the same crossing parity as ray_tracing over the full ring.
 // CERTAIN edges lie > 1e-3 nm to the right of the whole cell: x <= xints holds whatever the rounding of xints.
 __device__ __forceinline__ bool in_bounds(const float* rec, float x, float y) {
-    return rec[ATC_P_MINX] <= x && x <= rec[ATC_P_MAXX] && rec[ATC_P_MINY] <= y && y <= rec[ATC_P_MAXY];
+    const float4 b = *reinterpret_cast<const float4*>(rec);  // minx, miny, maxx, maxy
+    return b.x <= x && x <= b.z && b.y <= y && y <= b.w;
 }
-// `gh` = the 8-word grid header (staged in LDS by the caller), `grid` = the grid in global memory.
-// K = sector constants read with UNIFORM indices from global memory (scalar loads -> SGPRs, no VGPR cost);
-// S = the LDS copy, used where lanes index differently (polygon records, ring vertices, entry table).
-__device__ __forceinline__ int find_mva(const float* __restrict__ K, const float* S, const float* gh,
-                                        const float* __restrict__ grid, float x, float y) {
-    const float* tab = S + (int)K[ATC_H_OFF_POLY];
+__device__ __forceinline__ int find_mva(const float* __restrict__ K, const float* __restrict__ grid, float x, float y,
+                                        float* height) {
+    const float* tab = K + (int)K[ATC_H_OFF_POLY];
+    *height = 0.0f;
     if (grid) {
-        const float fx = (x - gh[ATC_G_X0]) * gh[ATC_G_INV];
-        const float fy = (y - gh[ATC_G_Y0]) * gh[ATC_G_INV];
-        const float nx = gh[ATC_G_NX], ny = gh[ATC_G_NY];
+        const float fx = (x - grid[ATC_G_X0]) * grid[ATC_G_INV];
+        const float fy = (y - grid[ATC_G_Y0]) * grid[ATC_G_INV];
+        const float nx = grid[ATC_G_NX], ny = grid[ATC_G_NY];
         if (!(fx >= 0.0f && fx < nx && fy >= 0.0f && fy < ny)) return -1;  // beyond the padded bbox (also NaN)
         const float2 cell = *reinterpret_cast<const float2*>(grid + ATC_G_HDR + 2 * ((int)fy * (int)nx + (int)fx));
         const int n = (int)cell.x;
-        if (n == 0) return (int)cell.y - 1;
-        const float4* rec = reinterpret_cast<const float4*>(grid + (int)gh[ATC_G_OFF_POOL]) + 2 * (int)cell.y;
+        if (n <= 0) {  // clean cell: (-(polygon + 1), height) or (0, 0) = outside
+            *height = cell.y;
+            return -n - 1;
+        }
+        const float4* rec = reinterpret_cast<const float4*>(grid + (int)grid[ATC_G_OFF_POOL]) + 2 * (int)cell.y;
         bool inside = false;
         for (int e = 0; e < n; ++e) {
             const float4 g = rec[2 * e];      // p1x, p1y, p2x, p2y
@@ -143,7 +148,13 @@ __device__ __forceinline__ int find_mva(const float* __restrict__ K, const float
                 inside = inside != cross;
             }
             if (code & ATC_GE_LAST) {
-                if (inside && in_bounds(tab + (code >> 2) * ATC_P_WORDS, x, y)) return code >> 2;
+                if (inside) {
+                    const float* pr = tab + (code >> 2) * ATC_P_WORDS;
+                    if (in_bounds(pr, x, y)) {
+                        *height = pr[ATC_P_HEIGHT];
+                        return code >> 2;
+                    }
+                }
                 inside = false;
             }
         }
@@ -152,7 +163,10 @@ __device__ __forceinline__ int find_mva(const float* __restrict__ K, const float
     const int n_mva = (int)K[ATC_H_N_MVA];
     for (int p = 0; p < n_mva; ++p) {
         const float* rec = tab + p * ATC_P_WORDS;
-        if (in_bounds(rec, x, y) && ray_tracing(x, y, S + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT])) return p;
+        if (in_bounds(rec, x, y) && ray_tracing(x, y, K + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT])) {
+            *height = rec[ATC_P_HEIGHT];
+            return p;
+        }
     }
     return -1;
 }
@@ -242,10 +256,9 @@ struct Aircraft {
 };
 
 // atc_gym.py:346-348 + model.py:13-52: aircraft k of env e enters at an entry point.
-__device__ __forceinline__ Aircraft spawn(const float* __restrict__ K, const float* S, const atc_params_t& p, int e, int k,
-                                          int episode) {
+__device__ __forceinline__ Aircraft spawn(const float* __restrict__ K, const atc_params_t& p, int e, int k, int episode) {
     const int n_entry = (int)K[ATC_H_N_ENTRY];
-    const float* tab = S + (int)K[ATC_H_OFF_ENTRY];
+    const float* tab = K + (int)K[ATC_H_OFF_ENTRY];
     int ei, li;
     if (p.mode & ATC_M_RANDOM_ENTRY) {
         const uint64_t u = draw(p.seed, (uint32_t)e, (uint32_t)episode, (uint32_t)k);

@@ -7,8 +7,10 @@
 //   phi target), last_vh = float2 — a wavefront moves each array with ONE 16-byte (8-byte) access per lane, consecutive
 //   lanes on consecutive records (1 KiB per wave-instruction); the per-env record (12 words) is read with three 16-byte
 //   loads that the W lanes of an env share.  All per-lane indices are 32-bit offsets from uniform base pointers.
-//   The sector (polygons, corridor, constants: ~2 KB) is staged once per workgroup in LDS; the optional MVA lookup grid
-//   stays in global memory (L2 resident, one 4-byte gather per aircraft).
+//   The sector blob (constants, polygons, lookup grid) stays in global memory: constants are read with uniform indices
+//   (scalar loads -> SGPRs), the MVA lookup is one 8-byte L2 gather per aircraft (+ a few 16-byte edge records in cells
+//   that touch a polygon border).  There is no per-workgroup staging prologue and no block barrier: the first thing a
+//   wavefront does is issue its state loads.
 //   The O(N^2) separation scan stages (x, y, h, active) of the wavefront's aircraft in LDS; every lane walks its env's
 //   W partners (LDS broadcast reads), and the per-env minimum separation / conflict / reward / done are reduced with
 //   wavefront xor-shuffles and a ballot — no block barrier, no atomics, no MFMA (there is no dense contraction here).
@@ -53,8 +55,13 @@ static int fail_hip(hipError_t e, const char* what) {
         if (_e != hipSuccess) return fail_hip(_e, #expr); \
     } while (0)
 
-constexpr int kBlock = 256;
-constexpr int kStepExtraWords = 32;  // LDS words after the sector in k_step: norm scale/shift (2 x 12) + grid header (8)
+#ifndef ATC_BLOCK
+#define ATC_BLOCK 256
+#endif
+#ifndef ATC_NT
+#define ATC_NT 0  // non-temporal streams for actions / observations / flags: measured SLOWER (36.1 vs 32.0 us), kept off
+#endif
+constexpr int kBlock = ATC_BLOCK;
 #ifndef ATC_ABLATE
 #define ATC_ABLATE 0  // developer-only timing ablations (tools/ablate.sh); the shipped build always uses 0
 #endif
@@ -116,11 +123,22 @@ struct PairScan16<16> {
     static __device__ __forceinline__ void run(float, float, float, float, float, float&, int&) {}
 };
 
-__device__ __forceinline__ void stage_sector(float* S, const float* __restrict__ blob, int lds_words) {
-    for (int i = threadIdx.x; i < lds_words; i += kBlock) S[i] = blob[i];
-    __syncthreads();
+template <typename T>
+__device__ __forceinline__ void stream_store(T* p, T v) {
+#if ATC_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
 }
-
+template <typename T>
+__device__ __forceinline__ T stream_load(const T* p) {
+#if ATC_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 __device__ __forceinline__ void store_obs(float* __restrict__ dst, const float* o) {
     // 10 floats = 40 B per aircraft: 8-byte aligned -> five 8-byte stores
     float2* d = reinterpret_cast<float2*>(dst);
@@ -142,24 +160,11 @@ __global__ void __launch_bounds__(kBlock, ATC_MIN_WAVES)
 k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N, int T, atc_state_t st,
        const float* __restrict__ actions, atc_out_t out, atc_params_t p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* S = smem;
-    const int w0 = (lds_words + 3) & ~3;
-    float* normA = smem + w0;        // [10] 1 / (0.5 max)                       (atc_gym.py:187-189 as one fma)
-    float* normB = smem + w0 + 12;   // [10] -(min + 0.5 max) / (0.5 max)
-    float* gh = smem + w0 + 24;      // [8]  lookup-grid header
-    float4* pos = reinterpret_cast<float4*>(smem + w0 + kStepExtraWords);    // [kBlock] pair-scan staging (W != 16)
-    float* obs_stage = smem + w0 + kStepExtraWords + (W > 1 ? kBlock * 4 : 0);  // [4 waves][64 x 10] obs transpose
-    const float* __restrict__ K = blob;  // uniform-index constant reads -> scalar loads
-    stage_sector(S, blob, lds_words);
-    if (threadIdx.x < ATC_OBS_DIM) {
-        const float half = 0.5f * S[ATC_C_NORM_MAX + threadIdx.x];
-        normA[threadIdx.x] = 1.0f / half;
-        normB[threadIdx.x] = -(S[ATC_C_NORM_MIN + threadIdx.x] + half) / half;
-    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + ATC_G_HDR) {
-        gh[threadIdx.x - 64] = off_grid ? blob[off_grid + threadIdx.x - 64] : 0.0f;
-    }
-    __syncthreads();
-    const float* grid = off_grid ? blob + off_grid : nullptr;
+    float4* pos = reinterpret_cast<float4*>(smem);                    // [kBlock] pair-scan staging (W != 1, 16)
+    float* obs_stage = smem + ((W > 1 && W != 16) ? kBlock * 4 : 0);  // [4 waves][64 x 10] obs transpose
+    const float* __restrict__ K = blob;  // the sector: uniform-index reads -> scalar loads
+    const float* __restrict__ grid = off_grid ? blob + off_grid : nullptr;
+    (void)lds_words;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -205,7 +210,8 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
         // branch-free form of: invalid target -> ValueError -> -1 reward, nothing applied, last_action kept
         // (atc_gym.py:303-315); valid -> rate-limited move, actions_taken++ unless |target - last| < discriminator
         {
-            const float a_v = act_t[i * 3u + 0u], a_h = act_t[i * 3u + 1u], a_p = act_t[i * 3u + 2u];
+            const float a_v = stream_load(act_t + i * 3u + 0u), a_h = stream_load(act_t + i * 3u + 1u),
+                        a_p = stream_load(act_t + i * 3u + 2u);
             const float v_min = K[ATC_C_V_MIN], v_max = K[ATC_C_V_MAX], h_min = K[ATC_C_H_MIN], h_max = K[ATC_C_H_MAX];
             // atc_gym.py:64-78: offset (v_min,0,0); factor (10,100,1) discrete | (v_max-v_min, h_max, 360) continuous
             const float fac_v = discrete ? 10.0f : v_max - v_min;
@@ -261,8 +267,8 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
         // ---- MVA floor (atc_gym.py:146-161) ----------------------------------------------------------------------------
         float mva = 0.0f;
         {
-            const int pi = (ATC_ABLATE & 1) ? 0 : find_mva(K, S, gh, grid, x32, y32);
-            const float hgt = S[(int)K[ATC_H_OFF_POLY] + (pi < 0 ? 0 : pi) * ATC_P_WORDS + ATC_P_HEIGHT];
+            float hgt = 0.0f;
+            const int pi = (ATC_ABLATE & 1) ? 0 : find_mva(K, grid, x32, y32, &hgt);
             mva = pi >= 0 ? hgt : 0.0f;                    // atc_gym.py:161: mva = 0 outside
             const bool below = pi >= 0 && a.h < mva;
             r = pi < 0 ? -50.0f : (below ? -200.0f : r);
@@ -336,9 +342,9 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
             }
             const int n_noise = (int)K[ATC_H_N_NOISE];
             for (int q = 0; q < n_noise; ++q) {  // extension (README.md:62): noise-abatement areas
-                const float* rec = S + (int)K[ATC_H_OFF_POLY] + ((int)K[ATC_H_N_MVA] + q) * ATC_P_WORDS;
+                const float* rec = K + (int)K[ATC_H_OFF_POLY] + ((int)K[ATC_H_N_MVA] + q) * ATC_P_WORDS;
                 if (in_bounds(rec, x32, y32) && a.h < rec[ATC_P_HEIGHT] &&
-                    ray_tracing(x32, y32, S + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT])) {
+                    ray_tracing(x32, y32, K + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT])) {
                     r -= rec[ATC_P_PENALTY];
                     fl |= ATC_F_NOISE;
                 }
@@ -351,7 +357,8 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
             }
             if (p.mode & ATC_M_NORMALIZE) {  // atc_gym.py:187-189: (s - min - max/2) / (max/2) as one fma
 #pragma unroll
-                for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = active ? fmaf(ob.o[c], normA[c], normB[c]) : 0.0f;
+                for (int c = 0; c < ATC_OBS_DIM; ++c)
+                    o[c] = active ? fmaf(ob.o[c], K[ATC_C_NORM_A + c], K[ATC_C_NORM_B + c]) : 0.0f;
             } else {
 #pragma unroll
                 for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = active ? ob.o[c] : 0.0f;
@@ -375,7 +382,7 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
         n_actions += env_acts;
 
         if (lane_valid) {
-            (out.flags + sBN)[i] = fl;
+            stream_store(out.flags + sBN + i, fl);
             if (FULL && out.ac_reward) (out.ac_reward + sBN)[i] = r;
         }
         if (env_valid && k == 0) {
@@ -395,7 +402,7 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
             win_bits = ((win_bits << 1) | (amask == 0 ? 1u : 0u)) & 0x3ffu;
             if (lane_valid) {
                 if (FULL && out.term_obs) store_obs(out.term_obs + sBN * ATC_OBS_DIM + i * ATC_OBS_DIM, o);
-                a = spawn(K, S, p, e, k, episode);
+                a = spawn(K, p, e, k, episode);
                 const Obs ob = get_state(K, (float)a.x, (float)a.y, a.h, a.phi, a.v, 0.0f);
 #pragma unroll
                 for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = ob.o[c];
@@ -425,7 +432,16 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int idx = j * 64 + lane;
-                if (idx < 64 * ATC_OBS_DIM / 4) dst[idx] = src[idx];
+                if (idx < 64 * ATC_OBS_DIM / 4) {
+                    const float4 v = src[idx];
+#if ATC_NT
+                    float* d4 = reinterpret_cast<float*>(dst + idx);
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(d4));
+#else
+                    dst[idx] = v;
+#endif
+                }
             }
             __builtin_amdgcn_wave_barrier();
         } else if (lane_valid) {
@@ -454,15 +470,13 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
 __global__ void __launch_bounds__(kBlock)
 k_reset(const float* __restrict__ blob, int lds_words, int B, int N, atc_state_t st, const uint8_t* __restrict__ mask,
         float* __restrict__ obs, atc_params_t p, int first) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* S = smem;
-    stage_sector(S, blob, lds_words);
+    (void)lds_words;
     const uint32_t BN = (uint32_t)B * (uint32_t)N;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < BN; i += gridDim.x * kBlock) {
         const int e = (int)(i / (uint32_t)N), k = (int)(i % (uint32_t)N);
         if (mask && !mask[e]) continue;
         const int episode = first ? 0 : st.env[(size_t)e * ATC_ENV_WORDS + ATC_ENV_EPISODES];
-        const Aircraft a = spawn(blob, S, p, e, k, episode);
+        const Aircraft a = spawn(blob, p, e, k, episode);
         reinterpret_cast<double2*>(st.pos)[i] = make_double2(a.x, a.y);
         // atc_gym.py:86: last_action = [0,0,0] once, in __init__ — never on reset (quirk Q7)
         const float la_p = first ? 0.0f : st.kin[(size_t)i * 4 + 3];
@@ -478,9 +492,7 @@ k_reset(const float* __restrict__ blob, int lds_words, int B, int N, atc_state_t
 __global__ void __launch_bounds__(kBlock)
 k_observe(const float* __restrict__ blob, int lds_words, int B, int N, atc_state_t st, const uint8_t* __restrict__ mask,
           float* __restrict__ obs) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* S = smem;
-    stage_sector(S, blob, lds_words);
+    (void)lds_words;
     const uint32_t BN = (uint32_t)B * (uint32_t)N;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < BN; i += gridDim.x * kBlock) {
         const int e = (int)(i / (uint32_t)N);
@@ -520,16 +532,12 @@ k_reset_env(int B, int N, atc_state_t st, const uint8_t* __restrict__ mask, int 
 __global__ void __launch_bounds__(kBlock)
 k_query_mva(const float* __restrict__ blob, int lds_words, int off_grid, int n, const float* __restrict__ x,
             const float* __restrict__ y, int32_t* __restrict__ out_h, int32_t* __restrict__ out_idx) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* gh = smem + ((lds_words + 3) & ~3);
-    if (threadIdx.x < ATC_G_HDR) gh[threadIdx.x] = off_grid ? blob[off_grid + threadIdx.x] : 0.0f;
-    stage_sector(smem, blob, lds_words);
-    const float* S = smem;
+    (void)lds_words;
     const float* grid = off_grid ? blob + off_grid : nullptr;
-    const float* polytab = S + (int)S[ATC_H_OFF_POLY];
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const int pi = find_mva(blob, S, gh, grid, x[i], y[i]);
-        if (out_h) out_h[i] = pi >= 0 ? (int32_t)polytab[pi * ATC_P_WORDS + ATC_P_HEIGHT] : -1;
+        float hgt;
+        const int pi = find_mva(blob, grid, x[i], y[i], &hgt);
+        if (out_h) out_h[i] = pi >= 0 ? (int32_t)hgt : -1;
         if (out_idx) out_idx[i] = pi;
     }
 }
@@ -537,9 +545,7 @@ __global__ void __launch_bounds__(kBlock)
 k_query_corridor(const float* __restrict__ blob, int lds_words, int n, const float* __restrict__ x,
                  const float* __restrict__ y, const float* __restrict__ h, const float* __restrict__ phi, int angle_only,
                  uint8_t* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    stage_sector(smem, blob, lds_words);
-    const float* S = smem;
+    (void)lds_words;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
         out[i] = angle_only ? inside_corridor_angle(blob, x[i], y[i], phi[i])
                             : inside_corridor(blob, x[i], y[i], h[i], phi[i]);
@@ -548,9 +554,7 @@ __global__ void __launch_bounds__(kBlock)
 k_query_shaping(const float* __restrict__ blob, int lds_words, int n, const float* __restrict__ d_faf,
                 const float* __restrict__ phi_rel_faf, const float* __restrict__ phi_plane, const float* __restrict__ h,
                 const float* __restrict__ on_gp, float* __restrict__ out3) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    stage_sector(smem, blob, lds_words);
-    const float* S = smem;
+    (void)lds_words;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const Shaping s = shaping_rewards(blob, d_faf[i], phi_rel_faf[i], relative_angle(blob[ATC_C_PHI_TO_RWY], phi_plane[i]),
                                           h[i], on_gp[i]);
@@ -570,9 +574,9 @@ static int grid_for(const atc_scenario* s, long long threads) {
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
-static size_t lds_bytes(const atc_scenario* s, bool pair_scan, bool step_kernel = false) {
-    size_t w = (size_t)((s->lds_words + 3) & ~3);
-    if (step_kernel) w += kStepExtraWords + (size_t)(kBlock / 64) * 64 * ATC_OBS_DIM;  // + obs transpose stage
+static size_t lds_bytes(const atc_scenario*, bool pair_scan, bool step_kernel = false) {
+    size_t w = 0;  // the sector is not staged: LDS only holds the obs transpose stage and the pair-scan staging
+    if (step_kernel) w += (size_t)(kBlock / 64) * 64 * ATC_OBS_DIM;
     if (pair_scan) w += (size_t)kBlock * 4;
     return w * sizeof(float);
 }
@@ -580,7 +584,7 @@ static size_t lds_bytes(const atc_scenario* s, bool pair_scan, bool step_kernel 
 template <int W, bool FULL>
 static int launch_step2(const atc_scenario* s, int B, int N, int T, const atc_state_t* st, const float* actions,
                         const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
-    const size_t lds = lds_bytes(s, W > 1, true);
+    const size_t lds = lds_bytes(s, W > 1 && W != 16, true);
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<W, FULL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -641,10 +645,6 @@ int atc_scenario_create(const float* blob_host, size_t n_words, int device, atc_
         return fail_hip(e, "hipGetDeviceProperties");
     }
     s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if ((size_t)s->lds_words * 4 + kBlock * 16 + kStepExtraWords * 4 + 4 * 64 * ATC_OBS_DIM * 4 + 64 > 160 * 1024) {
-        delete s;
-        return fail_arg("sector does not fit the 160 KB LDS");
-    }
     e = hipMalloc(&s->d_blob, n_words * sizeof(float));
     if (e != hipSuccess) {
         delete s;
@@ -671,7 +671,7 @@ int atc_query_mva(const atc_scenario_t* s, int n, const float* x, const float* y
                   void* stream) {
     if (!s || !x || !y || !out_h || n < 0) return fail_arg("null pointer / negative n");
     if (n == 0) return ATC_OK;
-    hipLaunchKernelGGL(k_query_mva, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false) + 64, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_query_mva, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false), (hipStream_t)stream,
                        s->d_blob, s->lds_words, use_grid ? s->off_grid : 0, n, x, y, out_h, (int32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     return ATC_OK;
@@ -681,7 +681,7 @@ int atc_query_mva_index(const atc_scenario_t* s, int n, const float* x, const fl
                         void* stream) {
     if (!s || !x || !y || !out_idx || n < 0) return fail_arg("null pointer / negative n");
     if (n == 0) return ATC_OK;
-    hipLaunchKernelGGL(k_query_mva, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false) + 64, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_query_mva, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false), (hipStream_t)stream,
                        s->d_blob, s->lds_words, use_grid ? s->off_grid : 0, n, x, y, (int32_t*)nullptr, out_idx);
     HIP_TRY(hipGetLastError());
     return ATC_OK;

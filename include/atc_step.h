@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ATC_ABI_VERSION 5
+#define ATC_ABI_VERSION 6
 
 /* ---------------------------------------------------------------------------------------------
  * Scenario blob: one flat array of 32-bit floats (device copy) compiled on the host from the sector
@@ -35,7 +35,7 @@ extern "C" {
  * envs/atc/atc_gym.py:45-58,88-110).  Integer fields are stored as exactly representable floats.
  * The float64 master (used by the f64 oracle) has the identical word layout.
  * ------------------------------------------------------------------------------------------- */
-#define ATC_BLOB_VERSION 1005.0f
+#define ATC_BLOB_VERSION 1006.0f
 enum {
     ATC_H_VERSION = 0,   /* ATC_BLOB_VERSION */
     ATC_H_NWORDS = 1,    /* total words */
@@ -71,7 +71,9 @@ enum {
     ATC_C_ALIGNED_OK = 93, /* 1 if the reference's angle window (model.py:216-229) accepts phi == phi_to_runway exactly,
                               evaluated on the host with the reference's own expression (np.dot / arccos) */
     ATC_C_TRI_BBOX = 96,  /* x0,y0,x1,y1 of the corridor_horizontal triangle (exact early-out for model.py:198) */
-    ATC_C_END = 104
+    ATC_C_NORM_A = 104,   /* 10 words: 1 / (0.5 max)              — normalisation (atc_gym.py:187-189) as one fma:  */
+    ATC_C_NORM_B = 114,   /* 10 words: -(min + 0.5 max) / (0.5 max)                  obs = raw * A + B (float32) */
+    ATC_C_END = 128
 };
 /* polygon table record (8 words) */
 enum { ATC_P_MINX = 0, ATC_P_MINY = 1, ATC_P_MAXX = 2, ATC_P_MAXY = 3,
@@ -85,8 +87,9 @@ enum { ATC_E_X = 0, ATC_E_Y = 1, ATC_E_PHI = 2, ATC_E_NLEV = 3, ATC_E_LEV0 = 4, 
 /* lookup grid (optional acceleration structure for Airspace.find_mva, model.py:282-289; results identical to the
  * ordered polygon scan by construction — see atc_hip/scenario.py:build_grid).  16-byte aligned in the blob.
  *   header 8 words : x0, y0, 1/cell, nx, ny, offset of the edge pool (from grid start), number of edge records, 0
- *   cells  ny*nx*2 : (n_records, first_record) -> dirty cell: walk that many edge records
- *                    (0, polygon index + 1)    -> clean cell: every point has this answer (0 = outside the airspace)
+ *   cells  ny*nx*2 : (n_records >= 1, first_record)   -> dirty cell: walk that many edge records
+ *                    (-(polygon + 1), MVA height)     -> clean cell: every point has this answer
+ *                    (0, 0)                           -> clean cell outside the airspace
  *   pool           : 8-word edge records  p1x, p1y, p2x, p2y, min(p1y,p2y), max(p1y,p2y), max(p1x,p2x),
  *                    code = 4 * polygon index + flags                                                                 */
 enum { ATC_G_X0 = 0, ATC_G_Y0 = 1, ATC_G_INV = 2, ATC_G_NX = 3, ATC_G_NY = 4, ATC_G_OFF_POOL = 5, ATC_G_NREC = 6,

@@ -65,7 +65,7 @@ def test_dense_scenario_slots_are_conflict_free():
     assert c.n_noise == 4
 
 
-def _walk_grid(b, g, tabs, x, y):
+def _walk_grid(b, g, tabs, tabs_h, x, y):
     """Host emulation (float64) of the device's grid walk (csrc/atc_device.h: find_mva)."""
     x0, y0, inv, nx, ny = b[g + L.G_X0], b[g + L.G_Y0], b[g + L.G_INV], int(b[g + L.G_NX]), int(b[g + L.G_NY])
     fx, fy = (x - x0) * inv, (y - y0) * inv
@@ -73,8 +73,10 @@ def _walk_grid(b, g, tabs, x, y):
         return -1
     c = g + L.G_HDR + 2 * (int(fy) * nx + int(fx))
     n, v = int(b[c]), int(b[c + 1])
-    if n == 0:
-        return v - 1
+    if n <= 0:
+        if n < 0:
+            assert b[c + 1] == tabs_h[-n - 1]
+        return -n - 1
     pool = g + int(b[g + L.G_OFF_POOL])
     inside = False
     for e in range(n):
@@ -116,7 +118,7 @@ def test_grid_matches_ordered_scan_on_host(scen, cell):
     n_dirty = 0
     for x, y in pts:
         truth = _first_polygon(x, y, c.mva_rings, c.mva_bounds)
-        assert _walk_grid(b, g, c.mva_bounds, x, y) == truth, (x, y)
+        assert _walk_grid(b, g, c.mva_bounds, c.mva_heights, x, y) == truth, (x, y)
     cells = b[g + L.G_HDR: g + L.G_HDR + 2 * int(b[g + L.G_NX]) * int(b[g + L.G_NY])].reshape(-1, 2)
     n_dirty = int((cells[:, 0] > 0).sum())
     assert 0 < n_dirty < 0.45 * len(cells)
