@@ -55,3 +55,12 @@
 #include "atc_oracle_impl.h"
 
 int atc_oracle_abi_version(void) { return ATC_ABI_VERSION; }
+
+#ifdef _OPENMP
+#include <omp.h>
+void atc_oracle_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int atc_oracle_max_threads(void) { return omp_get_max_threads(); }
+#else
+void atc_oracle_set_threads(int n) { (void)n; }
+int atc_oracle_max_threads(void) { return 1; }
+#endif

@@ -299,6 +299,11 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
     const int n_noise = (int)S[ATC_H_N_NOISE];
     const int off_poly = (int)S[ATC_H_OFF_POLY];
 
+    /* envs are independent: the all-cores CPU baseline (bench.py) runs this loop under OpenMP; results do not depend on
+     * the thread count (no cross-env state) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (B >= 64)
+#endif
     for (int e = 0; e < B; ++e) {
         st->timesteps[e] += 1; /* atc_gym.py:135 */
         const int t = st->timesteps[e];

@@ -46,7 +46,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             build()
         _lib = C.CDLL(LIB_PATH)
+        _lib.atc_oracle_set_threads(1)  # default: scalar single-thread restatement
     return _lib
+
+
+def set_threads(n):
+    """OpenMP threads used by atc_oracle_step_* (1 = the scalar single-core port)."""
+    lib().atc_oracle_set_threads(int(n))
 
 
 def _ptr(a):

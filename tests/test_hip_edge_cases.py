@@ -1,0 +1,169 @@
+"""GPU edge cases of the C-ABI / AtcVecEnv: ragged shapes, degenerate sizes, hostile inputs, argument errors."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.mark.parametrize("B,N", [(1, 1), (1, 2), (3, 3), (5, 7), (257, 1), (63, 16), (65, 16), (2, 33), (1, 64), (3, 64)])
+def test_ragged_shapes_match_oracle(B, N):
+    """Batch sizes that do not fill a wavefront / workgroup, aircraft counts that are not powers of two (idle lanes in a
+    group), single env, maximum N: every output must match the fp32 oracle."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+    from oracle import oracle as O
+    scn = scenarios.LOWWDense() if N > 54 else scenarios.LOWW(random_entrypoints=True)
+    comp = scenarios.compile_scenario(scn, grid_cell=0.5)
+    env = AtcVecEnv(B, N, scenario=scn, auto_reset=True, spawn="lattice", want_raw_obs=True, want_min_sep=True)
+    orc = O.OracleEnv(comp, B, N, O.make_params(auto_reset=True), np.float32)
+    rng = np.random.default_rng(B * 100 + N)
+    half = 0.5 * comp.norm_max.astype(np.float64)
+    for t in range(60):
+        if t % 10 == 0:
+            a = rng.uniform(-1.05, 1.05, (B, N, 3)).astype(np.float32)
+        obs, rew, done, info = env.step(a)
+        orc.step(a)
+        assert np.array_equal(info["flags"].cpu().numpy().astype(np.uint32), orc.flags), t
+        assert np.array_equal(done.cpu().numpy(), orc.done), t
+        o = obs.cpu().numpy().reshape(B, N, 10)
+        assert np.all(np.abs(o - orc.obs) <= 1e-5 * np.maximum(1.0, np.abs(orc.obs))), t
+        assert np.all(np.abs(info["original_state"].cpu().numpy().reshape(B, N, 10) - orc.raw_obs) <= 1e-5 * half), t
+        assert np.all(np.abs(rew.cpu().numpy() - orc.reward) <= 2e-5 * np.maximum(1.0, np.abs(orc.reward)) * max(1, N // 4)), t
+        ms = info["min_separation"].cpu().numpy()
+        assert np.all(np.abs(ms - orc.min_sep) <= 1e-5 * np.maximum(1.0, np.abs(orc.min_sep))), t
+    assert np.array_equal(env.timesteps.cpu().numpy(), orc.timesteps)
+    assert np.array_equal(env.active_mask.cpu().numpy().astype(np.uint64), orc.active_mask)
+    env.close()
+
+
+def test_hostile_actions_do_not_break_the_batch():
+    """NaN / inf / huge action components poison at most their own env: the launch succeeds, other envs are unaffected and
+    match a run without the hostile rows."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+    scn = scenarios.LOWW(random_entrypoints=True)
+    B, N = 256, 4
+    env = AtcVecEnv(B, N, scenario=scn, auto_reset=True)
+    ref = AtcVecEnv(B, N, scenario=scn, auto_reset=True)
+    rng = np.random.default_rng(0)
+    bad_rows = [3, 77, 200]
+    for t in range(40):
+        a = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+        b = a.copy()
+        b[3, 1, :] = np.nan
+        b[77, 0, 2] = np.inf
+        b[200, 2, :] = [1e30, -1e30, 1e38]
+        obs, rew, done, info = env.step(b)
+        o2, r2, d2, i2 = ref.step(a)
+        good = np.ones(B, bool)
+        good[bad_rows] = False
+        g = torch.as_tensor(good).cuda()
+        assert torch.equal(obs[g], o2[g]) and torch.equal(rew[g], r2[g]) and torch.equal(info["flags"][g], i2["flags"][g])
+    torch.cuda.synchronize()
+    # invalid (out of range / NaN) speed and altitude targets are absorbed as flags, never raised (atc_gym.py:312-315)
+    fl = info["flags"].cpu().numpy()
+    assert fl[200, 2] & (H.F_INVALID_V | H.F_INVALID_H)
+    env.close()
+    ref.close()
+
+
+def test_argument_errors_are_reported_not_raised_from_c():
+    torch = _torch()
+    from atc_hip import lib
+    from atc_hip.vec_env import AtcVecEnv
+    env = AtcVecEnv(4, 2)
+    L = lib.load()
+    a = torch.zeros(4 * 2 * 3, device="cuda")
+    st, out, p = env._state, env._out, env.params
+    stream = env._stream()
+    assert L.atc_step(env.sector.handle, 0, 2, C.byref(st), a.data_ptr(), C.byref(out), C.byref(p), stream) == -1
+    assert b"B >= 1" in L.atc_last_error()
+    assert L.atc_step(env.sector.handle, 4, 65, C.byref(st), a.data_ptr(), C.byref(out), C.byref(p), stream) == -1
+    assert L.atc_step(None, 4, 2, C.byref(st), a.data_ptr(), C.byref(out), C.byref(p), stream) == -1
+    assert L.atc_step(env.sector.handle, 4, 2, C.byref(st), None, C.byref(out), C.byref(p), stream) == -1
+    assert L.atc_rollout(env.sector.handle, 4, 2, 0, C.byref(st), a.data_ptr(), C.byref(out), C.byref(p), stream) == -1
+    bad = lib.AtcState(st.pos, None, st.last_vh, st.env)
+    assert L.atc_step(env.sector.handle, 4, 2, C.byref(bad), a.data_ptr(), C.byref(out), C.byref(p), stream) == -1
+    assert b"null" in L.atc_last_error()
+    too_big = 2 ** 27  # 2^27 x 64 aircraft x 40 B >> 4 GiB
+    assert L.atc_step(env.sector.handle, too_big, 64, C.byref(st), a.data_ptr(), C.byref(out), C.byref(p), stream) == -1
+    assert b"split the batch" in L.atc_last_error()
+    # a blob of the wrong version is refused
+    blob = env.compiled.blob32.copy()
+    blob[0] = 1.0
+    h = C.c_void_p()
+    assert L.atc_scenario_create(blob.ctypes.data_as(C.c_void_p), blob.size, 0, C.byref(h)) == -1
+    with pytest.raises(ValueError):
+        env.step(np.zeros((4, 2, 2), np.float32))
+    with pytest.raises(ValueError):
+        AtcVecEnv(4, 65)
+    # still healthy afterwards
+    obs, rew, done, info = env.step(np.zeros((4, 2, 3), np.float32))
+    assert bool(torch.isfinite(obs).all())
+    env.close()
+
+
+def test_masked_reset_only_touches_selected_envs():
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    env = AtcVecEnv(8, 2, auto_reset=False)
+    a = np.random.default_rng(0).uniform(-1, 1, (8, 2, 3)).astype(np.float32)
+    for _ in range(5):
+        env.step(a)
+    before = (env.pos.clone(), env.kin.clone(), env.env.clone())
+    mask = np.array([0, 1, 0, 0, 1, 0, 0, 1], np.uint8)
+    env.reset(mask=mask)
+    m = torch.as_tensor(mask.astype(bool)).cuda()
+    assert torch.equal(env.env[~m], before[2][~m])
+    assert bool((env.timesteps[m] == 0).all()) and bool((env.timesteps[~m] == 5).all())
+    mm = m.repeat_interleave(2)
+    assert torch.equal(env.pos[~mm], before[0][~mm]) and not torch.equal(env.pos[mm], before[0][mm])
+    assert bool((env.episodes[m] == 2).all()) and bool((env.episodes[~m] == 1).all())
+    # last_action survives a reset (atc_gym.py:86 is only executed in __init__)
+    assert torch.equal(env.kin[:, 3], before[1][:, 3]) and bool((env.kin[:, 3] != 0).any())
+    env.close()
+
+
+def test_streams_and_graph_capture():
+    """The C-ABI launches on the caller's stream: works on a side stream and inside a captured HIP graph."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    env = AtcVecEnv(1024, 16, auto_reset=True)
+    ref = AtcVecEnv(1024, 16, auto_reset=True)
+    a = (torch.rand((1024, 16, 3), device="cuda") * 2 - 1).contiguous()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            env.step(a)
+    torch.cuda.current_stream().wait_stream(s)
+    for _ in range(3):
+        ref.step(a)
+    assert torch.equal(env.obs, ref.obs) and torch.equal(env.pos, ref.pos)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(4):
+            env.step(a)
+    for _ in range(2):
+        g.replay()
+    for _ in range(12):   # capture itself does not execute; 4 warm launches are not part of it
+        ref.step(a)
+    # graph: capture (0 executed) + 2 replays x 4 = 8 steps; bring ref to the same count
+    env2 = AtcVecEnv(1024, 16, auto_reset=True)
+    for _ in range(3 + 8):
+        env2.step(a)
+    torch.cuda.synchronize()
+    assert torch.equal(env.pos, env2.pos) and torch.equal(env.obs, env2.obs)
+    env.close(); ref.close(); env2.close()
