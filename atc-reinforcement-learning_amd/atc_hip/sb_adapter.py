@@ -1,0 +1,115 @@
+"""AtcSBVecEnv — stable-baselines-shaped VecEnv over AtcVecEnv.
+
+Counterpart of `SubprocVecEnv([make_env] * n)` + `Monitor` in the reference's trainer
+(learning/atc-gym-stable-baselines.py:69-80): same method names and return conventions (numpy arrays, list of info dicts,
+auto-reset with the reset observation returned and the terminal one under info["terminal_observation"],
+Monitor's info["episode"] = {"r", "l", "t"} for finished episodes, `get_attr`/`set_attr`/`env_method`), but all envs are
+stepped by ONE kernel launch and the Monitor statistics are accumulated on the device; only the per-step arrays cross
+PCIe (B x (10 N + 2) floats).  For throughput without host copies use AtcVecEnv directly (device tensors)."""
+import time
+
+import numpy as np
+
+from . import layout as L
+from .vec_env import AtcVecEnv
+
+
+class AtcSBVecEnv:
+    def __init__(self, num_envs, num_aircraft=1, sim_parameters=None, scenario=None, device=0, seed=0, **kw):
+        from envs.atc._spaces import Box, MultiDiscrete
+        self.vec = AtcVecEnv(num_envs, num_aircraft, sim_parameters=sim_parameters, scenario=scenario, device=device,
+                             auto_reset=True, seed=seed, want_raw_obs=True, want_term_obs=True, **kw)
+        self.num_envs = self.vec.B
+        n = self.vec.N
+        sp = self.vec.sim_parameters
+        if sp.discrete_action_space:  # atc_gym.py:72-74 (per aircraft)
+            self.action_space = MultiDiscrete([20, 380, 360] * n)
+        else:                         # atc_gym.py:81-82
+            self.action_space = Box(low=-np.ones(3 * n, np.float32), high=np.ones(3 * n, np.float32))
+        self.observation_space = Box(low=-1.0, high=1.0, shape=(L.OBS_DIM * n,))  # atc_gym.py:113
+        self.reward_range = (-3000.0, 23000.0)                                    # atc_gym.py:115
+        self.metadata = {'render.modes': ['human', 'rgb_array'], 'video.frames_per_second': 50}
+        self._t0 = time.time()
+        self._actions = None
+
+    # -- VecEnv protocol ---------------------------------------------------------------------------------------------
+    def reset(self):
+        """All envs restart; returns the RAW reset observations [B, 10 N] (atc_gym.py:365 returns the raw state)."""
+        return self.vec.reset().cpu().numpy().copy()
+
+    def step_async(self, actions):
+        self._actions = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.vec.N, L.ACT_DIM)
+
+    def step_wait(self):
+        vec = self.vec
+        obs, rew, done, info = vec.step(self._actions)
+        torch = vec.torch
+        pack = torch.cat([obs, info["original_state"], info["terminal_observation"],
+                          rew[:, None], done[:, None].to(torch.float32), vec.ep_return[:, None],
+                          vec.ep_length[:, None].to(torch.float32)], dim=1).cpu().numpy()   # one device->host hop
+        d = vec.obs_dim
+        obs_h, raw_h, term_h = pack[:, :d], pack[:, d:2 * d], pack[:, 2 * d:3 * d]
+        rew_h, done_h = pack[:, 3 * d], pack[:, 3 * d + 1] != 0
+        ep_r, ep_l = pack[:, 3 * d + 2], pack[:, 3 * d + 3]
+        now = round(time.time() - self._t0, 6)
+        infos = []
+        for b in range(self.num_envs):
+            item = {"original_state": raw_h[b]}
+            if done_h[b]:
+                item["terminal_observation"] = term_h[b]
+                item["episode"] = {"r": float(ep_r[b]), "l": int(ep_l[b]), "t": now}
+            infos.append(item)
+        return obs_h.copy(), rew_h.copy(), done_h.copy(), infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        self.vec.close()
+
+    def seed(self, seed=None):
+        return self.vec.seed(seed)
+
+    def get_attr(self, attr_name, indices=None):
+        """`actions_per_timestep`, `winning_ratio` (read by the reference's TensorBoard callback,
+        learning/atc-gym-stable-baselines.py:34,36), counters, and constant attributes of the env."""
+        if attr_name in ("timestep_limit",):
+            vals = [self.vec.timestep_limit] * self.num_envs
+            return vals if indices is None else [vals[i] for i in self._idx(indices)]
+        return self.vec.get_attr(attr_name, None if indices is None else self._idx(indices))
+
+    def set_attr(self, attr_name, value, indices=None):
+        """Per-env counters that the reference exposes as plain attributes can be overwritten (e.g. `timesteps`)."""
+        t = {"timesteps": self.vec.timesteps, "actions_taken": self.vec.actions_taken,
+             "total_reward": self.vec.total_reward}.get(attr_name)
+        if t is None:
+            raise AttributeError("cannot set %r on the batched env" % attr_name)
+        for i in (range(self.num_envs) if indices is None else self._idx(indices)):
+            t[i] = value
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        """`reset` and `seed` per env (what SB wrappers call); other methods of the single-env class have no batched
+        meaning."""
+        idx = list(range(self.num_envs)) if indices is None else self._idx(indices)
+        if method_name == "reset":
+            mask = np.zeros(self.num_envs, np.uint8)
+            mask[idx] = 1
+            obs = self.vec.reset(mask=mask).cpu().numpy()
+            return [obs[i].copy() for i in idx]
+        if method_name == "seed":
+            return [self.vec.seed(*args, **kwargs)[0] for _ in idx]
+        raise AttributeError("env_method(%r) is not available on the batched env" % method_name)
+
+    def get_images(self):
+        from . import render
+        return [render.rgb_array(self.vec, env=b) for b in range(self.num_envs)]
+
+    def render(self, mode="human"):
+        if mode == "rgb_array":
+            from . import render
+            return render.rgb_array(self.vec, env=0)
+        return None
+
+    def _idx(self, indices):
+        return [indices] if isinstance(indices, int) else list(indices)

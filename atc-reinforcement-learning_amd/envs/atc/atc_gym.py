@@ -197,10 +197,11 @@ class AtcGym(Env):
         return self.state
 
     def render(self, mode='human'):
-        """The pyglet viewer of the reference (atc_gym.py:367-552) is out of scope; `rgb_array` gives a
-        blank frame so recorders keep working."""
+        """The pyglet window of the reference (atc_gym.py:367-552) is out of scope; `rgb_array` is served by
+        the headless numpy renderer (atc_hip/render.py) so recorders keep working, `human` is a no-op."""
         if mode == 'rgb_array':
-            return np.zeros((800, 800, 3), dtype=np.uint8)
+            from atc_hip import render
+            return render.rgb_array(self._vec, env=0)
         return None
 
     def close(self):

@@ -1,2 +1,2 @@
-timeout 1500 python -m pytest tests/test_hip_edge_cases.py -m gpu -q > gpurun_out/pytest_edge.log 2>&1; echo rc=$? >> gpurun_out/pytest_edge.log
-tail -40 gpurun_out/pytest_edge.log
+timeout 900 python -m pytest tests/test_sb_adapter.py -m gpu -q > gpurun_out/pytest_sb.log 2>&1; echo rc=$? >> gpurun_out/pytest_sb.log
+tail -12 gpurun_out/pytest_sb.log

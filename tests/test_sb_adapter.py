@@ -1,0 +1,78 @@
+"""GPU test of the stable-baselines-shaped adapter: AtcSBVecEnv must behave like a list of the reference-surface AtcGym
+envs driven the way SubprocVecEnv + Monitor drive them (step, auto-reset returning the reset observation, episode
+statistics)."""
+import numpy as np
+import pytest
+
+import helpers as H  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def test_adapter_equals_loop_of_single_envs():
+    import random
+    from atc_hip.sb_adapter import AtcSBVecEnv
+    from envs.atc import atc_gym
+    B = 6
+    venv = AtcSBVecEnv(B)                      # default LOWW, one entry point -> resets are deterministic
+    singles = [atc_gym.AtcGym() for _ in range(B)]
+    obs = venv.reset()
+    sobs = np.stack([e.reset() for e in singles])
+    assert np.allclose(obs, sobs, atol=1e-5)
+    assert venv.observation_space.shape == (10,) and venv.action_space.shape == (3,)
+    rng = np.random.default_rng(0)
+    ep_returns = [0.0] * B
+    ep_lens = [0] * B
+    finished = 0
+    for t in range(700):
+        if t % 25 == 0:
+            a = rng.uniform(-1, 1, (B, 3)).astype(np.float32)
+            a[:, 1] = -1.0 + 0.1 * a[:, 1]      # low altitude targets: episodes end within a few hundred steps
+        o, r, d, infos = venv.step(a)
+        for b, e in enumerate(singles):
+            so, sr, sd, si = e.step(a[b])
+            ep_returns[b] += sr
+            ep_lens[b] += 1
+            assert bool(d[b]) == sd
+            assert abs(r[b] - sr) <= 1e-5 * max(1.0, abs(sr))
+            assert np.allclose(infos[b]["original_state"], si["original_state"], rtol=1e-6, atol=1e-4)
+            if sd:
+                finished += 1
+                assert np.allclose(infos[b]["terminal_observation"], so, atol=1e-5)
+                assert infos[b]["episode"]["l"] == ep_lens[b]
+                assert abs(infos[b]["episode"]["r"] - ep_returns[b]) <= 2e-5 * max(1.0, abs(ep_returns[b]))
+                so = e.reset()                  # what a SubprocVecEnv worker does
+                ep_returns[b], ep_lens[b] = 0.0, 0
+            else:
+                assert "episode" not in infos[b]
+            assert np.allclose(o[b], so, atol=1e-5)
+    assert finished >= B
+    assert np.allclose(venv.get_attr("actions_per_timestep"), [e.actions_per_timestep for e in singles], atol=1e-12)
+    assert venv.get_attr("timesteps") == [e.timesteps for e in singles]
+    # winning_ratio: the batched ring counts won episodes among the last 10; no wins happen in this scenario
+    assert venv.get_attr("winning_ratio") == [0.0] * B == [e.winning_ratio for e in singles]
+    venv.set_attr("timesteps", 5995, indices=[2])
+    assert venv.get_attr("timesteps", indices=2) == [5995]
+    first = venv.env_method("reset", indices=[1, 4])
+    assert len(first) == 2 and first[0][2] == 15000.0
+    venv.close()
+    for e in singles:
+        e.close()
+
+
+def test_rgb_array_renders_aircraft():
+    from atc_hip import render
+    from envs.atc import atc_gym
+    env = atc_gym.AtcGym()
+    img = env.render(mode='rgb_array')
+    assert img.shape == (800, 800, 3) and img.dtype == np.uint8
+    bg, view = render.background(env._vec.compiled, 800)
+    u, v = view.px([[10.0, 51.0]])[0]                      # the LOWW entry point (scenarios.py:205-207)
+    assert tuple(img[int(round(v)), int(round(u))]) == render.AIRCRAFT
+    assert (img != bg).any(axis=2).sum() >= 25             # marker + heading tick
+    assert env.render(mode='human') is None
+    for _ in range(50):
+        env.step(np.array([0.0, 0.0, -0.5]))
+    img2 = env.render(mode='rgb_array')
+    assert (img2 != img).any()
+    env.close()
