@@ -105,8 +105,9 @@ def _ring_edges(ring):
     return np.array([[a[0], a[1], b[0], b[1]] for a, b in e if a[1] != b[1]], dtype=np.float64).reshape(-1, 4)
 
 
-GRID_EDGE_WORDS = 8      # p1x, p1y, p2x, p2y, min(p1y,p2y), max(p1y,p2y), max(p1x,p2x), 4 * polygon index + flags
-GRID_F_LAST = 1.0        # last edge record of its polygon: evaluate the parity now
+GRID_EDGE_WORDS = 8      # edge: p1x, p1y, p2x, p2y | min(p1y,p2y), max(p1y,p2y), max(p1x,p2x), 4 * polygon index + flags
+#                          terminator: polygon bounds x0, y0, x1, y1 | polygon height, 0, 0, 4 * polygon index + TERM
+GRID_F_TERM = 1.0        # terminator record of a polygon: evaluate the parity + bounds test now
 GRID_F_CERTAIN = 2.0     # every point of the cell lies left of this edge: crossing needs no intersection test
 
 
@@ -119,7 +120,8 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None):
       x <= max(p1x,p2x), then x <= x-intersection) can only count an edge whose y-span meets the cell's y-span and whose
       x-max is not left of the cell; all other edges contribute nothing for ANY point of the cell, so dropping them leaves
       every crossing count — hence the result of ray_tracing — unchanged.  The device walks the listed edges polygon by
-      polygon (list order = priority) with the reference's own formula and bbox test.  Edges that lie entirely to the
+      polygon (list order = priority) with the reference's own formula; each polygon's edges are followed by a terminator
+      record carrying its bounds (the inclusive bbox test of model.py:286) and its height, so the walk is self-contained.  Edges that lie entirely to the
       right of the cell by more than 1e-3 nm are marked CERTAIN: x <= xints holds for every point of the cell whatever the
       rounding of xints (which stays within a few ulps of [min(p1x,p2x), max(p1x,p2x)]), so the division is skipped.
     Cell bounds are inflated by `slack` (guard + fp32 indexing error) so that a point the device bins into a neighbouring
@@ -181,12 +183,13 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None):
                     continue
                 certain = cx1s < xmin[idx] - 1e-3
                 order = np.argsort(certain, kind="stable")  # intersection-test edges first: lanes diverge less
-                for n_, k in enumerate(order):
-                    flags = (GRID_F_LAST if n_ == len(order) - 1 else 0.0) + (GRID_F_CERTAIN if certain[k] else 0.0)
+                for k in order:
                     ek = e[idx[k]]
                     pool.append([ek[0], ek[1], ek[2], ek[3], min(ek[1], ek[3]), max(ek[1], ek[3]), max(ek[0], ek[2]),
-                                 4.0 * pi + flags])
+                                 4.0 * pi + (GRID_F_CERTAIN if certain[k] else 0.0)])
                     n_rec += 1
+                pool.append([b[0], b[1], b[2], b[3], heights[pi], 0.0, 0.0, 4.0 * pi + GRID_F_TERM])
+                n_rec += 1
             cells[j, i, 0] = n_rec - first
             cells[j, i, 1] = first
             if n_rec == first:  # near an edge of a polygon whose bounds exclude the cell: nothing can match

@@ -114,6 +114,7 @@ __device__ __forceinline__ bool ray_tracing(float x, float y, const float* ring,
 // for some point of the cell; every other edge fails one of `y > min`, `y <= max`, `x <= max` for the whole cell, so
 // walking the list with the reference's formula yields the same crossing parity as ray_tracing over the full ring.
 // CERTAIN edges lie > 1e-3 nm to the right of the whole cell: x <= xints holds whatever the rounding of xints.
+// Each polygon's edges end with a terminator record holding its bounds (model.py:286) and height.
 __device__ __forceinline__ bool in_bounds(const float* rec, float x, float y) {
     const float4 b = *reinterpret_cast<const float4*>(rec);  // minx, miny, maxx, maxy
     return b.x <= x && x <= b.z && b.y <= y && y <= b.w;
@@ -133,29 +134,39 @@ __device__ __forceinline__ int find_mva(const float* __restrict__ K, const float
             *height = cell.y;
             return -n - 1;
         }
+        // Records are fetched in batches of kBatch (both 16-byte halves of each, all loads issued before the first use):
+        // one L2 round trip per batch instead of one per record.  Indices past the list are clamped (loads stay in
+        // bounds) and their records ignored.
         const float4* rec = reinterpret_cast<const float4*>(grid + (int)grid[ATC_G_OFF_POOL]) + 2 * (int)cell.y;
+        constexpr int kBatch = 4;
         bool inside = false;
-        for (int e = 0; e < n; ++e) {
-            const float4 g = rec[2 * e];      // p1x, p1y, p2x, p2y
-            const float4 m = rec[2 * e + 1];  // min(p1y,p2y), max(p1y,p2y), max(p1x,p2x), 4 * polygon + flags
-            const int code = (int)m.w;
-            if (y > m.x && y <= m.y && x <= m.z) {  // the three cheap tests of model.py:328-330
-                bool cross = (code & ATC_GE_CERTAIN) != 0;
-                if (!cross) {
-                    const float xints = (y - g.y) * (g.z - g.x) / (g.w - g.y) + g.x;
-                    cross = (g.x == g.z) || x <= xints;
-                }
-                inside = inside != cross;
+        for (int base = 0; base < n; base += kBatch) {
+            float4 g[kBatch], m[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int e = min(base + u, n - 1);
+                g[u] = rec[2 * e];
+                m[u] = rec[2 * e + 1];
             }
-            if (code & ATC_GE_LAST) {
-                if (inside) {
-                    const float* pr = tab + (code >> 2) * ATC_P_WORDS;
-                    if (in_bounds(pr, x, y)) {
-                        *height = pr[ATC_P_HEIGHT];
-                        return code >> 2;
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                if (base + u < n) {
+                    const int code = (int)m[u].w;
+                    if (code & ATC_GE_TERM) {  // g = polygon bounds, m.x = polygon height
+                        if (inside && g[u].x <= x && x <= g[u].z && g[u].y <= y && y <= g[u].w) {
+                            *height = m[u].x;
+                            return code >> 2;
+                        }
+                        inside = false;
+                    } else if (y > m[u].x && y <= m[u].y && x <= m[u].z) {  // the three cheap tests of model.py:328-330
+                        bool cross = (code & ATC_GE_CERTAIN) != 0;
+                        if (!cross) {
+                            const float xints = (y - g[u].y) * (g[u].z - g[u].x) / (g[u].w - g[u].y) + g[u].x;
+                            cross = (g[u].x == g[u].z) || x <= xints;
+                        }
+                        inside = inside != cross;
                     }
                 }
-                inside = false;
             }
         }
         return -1;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ATC_ABI_VERSION 6
+#define ATC_ABI_VERSION 7
 
 /* ---------------------------------------------------------------------------------------------
  * Scenario blob: one flat array of 32-bit floats (device copy) compiled on the host from the sector
@@ -35,7 +35,7 @@ extern "C" {
  * envs/atc/atc_gym.py:45-58,88-110).  Integer fields are stored as exactly representable floats.
  * The float64 master (used by the f64 oracle) has the identical word layout.
  * ------------------------------------------------------------------------------------------- */
-#define ATC_BLOB_VERSION 1006.0f
+#define ATC_BLOB_VERSION 1007.0f
 enum {
     ATC_H_VERSION = 0,   /* ATC_BLOB_VERSION */
     ATC_H_NWORDS = 1,    /* total words */
@@ -90,11 +90,13 @@ enum { ATC_E_X = 0, ATC_E_Y = 1, ATC_E_PHI = 2, ATC_E_NLEV = 3, ATC_E_LEV0 = 4, 
  *   cells  ny*nx*2 : (n_records >= 1, first_record)   -> dirty cell: walk that many edge records
  *                    (-(polygon + 1), MVA height)     -> clean cell: every point has this answer
  *                    (0, 0)                           -> clean cell outside the airspace
- *   pool           : 8-word edge records  p1x, p1y, p2x, p2y, min(p1y,p2y), max(p1y,p2y), max(p1x,p2x),
+ *   pool           : 8-word records, two 16-byte halves G | M:
+ *                    edge       G = p1x, p1y, p2x, p2y          M = min(p1y,p2y), max(p1y,p2y), max(p1x,p2x), code
+ *                    terminator G = polygon bounds x0,y0,x1,y1  M = polygon height, 0, 0, code        (ends a polygon)
  *                    code = 4 * polygon index + flags                                                                 */
 enum { ATC_G_X0 = 0, ATC_G_Y0 = 1, ATC_G_INV = 2, ATC_G_NX = 3, ATC_G_NY = 4, ATC_G_OFF_POOL = 5, ATC_G_NREC = 6,
        ATC_G_HDR = 8, ATC_GE_WORDS = 8 };
-#define ATC_GE_LAST 1    /* last edge record of its polygon: evaluate parity (+ bounds test) now */
+#define ATC_GE_TERM 1    /* terminator record of a polygon: evaluate parity + bounds test now (model.py:286-287) */
 #define ATC_GE_CERTAIN 2 /* the cell lies entirely left of this edge: crossing iff the y test passes */
 
 #define ATC_MAX_AIRCRAFT 64

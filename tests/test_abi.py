@@ -43,7 +43,7 @@ def test_layout_matches_header():
     assert checked > 60
     assert L.ABI_VERSION == int(re.search(r"#define ATC_ABI_VERSION (\d+)", text).group(1))
     assert L.BLOB_VERSION == float(re.search(r"#define ATC_BLOB_VERSION ([\d.]+)f", text).group(1))
-    assert int(re.search(r"#define ATC_GE_LAST (\d+)", text).group(1)) == 1
+    assert int(re.search(r"#define ATC_GE_TERM (\d+)", text).group(1)) == 1
     assert int(re.search(r"#define ATC_GE_CERTAIN (\d+)", text).group(1)) == 2
     assert L.MAX_AIRCRAFT == 64 and L.OBS_DIM == 10 and L.ACT_DIM == 3
 

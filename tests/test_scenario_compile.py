@@ -81,7 +81,14 @@ def _walk_grid(b, g, tabs, tabs_h, x, y):
     inside = False
     for e in range(n):
         r = b[pool + (v + e) * L.GE_WORDS: pool + (v + e + 1) * L.GE_WORDS]
-        p1x, p1y, p2x, p2y, pi, fl = r[0], r[1], r[2], r[3], int(r[7]) // 4, int(r[7]) % 4
+        pi, fl = int(r[7]) // 4, int(r[7]) % 4
+        if fl & 1:  # terminator: bounds + height
+            assert tuple(r[0:4]) == tuple(tabs[pi]) and r[4] == tabs_h[pi]
+            if inside and r[0] <= x <= r[2] and r[1] <= y <= r[3]:
+                return pi
+            inside = False
+            continue
+        p1x, p1y, p2x, p2y = r[0], r[1], r[2], r[3]
         assert (r[4], r[5], r[6]) == (min(p1y, p2y), max(p1y, p2y), max(p1x, p2x))
         if y > r[4] and y <= r[5] and x <= r[6]:
             cross = bool(fl & 2)
@@ -89,11 +96,6 @@ def _walk_grid(b, g, tabs, tabs_h, x, y):
                 xints = (y - p1y) * (p2x - p1x) / (p2y - p1y) + p1x
                 cross = p1x == p2x or x <= xints
             inside = inside != cross
-        if fl & 1:
-            bb = tabs[pi]
-            if inside and bb[0] <= x <= bb[2] and bb[1] <= y <= bb[3]:
-                return pi
-            inside = False
     return -1
 
 
