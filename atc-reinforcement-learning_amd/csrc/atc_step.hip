@@ -58,12 +58,26 @@ static int fail_hip(hipError_t e, const char* what) {
 #ifndef ATC_BLOCK
 #define ATC_BLOCK 256
 #endif
-#ifndef ATC_NT
-#define ATC_NT 0  // non-temporal streams for actions / observations / flags: measured SLOWER (36.1 vs 32.0 us), kept off
+#ifndef ATC_NT_LOAD
+#define ATC_NT_LOAD 0   // non-temporal action loads: measured SLOWER (36.0 vs 31.9 us)
+#endif
+#ifndef ATC_NT_STORE
+#define ATC_NT_STORE 1  // non-temporal observation / flag stores (write-once streams): 30.7 vs 31.9 us
 #endif
 constexpr int kBlock = ATC_BLOCK;
 #ifndef ATC_ABLATE
 #define ATC_ABLATE 0  // developer-only timing ablations (tools/ablate.sh); the shipped build always uses 0
+#endif
+#ifndef ATC_TRACE
+#define ATC_TRACE 0  // developer-only: per-wavefront s_memtime stamps at phase boundaries (pointer smuggled in params)
+#endif
+#if ATC_TRACE
+#define ATC_STAMP(n) do { if (lane == 0 && trace) trace[(size_t)(blockIdx.x * (kBlock / 64) + (tid >> 6)) * 8 + (n)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ATC_STAMP(n) do {} while (0)
+#endif
+#ifndef ATC_STAGGER
+#define ATC_STAGGER 5  // measured: 5 -> 31.1 us vs 31.8 us without (8: 31.9, 12: 33.1) | first-round workgroups sleep hash(blockIdx) * ATC_STAGGER * 64 cycles (0..31 steps) before starting
 #endif
 #ifndef ATC_GRID_CAP
 #define ATC_GRID_CAP 8   // workgroups per CU before the kernels grid-stride
@@ -125,7 +139,7 @@ struct PairScan16<16> {
 
 template <typename T>
 __device__ __forceinline__ void stream_store(T* p, T v) {
-#if ATC_NT
+#if ATC_NT_STORE
     __builtin_nontemporal_store(v, p);
 #else
     *p = v;
@@ -133,7 +147,7 @@ __device__ __forceinline__ void stream_store(T* p, T v) {
 }
 template <typename T>
 __device__ __forceinline__ T stream_load(const T* p) {
-#if ATC_NT
+#if ATC_NT_LOAD
     return __builtin_nontemporal_load(p);
 #else
     return *p;
@@ -164,10 +178,23 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
     float* obs_stage = smem + ((W > 1 && W != 16) ? kBlock * 4 : 0);  // [4 waves][64 x 10] obs transpose
     const float* __restrict__ K = blob;  // the sector: uniform-index reads -> scalar loads
     const float* __restrict__ grid = off_grid ? blob + off_grid : nullptr;
-    (void)lds_words;
+    const int first_round = lds_words;  // (argument slot reused) workgroups resident at launch: n_cu * 4
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+#if ATC_TRACE
+    unsigned long long* trace = reinterpret_cast<unsigned long long*>(
+        ((unsigned long long)p.reserved0) | ((unsigned long long)__float_as_uint(p.reserved1) << 32));
+#endif
+#if ATC_STAGGER
+    // All resident wavefronts of a launch start together and then move through load -> compute -> store in lockstep, so
+    // the memory system and the SIMDs take turns idling.  De-phase the first round once; later rounds inherit the spread.
+    if (blockIdx.x < (unsigned)first_round) {
+        const unsigned d = ((blockIdx.x * 2654435761u) >> 27);
+        for (unsigned q = 0; q < d; ++q) __builtin_amdgcn_s_sleep(ATC_STAGGER);
+    }
+#endif
+    ATC_STAMP(0);
     const uint32_t BN = (uint32_t)B * (uint32_t)N;      // host guarantees B*N*40 bytes < 4 GiB: 32-bit lane offsets
     const uint32_t slots = (uint32_t)B * (uint32_t)W;
     const uint32_t slot0 = blockIdx.x * kBlock;
@@ -255,6 +282,7 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
                 la_p = active ? tp : la_p;
             }
         }
+        ATC_STAMP(1);
         // ---- Airplane.step (model.py:122-129): rot_matrix(phi) . [0, (v/3600) dt] ------------------------------------
         {
             const float dist = active ? (a.v / 3600.0f) * dt : 0.0f;
@@ -264,6 +292,7 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
             a.y += (double)(cs * dist);
         }
         const float x32 = (float)a.x, y32 = (float)a.y;
+        ATC_STAMP(2);
         // ---- MVA floor (atc_gym.py:146-161) ----------------------------------------------------------------------------
         float mva = 0.0f;
         {
@@ -275,6 +304,7 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
             fl |= pi < 0 ? (uint32_t)ATC_F_OUTSIDE : (below ? (uint32_t)ATC_F_BELOW_MVA : 0u);
         }
 
+        ATC_STAMP(3);
         // ---- separation scan (extension; README.md:51): 3 nm / 1000 ft among aircraft active at step start -----------
         // Every lane visits its env's other W-1 slots (never itself); aircraft that are not under control are staged
         // at x = 1e18 so that they neither conflict nor enter the minimum — branch-free.
@@ -311,6 +341,7 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
             fl |= conflict ? (uint32_t)ATC_F_CONFLICT : 0u;
         }
 
+        ATC_STAMP(4);
         // ---- win / timeout overrides (atc_gym.py:163-173) ---------------------------------------------------------------
         if (!(ATC_ABLATE & 4) && inside_corridor(K, x32, y32, a.h, a.phi)) {
             int bonus = (p.timestep_limit - t) * 5;
@@ -370,6 +401,7 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
         fl = active ? fl : (lane_valid ? (uint32_t)ATC_F_INACTIVE : 0u);
         if (!active) min_d2 = 1e30f;
 
+        ATC_STAMP(5);
         // ---- per-env reductions over the W lanes of the group ------------------------------------------------------------
         const float env_r = group_sum<W>(r);
         const int env_acts = group_sum_i<W>(acts);
@@ -434,7 +466,7 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
                 const int idx = j * 64 + lane;
                 if (idx < 64 * ATC_OBS_DIM / 4) {
                     const float4 v = src[idx];
-#if ATC_NT
+#if ATC_NT_STORE
                     float* d4 = reinterpret_cast<float*>(dst + idx);
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(d4));
@@ -449,6 +481,7 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
         }
     }
 
+    ATC_STAMP(6);
     // ---- write back persistent state ---------------------------------------------------------------------------------------
     if (lane_valid) {
         reinterpret_cast<double2*>(st.pos)[i] = make_double2(a.x, a.y);
@@ -462,6 +495,7 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
         er[1] = make_int4(__float_as_int(total_reward), __float_as_int(ep_return), (int)win_bits, 0);
         er[2] = make_int4((int)(uint32_t)(amask & 0xffffffffu), (int)(uint32_t)(amask >> 32), 0, 0);
     }
+    ATC_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -590,8 +624,8 @@ static int launch_step2(const atc_scenario* s, int B, int N, int T, const atc_st
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long long slots = (long long)B * W;
     const int grid = (int)((slots + kBlock - 1) / kBlock);  // one workgroup per 256 slots, no grid-stride loop
-    hipLaunchKernelGGL((k_step<W, FULL>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->lds_words, s->off_grid, B, N,
-                       T, *st, actions, *out, *p);
+    hipLaunchKernelGGL((k_step<W, FULL>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->n_cu * (1024 / kBlock),
+                       s->off_grid, B, N, T, *st, actions, *out, *p);
     HIP_TRY(hipGetLastError());
     return ATC_OK;
 }
