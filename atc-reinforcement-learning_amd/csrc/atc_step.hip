@@ -79,6 +79,9 @@ constexpr int kBlock = ATC_BLOCK;
 #ifndef ATC_STAGGER
 #define ATC_STAGGER 5  // measured: 5 -> 31.1 us vs 31.8 us without (8: 31.9, 12: 33.1) | first-round workgroups sleep hash(blockIdx) * ATC_STAGGER * 64 cycles (0..31 steps) before starting
 #endif
+#ifndef ATC_LATE_ENV
+#define ATC_LATE_ENV 0
+#endif
 #ifndef ATC_GRID_CAP
 #define ATC_GRID_CAP 8   // workgroups per CU before the kernels grid-stride
 #endif
@@ -89,22 +92,53 @@ constexpr int kBlock = ATC_BLOCK;
 // ---------------------------------------------------------------------------------------------------------------
 // wavefront-group helpers (groups of W consecutive lanes, W a power of two <= 64)
 // ---------------------------------------------------------------------------------------------------------------
+// Butterfly exchange partner for reductions over groups of W lanes.  Inside a DPP row (W <= 16) the stages are
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror: after each stage both halves of the growing
+// block hold the same value, so the mirrored pairings are as good as xor pairings — and they are VALU operand modifiers
+// (no ds_bpermute, no index registers).  Wider groups fall back to __shfl_xor for the cross-row stages.
+template <int STAGE>
+__device__ __forceinline__ int dpp_stage(int v) {
+    constexpr int ctrl = STAGE == 1 ? 0xB1 : STAGE == 2 ? 0x4E : STAGE == 4 ? 0x141 : 0x140;
+    return __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, false);
+}
+template <int O>
+__device__ __forceinline__ float xchg(float v) {
+    if (O <= 8) return __int_as_float(dpp_stage<O>(__float_as_int(v)));
+    return __shfl_xor(v, O, 64);
+}
+template <int O>
+__device__ __forceinline__ int xchg(int v) {
+    if (O <= 8) return dpp_stage<O>(v);
+    return __shfl_xor(v, O, 64);
+}
 template <int W>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (W > 1) v += xchg<1>(v);
+    if (W > 2) v += xchg<2>(v);
+    if (W > 4) v += xchg<4>(v);
+    if (W > 8) v += xchg<8>(v);
+    if (W > 16) v += xchg<16>(v);
+    if (W > 32) v += xchg<32>(v);
     return v;
 }
 template <int W>
 __device__ __forceinline__ int group_sum_i(int v) {
-#pragma unroll
-    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (W > 1) v += xchg<1>(v);
+    if (W > 2) v += xchg<2>(v);
+    if (W > 4) v += xchg<4>(v);
+    if (W > 8) v += xchg<8>(v);
+    if (W > 16) v += xchg<16>(v);
+    if (W > 32) v += xchg<32>(v);
     return v;
 }
 template <int W>
 __device__ __forceinline__ float group_min(float v) {
-#pragma unroll
-    for (int o = W / 2; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    if (W > 1) v = fminf(v, xchg<1>(v));
+    if (W > 2) v = fminf(v, xchg<2>(v));
+    if (W > 4) v = fminf(v, xchg<4>(v));
+    if (W > 8) v = fminf(v, xchg<8>(v));
+    if (W > 16) v = fminf(v, xchg<16>(v));
+    if (W > 32) v = fminf(v, xchg<32>(v));
     return v;
 }
 template <int W>
@@ -137,6 +171,16 @@ struct PairScan16<16> {
     static __device__ __forceinline__ void run(float, float, float, float, float, float&, int&) {}
 };
 
+// Per-lane addressing = uniform 64-bit base + 32-bit BYTE offset (the host guarantees B*N*40 < 4 GiB): the compiler can
+// then use the scalar-base addressing form and does not keep a 64-bit address pair per array alive in VGPRs.
+template <typename T>
+__device__ __forceinline__ T* at(void* base, uint32_t byte_off) {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ const T* at(const void* base, uint32_t byte_off) {
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 template <typename T>
 __device__ __forceinline__ void stream_store(T* p, T v) {
 #if ATC_NT_STORE
@@ -189,7 +233,8 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
 #if ATC_STAGGER
     // All resident wavefronts of a launch start together and then move through load -> compute -> store in lockstep, so
     // the memory system and the SIMDs take turns idling.  De-phase the first round once; later rounds inherit the spread.
-    if (blockIdx.x < (unsigned)first_round) {
+    // Only worth it when the launch runs for several rounds of resident workgroups (small launches would just start late).
+    if (blockIdx.x < (unsigned)first_round && gridDim.x >= 3u * (unsigned)first_round) {
         const unsigned d = ((blockIdx.x * 2654435761u) >> 27);
         for (unsigned q = 0; q < d; ++q) __builtin_amdgcn_s_sleep(ATC_STAGGER);
     }
@@ -206,15 +251,24 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
     const uint32_t i = lane_valid ? (uint32_t)e * (uint32_t)N + (uint32_t)k : BN - 1u;
 
     // ---- load persistent state (16-byte records; the W lanes of an env share the env record) -------------------------
-    const int4* erp = reinterpret_cast<const int4*>(st.env) + (uint32_t)e * (ATC_ENV_WORDS / 4);
+    const int4* erp = at<int4>(st.env, (uint32_t)e * (ATC_ENV_WORDS * 4u));
+#if ATC_LATE_ENV
+    // only the words needed early are loaded here (timesteps, mask); the bookkeeping words are loaded in the epilogue
+    int t = reinterpret_cast<const int*>(erp)[ATC_ENV_TIMESTEPS];
+    const int2 e2 = *reinterpret_cast<const int2*>(reinterpret_cast<const int*>(erp) + ATC_ENV_MASK_LO);
+    int n_actions = 0, episode = 0, ep_length = 0;
+    float total_reward = 0.0f, ep_return = 0.0f;
+    uint32_t win_bits = 0;
+#else
     const int4 e0 = erp[0], e1 = erp[1], e2 = erp[2];
     int t = e0.x, n_actions = e0.y, episode = e0.z, ep_length = e0.w;
     float total_reward = __int_as_float(e1.x), ep_return = __int_as_float(e1.y);
     uint32_t win_bits = (uint32_t)e1.z;
+#endif
     uint64_t amask = (uint64_t)(uint32_t)e2.x | ((uint64_t)(uint32_t)e2.y << 32);
-    const double2 ps = reinterpret_cast<const double2*>(st.pos)[i];
-    const float4 kn = reinterpret_cast<const float4*>(st.kin)[i];
-    const float2 lv = reinterpret_cast<const float2*>(st.last_vh)[i];
+    const double2 ps = *at<double2>(st.pos, i * 16u);
+    const float4 kn = *at<float4>(st.kin, i * 16u);
+    const float2 lv = *at<float2>(st.last_vh, i * 8u);
     Aircraft a = {ps.x, ps.y, kn.x, kn.y, kn.z};
     float la_p = kn.w, la_v = lv.x, la_h = lv.y;
     bool la_changed = false;
@@ -237,8 +291,8 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
         // branch-free form of: invalid target -> ValueError -> -1 reward, nothing applied, last_action kept
         // (atc_gym.py:303-315); valid -> rate-limited move, actions_taken++ unless |target - last| < discriminator
         {
-            const float a_v = stream_load(act_t + i * 3u + 0u), a_h = stream_load(act_t + i * 3u + 1u),
-                        a_p = stream_load(act_t + i * 3u + 2u);
+            const float a_v = stream_load(at<float>(act_t, i * 12u)), a_h = stream_load(at<float>(act_t, i * 12u + 4u)),
+                        a_p = stream_load(at<float>(act_t, i * 12u + 8u));
             const float v_min = K[ATC_C_V_MIN], v_max = K[ATC_C_V_MAX], h_min = K[ATC_C_H_MIN], h_max = K[ATC_C_H_MAX];
             // atc_gym.py:64-78: offset (v_min,0,0); factor (10,100,1) discrete | (v_max-v_min, h_max, 360) continuous
             const float fac_v = discrete ? 10.0f : v_max - v_min;
@@ -384,7 +438,7 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
                 float z[ATC_OBS_DIM];
 #pragma unroll
                 for (int c = 0; c < ATC_OBS_DIM; ++c) z[c] = active ? ob.o[c] : 0.0f;  // zeros for handed-over aircraft
-                store_obs(out.raw_obs + sBN * ATC_OBS_DIM + i * ATC_OBS_DIM, z);
+                store_obs(at<float>(out.raw_obs + sBN * ATC_OBS_DIM, i * 40u), z);
             }
             if (p.mode & ATC_M_NORMALIZE) {  // atc_gym.py:187-189: (s - min - max/2) / (max/2) as one fma
 #pragma unroll
@@ -402,6 +456,17 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
         if (!active) min_d2 = 1e30f;
 
         ATC_STAMP(5);
+#if ATC_LATE_ENV
+        if (step == 0) {
+            const int4 e0 = erp[0], e1 = erp[1];
+            n_actions = e0.y;
+            episode = e0.z;
+            ep_length = e0.w;
+            total_reward = __int_as_float(e1.x);
+            ep_return = __int_as_float(e1.y);
+            win_bits = (uint32_t)e1.z;
+        }
+#endif
         // ---- per-env reductions over the W lanes of the group ------------------------------------------------------------
         const float env_r = group_sum<W>(r);
         const int env_acts = group_sum_i<W>(acts);
@@ -414,16 +479,16 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
         n_actions += env_acts;
 
         if (lane_valid) {
-            stream_store(out.flags + sBN + i, fl);
-            if (FULL && out.ac_reward) (out.ac_reward + sBN)[i] = r;
+            stream_store(at<uint32_t>(out.flags + sBN, i * 4u), fl);
+            if (FULL && out.ac_reward) *at<float>(out.ac_reward + sBN, i * 4u) = r;
         }
         if (env_valid && k == 0) {
-            (out.reward + sB)[e] = env_r;
-            (out.done + sB)[e] = done ? 1 : 0;
+            *at<float>(out.reward + sB, (uint32_t)e * 4u) = env_r;
+            *at<uint8_t>(out.done + sB, (uint32_t)e) = done ? 1 : 0;
         }
         if (FULL && out.min_sep) {
             const float m2 = (W > 1) ? group_min<W>(min_d2) : 1e30f;
-            if (env_valid && k == 0) (out.min_sep + sB)[e] = (m2 >= 1e30f) ? 1e30f : sqrtf(m2);
+            if (env_valid && k == 0) *at<float>(out.min_sep + sB, (uint32_t)e * 4u) = (m2 >= 1e30f) ? 1e30f : sqrtf(m2);
         }
 
         if (done && (p.mode & ATC_M_AUTO_RESET)) {
@@ -433,7 +498,7 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
             ep_length = t;
             win_bits = ((win_bits << 1) | (amask == 0 ? 1u : 0u)) & 0x3ffu;
             if (lane_valid) {
-                if (FULL && out.term_obs) store_obs(out.term_obs + sBN * ATC_OBS_DIM + i * ATC_OBS_DIM, o);
+                if (FULL && out.term_obs) store_obs(at<float>(out.term_obs + sBN * ATC_OBS_DIM, i * 40u), o);
                 a = spawn(K, p, e, k, episode);
                 const Obs ob = get_state(K, (float)a.x, (float)a.y, a.h, a.phi, a.v, 0.0f);
 #pragma unroll
@@ -459,38 +524,38 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float4* dst = reinterpret_cast<float4*>(obs_t + (size_t)(slot0 + (uint32_t)(tid & ~63)) * ATC_OBS_DIM);
+            const uint32_t wave_off = (slot0 + (uint32_t)(tid & ~63)) * 40u;  // first aircraft of this wavefront (N == W)
             const float4* src = reinterpret_cast<const float4*>(tb);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int idx = j * 64 + lane;
                 if (idx < 64 * ATC_OBS_DIM / 4) {
                     const float4 v = src[idx];
+                    float* d4 = at<float>(obs_t, wave_off + (uint32_t)idx * 16u);
 #if ATC_NT_STORE
-                    float* d4 = reinterpret_cast<float*>(dst + idx);
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(d4));
 #else
-                    dst[idx] = v;
+                    *reinterpret_cast<float4*>(d4) = v;
 #endif
                 }
             }
             __builtin_amdgcn_wave_barrier();
         } else if (lane_valid) {
-            store_obs(obs_t + i * ATC_OBS_DIM, o);
+            store_obs(at<float>(obs_t, i * 40u), o);
         }
     }
 
     ATC_STAMP(6);
     // ---- write back persistent state ---------------------------------------------------------------------------------------
     if (lane_valid) {
-        reinterpret_cast<double2*>(st.pos)[i] = make_double2(a.x, a.y);
-        reinterpret_cast<float4*>(st.kin)[i] = make_float4(a.h, a.phi, a.v, la_p);
+        *at<double2>(st.pos, i * 16u) = make_double2(a.x, a.y);
+        *at<float4>(st.kin, i * 16u) = make_float4(a.h, a.phi, a.v, la_p);
         // actions are typically held for many steps: write last v/h targets back only where they changed
-        if (la_changed) reinterpret_cast<float2*>(st.last_vh)[i] = make_float2(la_v, la_h);
+        if (la_changed) *at<float2>(st.last_vh, i * 8u) = make_float2(la_v, la_h);
     }
     if (env_valid && k == 0) {
-        int4* er = reinterpret_cast<int4*>(st.env) + (uint32_t)e * (ATC_ENV_WORDS / 4);
+        int4* er = at<int4>(st.env, (uint32_t)e * (ATC_ENV_WORDS * 4u));
         er[0] = make_int4(t, n_actions, episode, ep_length);
         er[1] = make_int4(__float_as_int(total_reward), __float_as_int(ep_return), (int)win_bits, 0);
         er[2] = make_int4((int)(uint32_t)(amask & 0xffffffffu), (int)(uint32_t)(amask >> 32), 0, 0);

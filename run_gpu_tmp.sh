@@ -1,6 +1,3 @@
-for rep in 1 2 3; do
-ATC_LIBATCSTEP=$PWD/build_variants/libatcstep_nts0.so timeout 300 python bench.py --no-cpu-baseline --steps 2000 --warmup 300 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('nts0', round(d['ms_per_step']*1000,2), round(d['roofline']['frac'],4))"
-timeout 300 python bench.py --no-cpu-baseline --steps 2000 --warmup 300 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('nts1', round(d['ms_per_step']*1000,2), round(d['roofline']['frac'],4))"
+for args in "--sep-nm 3" "--envs 4096 --aircraft 64" "--aircraft 1" "--envs 8192"; do
+  timeout 300 python bench.py --no-cpu-baseline --steps 2000 --warmup 300 $args 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$args', round(d['ms_per_step']*1000,2), round(d['roofline']['frac'],4), d['config']['episodes_finished'])"
 done
-timeout 1500 python -m pytest tests -m gpu -q -x -k "not full_size" > gpurun_out/pytest_gpu10.log 2>&1; echo rc=$? >> gpurun_out/pytest_gpu10.log
-tail -3 gpurun_out/pytest_gpu10.log
