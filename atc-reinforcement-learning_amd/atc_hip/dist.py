@@ -19,12 +19,18 @@ def world():
 def init(backend=None):
     """Initialises the default process group when WORLD_SIZE > 1 (nccl on GPU, gloo otherwise)."""
     rank, ws, local = world()
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)  # one process per GPU: bind before the communicator is created
     if ws > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (required by the host driver for RCCL)
+        if backend == "nccl":
+            dist.init_process_group(backend=backend, rank=rank, world_size=ws, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=ws)
     return rank, ws, local
 
 

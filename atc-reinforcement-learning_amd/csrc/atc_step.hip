@@ -29,7 +29,6 @@ using namespace atc;
 struct atc_scenario {
     float* d_blob;   // device copy of the whole blob (constants + polygons + entries [+ grid])
     int n_words;
-    int lds_words;   // words staged into LDS (everything before the grid)
     int off_grid;    // 0 = no grid
     int device;
     int n_cu;
@@ -78,9 +77,6 @@ constexpr int kBlock = ATC_BLOCK;
 #endif
 #ifndef ATC_STAGGER
 #define ATC_STAGGER 5  // measured: 5 -> 31.1 us vs 31.8 us without (8: 31.9, 12: 33.1) | first-round workgroups sleep hash(blockIdx) * ATC_STAGGER * 64 cycles (0..31 steps) before starting
-#endif
-#ifndef ATC_LATE_ENV
-#define ATC_LATE_ENV 0
 #endif
 #ifndef ATC_GRID_CAP
 #define ATC_GRID_CAP 8   // workgroups per CU before the kernels grid-stride
@@ -215,14 +211,14 @@ __device__ __forceinline__ void store_obs(float* __restrict__ dst, const float* 
 // ---------------------------------------------------------------------------------------------------------------
 template <int W, bool FULL>
 __global__ void __launch_bounds__(kBlock, ATC_MIN_WAVES)
-k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N, int T, atc_state_t st,
+k_step(const float* __restrict__ blob, int first_round, int off_grid, int B, int N, int T, atc_state_t st,
        const float* __restrict__ actions, atc_out_t out, atc_params_t p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4* pos = reinterpret_cast<float4*>(smem);                    // [kBlock] pair-scan staging (W != 1, 16)
     float* obs_stage = smem + ((W > 1 && W != 16) ? kBlock * 4 : 0);  // [4 waves][64 x 10] obs transpose
     const float* __restrict__ K = blob;  // the sector: uniform-index reads -> scalar loads
     const float* __restrict__ grid = off_grid ? blob + off_grid : nullptr;
-    const int first_round = lds_words;  // (argument slot reused) workgroups resident at launch: n_cu * 4
+    // first_round = workgroups resident at launch (n_cu * 4), see ATC_STAGGER
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -252,19 +248,10 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
 
     // ---- load persistent state (16-byte records; the W lanes of an env share the env record) -------------------------
     const int4* erp = at<int4>(st.env, (uint32_t)e * (ATC_ENV_WORDS * 4u));
-#if ATC_LATE_ENV
-    // only the words needed early are loaded here (timesteps, mask); the bookkeeping words are loaded in the epilogue
-    int t = reinterpret_cast<const int*>(erp)[ATC_ENV_TIMESTEPS];
-    const int2 e2 = *reinterpret_cast<const int2*>(reinterpret_cast<const int*>(erp) + ATC_ENV_MASK_LO);
-    int n_actions = 0, episode = 0, ep_length = 0;
-    float total_reward = 0.0f, ep_return = 0.0f;
-    uint32_t win_bits = 0;
-#else
     const int4 e0 = erp[0], e1 = erp[1], e2 = erp[2];
     int t = e0.x, n_actions = e0.y, episode = e0.z, ep_length = e0.w;
     float total_reward = __int_as_float(e1.x), ep_return = __int_as_float(e1.y);
     uint32_t win_bits = (uint32_t)e1.z;
-#endif
     uint64_t amask = (uint64_t)(uint32_t)e2.x | ((uint64_t)(uint32_t)e2.y << 32);
     const double2 ps = *at<double2>(st.pos, i * 16u);
     const float4 kn = *at<float4>(st.kin, i * 16u);
@@ -456,17 +443,6 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
         if (!active) min_d2 = 1e30f;
 
         ATC_STAMP(5);
-#if ATC_LATE_ENV
-        if (step == 0) {
-            const int4 e0 = erp[0], e1 = erp[1];
-            n_actions = e0.y;
-            episode = e0.z;
-            ep_length = e0.w;
-            total_reward = __int_as_float(e1.x);
-            ep_return = __int_as_float(e1.y);
-            win_bits = (uint32_t)e1.z;
-        }
-#endif
         // ---- per-env reductions over the W lanes of the group ------------------------------------------------------------
         const float env_r = group_sum<W>(r);
         const int env_acts = group_sum_i<W>(acts);
@@ -567,9 +543,8 @@ k_step(const float* __restrict__ blob, int lds_words, int off_grid, int B, int N
 // reset kernel (AtcGym.reset, atc_gym.py:337-365)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_reset(const float* __restrict__ blob, int lds_words, int B, int N, atc_state_t st, const uint8_t* __restrict__ mask,
+k_reset(const float* __restrict__ blob, int B, int N, atc_state_t st, const uint8_t* __restrict__ mask,
         float* __restrict__ obs, atc_params_t p, int first) {
-    (void)lds_words;
     const uint32_t BN = (uint32_t)B * (uint32_t)N;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < BN; i += gridDim.x * kBlock) {
         const int e = (int)(i / (uint32_t)N), k = (int)(i % (uint32_t)N);
@@ -589,9 +564,8 @@ k_reset(const float* __restrict__ blob, int lds_words, int B, int N, atc_state_t
 }
 // _get_state(0) of the current state (atc_gym.py:351)
 __global__ void __launch_bounds__(kBlock)
-k_observe(const float* __restrict__ blob, int lds_words, int B, int N, atc_state_t st, const uint8_t* __restrict__ mask,
+k_observe(const float* __restrict__ blob, int B, int N, atc_state_t st, const uint8_t* __restrict__ mask,
           float* __restrict__ obs) {
-    (void)lds_words;
     const uint32_t BN = (uint32_t)B * (uint32_t)N;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < BN; i += gridDim.x * kBlock) {
         const int e = (int)(i / (uint32_t)N);
@@ -629,9 +603,8 @@ k_reset_env(int B, int N, atc_state_t st, const uint8_t* __restrict__ mask, int 
 // query kernels
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_query_mva(const float* __restrict__ blob, int lds_words, int off_grid, int n, const float* __restrict__ x,
+k_query_mva(const float* __restrict__ blob, int off_grid, int n, const float* __restrict__ x,
             const float* __restrict__ y, int32_t* __restrict__ out_h, int32_t* __restrict__ out_idx) {
-    (void)lds_words;
     const float* grid = off_grid ? blob + off_grid : nullptr;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         float hgt;
@@ -641,19 +614,17 @@ k_query_mva(const float* __restrict__ blob, int lds_words, int off_grid, int n, 
     }
 }
 __global__ void __launch_bounds__(kBlock)
-k_query_corridor(const float* __restrict__ blob, int lds_words, int n, const float* __restrict__ x,
+k_query_corridor(const float* __restrict__ blob, int n, const float* __restrict__ x,
                  const float* __restrict__ y, const float* __restrict__ h, const float* __restrict__ phi, int angle_only,
                  uint8_t* __restrict__ out) {
-    (void)lds_words;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
         out[i] = angle_only ? inside_corridor_angle(blob, x[i], y[i], phi[i])
                             : inside_corridor(blob, x[i], y[i], h[i], phi[i]);
 }
 __global__ void __launch_bounds__(kBlock)
-k_query_shaping(const float* __restrict__ blob, int lds_words, int n, const float* __restrict__ d_faf,
+k_query_shaping(const float* __restrict__ blob, int n, const float* __restrict__ d_faf,
                 const float* __restrict__ phi_rel_faf, const float* __restrict__ phi_plane, const float* __restrict__ h,
                 const float* __restrict__ on_gp, float* __restrict__ out3) {
-    (void)lds_words;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const Shaping s = shaping_rewards(blob, d_faf[i], phi_rel_faf[i], relative_angle(blob[ATC_C_PHI_TO_RWY], phi_plane[i]),
                                           h[i], on_gp[i]);
@@ -735,7 +706,6 @@ int atc_scenario_create(const float* blob_host, size_t n_words, int device, atc_
     atc_scenario* s = new atc_scenario();
     s->n_words = (int)n_words;
     s->off_grid = (int)blob_host[ATC_H_OFF_GRID];
-    s->lds_words = s->off_grid ? s->off_grid : (int)n_words;
     s->device = device;
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, device);
@@ -771,7 +741,7 @@ int atc_query_mva(const atc_scenario_t* s, int n, const float* x, const float* y
     if (!s || !x || !y || !out_h || n < 0) return fail_arg("null pointer / negative n");
     if (n == 0) return ATC_OK;
     hipLaunchKernelGGL(k_query_mva, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false), (hipStream_t)stream,
-                       s->d_blob, s->lds_words, use_grid ? s->off_grid : 0, n, x, y, out_h, (int32_t*)nullptr);
+                       s->d_blob, use_grid ? s->off_grid : 0, n, x, y, out_h, (int32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     return ATC_OK;
 }
@@ -781,7 +751,7 @@ int atc_query_mva_index(const atc_scenario_t* s, int n, const float* x, const fl
     if (!s || !x || !y || !out_idx || n < 0) return fail_arg("null pointer / negative n");
     if (n == 0) return ATC_OK;
     hipLaunchKernelGGL(k_query_mva, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false), (hipStream_t)stream,
-                       s->d_blob, s->lds_words, use_grid ? s->off_grid : 0, n, x, y, (int32_t*)nullptr, out_idx);
+                       s->d_blob, use_grid ? s->off_grid : 0, n, x, y, (int32_t*)nullptr, out_idx);
     HIP_TRY(hipGetLastError());
     return ATC_OK;
 }
@@ -791,7 +761,7 @@ int atc_query_corridor(const atc_scenario_t* s, int n, const float* x, const flo
     if (!s || !x || !y || !h || !phi || !out || n < 0) return fail_arg("null pointer / negative n");
     if (n == 0) return ATC_OK;
     hipLaunchKernelGGL(k_query_corridor, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false), (hipStream_t)stream,
-                       s->d_blob, s->lds_words, n, x, y, h, phi, angle_only, out);
+                       s->d_blob, n, x, y, h, phi, angle_only, out);
     HIP_TRY(hipGetLastError());
     return ATC_OK;
 }
@@ -802,7 +772,7 @@ int atc_query_shaping(const atc_scenario_t* s, int n, const float* d_faf, const 
         return fail_arg("null pointer / negative n");
     if (n == 0) return ATC_OK;
     hipLaunchKernelGGL(k_query_shaping, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false), (hipStream_t)stream,
-                       s->d_blob, s->lds_words, n, d_faf, phi_rel_faf, phi_plane, h, on_gp, out3);
+                       s->d_blob, n, d_faf, phi_rel_faf, phi_plane, h, on_gp, out3);
     HIP_TRY(hipGetLastError());
     return ATC_OK;
 }
@@ -815,7 +785,7 @@ int atc_reset(const atc_scenario_t* s, int B, int N, const atc_state_t* st, cons
     if ((unsigned long long)B * N * ATC_OBS_DIM * 4ull >= (1ull << 32)) return fail_arg("B*N too large for one launch");
     hipStream_t q = (hipStream_t)stream;
     hipLaunchKernelGGL(k_reset, dim3(grid_for(s, (long long)B * N)), dim3(kBlock), lds_bytes(s, false), q, s->d_blob,
-                       s->lds_words, B, N, *st, mask, obs, *p, first);
+                       B, N, *st, mask, obs, *p, first);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_reset_env, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, q, B, N, *st, mask, first);
     HIP_TRY(hipGetLastError());
@@ -827,7 +797,7 @@ int atc_observe(const atc_scenario_t* s, int B, int N, const atc_state_t* st, co
     if (!s || !st || !obs || !p) return fail_arg("null pointer");
     if (B < 1 || N < 1 || N > ATC_MAX_AIRCRAFT) return fail_arg("need B >= 1, 1 <= N <= 64");
     hipLaunchKernelGGL(k_observe, dim3(grid_for(s, (long long)B * N)), dim3(kBlock), lds_bytes(s, false),
-                       (hipStream_t)stream, s->d_blob, s->lds_words, B, N, *st, mask, obs);
+                       (hipStream_t)stream, s->d_blob, B, N, *st, mask, obs);
     HIP_TRY(hipGetLastError());
     return ATC_OK;
 }

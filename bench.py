@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollout", type=int, default=0, help="fuse this many steps per launch (0 = one launch per step)")
     ap.add_argument("--sep-nm", type=float, default=3.0, help="developer knob: separation minimum (0 disables conflicts)")
+    ap.add_argument("--graph", action="store_true", help="replay the %d-step action-hold block as one captured HIP graph "
+                    "(removes per-launch host overhead; matters for the small launch-bound configs)" % HOLD)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -118,7 +120,27 @@ def main():
     n_ring = max(2, min(64, (K + W) // HOLD + 1))
     ring = [torch.rand((B, N, 3), generator=g, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(n_ring)]
 
+    graph = None
+    act_buf = None
+    if args.graph:
+        assert not args.rollout and (K % HOLD == 0) and (W % HOLD == 0), "--graph needs steps/warmup multiples of %d" % HOLD
+        act_buf = ring[0].clone()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):      # warm-up on a side stream as torch requires before capture
+            env.step(act_buf)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(HOLD):
+                env.step(act_buf)
+
     def run(n_steps, t_base):
+        if graph is not None:
+            for s in range(0, n_steps, HOLD):
+                act_buf.copy_(ring[((t_base + s) // HOLD) % n_ring], non_blocking=True)
+                graph.replay()
+            return
         if args.rollout:
             T = args.rollout
             assert n_steps % T == 0 and HOLD % T == 0 or T % HOLD == 0
@@ -180,7 +202,8 @@ def main():
                                    "normalisation on, continuous actions U(-1,1) re-sampled every %d steps, auto-reset, "
                                    "O(N^2) separation scan, MVA lookup grid 0.5 nm" % (B, N, B * ws, type(scn).__name__, HOLD),
                        "envs_per_gpu": B, "aircraft_per_env": N, "launch": "rollout T=%d" % args.rollout if args.rollout
-                       else "one atc_step launch per step", "parallelism": "env-sharded x%d, no step-path collective, "
+                       else ("one atc_step launch per step, %d-step blocks replayed as a captured HIP graph" % HOLD
+                             if args.graph else "one atc_step launch per step"), "parallelism": "env-sharded x%d, no step-path collective, "
                        "1 all-gather of episode returns per rollout" % ws,
                        "episodes_finished": int(episodes), "positions": "f64 accumulators"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
