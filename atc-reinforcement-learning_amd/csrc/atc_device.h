@@ -12,6 +12,13 @@
 
 namespace atc {
 
+// Aircraft performance limits and the action discriminator are hard-coded in the reference (Airplane.__init__ defaults,
+// model.py:13,45-50, never overridden by atc_gym.py:347; atc_gym.py:84).  They are compile-time constants here too — the
+// blob still carries them and atc_scenario_create() refuses a blob whose values differ.
+constexpr float kVMin = 100.0f, kVMax = 300.0f, kHMin = 0.0f, kHMax = 38000.0f;
+constexpr float kAMin = -5.0f, kAMax = 5.0f, kHDotMin = -41.0f, kHDotMax = 15.0f, kPhiDotMin = -3.0f, kPhiDotMax = 3.0f;
+constexpr float kDiscrV = 5.0f, kDiscrH = 50.0f, kDiscrPhi = 0.5f, kVInit = 250.0f;
+
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kDegToRad = (float)(3.14159265358979323846 / 180.0);
 constexpr float kRadToDeg = (float)(180.0 / 3.14159265358979323846);
@@ -285,7 +292,7 @@ __device__ __forceinline__ Aircraft spawn(const float* __restrict__ K, const atc
     a.y = (double)rec[ATC_E_Y];
     a.phi = rec[ATC_E_PHI];
     a.h = rec[ATC_E_LEV0 + li] * 100.0f;
-    a.v = K[ATC_C_V_INIT];
+    a.v = kVInit;
     return a;
 }
 

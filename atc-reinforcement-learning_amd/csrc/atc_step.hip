@@ -151,20 +151,23 @@ template <int D>
 __device__ __forceinline__ float row_ror(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + D, 0xf, 0xf, false));
 }
-template <int D>
+// margin = max(d^2 - sep^2, |dh| - sep_ft) is negative exactly when both separation minima are violated (the sign of an
+// IEEE difference is exact), so "any partner in conflict" is min over partners of margin < 0 — four VALU operations per
+// partner, no compares, no mask arithmetic.
+template <int D, bool WANT_MIN>
 struct PairScan16 {
     static __device__ __forceinline__ void run(float xs, float y, float h, float sep2, float sep_ft, float& min_d2,
-                                               int& conflict) {
+                                               float& margin) {
         const float dx = xs - row_ror<D>(xs), dy = y - row_ror<D>(y), dh = h - row_ror<D>(h);
         const float d2 = fmaf(dx, dx, dy * dy);
-        min_d2 = fminf(min_d2, d2);
-        conflict |= (int)(d2 < sep2) & (int)(fabsf(dh) < sep_ft);
-        PairScan16<D + 1>::run(xs, y, h, sep2, sep_ft, min_d2, conflict);
+        if (WANT_MIN) min_d2 = fminf(min_d2, d2);
+        margin = fminf(margin, fmaxf(d2 - sep2, fabsf(dh) - sep_ft));
+        PairScan16<D + 1, WANT_MIN>::run(xs, y, h, sep2, sep_ft, min_d2, margin);
     }
 };
-template <>
-struct PairScan16<16> {
-    static __device__ __forceinline__ void run(float, float, float, float, float, float&, int&) {}
+template <bool WANT_MIN>
+struct PairScan16<16, WANT_MIN> {
+    static __device__ __forceinline__ void run(float, float, float, float, float, float&, float&) {}
 };
 
 // Per-lane addressing = uniform 64-bit base + 32-bit BYTE offset (the host guarantees B*N*40 < 4 GiB): the compiler can
@@ -209,6 +212,351 @@ __device__ __forceinline__ void store_obs(float* __restrict__ dst, const float* 
 //   The body is straight-line for every lane: lanes whose aircraft is not under control compute on their frozen state and
 //   the results are discarded by selects; only the rare paths (dirty grid cells, corridor interior, auto-reset) branch.
 // ---------------------------------------------------------------------------------------------------------------
+struct LaneIds {        // who this lane is (one aircraft slot of one env)
+    int tid, lane, e, k;
+    uint32_t i;         // aircraft index env * N + k (clamped into range for lanes without an aircraft)
+    uint32_t slot0;     // first slot of the workgroup's tile
+    bool env_valid, lane_valid, wave_full;
+};
+struct LaneState {      // persistent per-aircraft state held in registers
+    Aircraft a;
+    float la_v, la_h, la_p;
+    bool la_changed;
+};
+struct EnvState {       // persistent per-env record (replicated in the W lanes of the env)
+    int t, n_actions, episode, ep_length;
+    float total_reward, ep_return;
+    uint32_t win_bits;
+    uint64_t amask;
+};
+struct Mid {            // what the first half of a step hands to the second
+    bool active;
+    float r;
+    uint32_t fl;
+    int acts;
+    float mva, x32, y32;
+};
+struct StepOut {        // per-step output bases (uniform pointers)
+    float* obs;
+    uint32_t* flags;
+    float* reward;
+    uint8_t* done;
+    float *raw_obs, *ac_reward, *min_sep, *term_obs;
+};
+
+template <int W>
+__device__ __forceinline__ LaneIds make_ids(uint32_t slot0, int B, int N) {
+    LaneIds d;
+    d.tid = threadIdx.x;
+    d.lane = d.tid & 63;
+    d.slot0 = slot0;
+    const uint32_t slots = (uint32_t)B * (uint32_t)W;
+    const uint32_t slot = slot0 + d.tid;
+    d.env_valid = slot < slots;
+    d.e = d.env_valid ? (int)(slot / W) : B - 1;  // clamped: loads stay in bounds, results are never stored
+    d.k = (int)(slot % W);
+    d.lane_valid = d.env_valid && d.k < N;
+    d.i = d.lane_valid ? (uint32_t)d.e * (uint32_t)N + (uint32_t)d.k : (uint32_t)B * (uint32_t)N - 1u;
+    if (ATC_ABLATE & 64) {  // developer-only "no HBM traffic" timing: every workgroup works on the first 256 aircraft
+        d.i &= 255u;
+        d.e &= 15;
+        d.slot0 = 0;
+    }
+    d.wave_full = (N == W) && (slot0 + (uint32_t)(d.tid | 63) < slots);
+    return d;
+}
+
+// ---- first half of AtcGym.step: timestep, action decode + rate limits, kinematics, MVA floor -----------------------
+__device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const float* __restrict__ grid,
+                                           const atc_params_t& p, const LaneIds& d, float a_v, float a_h, float a_p,
+                                           LaneState& ls, EnvState& es) {
+    Mid m;
+    Aircraft& a = ls.a;
+    const float dt = p.dt;
+    const bool discrete = (p.mode & ATC_M_DISCRETE) != 0;
+    es.t += 1;  // atc_gym.py:135
+    const bool active = d.lane_valid && ((es.amask >> d.k) & 1ull);
+    uint32_t fl = 0;
+    float r = -0.05f * dt;  // atc_gym.py:137
+    int acts = 0;
+    // ---- _action_with_reward x3 (atc_gym.py:139-141,299-335) -> Airplane.action_* (model.py:60-120) ------------------
+    // branch-free form of: invalid target -> ValueError -> -1 reward, nothing applied, last_action kept
+    // (atc_gym.py:303-315); valid -> rate-limited move, actions_taken++ unless |target - last| < discriminator
+    {
+        constexpr float v_min = kVMin, v_max = kVMax, h_min = kHMin, h_max = kHMax;
+        // atc_gym.py:64-78: offset (v_min,0,0); factor (10,100,1) discrete | (v_max-v_min, h_max, 360) continuous
+        const float fac_v = discrete ? 10.0f : v_max - v_min;
+        const float fac_h = discrete ? 100.0f : h_max;
+        const float fac_p = discrete ? 1.0f : 360.0f;
+        const float tv = discrete ? a_v * fac_v + v_min : a_v * fac_v / 2.0f + fac_v / 2.0f + v_min;
+        const float th = discrete ? a_h * fac_h + 0.0f : a_h * fac_h / 2.0f + fac_h / 2.0f + 0.0f;
+        const float tp = discrete ? a_p * fac_p + 0.0f : a_p * fac_p / 2.0f + fac_p / 2.0f + 0.0f;
+        {
+            const bool valid = !(tv < v_min || tv > v_max);
+            const bool ok = valid && active;
+            float dd = tv - a.v;
+            dd = fminf(dd, kAMax * dt);
+            dd = fmaxf(dd, kAMin * dt);
+            a.v = ok ? a.v + dd : a.v;
+            acts += (ok && !(fabsf(tv - ls.la_v) < kDiscrV)) ? 1 : 0;
+            ls.la_changed = ls.la_changed || (ok && tv != ls.la_v);
+            ls.la_v = ok ? tv : ls.la_v;
+            r = valid ? r : r - 1.0f;
+            fl |= valid ? 0u : (uint32_t)ATC_F_INVALID_V;
+        }
+        {
+            const bool valid = !(th < h_min || th > h_max);
+            const bool ok = valid && active;
+            float dd = th - a.h;
+            dd = fminf(dd, kHDotMax * dt);
+            dd = fmaxf(dd, kHDotMin * dt);
+            a.h = ok ? a.h + dd : a.h;
+            acts += (ok && !(fabsf(th - ls.la_h) < kDiscrH)) ? 1 : 0;
+            ls.la_changed = ls.la_changed || (ok && th != ls.la_h);
+            ls.la_h = ok ? th : ls.la_h;
+            r = valid ? r : r - 1.0f;
+            fl |= valid ? 0u : (uint32_t)ATC_F_INVALID_H;
+        }
+        {
+            float dd = tp - a.phi;
+            dd = fminf(dd, kPhiDotMax * dt);
+            dd = fmaxf(dd, kPhiDotMin * dt);
+            a.phi = active ? a.phi + dd : a.phi;
+            acts += (active && !(fabsf(tp - ls.la_p) < kDiscrPhi)) ? 1 : 0;
+            ls.la_p = active ? tp : ls.la_p;
+        }
+    }
+    // ---- Airplane.step (model.py:122-129): rot_matrix(phi) . [0, (v/3600) dt] ----------------------------------------
+    {
+        const float dist = active ? (a.v / 3600.0f) * dt : 0.0f;
+        float sn, cs;
+        if (ATC_ABLATE & 32) { sn = 0.6f; cs = 0.8f; } else sincos_deg(a.phi, &sn, &cs);
+        a.x += (double)(sn * dist);
+        a.y += (double)(cs * dist);
+    }
+    m.x32 = (float)a.x;
+    m.y32 = (float)a.y;
+    // ---- MVA floor (atc_gym.py:146-161) --------------------------------------------------------------------------------
+    {
+        float hgt = 0.0f;
+        const int pi = (ATC_ABLATE & 1) ? 0 : find_mva(K, grid, m.x32, m.y32, &hgt);
+        m.mva = pi >= 0 ? hgt : 0.0f;                  // atc_gym.py:161: mva = 0 outside
+        const bool below = pi >= 0 && a.h < m.mva;
+        r = pi < 0 ? -50.0f : (below ? -200.0f : r);
+        fl |= pi < 0 ? (uint32_t)ATC_F_OUTSIDE : (below ? (uint32_t)ATC_F_BELOW_MVA : 0u);
+    }
+    m.active = active;
+    m.r = r;
+    m.fl = fl;
+    m.acts = acts;
+    return m;
+}
+
+// ---- second half: separation scan, win/timeout, observation, shaping, reductions, outputs, auto-reset --------------
+template <int W, bool FULL>
+__device__ __forceinline__ void step_part_b(const float* __restrict__ K, const atc_params_t& p, int N, const LaneIds& d,
+                                            const Mid& m, LaneState& ls, EnvState& es, const StepOut& so, float4* pos,
+                                            float* obs_stage) {
+    Aircraft& a = ls.a;
+    const bool active = m.active;
+    const float x32 = m.x32, y32 = m.y32;
+    float r = m.r;
+    uint32_t fl = m.fl;
+    int acts = m.acts;
+    const int tid = d.tid, lane = d.lane, k = d.k, e = d.e;
+    const uint32_t i = d.i;
+
+    // ---- separation scan (extension; README.md:51): 3 nm / 1000 ft among aircraft active at step start ---------------
+    // Every lane visits its env's other W-1 slots (never itself); aircraft that are not under control are staged
+    // at x = 1e18 so that they neither conflict nor enter the minimum — branch-free.
+    float min_d2 = 1e30f;
+    if (W > 1 && !(ATC_ABLATE & 2)) {
+        const float xs = active ? x32 : 1e18f;
+        const float sep2 = p.sep_nm * p.sep_nm;
+        float margin = 1e30f;  // min over partners of max(d^2 - sep^2, |dh| - sep_ft): conflict iff negative
+        if (W == 16) {
+            PairScan16<1, FULL>::run(xs, y32, a.h, sep2, p.sep_ft, min_d2, margin);
+        } else {
+            pos[tid] = make_float4(xs, y32, a.h, 0.0f);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int gbase = tid & ~(W - 1);
+            constexpr int U = (W >= 32) ? 3 : (W >= 8 ? 7 : (W > 1 ? W - 1 : 1));  // per batch: 63 = 21x3, 31 = 10x3+1
+#pragma unroll 1
+            for (int d0 = 1; d0 < W; d0 += U) {
+                float4 q[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) q[u] = pos[gbase + ((k + d0 + u) & (W - 1))];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float dx = xs - q[u].x, dy = y32 - q[u].y;
+                    const float d2 = (d0 + u < W) ? fmaf(dx, dx, dy * dy) : 1e36f;  // tail of the last batch
+                    if (FULL) min_d2 = fminf(min_d2, d2);
+                    margin = fminf(margin, fmaxf(d2 - sep2, fabsf(a.h - q[u].z) - p.sep_ft));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        const bool conflict = margin < 0.0f;
+        r = conflict ? p.conflict_reward : r;
+        fl |= conflict ? (uint32_t)ATC_F_CONFLICT : 0u;
+    }
+
+    // ---- win / timeout overrides (atc_gym.py:163-173) -------------------------------------------------------------------
+    if (!(ATC_ABLATE & 4) && inside_corridor(K, x32, y32, a.h, a.phi)) {
+        int bonus = (p.timestep_limit - es.t) * 5;
+        bonus = bonus < 0 ? 0 : bonus;
+        r = (float)(10000 + bonus);
+        fl |= ATC_F_WON;
+    }
+    {
+        const bool timeout = es.t > p.timestep_limit;
+        r = timeout ? -200.0f : r;
+        fl |= timeout ? (uint32_t)ATC_F_TIMEOUT : 0u;
+    }
+    // ---- observation, shaping, noise areas, normalisation (atc_gym.py:175-189) ------------------------------------------
+    float o[ATC_OBS_DIM];
+    {
+        Obs ob;
+        if (ATC_ABLATE & 8) {
+#pragma unroll
+            for (int c = 0; c < ATC_OBS_DIM; ++c) ob.o[c] = x32;
+            ob.d_faf = ob.phi_rel_faf = ob.on_gp = y32;
+        } else {
+            ob = get_state(K, x32, y32, a.h, a.phi, a.v, m.mva);
+        }
+        if ((p.mode & ATC_M_REWARD_SHAPING) && !(ATC_ABLATE & 8)) {
+            const Shaping sh = shaping_rewards(K, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp);
+            r += sh.pos;
+            r += sh.ang;
+            r += sh.gs;
+        }
+        const int n_noise = (int)K[ATC_H_N_NOISE];
+        for (int q = 0; q < n_noise; ++q) {  // extension (README.md:62): noise-abatement areas
+            const float* rec = K + (int)K[ATC_H_OFF_POLY] + ((int)K[ATC_H_N_MVA] + q) * ATC_P_WORDS;
+            if (in_bounds(rec, x32, y32) && a.h < rec[ATC_P_HEIGHT] &&
+                ray_tracing(x32, y32, K + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT])) {
+                r -= rec[ATC_P_PENALTY];
+                fl |= ATC_F_NOISE;
+            }
+        }
+        if (FULL && so.raw_obs && d.lane_valid) {
+            float z[ATC_OBS_DIM];
+#pragma unroll
+            for (int c = 0; c < ATC_OBS_DIM; ++c) z[c] = active ? ob.o[c] : 0.0f;  // zeros for handed-over aircraft
+            store_obs(at<float>(so.raw_obs, i * 40u), z);
+        }
+        if (p.mode & ATC_M_NORMALIZE) {  // atc_gym.py:187-189: (s - min - max/2) / (max/2) as one fma
+#pragma unroll
+            for (int c = 0; c < ATC_OBS_DIM; ++c)
+                o[c] = active ? fmaf(ob.o[c], K[ATC_C_NORM_A + c], K[ATC_C_NORM_B + c]) : 0.0f;
+        } else {
+#pragma unroll
+            for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = active ? ob.o[c] : 0.0f;
+        }
+    }
+    // lanes without an aircraft under control: nothing happened
+    r = active ? r : 0.0f;
+    acts = active ? acts : 0;
+    fl = active ? fl : (d.lane_valid ? (uint32_t)ATC_F_INACTIVE : 0u);
+    if (!active) min_d2 = 1e30f;
+
+    // ---- per-env reductions over the W lanes of the group ----------------------------------------------------------------
+    const float env_r = group_sum<W>(r);
+    const int env_acts = group_sum_i<W>(acts);
+    const uint64_t won = group_ballot<W>((fl & ATC_F_WON) != 0, lane);
+    const uint64_t term = group_ballot<W>(
+        (fl & (ATC_F_BELOW_MVA | ATC_F_OUTSIDE | ATC_F_CONFLICT | ATC_F_TIMEOUT)) != 0, lane);
+    es.amask &= ~won;
+    const bool done = d.env_valid && (term != 0 || es.amask == 0);
+    es.total_reward += env_r;  // atc_gym.py:194-197
+    es.n_actions += env_acts;
+
+    if (d.lane_valid) {
+        stream_store(at<uint32_t>(so.flags, i * 4u), fl);
+        if (FULL && so.ac_reward) *at<float>(so.ac_reward, i * 4u) = r;
+    }
+    if (d.env_valid && k == 0) {
+        *at<float>(so.reward, (uint32_t)e * 4u) = env_r;
+        *at<uint8_t>(so.done, (uint32_t)e) = done ? 1 : 0;
+    }
+    if (FULL && so.min_sep) {
+        const float m2 = (W > 1) ? group_min<W>(min_d2) : 1e30f;
+        if (d.env_valid && k == 0) *at<float>(so.min_sep, (uint32_t)e * 4u) = (m2 >= 1e30f) ? 1e30f : sqrtf(m2);
+    }
+
+    if (done && (p.mode & ATC_M_AUTO_RESET)) {
+        // VecEnv semantics: the env restarts inside the step; the returned obs is the RAW reset state
+        // (atc_gym.py:351,365: reset() returns the un-normalised state computed with mva = 0).
+        es.ep_return = es.total_reward;
+        es.ep_length = es.t;
+        es.win_bits = ((es.win_bits << 1) | (es.amask == 0 ? 1u : 0u)) & 0x3ffu;
+        if (d.lane_valid) {
+            if (FULL && so.term_obs) store_obs(at<float>(so.term_obs, i * 40u), o);
+            a = spawn(K, p, e, k, es.episode);
+            const Obs ob = get_state(K, (float)a.x, (float)a.y, a.h, a.phi, a.v, 0.0f);
+#pragma unroll
+            for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = ob.o[c];
+        }
+        es.total_reward = 0.0f;
+        es.n_actions = 0;
+        es.t = 0;
+        es.episode += 1;
+        es.amask = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
+    }
+
+    // ---- observation store: [aircraft][10] rows are 40 B apart, so per-lane stores would scatter 8-byte pieces over 20
+    //      cache lines per instruction; a full wavefront instead transposes its 64 x 10 block through LDS and writes 2 560
+    //      contiguous bytes as 16-byte stores.
+    if (ATC_ABLATE & 16) {
+        if (d.lane_valid && o[0] == 12345.678f) so.obs[i] = o[1];
+    } else if (d.wave_full) {
+        float* tb = obs_stage + (tid >> 6) * (64 * ATC_OBS_DIM);
+#pragma unroll
+        for (int c = 0; c < ATC_OBS_DIM; ++c) tb[lane * ATC_OBS_DIM + c] = o[c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t wave_off = (d.slot0 + (uint32_t)(tid & ~63)) * 40u;  // first aircraft of this wavefront (N == W)
+        const float4* src = reinterpret_cast<const float4*>(tb);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int idx = j * 64 + lane;
+            if (idx < 64 * ATC_OBS_DIM / 4) {
+                const float4 v = src[idx];
+                float* d4 = at<float>(so.obs, wave_off + (uint32_t)idx * 16u);
+#if ATC_NT_STORE
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(d4));
+#else
+                *reinterpret_cast<float4*>(d4) = v;
+#endif
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else if (d.lane_valid) {
+        store_obs(at<float>(so.obs, i * 40u), o);
+    }
+}
+
+__device__ __forceinline__ void store_lane_state(const atc_state_t& st, const LaneIds& d, const LaneState& ls) {
+    if (d.lane_valid) {
+        *at<double2>(st.pos, d.i * 16u) = make_double2(ls.a.x, ls.a.y);
+        *at<float4>(st.kin, d.i * 16u) = make_float4(ls.a.h, ls.a.phi, ls.a.v, ls.la_p);
+        // actions are typically held for many steps: write last v/h targets back only where they changed
+        if (ls.la_changed) *at<float2>(st.last_vh, d.i * 8u) = make_float2(ls.la_v, ls.la_h);
+    }
+}
+__device__ __forceinline__ void store_env_state(const atc_state_t& st, const LaneIds& d, const EnvState& es) {
+    if (d.env_valid && d.k == 0) {
+        int4* er = at<int4>(st.env, (uint32_t)d.e * (ATC_ENV_WORDS * 4u));
+        er[0] = make_int4(es.t, es.n_actions, es.episode, es.ep_length);
+        er[1] = make_int4(__float_as_int(es.total_reward), __float_as_int(es.ep_return), (int)es.win_bits, 0);
+        er[2] = make_int4((int)(uint32_t)(es.amask & 0xffffffffu), (int)(uint32_t)(es.amask >> 32), 0, 0);
+    }
+}
+
 template <int W, bool FULL>
 __global__ void __launch_bounds__(kBlock, ATC_MIN_WAVES)
 k_step(const float* __restrict__ blob, int first_round, int off_grid, int B, int N, int T, atc_state_t st,
@@ -218,325 +566,128 @@ k_step(const float* __restrict__ blob, int first_round, int off_grid, int B, int
     float* obs_stage = smem + ((W > 1 && W != 16) ? kBlock * 4 : 0);  // [4 waves][64 x 10] obs transpose
     const float* __restrict__ K = blob;  // the sector: uniform-index reads -> scalar loads
     const float* __restrict__ grid = off_grid ? blob + off_grid : nullptr;
-    // first_round = workgroups resident at launch (n_cu * 4), see ATC_STAGGER
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
 #if ATC_TRACE
+    const int tid = threadIdx.x, lane = tid & 63;
     unsigned long long* trace = reinterpret_cast<unsigned long long*>(
         ((unsigned long long)p.reserved0) | ((unsigned long long)__float_as_uint(p.reserved1) << 32));
 #endif
 #if ATC_STAGGER
     // All resident wavefronts of a launch start together and then move through load -> compute -> store in lockstep, so
-    // the memory system and the SIMDs take turns idling.  De-phase the first round once; later rounds inherit the spread.
-    // Only worth it when the launch runs for several rounds of resident workgroups (small launches would just start late).
+    // the memory system and the SIMDs take turns idling.  De-phase the first round (first_round = workgroups resident at
+    // launch, n_cu * 4) once; later rounds inherit the spread.  Only worth it when the launch runs for several rounds
+    // (small launches would just start late).
     if (blockIdx.x < (unsigned)first_round && gridDim.x >= 3u * (unsigned)first_round) {
-        const unsigned d = ((blockIdx.x * 2654435761u) >> 27);
-        for (unsigned q = 0; q < d; ++q) __builtin_amdgcn_s_sleep(ATC_STAGGER);
+        const unsigned dly = ((blockIdx.x * 2654435761u) >> 27);
+        for (unsigned q = 0; q < dly; ++q) __builtin_amdgcn_s_sleep(ATC_STAGGER);
     }
 #endif
     ATC_STAMP(0);
     const uint32_t BN = (uint32_t)B * (uint32_t)N;      // host guarantees B*N*40 bytes < 4 GiB: 32-bit lane offsets
-    const uint32_t slots = (uint32_t)B * (uint32_t)W;
-    const uint32_t slot0 = blockIdx.x * kBlock;
-    const uint32_t slot = slot0 + tid;
-    const bool env_valid = slot < slots;
-    const int e = env_valid ? (int)(slot / W) : B - 1;  // clamped: loads stay in bounds, results are never stored
-    const int k = (int)(slot % W);
-    const bool lane_valid = env_valid && k < N;
-    const uint32_t i = lane_valid ? (uint32_t)e * (uint32_t)N + (uint32_t)k : BN - 1u;
+    const LaneIds d = make_ids<W>(blockIdx.x * kBlock, B, N);
 
     // ---- load persistent state (16-byte records; the W lanes of an env share the env record) -------------------------
-    const int4* erp = at<int4>(st.env, (uint32_t)e * (ATC_ENV_WORDS * 4u));
+    const int4* erp = at<int4>(st.env, (uint32_t)d.e * (ATC_ENV_WORDS * 4u));
     const int4 e0 = erp[0], e1 = erp[1], e2 = erp[2];
-    int t = e0.x, n_actions = e0.y, episode = e0.z, ep_length = e0.w;
-    float total_reward = __int_as_float(e1.x), ep_return = __int_as_float(e1.y);
-    uint32_t win_bits = (uint32_t)e1.z;
-    uint64_t amask = (uint64_t)(uint32_t)e2.x | ((uint64_t)(uint32_t)e2.y << 32);
-    const double2 ps = *at<double2>(st.pos, i * 16u);
-    const float4 kn = *at<float4>(st.kin, i * 16u);
-    const float2 lv = *at<float2>(st.last_vh, i * 8u);
-    Aircraft a = {ps.x, ps.y, kn.x, kn.y, kn.z};
-    float la_p = kn.w, la_v = lv.x, la_h = lv.y;
-    bool la_changed = false;
-
-    const float dt = p.dt;
-    const bool discrete = (p.mode & ATC_M_DISCRETE) != 0;
-    const uint64_t full_mask = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
+    EnvState es = {e0.x, e0.y, e0.z, e0.w, __int_as_float(e1.x), __int_as_float(e1.y), (uint32_t)e1.z,
+                   (uint64_t)(uint32_t)e2.x | ((uint64_t)(uint32_t)e2.y << 32)};
+    const double2 ps = *at<double2>(st.pos, d.i * 16u);
+    const float4 kn = *at<float4>(st.kin, d.i * 16u);
+    const float2 lv = *at<float2>(st.last_vh, d.i * 8u);
+    LaneState ls = {{ps.x, ps.y, kn.x, kn.y, kn.z}, lv.x, lv.y, kn.w, false};
 
     for (int step = 0; step < T; ++step) {
         const size_t sBN = (size_t)step * BN, sB = (size_t)step * (uint32_t)B;  // uniform (scalar) per-step bases
         const float* act_t = actions + sBN * 3;
-        float* obs_t = out.obs + sBN * ATC_OBS_DIM;
-        t += 1;  // atc_gym.py:135
-        const bool active = lane_valid && ((amask >> k) & 1ull);
-        uint32_t fl = 0;
-        float r = -0.05f * dt;  // atc_gym.py:137
-        int acts = 0;
-
-        // ---- _action_with_reward x3 (atc_gym.py:139-141,299-335) -> Airplane.action_* (model.py:60-120) --------------
-        // branch-free form of: invalid target -> ValueError -> -1 reward, nothing applied, last_action kept
-        // (atc_gym.py:303-315); valid -> rate-limited move, actions_taken++ unless |target - last| < discriminator
-        {
-            const float a_v = stream_load(at<float>(act_t, i * 12u)), a_h = stream_load(at<float>(act_t, i * 12u + 4u)),
-                        a_p = stream_load(at<float>(act_t, i * 12u + 8u));
-            const float v_min = K[ATC_C_V_MIN], v_max = K[ATC_C_V_MAX], h_min = K[ATC_C_H_MIN], h_max = K[ATC_C_H_MAX];
-            // atc_gym.py:64-78: offset (v_min,0,0); factor (10,100,1) discrete | (v_max-v_min, h_max, 360) continuous
-            const float fac_v = discrete ? 10.0f : v_max - v_min;
-            const float fac_h = discrete ? 100.0f : h_max;
-            const float fac_p = discrete ? 1.0f : 360.0f;
-            const float tv = discrete ? a_v * fac_v + v_min : a_v * fac_v / 2.0f + fac_v / 2.0f + v_min;
-            const float th = discrete ? a_h * fac_h + 0.0f : a_h * fac_h / 2.0f + fac_h / 2.0f + 0.0f;
-            const float tp = discrete ? a_p * fac_p + 0.0f : a_p * fac_p / 2.0f + fac_p / 2.0f + 0.0f;
-            {
-                const bool valid = !(tv < v_min || tv > v_max);
-                const bool ok = valid && active;
-                float d = tv - a.v;
-                d = fminf(d, K[ATC_C_A_MAX] * dt);
-                d = fmaxf(d, K[ATC_C_A_MIN] * dt);
-                a.v = ok ? a.v + d : a.v;
-                acts += (ok && !(fabsf(tv - la_v) < K[ATC_C_ACT_DISCR + 0])) ? 1 : 0;
-                la_changed = la_changed || (ok && tv != la_v);
-                la_v = ok ? tv : la_v;
-                r = valid ? r : r - 1.0f;
-                fl |= valid ? 0u : (uint32_t)ATC_F_INVALID_V;
-            }
-            {
-                const bool valid = !(th < h_min || th > h_max);
-                const bool ok = valid && active;
-                float d = th - a.h;
-                d = fminf(d, K[ATC_C_HDOT_MAX] * dt);
-                d = fmaxf(d, K[ATC_C_HDOT_MIN] * dt);
-                a.h = ok ? a.h + d : a.h;
-                acts += (ok && !(fabsf(th - la_h) < K[ATC_C_ACT_DISCR + 1])) ? 1 : 0;
-                la_changed = la_changed || (ok && th != la_h);
-                la_h = ok ? th : la_h;
-                r = valid ? r : r - 1.0f;
-                fl |= valid ? 0u : (uint32_t)ATC_F_INVALID_H;
-            }
-            {
-                float d = tp - a.phi;
-                d = fminf(d, K[ATC_C_PHIDOT_MAX] * dt);
-                d = fmaxf(d, K[ATC_C_PHIDOT_MIN] * dt);
-                a.phi = active ? a.phi + d : a.phi;
-                acts += (active && !(fabsf(tp - la_p) < K[ATC_C_ACT_DISCR + 2])) ? 1 : 0;
-                la_p = active ? tp : la_p;
-            }
-        }
+        StepOut so = {out.obs + sBN * ATC_OBS_DIM, out.flags + sBN, out.reward + sB, out.done + sB,
+                      FULL && out.raw_obs ? out.raw_obs + sBN * ATC_OBS_DIM : nullptr,
+                      FULL && out.ac_reward ? out.ac_reward + sBN : nullptr,
+                      FULL && out.min_sep ? out.min_sep + sB : nullptr,
+                      FULL && out.term_obs ? out.term_obs + sBN * ATC_OBS_DIM : nullptr};
+        const float a_v = stream_load(at<float>(act_t, d.i * 12u)), a_h = stream_load(at<float>(act_t, d.i * 12u + 4u)),
+                    a_p = stream_load(at<float>(act_t, d.i * 12u + 8u));
         ATC_STAMP(1);
-        // ---- Airplane.step (model.py:122-129): rot_matrix(phi) . [0, (v/3600) dt] ------------------------------------
-        {
-            const float dist = active ? (a.v / 3600.0f) * dt : 0.0f;
-            float sn, cs;
-            if (ATC_ABLATE & 32) { sn = 0.6f; cs = 0.8f; } else sincos_deg(a.phi, &sn, &cs);
-            a.x += (double)(sn * dist);
-            a.y += (double)(cs * dist);
-        }
-        const float x32 = (float)a.x, y32 = (float)a.y;
-        ATC_STAMP(2);
-        // ---- MVA floor (atc_gym.py:146-161) ----------------------------------------------------------------------------
-        float mva = 0.0f;
-        {
-            float hgt = 0.0f;
-            const int pi = (ATC_ABLATE & 1) ? 0 : find_mva(K, grid, x32, y32, &hgt);
-            mva = pi >= 0 ? hgt : 0.0f;                    // atc_gym.py:161: mva = 0 outside
-            const bool below = pi >= 0 && a.h < mva;
-            r = pi < 0 ? -50.0f : (below ? -200.0f : r);
-            fl |= pi < 0 ? (uint32_t)ATC_F_OUTSIDE : (below ? (uint32_t)ATC_F_BELOW_MVA : 0u);
-        }
-
+        const Mid m = step_part_a(K, grid, p, d, a_v, a_h, a_p, ls, es);
         ATC_STAMP(3);
-        // ---- separation scan (extension; README.md:51): 3 nm / 1000 ft among aircraft active at step start -----------
-        // Every lane visits its env's other W-1 slots (never itself); aircraft that are not under control are staged
-        // at x = 1e18 so that they neither conflict nor enter the minimum — branch-free.
-        float min_d2 = 1e30f;
-        if (W > 1 && !(ATC_ABLATE & 2)) {
-            const float xs = active ? x32 : 1e18f;
-            const float sep2 = p.sep_nm * p.sep_nm;
-            int conflict = 0;
-            if (W == 16) {
-                PairScan16<1>::run(xs, y32, a.h, sep2, p.sep_ft, min_d2, conflict);
-            } else {
-                pos[tid] = make_float4(xs, y32, a.h, 0.0f);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int gbase = tid & ~(W - 1);
-                constexpr int U = (W >= 32) ? 3 : (W >= 8 ? 7 : (W > 1 ? W - 1 : 1));  // per batch: 63 = 21x3, 31 = 10x3+1
-#pragma unroll 1
-                for (int d0 = 1; d0 < W; d0 += U) {
-                    float4 q[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) q[u] = pos[gbase + ((k + d0 + u) & (W - 1))];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const float dx = xs - q[u].x, dy = y32 - q[u].y;
-                        const float d2 = (d0 + u < W) ? fmaf(dx, dx, dy * dy) : 1e36f;  // tail of the last batch
-                        min_d2 = fminf(min_d2, d2);
-                        conflict |= (int)(d2 < sep2) & (int)(fabsf(a.h - q[u].z) < p.sep_ft);
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            r = conflict ? p.conflict_reward : r;
-            fl |= conflict ? (uint32_t)ATC_F_CONFLICT : 0u;
-        }
-
-        ATC_STAMP(4);
-        // ---- win / timeout overrides (atc_gym.py:163-173) ---------------------------------------------------------------
-        if (!(ATC_ABLATE & 4) && inside_corridor(K, x32, y32, a.h, a.phi)) {
-            int bonus = (p.timestep_limit - t) * 5;
-            bonus = bonus < 0 ? 0 : bonus;
-            r = (float)(10000 + bonus);
-            fl |= ATC_F_WON;
-        }
-        {
-            const bool timeout = t > p.timestep_limit;
-            r = timeout ? -200.0f : r;
-            fl |= timeout ? (uint32_t)ATC_F_TIMEOUT : 0u;
-        }
-        // ---- observation, shaping, noise areas, normalisation (atc_gym.py:175-189) --------------------------------------
-        float o[ATC_OBS_DIM];
-        {
-            Obs ob;
-            if (ATC_ABLATE & 8) {
-#pragma unroll
-                for (int c = 0; c < ATC_OBS_DIM; ++c) ob.o[c] = x32;
-                ob.d_faf = ob.phi_rel_faf = ob.on_gp = y32;
-            } else {
-                ob = get_state(K, x32, y32, a.h, a.phi, a.v, mva);
-            }
-            if ((p.mode & ATC_M_REWARD_SHAPING) && !(ATC_ABLATE & 8)) {
-                const Shaping sh = shaping_rewards(K, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp);
-                r += sh.pos;
-                r += sh.ang;
-                r += sh.gs;
-            }
-            const int n_noise = (int)K[ATC_H_N_NOISE];
-            for (int q = 0; q < n_noise; ++q) {  // extension (README.md:62): noise-abatement areas
-                const float* rec = K + (int)K[ATC_H_OFF_POLY] + ((int)K[ATC_H_N_MVA] + q) * ATC_P_WORDS;
-                if (in_bounds(rec, x32, y32) && a.h < rec[ATC_P_HEIGHT] &&
-                    ray_tracing(x32, y32, K + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT])) {
-                    r -= rec[ATC_P_PENALTY];
-                    fl |= ATC_F_NOISE;
-                }
-            }
-            if (FULL && out.raw_obs && lane_valid) {
-                float z[ATC_OBS_DIM];
-#pragma unroll
-                for (int c = 0; c < ATC_OBS_DIM; ++c) z[c] = active ? ob.o[c] : 0.0f;  // zeros for handed-over aircraft
-                store_obs(at<float>(out.raw_obs + sBN * ATC_OBS_DIM, i * 40u), z);
-            }
-            if (p.mode & ATC_M_NORMALIZE) {  // atc_gym.py:187-189: (s - min - max/2) / (max/2) as one fma
-#pragma unroll
-                for (int c = 0; c < ATC_OBS_DIM; ++c)
-                    o[c] = active ? fmaf(ob.o[c], K[ATC_C_NORM_A + c], K[ATC_C_NORM_B + c]) : 0.0f;
-            } else {
-#pragma unroll
-                for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = active ? ob.o[c] : 0.0f;
-            }
-        }
-        // lanes without an aircraft under control: nothing happened
-        r = active ? r : 0.0f;
-        acts = active ? acts : 0;
-        fl = active ? fl : (lane_valid ? (uint32_t)ATC_F_INACTIVE : 0u);
-        if (!active) min_d2 = 1e30f;
-
+        step_part_b<W, FULL>(K, p, N, d, m, ls, es, so, pos, obs_stage);
         ATC_STAMP(5);
-        // ---- per-env reductions over the W lanes of the group ------------------------------------------------------------
-        const float env_r = group_sum<W>(r);
-        const int env_acts = group_sum_i<W>(acts);
-        const uint64_t won = group_ballot<W>((fl & ATC_F_WON) != 0, lane);
-        const uint64_t term = group_ballot<W>(
-            (fl & (ATC_F_BELOW_MVA | ATC_F_OUTSIDE | ATC_F_CONFLICT | ATC_F_TIMEOUT)) != 0, lane);
-        amask &= ~won;
-        const bool done = env_valid && (term != 0 || amask == 0);
-        total_reward += env_r;  // atc_gym.py:194-197
-        n_actions += env_acts;
-
-        if (lane_valid) {
-            stream_store(at<uint32_t>(out.flags + sBN, i * 4u), fl);
-            if (FULL && out.ac_reward) *at<float>(out.ac_reward + sBN, i * 4u) = r;
-        }
-        if (env_valid && k == 0) {
-            *at<float>(out.reward + sB, (uint32_t)e * 4u) = env_r;
-            *at<uint8_t>(out.done + sB, (uint32_t)e) = done ? 1 : 0;
-        }
-        if (FULL && out.min_sep) {
-            const float m2 = (W > 1) ? group_min<W>(min_d2) : 1e30f;
-            if (env_valid && k == 0) *at<float>(out.min_sep + sB, (uint32_t)e * 4u) = (m2 >= 1e30f) ? 1e30f : sqrtf(m2);
-        }
-
-        if (done && (p.mode & ATC_M_AUTO_RESET)) {
-            // VecEnv semantics: the env restarts inside the step; the returned obs is the RAW reset state
-            // (atc_gym.py:351,365: reset() returns the un-normalised state computed with mva = 0).
-            ep_return = total_reward;
-            ep_length = t;
-            win_bits = ((win_bits << 1) | (amask == 0 ? 1u : 0u)) & 0x3ffu;
-            if (lane_valid) {
-                if (FULL && out.term_obs) store_obs(at<float>(out.term_obs + sBN * ATC_OBS_DIM, i * 40u), o);
-                a = spawn(K, p, e, k, episode);
-                const Obs ob = get_state(K, (float)a.x, (float)a.y, a.h, a.phi, a.v, 0.0f);
-#pragma unroll
-                for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = ob.o[c];
-            }
-            total_reward = 0.0f;
-            n_actions = 0;
-            t = 0;
-            episode += 1;
-            amask = full_mask;
-        }
-
-        // ---- observation store: [aircraft][10] rows are 40 B apart, so per-lane stores would scatter 8-byte pieces over
-        //      20 cache lines per instruction; a full wavefront instead transposes its 64 x 10 block through LDS and writes
-        //      2 560 contiguous bytes as 16-byte stores.
-        const bool wave_full = (N == W) && (slot0 + (uint32_t)(tid | 63) < slots);
-        if (ATC_ABLATE & 16) {
-            if (lane_valid && o[0] == 12345.678f) obs_t[i] = o[1];
-        } else if (wave_full) {
-            float* tb = obs_stage + (tid >> 6) * (64 * ATC_OBS_DIM);
-#pragma unroll
-            for (int c = 0; c < ATC_OBS_DIM; ++c) tb[lane * ATC_OBS_DIM + c] = o[c];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint32_t wave_off = (slot0 + (uint32_t)(tid & ~63)) * 40u;  // first aircraft of this wavefront (N == W)
-            const float4* src = reinterpret_cast<const float4*>(tb);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int idx = j * 64 + lane;
-                if (idx < 64 * ATC_OBS_DIM / 4) {
-                    const float4 v = src[idx];
-                    float* d4 = at<float>(obs_t, wave_off + (uint32_t)idx * 16u);
-#if ATC_NT_STORE
-                    typedef float v4f __attribute__((ext_vector_type(4)));
-                    __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(d4));
-#else
-                    *reinterpret_cast<float4*>(d4) = v;
-#endif
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        } else if (lane_valid) {
-            store_obs(at<float>(obs_t, i * 40u), o);
-        }
     }
-
     ATC_STAMP(6);
-    // ---- write back persistent state ---------------------------------------------------------------------------------------
-    if (lane_valid) {
-        *at<double2>(st.pos, i * 16u) = make_double2(a.x, a.y);
-        *at<float4>(st.kin, i * 16u) = make_float4(a.h, a.phi, a.v, la_p);
-        // actions are typically held for many steps: write last v/h targets back only where they changed
-        if (la_changed) *at<float2>(st.last_vh, i * 8u) = make_float2(la_v, la_h);
-    }
-    if (env_valid && k == 0) {
-        int4* er = at<int4>(st.env, (uint32_t)e * (ATC_ENV_WORDS * 4u));
-        er[0] = make_int4(t, n_actions, episode, ep_length);
-        er[1] = make_int4(__float_as_int(total_reward), __float_as_int(ep_return), (int)win_bits, 0);
-        er[2] = make_int4((int)(uint32_t)(amask & 0xffffffffu), (int)(uint32_t)(amask >> 32), 0, 0);
-    }
+    // ---- write back persistent state -----------------------------------------------------------------------------------
+    store_lane_state(st, d, ls);
+    store_env_state(st, d, es);
     ATC_STAMP(7);
+}
+
+#ifndef ATC_PIPE_WAVES
+#define ATC_PIPE_WAVES 3  // wavefronts per SIMD the pipelined kernel is register-budgeted for
+#endif
+// ---------------------------------------------------------------------------------------------------------------
+// Software-pipelined single-step kernel for large launches (fast variant only, T = 1): persistent workgroups walk the
+// tiles of 256 slots with stride gridDim.x and PREFETCH the next tile's aircraft state and actions (16 registers) right
+// after the current tile's last dependent gather (the MVA lookup), so those loads are in flight during the second half of
+// the step instead of stalling the next tile's first instruction.
+// ---------------------------------------------------------------------------------------------------------------
+struct Prefetch {
+    double2 ps;
+    float4 kn;
+    float2 lv;
+    float a_v, a_h, a_p;
+    int t;
+    int2 mask;
+};
+template <int W>
+__device__ __forceinline__ Prefetch prefetch_tile(const atc_state_t& st, const float* __restrict__ actions, uint32_t tile,
+                                                  int B, int N) {
+    const LaneIds d = make_ids<W>(tile * kBlock, B, N);
+    Prefetch f;
+    f.ps = *at<double2>(st.pos, d.i * 16u);
+    f.kn = *at<float4>(st.kin, d.i * 16u);
+    f.lv = *at<float2>(st.last_vh, d.i * 8u);
+    f.a_v = *at<float>(actions, d.i * 12u);
+    f.a_h = *at<float>(actions, d.i * 12u + 4u);
+    f.a_p = *at<float>(actions, d.i * 12u + 8u);
+    const int* er = at<int>(st.env, (uint32_t)d.e * (ATC_ENV_WORDS * 4u));
+    f.t = er[ATC_ENV_TIMESTEPS];
+    f.mask = *reinterpret_cast<const int2*>(er + ATC_ENV_MASK_LO);
+    return f;
+}
+template <int W>
+__global__ void __launch_bounds__(kBlock, ATC_PIPE_WAVES)
+k_step_pipe(const float* __restrict__ blob, int off_grid, int B, int N, atc_state_t st, const float* __restrict__ actions,
+            atc_out_t out, atc_params_t p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float4* pos = reinterpret_cast<float4*>(smem);
+    float* obs_stage = smem + ((W > 1 && W != 16) ? kBlock * 4 : 0);
+    const float* __restrict__ K = blob;
+    const float* __restrict__ grid = off_grid ? blob + off_grid : nullptr;
+    const uint32_t n_tiles = ((uint32_t)B * (uint32_t)W + kBlock - 1) / kBlock;
+    uint32_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    Prefetch f = prefetch_tile<W>(st, actions, tile, B, N);
+    const StepOut so = {out.obs, out.flags, out.reward, out.done, nullptr, nullptr, nullptr, nullptr};
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const LaneIds d = make_ids<W>(tile * kBlock, B, N);
+        LaneState ls = {{f.ps.x, f.ps.y, f.kn.x, f.kn.y, f.kn.z}, f.lv.x, f.lv.y, f.kn.w, false};
+        EnvState es;
+        es.t = f.t;
+        es.amask = (uint64_t)(uint32_t)f.mask.x | ((uint64_t)(uint32_t)f.mask.y << 32);
+        const Mid m = step_part_a(K, grid, p, d, f.a_v, f.a_h, f.a_p, ls, es);
+        // bookkeeping words of this tile's env record (needed only by the reductions at the end of the step) ...
+        const int4* erp = at<int4>(st.env, (uint32_t)d.e * (ATC_ENV_WORDS * 4u));
+        const int4 e0 = erp[0], e1 = erp[1];
+        // ... and the next tile's state: both are in flight during the second half of this step
+        const uint32_t next = tile + gridDim.x;
+        if (next < n_tiles) f = prefetch_tile<W>(st, actions, next, B, N);
+        es.n_actions = e0.y;
+        es.episode = e0.z;
+        es.ep_length = e0.w;
+        es.total_reward = __int_as_float(e1.x);
+        es.ep_return = __int_as_float(e1.y);
+        es.win_bits = (uint32_t)e1.z;
+        step_part_b<W, false>(K, p, N, d, m, ls, es, so, pos, obs_stage);
+        store_lane_state(st, d, ls);
+        store_env_state(st, d, es);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -665,10 +816,26 @@ static int launch_step2(const atc_scenario* s, int B, int N, int T, const atc_st
     HIP_TRY(hipGetLastError());
     return ATC_OK;
 }
+#ifndef ATC_PIPE
+#define ATC_PIPE 0  // 1: large single-step launches use the software-pipelined persistent kernel
+#endif
 template <int W>
 static int launch_step(const atc_scenario* s, int B, int N, int T, const atc_state_t* st, const float* actions,
                        const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
     const bool full = out->raw_obs || out->ac_reward || out->min_sep || out->term_obs;
+#if ATC_PIPE
+    {
+        const long long tiles = ((long long)B * W + kBlock - 1) / kBlock;
+        const int resident = s->n_cu * ATC_PIPE_WAVES * (256 / kBlock);
+        if (T == 1 && !full && tiles >= 3LL * resident) {
+            const size_t lds = lds_bytes(s, W > 1 && W != 16, true);
+            hipLaunchKernelGGL((k_step_pipe<W>), dim3(resident), dim3(kBlock), lds, stream, s->d_blob, s->off_grid, B, N, *st,
+                               actions, *out, *p);
+            HIP_TRY(hipGetLastError());
+            return ATC_OK;
+        }
+    }
+#endif
     return full ? launch_step2<W, true>(s, B, N, T, st, actions, out, p, stream)
                 : launch_step2<W, false>(s, B, N, T, st, actions, out, p, stream);
 }
@@ -702,6 +869,14 @@ int atc_scenario_create(const float* blob_host, size_t n_words, int device, atc_
     if (n_words < ATC_C_END || blob_host[ATC_H_VERSION] != ATC_BLOB_VERSION || (size_t)blob_host[ATC_H_NWORDS] != n_words)
         return fail_arg("not a scenario blob of this ABI version");
     if ((int)blob_host[ATC_H_N_MVA] > 32) return fail_arg("at most 32 MVA polygons");
+    {   // compiled-in aircraft constants (csrc/atc_device.h) must match the blob
+        const float want[] = {kVMin, kVMax, kHMin, kHMax, kAMin, kAMax, kHDotMin, kHDotMax, kPhiDotMin, kPhiDotMax, kVInit};
+        for (int c = 0; c < 11; ++c)
+            if (blob_host[ATC_C_V_MIN + c] != want[c]) return fail_arg("aircraft limits differ from the compiled-in constants");
+        if (blob_host[ATC_C_ACT_DISCR] != kDiscrV || blob_host[ATC_C_ACT_DISCR + 1] != kDiscrH ||
+            blob_host[ATC_C_ACT_DISCR + 2] != kDiscrPhi)
+            return fail_arg("action discriminator differs from the compiled-in constants");
+    }
     HIP_TRY(hipSetDevice(device));
     atc_scenario* s = new atc_scenario();
     s->n_words = (int)n_words;

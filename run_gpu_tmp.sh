@@ -1,3 +1,5 @@
-timeout 2000 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu12.log 2>&1; echo rc=$? >> gpurun_out/pytest_gpu12.log
-tail -3 gpurun_out/pytest_gpu12.log
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 400 --warmup 100 --no-cpu-baseline 2>&1 | tail -2 | cut -c1-400
+timeout 1500 python -m pytest tests -m gpu -q -x -k "not full_size" > gpurun_out/pytest_gpu13.log 2>&1; echo rc=$? >> gpurun_out/pytest_gpu13.log
+tail -3 gpurun_out/pytest_gpu13.log
+for args in "--sep-nm 3" "--sep-nm 0" "--envs 4096 --aircraft 64" "--rollout 20"; do
+  timeout 300 python bench.py --no-cpu-baseline --steps 2000 --warmup 300 $args 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$args', round(d['ms_per_step']*1000,2), round(d['roofline']['frac'],4), d['config']['episodes_finished'])"
+done
