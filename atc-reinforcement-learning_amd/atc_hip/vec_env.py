@@ -77,6 +77,31 @@ class AtcVecEnv:
         self.reset(first=True)
 
     # ------------------------------------------------------------------------------------------------ plumbing
+    def pack_outputs(self):
+        """Re-homes obs / raw_obs / reward / flags / done of a small env batch in ONE contiguous byte buffer (plus a pinned
+        host mirror) so that a host-side caller (AtcGym) fetches a whole step result with a single device->host copy.
+        Returns (device_bytes, host_bytes, layout) with layout[name] = (offset, nbytes)."""
+        torch = self.torch
+        assert self.raw_obs is not None
+        B, N = self.B, self.N
+        sizes = [("obs", B * N * L.OBS_DIM * 4), ("raw_obs", B * N * L.OBS_DIM * 4), ("reward", B * 4),
+                 ("flags", B * N * 4), ("done", B)]
+        layout, off = {}, 0
+        for name, nb in sizes:
+            layout[name] = (off, nb)
+            off += (nb + 15) & ~15
+        dev = torch.zeros(off, dtype=torch.uint8, device=self.device)
+        host = torch.zeros(off, dtype=torch.uint8).pin_memory()
+        view = lambda name, dt, shape: dev[layout[name][0]:layout[name][0] + layout[name][1]].view(dt).view(shape)  # noqa: E731
+        self.obs = view("obs", torch.float32, (B, N * L.OBS_DIM))
+        self.raw_obs = view("raw_obs", torch.float32, (B, N * L.OBS_DIM))
+        self.reward = view("reward", torch.float32, (B,))
+        self.flags = view("flags", torch.int32, (B, N))
+        self.done = view("done", torch.uint8, (B,))
+        self._out = self._make_out(self.obs, self.raw_obs, self.reward, self.ac_reward, self.done, self.flags,
+                                   self.min_sep, self.term_obs)
+        return dev, host, layout
+
     @staticmethod
     def _make_out(*tensors):
         return _lib.AtcOut(*[(t.data_ptr() if t is not None else None) for t in tensors])

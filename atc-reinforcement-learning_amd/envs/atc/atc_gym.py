@@ -72,6 +72,12 @@ class AtcGym(Env):
         self._airspace = scenario.airspace
 
         self._vec = self._make_backend(sim_parameters, scenario, device)
+        torch = self._vec.torch
+        # one packed device buffer for everything step() returns + pinned host mirrors: 2 small copies per step
+        self._dev_out, self._host_out, self._out_layout = self._vec.pack_outputs()
+        self._host_env = torch.zeros(L.ENV_WORDS, dtype=torch.int32).pin_memory()
+        self._host_act = torch.zeros(3, dtype=torch.float32).pin_memory()
+        self._dev_act = torch.zeros((1, 1, 3), dtype=torch.float32, device=self._vec.device)
         comp = self._vec.compiled
         self._faf_mva = int(comp.faf_mva)
         self._world_x_min, self._world_y_min, self._world_x_max, self._world_y_max = comp.bbox
@@ -126,9 +132,10 @@ class AtcGym(Env):
         """atc_gym.py:128-192 — one launch of the HIP step kernel + the reference's Python-side bookkeeping."""
         vec = self._vec
         a = np.asarray(action, dtype=np.float32).reshape(1, 1, 3)
-        obs, reward, done, info = vec.step(a)
-        host = self._fetch(obs, info["original_state"], reward, done, info["flags"], vec.timesteps, vec.actions_taken)
-        state_out, raw, rew, dn, flags, self.timesteps, self.actions_taken = host
+        self._host_act.numpy()[:] = a.reshape(3)
+        self._dev_act.view(3).copy_(self._host_act, non_blocking=True)
+        vec.step(self._dev_act)
+        state_out, raw, rew, dn, flags, self.timesteps, self.actions_taken = self._fetch()
         self.done = False
         # one append per terminal cause, in the reference's order (atc_gym.py:151,158,165)
         if flags & (L.F_BELOW_MVA | L.F_OUTSIDE):
@@ -148,15 +155,19 @@ class AtcGym(Env):
         self._update_metrics(rew)
         return state_out, rew, self.done, {"original_state": self.state}
 
-    def _fetch(self, obs, raw, reward, done, flags, timesteps, actions_taken):
-        """Single device->host hop for everything step() returns."""
-        torch = self._vec.torch
-        pack = torch.cat([obs.reshape(-1), raw.reshape(-1), reward.reshape(-1),
-                          done.reshape(-1).to(torch.float32),
-                          flags.reshape(-1).to(torch.float32), timesteps.to(torch.float32),
-                          actions_taken.to(torch.float32)]).cpu().numpy()
-        return (pack[0:10].astype(np.float32), pack[10:20].astype(np.float32), float(pack[20]), bool(pack[21]),
-                int(pack[22]), int(pack[23]), int(pack[24]))
+    def _fetch(self):
+        """Two pinned device->host copies (packed step outputs, env record) and one synchronisation."""
+        vec = self._vec
+        self._host_out.copy_(self._dev_out, non_blocking=True)
+        self._host_env.copy_(vec.env[0], non_blocking=True)
+        vec.torch.cuda.current_stream(vec.device).synchronize()
+        h = self._host_out.numpy()
+        lay = self._out_layout
+        f32 = lambda name: h[lay[name][0]:lay[name][0] + lay[name][1]].view(np.float32)  # noqa: E731
+        env = self._host_env.numpy()
+        return (f32("obs").copy(), f32("raw_obs").copy(), float(f32("reward")[0]), bool(h[lay["done"][0]]),
+                int(h[lay["flags"][0]:lay["flags"][0] + 4].view(np.int32)[0]), int(env[L.ENV_TIMESTEPS]),
+                int(env[L.ENV_ACTIONS_TAKEN]))
 
     def _update_metrics(self, reward):
         """atc_gym.py:194-197"""
