@@ -58,18 +58,32 @@ def _time_oracle(n_aircraft, B, threads, seconds_target):
     return B * steps / dt, steps, dt
 
 
+def host_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box reports 256 logical
+    CPUs but the container's cpu.max allows 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(n_aircraft, seconds_target=12.0):
     """The fp32 CPU oracle (a scalar C port of the reference's step, oracle/) timed on the GPU box's host cores on a bounded
     sample of the same workload (same sector, spawn lattice, action protocol, auto-reset).  Primary figure: ONE core
     (scalar port, `cores` = 1); `all_cores` adds the same loop under OpenMP over envs on every host core."""
     v1, steps1, dt1 = _time_oracle(n_aircraft, 2048, 1, seconds_target)
-    ncpu = os.cpu_count() or 1
+    ncpu = host_cores()
     out = {"value": v1, "unit": "env-steps/s", "cores": 1, "kind": "port",
            "sample": "%d envs x %d aircraft x %d steps (%.1f s) of the same workload through oracle/ (fp32 C port of the "
-                     "reference step, gcc -O2, 1 thread); host has %d cores" % (2048, n_aircraft, steps1, dt1, ncpu)}
+                     "reference step, gcc -O2, 1 thread); host: %d logical CPUs, %d usable (affinity/cgroup quota)"
+                     % (2048, n_aircraft, steps1, dt1, os.cpu_count() or 1, ncpu)}
     if ncpu > 1:
         try:
-            Bm = 65536
+            Bm = 16384
             vm, stepsm, dtm = _time_oracle(n_aircraft, Bm, ncpu, 6.0)
             out["all_cores"] = {"value": vm, "unit": "env-steps/s", "cores": ncpu,
                                 "sample": "%d envs x %d aircraft x %d steps (%.1f s), OpenMP over envs" % (Bm, n_aircraft, stepsm, dtm)}
