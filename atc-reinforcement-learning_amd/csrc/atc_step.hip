@@ -154,19 +154,27 @@ __device__ __forceinline__ float row_ror(float v) {
 // margin = max(d^2 - sep^2, |dh| - sep_ft) is negative exactly when both separation minima are violated (the sign of an
 // IEEE difference is exact), so "any partner in conflict" is min over partners of margin < 0 — four VALU operations per
 // partner, no compares, no mask arithmetic.
+// Each unordered pair is evaluated ONCE: rotation D (1..8) makes a lane evaluate the partner D lanes away, and the inverse
+// rotation 16-D hands that pair's margin (and d^2) back to the partner, for which it is the same pair (d^2 and |dh| are
+// symmetric, so the values are bit-identical to what the partner would have computed).  D = 8 is its own inverse.
 template <int D, bool WANT_MIN>
 struct PairScan16 {
     static __device__ __forceinline__ void run(float xs, float y, float h, float sep2, float sep_ft, float& min_d2,
                                                float& margin) {
         const float dx = xs - row_ror<D>(xs), dy = y - row_ror<D>(y), dh = h - row_ror<D>(h);
         const float d2 = fmaf(dx, dx, dy * dy);
-        if (WANT_MIN) min_d2 = fminf(min_d2, d2);
-        margin = fminf(margin, fmaxf(d2 - sep2, fabsf(dh) - sep_ft));
+        const float m = fmaxf(d2 - sep2, fabsf(dh) - sep_ft);
+        margin = fminf(margin, m);
+        if (D < 8) margin = fminf(margin, row_ror<16 - D>(m));
+        if (WANT_MIN) {
+            min_d2 = fminf(min_d2, d2);
+            if (D < 8) min_d2 = fminf(min_d2, row_ror<16 - D>(d2));
+        }
         PairScan16<D + 1, WANT_MIN>::run(xs, y, h, sep2, sep_ft, min_d2, margin);
     }
 };
 template <bool WANT_MIN>
-struct PairScan16<16, WANT_MIN> {
+struct PairScan16<9, WANT_MIN> {
     static __device__ __forceinline__ void run(float, float, float, float, float, float&, float&) {}
 };
 
@@ -449,18 +457,22 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const a
         }
         if (p.mode & ATC_M_NORMALIZE) {  // atc_gym.py:187-189: (s - min - max/2) / (max/2) as one fma
 #pragma unroll
-            for (int c = 0; c < ATC_OBS_DIM; ++c)
-                o[c] = active ? fmaf(ob.o[c], K[ATC_C_NORM_A + c], K[ATC_C_NORM_B + c]) : 0.0f;
+            for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = fmaf(ob.o[c], K[ATC_C_NORM_A + c], K[ATC_C_NORM_B + c]);
         } else {
 #pragma unroll
-            for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = active ? ob.o[c] : 0.0f;
+            for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = ob.o[c];
         }
     }
-    // lanes without an aircraft under control: nothing happened
-    r = active ? r : 0.0f;
-    acts = active ? acts : 0;
-    fl = active ? fl : (d.lane_valid ? (uint32_t)ATC_F_INACTIVE : 0u);
-    if (!active) min_d2 = 1e30f;
+    // lanes without an aircraft under control: nothing happened.  Almost every wavefront has none, so the selects sit
+    // behind a wave-uniform test.
+    if (__ballot(!active) != 0ull) {
+#pragma unroll
+        for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = active ? o[c] : 0.0f;
+        r = active ? r : 0.0f;
+        acts = active ? acts : 0;
+        fl = active ? fl : (d.lane_valid ? (uint32_t)ATC_F_INACTIVE : 0u);
+        if (!active) min_d2 = 1e30f;
+    }
 
     // ---- per-env reductions over the W lanes of the group ----------------------------------------------------------------
     const float env_r = group_sum<W>(r);
