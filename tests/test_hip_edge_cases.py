@@ -167,3 +167,41 @@ def test_streams_and_graph_capture():
     torch.cuda.synchronize()
     assert torch.equal(env.pos, env2.pos) and torch.equal(env.obs, env2.obs)
     env.close(); ref.close(); env2.close()
+
+
+@pytest.mark.parametrize("N", [1, 4, 16, 64])
+def test_fast_and_full_kernel_variants_agree(N):
+    """k_step<W, false> (obs/reward/done/flags only) and k_step<W, true> (all optional outputs) must produce identical
+    results; a rollout with optional outputs must equal single steps."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+    scn = scenarios.LOWWDense() if N == 64 else scenarios.LOWW(random_entrypoints=True)
+    B = 300
+    fast = AtcVecEnv(B, N, scenario=scn, auto_reset=True, seed=5, spawn="random")
+    full = AtcVecEnv(B, N, scenario=scn, auto_reset=True, seed=5, spawn="random", want_raw_obs=True, want_ac_reward=True,
+                     want_min_sep=True, want_term_obs=True)
+    roll = AtcVecEnv(B, N, scenario=scn, auto_reset=True, seed=5, spawn="random")
+    g = torch.Generator(device="cpu").manual_seed(N)
+    T = 12
+    for block in range(6):
+        acts = (torch.rand((T, B, N, 3), generator=g) * 2.1 - 1.05).cuda()
+        out = {k: torch.empty((T,) + tuple(shape), dtype=dt, device="cuda") for k, shape, dt in (
+            ("obs", (B, N * 10), torch.float32), ("reward", (B,), torch.float32), ("done", (B,), torch.uint8),
+            ("flags", (B, N), torch.int32), ("raw_obs", (B, N * 10), torch.float32), ("ac_reward", (B, N), torch.float32),
+            ("min_sep", (B,), torch.float32), ("term_obs", (B, N * 10), torch.float32))}
+        roll.rollout(acts, out=out)
+        for t in range(T):
+            o1, r1, d1, i1 = fast.step(acts[t])
+            o2, r2, d2, i2 = full.step(acts[t])
+            assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(i1["flags"], i2["flags"])
+            assert torch.equal(out["obs"][t], o2) and torch.equal(out["reward"][t], r2) and torch.equal(out["flags"][t], i2["flags"])
+            assert torch.equal(out["raw_obs"][t], i2["original_state"]) and torch.equal(out["ac_reward"][t], i2["aircraft_reward"])
+            assert torch.equal(out["min_sep"][t], i2["min_separation"])
+            dn = d2 != 0
+            if bool(dn.any()):
+                assert torch.equal(out["term_obs"][t][dn], i2["terminal_observation"][dn])
+    assert torch.equal(fast.pos, full.pos) and torch.equal(fast.env, full.env) and torch.equal(roll.env, full.env)
+    assert torch.equal(roll.pos, full.pos) and torch.equal(roll.kin, full.kin) and torch.equal(roll.last_vh, full.last_vh)
+    for e in (fast, full, roll):
+        e.close()
