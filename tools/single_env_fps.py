@@ -1,23 +1,36 @@
 #!/usr/bin/env python3
-"""The reference's own benchmark protocol (learning/atc-gym-compute-performance.py:7-19) on the drop-in AtcGym:
-100 000 x env.step(one fixed sampled action), no reset on done, FPS = N / wall time."""
+"""Single-env throughput of the drop-in AtcGym under the reference's benchmark protocol
+(learning/atc-gym-compute-performance.py:7-19: ONE sampled action repeated, no reset on done, frames / wall-clock).
+
+    python tools/single_env_fps.py [--frames 100000] [--warmup 200]
+"""
+import argparse
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "atc-reinforcement-learning_amd")]
-import envs.atc.atc_gym as atc_gym  # noqa: E402
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "atc-reinforcement-learning_amd")]
 
-env = atc_gym.AtcGym()
-env.reset()
-nextaction = env.action_space.sample()
-num = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-for i in range(200):
-    env.step(nextaction)
-t0 = time.time()
-for i in range(num):
-    state, reward, done, info = env.step(nextaction)
-t1 = time.time()
-print("Finished!")
-print("FPS: %f" % (num / (t1 - t0)))
+
+def measure(frames, warmup):
+    from envs.atc.atc_gym import AtcGym
+    gym_env = AtcGym()
+    gym_env.reset()
+    fixed = gym_env.action_space.sample()
+    for _ in range(warmup):
+        gym_env.step(fixed)
+    began = time.perf_counter()
+    for _ in range(frames):
+        gym_env.step(fixed)
+    elapsed = time.perf_counter() - began
+    gym_env.close()
+    return frames / elapsed
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("frames", nargs="?", type=int, default=100000)
+    ap.add_argument("--warmup", type=int, default=200)
+    a = ap.parse_args()
+    print("FPS: %.1f  (%d frames, single AtcGym env on the GPU)" % (measure(a.frames, a.warmup), a.frames))
