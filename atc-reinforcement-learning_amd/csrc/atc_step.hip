@@ -11,10 +11,12 @@
 //   (scalar loads -> SGPRs), the MVA lookup is one 8-byte L2 gather per aircraft (+ a few 16-byte edge records in cells
 //   that touch a polygon border).  There is no per-workgroup staging prologue and no block barrier: the first thing a
 //   wavefront does is issue its state loads.
-//   The O(N^2) separation scan stages (x, y, h, active) of the wavefront's aircraft in LDS; every lane walks its env's
-//   W partners (LDS broadcast reads), and the per-env minimum separation / conflict / reward / done are reduced with
-//   wavefront xor-shuffles and a ballot — no block barrier, no atomics, no MFMA (there is no dense contraction here).
-//   Workgroup = 256 threads, grid-stride over env slots with a grid of at most 8 workgroups per CU.
+//   The O(N^2) separation scan: for N = 16 an env is one DPP row and partner state arrives by row rotation fused into
+//   the subtract (each pair evaluated once, the inverse rotation hands the result back); other widths stage (x, y, h) in
+//   LDS and read partners in batches.  Per-env reward / action count / minimum separation are reduced with DPP butterflies
+//   (wavefront shuffles beyond a row), done / won masks with a ballot — no block barrier, no atomics, no MFMA (there is no
+//   dense contraction on this path).
+//   Workgroup = 256 threads = 256 consecutive slots; one workgroup per tile (no grid-stride loop in the step kernel).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared   (see build.py)
 #include <hip/hip_runtime.h>
@@ -65,7 +67,7 @@ static int fail_hip(hipError_t e, const char* what) {
 #endif
 constexpr int kBlock = ATC_BLOCK;
 #ifndef ATC_ABLATE
-#define ATC_ABLATE 0  // developer-only timing ablations (tools/ablate.sh); the shipped build always uses 0
+#define ATC_ABLATE 0  // developer-only timing ablations (bit mask, see uses); the shipped build always uses 0
 #endif
 #ifndef ATC_TRACE
 #define ATC_TRACE 0  // developer-only: per-wavefront s_memtime stamps at phase boundaries (pointer smuggled in params)
@@ -76,10 +78,12 @@ constexpr int kBlock = ATC_BLOCK;
 #define ATC_STAMP(n) do {} while (0)
 #endif
 #ifndef ATC_STAGGER
-#define ATC_STAGGER 5  // measured: 5 -> 31.1 us vs 31.8 us without (8: 31.9, 12: 33.1) | first-round workgroups sleep hash(blockIdx) * ATC_STAGGER * 64 cycles (0..31 steps) before starting
+// first-round workgroups sleep hash(blockIdx) in 0..31 times ATC_STAGGER * 64 cycles before starting (see k_step);
+// measured: 5 -> 31.1 us vs 31.8 us without (8: 31.9 us, 12: 33.1 us)
+#define ATC_STAGGER 5
 #endif
 #ifndef ATC_GRID_CAP
-#define ATC_GRID_CAP 8   // workgroups per CU before the kernels grid-stride
+#define ATC_GRID_CAP 8   // workgroups per CU before the reset / observe / query kernels grid-stride
 #endif
 #ifndef ATC_MIN_WAVES
 #define ATC_MIN_WAVES 4  // waves per SIMD the step kernel is register-budgeted for (<= 128 VGPRs)
