@@ -205,3 +205,30 @@ def test_fast_and_full_kernel_variants_agree(N):
     assert torch.equal(roll.pos, full.pos) and torch.equal(roll.kin, full.kin) and torch.equal(roll.last_vh, full.last_vh)
     for e in (fast, full, roll):
         e.close()
+
+
+def test_huge_batch_uses_correct_offsets():
+    """B*N*40 B just below the 4 GiB limit of the 32-bit per-lane byte offsets (1 048 576 envs x 64 aircraft = 2.7 GB of
+    observations): the LAST envs of the huge batch (largest offsets) must equal the same envs run as a small batch — envs
+    are independent and the slot lattice does not depend on the env index."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+    scn = scenarios.LOWWDense()
+    B, N, tail = 1 << 20, 64, 96
+    big = AtcVecEnv(B, N, scenario=scn, auto_reset=True, spawn="lattice")
+    small = AtcVecEnv(tail, N, scenario=scn, auto_reset=True, spawn="lattice")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a_small = torch.rand((tail, N, 3), generator=g, device="cuda") * 2 - 1
+    a_big = torch.zeros((B, N, 3), device="cuda")
+    a_big[-tail:] = a_small
+    for t in range(6):
+        ob, rb, db, ib = big.step(a_big)
+        os_, rs, ds, is_ = small.step(a_small)
+        assert torch.equal(ob[-tail:], os_) and torch.equal(rb[-tail:], rs) and torch.equal(db[-tail:], ds)
+        assert torch.equal(ib["flags"][-tail:], is_["flags"])
+    assert torch.equal(big.pos[-tail * N:], small.pos) and torch.equal(big.env[-tail:], small.env)
+    # and the very first envs are untouched by anything the tail did
+    assert bool(torch.isfinite(ob[:4]).all())
+    big.close()
+    small.close()
