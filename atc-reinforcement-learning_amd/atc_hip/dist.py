@@ -19,8 +19,8 @@ def world():
 def init(backend=None):
     """Initialises the default process group when WORLD_SIZE > 1 (nccl on GPU, gloo otherwise)."""
     rank, ws, local = world()
-    if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend is None:  # ATC_DIST_BACKEND=gloo lets the multi-rank control flow be exercised on a box with one GPU
+        backend = os.environ.get("ATC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local)  # one process per GPU: bind before the communicator is created
     if ws > 1 and not dist.is_initialized():
@@ -52,12 +52,15 @@ def all_gather_stats(*tensors):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return [t.unsqueeze(0) for t in tensors]
     ws = dist.get_world_size()
+    host_staged = dist.get_backend() == "gloo"  # gloo gathers host tensors; RCCL gathers device tensors in place
     out = []
     for t in tensors:
-        t = t.contiguous()
-        g = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(g, t)  # concatenation along dim 0 (the layout both nccl/RCCL and gloo accept)
-        out.append(g.view((ws,) + tuple(t.shape)))
+        src = t.contiguous()
+        if host_staged and src.is_cuda:
+            src = src.cpu()
+        g = torch.empty((ws * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(g, src)  # concatenation along dim 0 (the layout both nccl/RCCL and gloo accept)
+        out.append(g.view((ws,) + tuple(src.shape)).to(t.device))
     return out
 
 
@@ -69,7 +72,7 @@ def barrier():
 def max_over_ranks(value, device):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -77,6 +80,6 @@ def max_over_ranks(value, device):
 def sum_over_ranks(value, device):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())

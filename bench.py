@@ -120,6 +120,7 @@ def main():
     rank, ws, local = D.init()
     assert ws == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (ws, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs the GPU (no CPU fallback)"
+    local = local % torch.cuda.device_count()  # == LOCAL_RANK on a real node; lets ATC_DIST_BACKEND=gloo share one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     B, N, K, W = args.envs, args.aircraft, args.steps, args.warmup
