@@ -253,7 +253,8 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
     n_vertw = 2 * sum(len(r) for r in rings)
     off_entry = off_vert + n_vertw
     n_entry = len(entrypoints)
-    end = off_entry + n_entry * L.E_WORDS
+    off_slot = (off_entry + n_entry * L.E_WORDS + 3) & ~3  # 16-byte aligned float4 records
+    end = off_slot + (4 * L.MAX_AIRCRAFT if n_entry else 0)
     grid = None
     off_grid = 0
     if grid_cell is not None and mva_rings:
@@ -269,6 +270,7 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
     b[L.H_N_ENTRY] = n_entry
     b[L.H_OFF_POLY], b[L.H_OFF_VERT], b[L.H_OFF_ENTRY], b[L.H_OFF_GRID] = off_poly, off_vert, off_entry, off_grid
     b[L.H_N_VERTW] = n_vertw
+    b[L.H_OFF_SLOT] = off_slot if n_entry else 0
     b[L.C_RWY_X], b[L.C_RWY_Y], b[L.C_RWY_H] = cg["x"], cg["y"], cg["h"]
     b[L.C_PHI_TO_RWY] = cg["phi_to_runway"]
     b[L.C_FAF_X], b[L.C_FAF_Y] = cg["faf"]
@@ -314,6 +316,9 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
         rec = off_entry + i * L.E_WORDS
         b[rec + L.E_X], b[rec + L.E_Y], b[rec + L.E_PHI], b[rec + L.E_NLEV] = ex, ey, ephi, len(levels)
         b[rec + L.E_LEV0:rec + L.E_LEV0 + len(levels)] = levels
+    for k in range(L.MAX_AIRCRAFT if n_entry else 0):  # slot lattice: entry k mod E, level (k div E) mod n_levels
+        ex, ey, ephi, levels = entrypoints[k % n_entry]
+        b[off_slot + 4 * k:off_slot + 4 * k + 4] = (ex, ey, ephi, levels[(k // n_entry) % len(levels)] * 100)
     if grid is not None:
         b[off_grid:off_grid + len(grid)] = grid
     assert end < 2 ** 24, "blob offsets must stay exactly representable in fp32"

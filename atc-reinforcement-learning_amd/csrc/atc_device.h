@@ -274,25 +274,28 @@ struct Aircraft {
 };
 
 // atc_gym.py:346-348 + model.py:13-52: aircraft k of env e enters at an entry point.
+// Lattice mode reads the per-slot record precomputed in the blob (one 16-byte load); random mode maps a 64-bit draw to
+// (entry, level) by multiply-shift — no integer division on the reset path.
 __device__ __forceinline__ Aircraft spawn(const float* __restrict__ K, const atc_params_t& p, int e, int k, int episode) {
-    const int n_entry = (int)K[ATC_H_N_ENTRY];
-    const float* tab = K + (int)K[ATC_H_OFF_ENTRY];
-    int ei, li;
-    if (p.mode & ATC_M_RANDOM_ENTRY) {
-        const uint64_t u = draw(p.seed, (uint32_t)e, (uint32_t)episode, (uint32_t)k);
-        ei = (int)((uint32_t)(u & 0xffffffffu) % (uint32_t)n_entry);
-        li = (int)((uint32_t)(u >> 32) % (uint32_t)(int)tab[ei * ATC_E_WORDS + ATC_E_NLEV]);
-    } else {
-        ei = k % n_entry;
-        li = (k / n_entry) % (int)tab[ei * ATC_E_WORDS + ATC_E_NLEV];
-    }
-    const float* rec = tab + ei * ATC_E_WORDS;
     Aircraft a;
+    a.v = kVInit;
+    if (!(p.mode & ATC_M_RANDOM_ENTRY)) {
+        const float4 rec = *reinterpret_cast<const float4*>(K + (int)K[ATC_H_OFF_SLOT] + 4 * k);
+        a.x = (double)rec.x;
+        a.y = (double)rec.y;
+        a.phi = rec.z;
+        a.h = rec.w;
+        return a;
+    }
+    const uint32_t n_entry = (uint32_t)(int)K[ATC_H_N_ENTRY];
+    const uint64_t u = draw(p.seed, (uint32_t)e, (uint32_t)episode, (uint32_t)k);
+    const int ei = (int)__umulhi((uint32_t)(u & 0xffffffffu), n_entry);
+    const float* rec = K + (int)K[ATC_H_OFF_ENTRY] + ei * ATC_E_WORDS;
+    const int li = (int)__umulhi((uint32_t)(u >> 32), (uint32_t)(int)rec[ATC_E_NLEV]);
     a.x = (double)rec[ATC_E_X];
     a.y = (double)rec[ATC_E_Y];
     a.phi = rec[ATC_E_PHI];
     a.h = rec[ATC_E_LEV0 + li] * 100.0f;
-    a.v = kVInit;
     return a;
 }
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ATC_ABI_VERSION 7
+#define ATC_ABI_VERSION 8
 
 /* ---------------------------------------------------------------------------------------------
  * Scenario blob: one flat array of 32-bit floats (device copy) compiled on the host from the sector
@@ -35,7 +35,7 @@ extern "C" {
  * envs/atc/atc_gym.py:45-58,88-110).  Integer fields are stored as exactly representable floats.
  * The float64 master (used by the f64 oracle) has the identical word layout.
  * ------------------------------------------------------------------------------------------- */
-#define ATC_BLOB_VERSION 1007.0f
+#define ATC_BLOB_VERSION 1008.0f
 enum {
     ATC_H_VERSION = 0,   /* ATC_BLOB_VERSION */
     ATC_H_NWORDS = 1,    /* total words */
@@ -47,6 +47,8 @@ enum {
     ATC_H_OFF_ENTRY = 7, /* word offset of entry-point table */
     ATC_H_OFF_GRID = 8,  /* word offset of the MVA lookup grid (0 = absent) */
     ATC_H_N_VERTW = 9,   /* words in the vertex pool */
+    ATC_H_OFF_SLOT = 10, /* word offset of the slot-lattice spawn table: 64 x (x, y, phi, h) for aircraft slot k =
+                            entry k mod n_entry at level (k div n_entry) mod n_levels (the non-random reset) */
     /* constants block */
     ATC_C_RWY_X = 16, ATC_C_RWY_Y = 17, ATC_C_RWY_H = 18,
     ATC_C_PHI_TO_RWY = 19,                /* (phi_from_runway + 180) % 360, model.py:163,245 */

@@ -218,27 +218,30 @@ static void FN(normalize)(const REAL* S, const float* raw, float* out) {
     }
 }
 
-/* atc_gym.py:346-348 + model.py:13-52: place aircraft `k` of env `e` at an entry point. */
+/* atc_gym.py:346-348 + model.py:13-52: place aircraft `k` of env `e` at an entry point.
+ * Lattice mode: slot k -> entry k mod E, level (k div E) mod n_levels (precomputed per slot in the blob).
+ * Random mode: a 64-bit draw keyed by (seed, env, episode, slot); entry = (lo32 * E) >> 32, level = (hi32 * n_levels) >> 32
+ * (multiply-shift range reduction: integer-only, so every implementation agrees). */
 static void FN(spawn)(const REAL* S, const atc_params_t* p, int e, int k, int episode, REAL* x, REAL* y, REAL* h,
                       REAL* phi, REAL* v) {
-    int n_entry = (int)S[ATC_H_N_ENTRY];
-    int ei, li;
-    if (p->mode & ATC_M_RANDOM_ENTRY) {
-        uint64_t u = FN(draw)(p->seed, (uint32_t)e, (uint32_t)episode, (uint32_t)k);
-        ei = (int)((uint32_t)(u & 0xffffffffu) % (uint32_t)n_entry);
-        const REAL* rec0 = S + (int)S[ATC_H_OFF_ENTRY] + ei * ATC_E_WORDS;
-        li = (int)((uint32_t)(u >> 32) % (uint32_t)(int)rec0[ATC_E_NLEV]);
-    } else {
-        ei = k % n_entry;
-        const REAL* rec0 = S + (int)S[ATC_H_OFF_ENTRY] + ei * ATC_E_WORDS;
-        li = (k / n_entry) % (int)rec0[ATC_E_NLEV];
+    *v = S[ATC_C_V_INIT];
+    if (!(p->mode & ATC_M_RANDOM_ENTRY)) {
+        const REAL* rec = S + (int)S[ATC_H_OFF_SLOT] + 4 * k;
+        *x = rec[0];
+        *y = rec[1];
+        *phi = rec[2];
+        *h = rec[3];
+        return;
     }
+    const uint32_t n_entry = (uint32_t)(int)S[ATC_H_N_ENTRY];
+    const uint64_t u = FN(draw)(p->seed, (uint32_t)e, (uint32_t)episode, (uint32_t)k);
+    const int ei = (int)(((u & 0xffffffffull) * n_entry) >> 32);
     const REAL* rec = S + (int)S[ATC_H_OFF_ENTRY] + ei * ATC_E_WORDS;
+    const int li = (int)(((u >> 32) * (uint32_t)(int)rec[ATC_E_NLEV]) >> 32);
     *x = rec[ATC_E_X];
     *y = rec[ATC_E_Y];
     *phi = rec[ATC_E_PHI];
     *h = rec[ATC_E_LEV0 + li] * (REAL)100;
-    *v = S[ATC_C_V_INIT];
 }
 
 /* AtcGym.reset (atc_gym.py:337-365) for env e; writes RAW obs computed with mva = 0 (atc_gym.py:351,365).
