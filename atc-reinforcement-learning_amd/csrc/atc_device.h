@@ -126,16 +126,34 @@ __device__ __forceinline__ bool in_bounds(const float* rec, float x, float y) {
     const float4 b = *reinterpret_cast<const float4*>(rec);  // minx, miny, maxx, maxy
     return b.x <= x && x <= b.z && b.y <= y && y <= b.w;
 }
-__device__ __forceinline__ int find_mva(const float* __restrict__ K, const float* __restrict__ grid, float x, float y,
-                                        float* height) {
-    const float* tab = K + (int)K[ATC_H_OFF_POLY];
-    *height = 0.0f;
+// The lookup is split so that the caller can issue the cell gather early and resolve it later: the L2 round trip then
+// overlaps independent work (in the step kernel: the whole separation scan) instead of stalling the wavefront.
+struct MvaCell {
+    float2 cell;   // (n_records | -(polygon + 1) | 0, first_record | height)
+    bool in_grid;  // false: beyond the padded bbox (also NaN) -> outside the airspace
+};
+__device__ __forceinline__ MvaCell mva_cell_load(const float* __restrict__ grid, float x, float y) {
+    MvaCell c;
+    c.cell = make_float2(0.0f, 0.0f);
+    c.in_grid = false;
     if (grid) {
         const float fx = (x - grid[ATC_G_X0]) * grid[ATC_G_INV];
         const float fy = (y - grid[ATC_G_Y0]) * grid[ATC_G_INV];
         const float nx = grid[ATC_G_NX], ny = grid[ATC_G_NY];
-        if (!(fx >= 0.0f && fx < nx && fy >= 0.0f && fy < ny)) return -1;  // beyond the padded bbox (also NaN)
-        const float2 cell = *reinterpret_cast<const float2*>(grid + ATC_G_HDR + 2 * ((int)fy * (int)nx + (int)fx));
+        c.in_grid = fx >= 0.0f && fx < nx && fy >= 0.0f && fy < ny;
+        // clamped index: the load is unconditional (no branch in front of it), the result is ignored when !in_grid
+        const int ix = c.in_grid ? (int)fx : 0, iy = c.in_grid ? (int)fy : 0;
+        c.cell = *reinterpret_cast<const float2*>(grid + ATC_G_HDR + 2 * (iy * (int)nx + ix));
+    }
+    return c;
+}
+__device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const float* __restrict__ grid, const MvaCell& c,
+                                           float x, float y, float* height) {
+    const float* tab = K + (int)K[ATC_H_OFF_POLY];
+    *height = 0.0f;
+    if (grid) {
+        if (!c.in_grid) return -1;
+        const float2 cell = c.cell;
         const int n = (int)cell.x;
         if (n <= 0) {  // clean cell: (-(polygon + 1), height) or (0, 0) = outside
             *height = cell.y;
@@ -187,6 +205,11 @@ __device__ __forceinline__ int find_mva(const float* __restrict__ K, const float
         }
     }
     return -1;
+}
+__device__ __forceinline__ int find_mva(const float* __restrict__ K, const float* __restrict__ grid, float x, float y,
+                                        float* height) {
+    const MvaCell c = mva_cell_load(grid, x, y);
+    return mva_resolve(K, grid, c, x, y, height);
 }
 
 // model.py:212-231 Corridor._inside_corridor_angle.

@@ -246,7 +246,8 @@ struct Mid {            // what the first half of a step hands to the second
     float r;
     uint32_t fl;
     int acts;
-    float mva, x32, y32;
+    float x32, y32;
+    MvaCell cell;       // MVA lookup cell, gather issued in the first half, resolved after the separation scan
 };
 struct StepOut {        // per-step output bases (uniform pointers)
     float* obs;
@@ -348,15 +349,8 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
     }
     m.x32 = (float)a.x;
     m.y32 = (float)a.y;
-    // ---- MVA floor (atc_gym.py:146-161) --------------------------------------------------------------------------------
-    {
-        float hgt = 0.0f;
-        const int pi = (ATC_ABLATE & 1) ? 0 : find_mva(K, grid, m.x32, m.y32, &hgt);
-        m.mva = pi >= 0 ? hgt : 0.0f;                  // atc_gym.py:161: mva = 0 outside
-        const bool below = pi >= 0 && a.h < m.mva;
-        r = pi < 0 ? -50.0f : (below ? -200.0f : r);
-        fl |= pi < 0 ? (uint32_t)ATC_F_OUTSIDE : (below ? (uint32_t)ATC_F_BELOW_MVA : 0u);
-    }
+    // MVA floor, first half: only ISSUE the lookup-cell gather here; nothing until the override chain needs its result
+    m.cell = mva_cell_load(grid, m.x32, m.y32);
     m.active = active;
     m.r = r;
     m.fl = fl;
@@ -366,9 +360,9 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
 
 // ---- second half: separation scan, win/timeout, observation, shaping, reductions, outputs, auto-reset --------------
 template <int W, bool FULL>
-__device__ __forceinline__ void step_part_b(const float* __restrict__ K, const atc_params_t& p, int N, const LaneIds& d,
-                                            const Mid& m, LaneState& ls, EnvState& es, const StepOut& so, float4* pos,
-                                            float* obs_stage) {
+__device__ __forceinline__ void step_part_b(const float* __restrict__ K, const float* __restrict__ grid,
+                                            const atc_params_t& p, int N, const LaneIds& d, const Mid& m, LaneState& ls,
+                                            EnvState& es, const StepOut& so, float4* pos, float* obs_stage) {
     Aircraft& a = ls.a;
     const bool active = m.active;
     const float x32 = m.x32, y32 = m.y32;
@@ -381,11 +375,22 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const a
     // ---- separation scan (extension; README.md:51): 3 nm / 1000 ft among aircraft active at step start ---------------
     // Every lane visits its env's other W-1 slots (never itself); aircraft that are not under control are staged
     // at x = 1e18 so that they neither conflict nor enter the minimum — branch-free.
+    // Where the MVA cell (gather issued in the first half) is resolved: after the separation scan, so that the L2 round
+    // trip overlaps the scan — except for W = 16, where the unrolled DPP scan already uses the whole register budget and
+    // keeping the cell in flight across it costs scratch spills (measured: 30.8 vs 28.1 us).
+    constexpr bool kResolveAfterScan = (W != 16);
+    float mva = 0.0f;
+    int pi = 0;
+    if (!kResolveAfterScan) {
+        float hgt = 0.0f;
+        pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, m.cell, x32, y32, &hgt);
+        mva = pi >= 0 ? hgt : 0.0f;
+    }
     float min_d2 = 1e30f;
+    float margin = 1e30f;  // min over partners of max(d^2 - sep^2, |dh| - sep_ft): conflict iff negative
     if (W > 1 && !(ATC_ABLATE & 2)) {
         const float xs = active ? x32 : 1e18f;
         const float sep2 = p.sep_nm * p.sep_nm;
-        float margin = 1e30f;  // min over partners of max(d^2 - sep^2, |dh| - sep_ft): conflict iff negative
         if (W == 16) {
             PairScan16<1, FULL>::run(xs, y32, a.h, sep2, p.sep_ft, min_d2, margin);
         } else {
@@ -410,6 +415,19 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const a
             }
             __builtin_amdgcn_wave_barrier();
         }
+    }
+    // ---- MVA floor (atc_gym.py:146-161), second half ---------------------------------------------------------------------
+    {
+        if (kResolveAfterScan) {
+            float hgt = 0.0f;
+            pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, m.cell, x32, y32, &hgt);
+            mva = pi >= 0 ? hgt : 0.0f;                // atc_gym.py:161: mva = 0 outside
+        }
+        const bool below = pi >= 0 && a.h < mva;
+        r = pi < 0 ? -50.0f : (below ? -200.0f : r);
+        fl |= pi < 0 ? (uint32_t)ATC_F_OUTSIDE : (below ? (uint32_t)ATC_F_BELOW_MVA : 0u);
+    }
+    {   // conflict override comes after the MVA overrides in the chain
         const bool conflict = margin < 0.0f;
         r = conflict ? p.conflict_reward : r;
         fl |= conflict ? (uint32_t)ATC_F_CONFLICT : 0u;
@@ -436,7 +454,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const a
             for (int c = 0; c < ATC_OBS_DIM; ++c) ob.o[c] = x32;
             ob.d_faf = ob.phi_rel_faf = ob.on_gp = y32;
         } else {
-            ob = get_state(K, x32, y32, a.h, a.phi, a.v, m.mva);
+            ob = get_state(K, x32, y32, a.h, a.phi, a.v, mva);
         }
         if ((p.mode & ATC_M_REWARD_SHAPING) && !(ATC_ABLATE & 8)) {
             const Shaping sh = shaping_rewards(K, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp);
@@ -624,7 +642,7 @@ k_step(const float* __restrict__ blob, int first_round, int off_grid, int B, int
         ATC_STAMP(1);
         const Mid m = step_part_a(K, grid, p, d, a_v, a_h, a_p, ls, es);
         ATC_STAMP(3);
-        step_part_b<W, FULL>(K, p, N, d, m, ls, es, so, pos, obs_stage);
+        step_part_b<W, FULL>(K, grid, p, N, d, m, ls, es, so, pos, obs_stage);
         ATC_STAMP(5);
     }
     ATC_STAMP(6);
@@ -700,7 +718,7 @@ k_step_pipe(const float* __restrict__ blob, int off_grid, int B, int N, atc_stat
         es.total_reward = __int_as_float(e1.x);
         es.ep_return = __int_as_float(e1.y);
         es.win_bits = (uint32_t)e1.z;
-        step_part_b<W, false>(K, p, N, d, m, ls, es, so, pos, obs_stage);
+        step_part_b<W, false>(K, grid, p, N, d, m, ls, es, so, pos, obs_stage);
         store_lane_state(st, d, ls);
         store_env_state(st, d, es);
     }
