@@ -15,7 +15,8 @@ from .vec_env import AtcVecEnv
 
 
 class AtcSBVecEnv:
-    def __init__(self, num_envs, num_aircraft=1, sim_parameters=None, scenario=None, device=0, seed=0, **kw):
+    def __init__(self, num_envs, num_aircraft=1, sim_parameters=None, scenario=None, device=0, seed=0, sparse_infos=None,
+                 **kw):
         from envs.atc._spaces import Box, MultiDiscrete
         self.vec = AtcVecEnv(num_envs, num_aircraft, sim_parameters=sim_parameters, scenario=scenario, device=device,
                              auto_reset=True, seed=seed, want_raw_obs=True, want_term_obs=True, **kw)
@@ -31,6 +32,12 @@ class AtcSBVecEnv:
         self.metadata = {'render.modes': ['human', 'rgb_array'], 'video.frames_per_second': 50}
         self._t0 = time.time()
         self._actions = None
+        # Building one dict per env per step is what bounds large batches.  With sparse infos only finished envs get their
+        # own dict (terminal_observation + Monitor's episode record, which is all stable-baselines reads); the others share
+        # one empty dict and the raw states of the whole batch are exposed as `self.original_state` [B, 10 N].
+        self.sparse_infos = (self.num_envs > 512) if sparse_infos is None else bool(sparse_infos)
+        self.original_state = None
+        self._no_info = {}
 
     # -- VecEnv protocol ---------------------------------------------------------------------------------------------
     def reset(self):
@@ -52,13 +59,20 @@ class AtcSBVecEnv:
         rew_h, done_h = pack[:, 3 * d], pack[:, 3 * d + 1] != 0
         ep_r, ep_l = pack[:, 3 * d + 2], pack[:, 3 * d + 3]
         now = round(time.time() - self._t0, 6)
-        infos = []
-        for b in range(self.num_envs):
-            item = {"original_state": raw_h[b]}
-            if done_h[b]:
-                item["terminal_observation"] = term_h[b]
-                item["episode"] = {"r": float(ep_r[b]), "l": int(ep_l[b]), "t": now}
-            infos.append(item)
+        self.original_state = raw_h
+        if self.sparse_infos:
+            infos = [self._no_info] * self.num_envs
+            for b in np.nonzero(done_h)[0]:
+                infos[b] = {"original_state": raw_h[b], "terminal_observation": term_h[b],
+                            "episode": {"r": float(ep_r[b]), "l": int(ep_l[b]), "t": now}}
+        else:
+            infos = []
+            for b in range(self.num_envs):
+                item = {"original_state": raw_h[b]}
+                if done_h[b]:
+                    item["terminal_observation"] = term_h[b]
+                    item["episode"] = {"r": float(ep_r[b]), "l": int(ep_l[b]), "t": now}
+                infos.append(item)
         return obs_h.copy(), rew_h.copy(), done_h.copy(), infos
 
     def step(self, actions):

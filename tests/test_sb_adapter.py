@@ -60,6 +60,26 @@ def test_adapter_equals_loop_of_single_envs():
         e.close()
 
 
+def test_sparse_infos_for_large_batches():
+    from atc_hip.sb_adapter import AtcSBVecEnv
+    venv = AtcSBVecEnv(1024)
+    assert venv.sparse_infos
+    venv.reset()
+    rng = np.random.default_rng(1)
+    a = rng.uniform(-1, 1, (1024, 3)).astype(np.float32)
+    a[:, 1] = -0.98
+    seen = 0
+    for t in range(320):
+        o, r, d, infos = venv.step(a)
+        assert len(infos) == 1024 and venv.original_state.shape == (1024, 10)
+        for b in np.nonzero(d)[0]:
+            assert infos[b]["episode"]["l"] > 0 and infos[b]["terminal_observation"].shape == (10,)
+            seen += 1
+        assert all(("episode" in infos[b]) == bool(d[b]) for b in range(0, 1024, 37))
+    assert seen > 100
+    venv.close()
+
+
 def test_rgb_array_renders_aircraft():
     from atc_hip import render
     from envs.atc import atc_gym
