@@ -10,6 +10,10 @@
 
 #include "../../include/atc_step.h"
 
+#ifndef ATC_MVA_BATCH
+#define ATC_MVA_BATCH 4  // edge records fetched per L2 round trip in dirty lookup cells (8 VGPRs each)
+#endif
+
 namespace atc {
 
 // Aircraft performance limits and the action discriminator are hard-coded in the reference (Airplane.__init__ defaults,
@@ -163,7 +167,7 @@ __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const fl
         // one L2 round trip per batch instead of one per record.  Indices past the list are clamped (loads stay in
         // bounds) and their records ignored.
         const float4* rec = reinterpret_cast<const float4*>(grid + (int)grid[ATC_G_OFF_POOL]) + 2 * (int)cell.y;
-        constexpr int kBatch = 4;
+        constexpr int kBatch = ATC_MVA_BATCH;
         bool inside = false;
         for (int base = 0; base < n; base += kBatch) {
             float4 g[kBatch], m[kBatch];
