@@ -175,6 +175,7 @@ def main():
                     "flags": torch.empty((T, B, N), dtype=torch.int32, device=dev)}
 
     run(W, 0)
+    D.all_gather_stats(env.ep_return, env.ep_length)  # untimed: creates the RCCL communicator / channels (N > 1)
     torch.cuda.synchronize(dev)
     D.barrier()
     torch.cuda.synchronize(dev)
