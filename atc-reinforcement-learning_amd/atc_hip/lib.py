@@ -33,7 +33,8 @@ class AtcOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in OUT_FIELDS]
 
 
-EXPORTS = ("atc_abi_version", "atc_last_error", "atc_scenario_create", "atc_scenario_destroy", "atc_query_mva",
+EXPORTS = ("atc_abi_version", "atc_last_error", "atc_host_mapped_ptr", "atc_scenario_create", "atc_scenario_destroy",
+           "atc_query_mva",
            "atc_query_mva_index", "atc_query_corridor", "atc_query_shaping", "atc_reset", "atc_observe", "atc_step",
            "atc_rollout")
 
@@ -53,6 +54,7 @@ def load():
     vp, ci = C.c_void_p, C.c_int
     lib.atc_abi_version.restype = ci
     lib.atc_last_error.restype = C.c_char_p
+    lib.atc_host_mapped_ptr.argtypes = [vp, C.POINTER(vp)]
     lib.atc_scenario_create.argtypes = [vp, C.c_size_t, ci, C.POINTER(vp)]
     lib.atc_scenario_destroy.argtypes = [vp]
     lib.atc_query_mva.argtypes = [vp, ci, vp, vp, vp, ci, vp]
@@ -75,6 +77,13 @@ def load():
 def check(rc):
     if rc != 0:
         raise RuntimeError("libatcstep: %s (code %d)" % (load().atc_last_error().decode(), rc))
+
+
+def mapped_ptr(tensor):
+    """Device address of a pinned (hipHostMalloc) CPU tensor: kernels access it zero-copy over the host link."""
+    dev = C.c_void_p()
+    check(load().atc_host_mapped_ptr(C.c_void_p(tensor.data_ptr()), C.byref(dev)))
+    return dev.value
 
 
 def _torch_cuda():

@@ -17,9 +17,14 @@ from . import lib as _lib
 class AtcVecEnv:
     def __init__(self, num_envs, num_aircraft=1, sim_parameters=None, scenario=None, device=0, auto_reset=True,
                  spawn="auto", seed=0, grid_cell=0.5, want_raw_obs=False, want_ac_reward=False, want_min_sep=False,
-                 want_term_obs=False, timestep_limit=6000, sep_nm=3.0, sep_ft=1000.0, conflict_reward=-200.0):
+                 want_term_obs=False, timestep_limit=6000, sep_nm=3.0, sep_ft=1000.0, conflict_reward=-200.0,
+                 host_mapped=False):
+        """host_mapped=True keeps state and outputs in pinned host memory mapped into the device (zero-copy): the kernels
+        read / write it over the host link, every call ends with a stream synchronisation, and what is returned are CPU
+        tensors.  Meant for tiny latency-bound batches (the single-env AtcGym); large batches belong in HBM."""
         torch = _lib._torch_cuda()
         self.torch = torch
+        self.host_mapped = bool(host_mapped)
         from envs.atc import model, scenarios
         self.sim_parameters = sim_parameters if sim_parameters is not None else model.SimParameters(1)
         self.scenario_obj = scenario if scenario is not None else scenarios.LOWW()
@@ -44,14 +49,17 @@ class AtcVecEnv:
                                        sep_nm=sep_nm, sep_ft=sep_ft, conflict_reward=conflict_reward)
         self.timestep_limit = timestep_limit
         B, N, BN, dev = self.B, self.N, self.B * self.N, self.device
-        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+        if self.host_mapped:
+            z = lambda shape, dt: torch.zeros(shape, dtype=dt).pin_memory()  # noqa: E731
+        else:
+            z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
         f32, f64, i32 = torch.float32, torch.float64, torch.int32
         # persistent state (atc_state_t): packed records, see include/atc_step.h
         self.pos = z((BN, 2), f64)            # x, y
         self.kin = z((BN, 4), f32)            # h, phi, v, last accepted phi target
         self.last_vh = z((BN, 2), f32)        # last accepted v / h targets
         self.env = z((B, L.ENV_WORDS), i32)   # per-env record
-        self._state = _lib.AtcState(*[getattr(self, n).data_ptr() for n in _lib.STATE_FIELDS])
+        self._state = _lib.AtcState(*[self._ptr(getattr(self, n)) for n in _lib.STATE_FIELDS])
         # named views into the records (live device memory, usable for reads and in-place writes)
         self.x, self.y = self.pos[:, 0], self.pos[:, 1]
         self.h, self.phi, self.v = self.kin[:, 0], self.kin[:, 1], self.kin[:, 2]
@@ -80,7 +88,8 @@ class AtcVecEnv:
     def pack_outputs(self):
         """Re-homes obs / raw_obs / reward / flags / done of a small env batch in ONE contiguous byte buffer (plus a pinned
         host mirror) so that a host-side caller (AtcGym) fetches a whole step result with a single device->host copy.
-        Returns (device_bytes, host_bytes, layout) with layout[name] = (offset, nbytes)."""
+        Returns (device_bytes, host_bytes, layout) with layout[name] = (offset, nbytes); in host-mapped mode the two are
+        the same pinned buffer and no copy is needed at all."""
         torch = self.torch
         assert self.raw_obs is not None
         B, N = self.B, self.N
@@ -90,8 +99,8 @@ class AtcVecEnv:
         for name, nb in sizes:
             layout[name] = (off, nb)
             off += (nb + 15) & ~15
-        dev = torch.zeros(off, dtype=torch.uint8, device=self.device)
         host = torch.zeros(off, dtype=torch.uint8).pin_memory()
+        dev = host if self.host_mapped else torch.zeros(off, dtype=torch.uint8, device=self.device)
         view = lambda name, dt, shape: dev[layout[name][0]:layout[name][0] + layout[name][1]].view(dt).view(shape)  # noqa: E731
         self.obs = view("obs", torch.float32, (B, N * L.OBS_DIM))
         self.raw_obs = view("raw_obs", torch.float32, (B, N * L.OBS_DIM))
@@ -102,9 +111,18 @@ class AtcVecEnv:
                                    self.min_sep, self.term_obs)
         return dev, host, layout
 
-    @staticmethod
-    def _make_out(*tensors):
-        return _lib.AtcOut(*[(t.data_ptr() if t is not None else None) for t in tensors])
+    def _ptr(self, t):
+        """Device address of a tensor this env hands to the library (mapped address for pinned host tensors)."""
+        if t is None:
+            return None
+        return t.data_ptr() if t.is_cuda else _lib.mapped_ptr(t)
+
+    def _make_out(self, *tensors):
+        return _lib.AtcOut(*[self._ptr(t) for t in tensors])
+
+    def _finish(self):
+        if self.host_mapped:  # results live in host memory: valid only once the stream has drained
+            self.torch.cuda.current_stream(self.device).synchronize()
 
     def _stream(self):
         return _lib.current_stream_ptr(self.device)
@@ -130,8 +148,9 @@ class AtcVecEnv:
             m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.atc_reset(self.sector.handle, self.B, self.N, C.byref(self._state),
-                                           m.data_ptr() if m is not None else None, self.obs.data_ptr(),
+                                           m.data_ptr() if m is not None else None, self._ptr(self.obs),
                                            C.byref(self.params), int(first), self._stream()))
+        self._finish()
         return self.obs
 
     def observe(self, mask=None):
@@ -142,14 +161,17 @@ class AtcVecEnv:
             m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.atc_observe(self.sector.handle, self.B, self.N, C.byref(self._state),
-                                             m.data_ptr() if m is not None else None, self.obs.data_ptr(),
+                                             m.data_ptr() if m is not None else None, self._ptr(self.obs),
                                              C.byref(self.params), self._stream()))
+        self._finish()
         return self.obs
 
     def _as_actions(self, actions, lead=()):
         torch = self.torch
         a = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions, dtype=np.float32))
-        a = a.to(device=self.device, dtype=torch.float32).contiguous()
+        if not (self.host_mapped and not a.is_cuda and a.is_pinned() and a.dtype == torch.float32):
+            a = a.to(device=self.device, dtype=torch.float32)
+        a = a.contiguous()
         want = int(np.prod(lead, dtype=np.int64)) * self.B * self.N * L.ACT_DIM if lead else self.B * self.N * L.ACT_DIM
         if a.numel() != want:
             raise ValueError("actions must have %d elements, got %d" % (want, a.numel()))
@@ -161,9 +183,10 @@ class AtcVecEnv:
         uint8, info) — device tensors that are overwritten by the next step."""
         a = self._as_actions(actions)
         with self.torch.cuda.device(self.device):
-            _lib.check(self._lib.atc_step(self.sector.handle, self.B, self.N, C.byref(self._state), a.data_ptr(),
+            _lib.check(self._lib.atc_step(self.sector.handle, self.B, self.N, C.byref(self._state), self._ptr(a),
                                           C.byref(self._out), C.byref(self.params), self._stream()))
         self._keep = a
+        self._finish()
         return self.obs, self.reward, self.done, self._info()
 
     def step_async(self, actions):
@@ -201,9 +224,10 @@ class AtcVecEnv:
         o = self._make_out(out["obs"], out.get("raw_obs"), out["reward"], out.get("ac_reward"), out["done"],
                            out["flags"], out.get("min_sep"), out.get("term_obs"))
         with torch.cuda.device(dev):
-            _lib.check(self._lib.atc_rollout(self.sector.handle, B, N, T, C.byref(self._state), a.data_ptr(),
+            _lib.check(self._lib.atc_rollout(self.sector.handle, B, N, T, C.byref(self._state), self._ptr(a),
                                              C.byref(o), C.byref(self.params), self._stream()))
         self._keep = a
+        self._finish()
         return out
 
     def get_attr(self, name, indices=None):

@@ -48,6 +48,7 @@ static int fail_arg(const char* msg) {
 }
 static int fail_hip(hipError_t e, const char* what) {
     snprintf(g_err, sizeof g_err, "HIP error in %s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();  // reported here: do not leave it as the runtime's sticky "last error" for the caller's framework
     return ATC_ERR_HIP;
 }
 #define HIP_TRY(expr)                                    \
@@ -897,6 +898,12 @@ extern "C" {
 
 int atc_abi_version(void) { return ATC_ABI_VERSION; }
 const char* atc_last_error(void) { return g_err; }
+
+int atc_host_mapped_ptr(const void* host, void** dev) {
+    if (!host || !dev) return fail_arg("null pointer");
+    HIP_TRY(hipHostGetDevicePointer(dev, const_cast<void*>(host), 0));
+    return 0;
+}
 
 int atc_scenario_create(const float* blob_host, size_t n_words, int device, atc_scenario_t** out) {
     if (!blob_host || !out) return fail_arg("null pointer");

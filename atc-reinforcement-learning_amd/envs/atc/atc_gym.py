@@ -73,11 +73,27 @@ class AtcGym(Env):
 
         self._vec = self._make_backend(sim_parameters, scenario, device)
         torch = self._vec.torch
-        # one packed device buffer for everything step() returns + pinned host mirrors: 2 small copies per step
-        self._dev_out, self._host_out, self._out_layout = self._vec.pack_outputs()
-        self._host_env = torch.zeros(L.ENV_WORDS, dtype=torch.int32).pin_memory()
+        # Zero-copy step: aircraft state, the action and everything step() returns live in pinned host memory that is
+        # mapped into the device (AtcVecEnv(host_mapped=True)); one step = write 3 floats, one kernel launch, one stream
+        # synchronisation, read the results in place.  No copy is launched around the step.
+        _, self._host_out, self._out_layout = self._vec.pack_outputs()
         self._host_act = torch.zeros(3, dtype=torch.float32).pin_memory()
-        self._dev_act = torch.zeros((1, 1, 3), dtype=torch.float32, device=self._vec.device)
+        self._act_np = self._host_act.numpy()
+        self._out_np = self._host_out.numpy()
+        self._env_np = self._vec.env.numpy()
+        lay = self._out_layout
+        f32 = lambda name: self._out_np[lay[name][0]:lay[name][0] + lay[name][1]].view(np.float32)  # noqa: E731
+        self._obs_np, self._raw_np, self._rew_np = f32("obs"), f32("raw_obs"), f32("reward")
+        self._flags_np = self._out_np[lay["flags"][0]:lay["flags"][0] + 4].view(np.int32)
+        self._done_np = self._out_np[lay["done"][0]:lay["done"][0] + 1]
+        import ctypes as C
+        from atc_hip import lib as _lib
+        v = self._vec
+        self._check = _lib.check
+        self._launch = lambda stream, _f=v._lib.atc_step, _h=v.sector.handle, _s=C.byref(v._state), \
+            _a=C.c_void_p(_lib.mapped_ptr(self._host_act)), _o=C.byref(v._out), _p=C.byref(v.params): \
+            _f(_h, 1, 1, _s, _a, _o, _p, stream)
+        self._current_stream = torch.cuda.current_stream
         comp = self._vec.compiled
         self._faf_mva = int(comp.faf_mva)
         self._world_x_min, self._world_y_min, self._world_x_max, self._world_y_max = comp.bbox
@@ -108,7 +124,7 @@ class AtcGym(Env):
     def _make_backend(sim_parameters, scenario, device):
         from atc_hip.vec_env import AtcVecEnv
         return AtcVecEnv(1, 1, sim_parameters=sim_parameters, scenario=scenario, device=device, auto_reset=False,
-                         spawn="lattice", want_raw_obs=True)
+                         spawn="lattice", want_raw_obs=True, host_mapped=True)
 
     @property
     def last_action(self):
@@ -130,12 +146,9 @@ class AtcGym(Env):
 
     def step(self, action):
         """atc_gym.py:128-192 — one launch of the HIP step kernel + the reference's Python-side bookkeeping."""
-        vec = self._vec
         a = np.asarray(action, dtype=np.float32).reshape(1, 1, 3)
-        self._host_act.numpy()[:] = a.reshape(3)
-        self._dev_act.view(3).copy_(self._host_act, non_blocking=True)
-        vec.step(self._dev_act)
-        state_out, raw, rew, dn, flags, self.timesteps, self.actions_taken = self._fetch()
+        self._act_np[:] = a.reshape(3)
+        state_out, raw, rew, dn, flags, self.timesteps, self.actions_taken = self._launch_and_fetch()
         self.done = False
         # one append per terminal cause, in the reference's order (atc_gym.py:151,158,165)
         if flags & (L.F_BELOW_MVA | L.F_OUTSIDE):
@@ -155,19 +168,16 @@ class AtcGym(Env):
         self._update_metrics(rew)
         return state_out, rew, self.done, {"original_state": self.state}
 
-    def _fetch(self):
-        """Two pinned device->host copies (packed step outputs, env record) and one synchronisation."""
-        vec = self._vec
-        self._host_out.copy_(self._dev_out, non_blocking=True)
-        self._host_env.copy_(vec.env[0], non_blocking=True)
-        vec.torch.cuda.current_stream(vec.device).synchronize()
-        h = self._host_out.numpy()
-        lay = self._out_layout
-        f32 = lambda name: h[lay[name][0]:lay[name][0] + lay[name][1]].view(np.float32)  # noqa: E731
-        env = self._host_env.numpy()
-        return (f32("obs").copy(), f32("raw_obs").copy(), float(f32("reward")[0]), bool(h[lay["done"][0]]),
-                int(h[lay["flags"][0]:lay["flags"][0] + 4].view(np.int32)[0]), int(env[L.ENV_TIMESTEPS]),
-                int(env[L.ENV_ACTIONS_TAKEN]))
+    def _launch_and_fetch(self):
+        """One launch of the step kernel on host-mapped buffers, one stream synchronisation, results read in place."""
+        stream = self._current_stream(self._vec.device)
+        rc = self._launch(stream.cuda_stream)
+        if rc:
+            self._check(rc)
+        stream.synchronize()
+        env = self._env_np[0]
+        return (self._obs_np.copy(), self._raw_np.copy(), float(self._rew_np[0]), bool(self._done_np[0]),
+                int(self._flags_np[0]), int(env[L.ENV_TIMESTEPS]), int(env[L.ENV_ACTIONS_TAKEN]))
 
     def _update_metrics(self, reward):
         """atc_gym.py:194-197"""
@@ -194,7 +204,7 @@ class AtcGym(Env):
         vec.reset()
         vec.set_state(0, 0, entry_point.x, entry_point.y, level * 100, entry_point.phi, 250)
         self._airplane.id = plane_id
-        self.state = vec.observe().reshape(-1).cpu().numpy().astype(np.float32)
+        self.state = vec.observe().reshape(-1).numpy().astype(np.float32)  # host-mapped: synchronised, copied here
         self.total_reward = 0
         self.last_reward = 0
         self._actions_ignoring_resets += self.actions_taken

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ATC_ABI_VERSION 8
+#define ATC_ABI_VERSION 9
 
 /* ---------------------------------------------------------------------------------------------
  * Scenario blob: one flat array of 32-bit floats (device copy) compiled on the host from the sector
@@ -185,6 +185,13 @@ const char* atc_last_error(void);
  * Replaces: AtcGym.__init__ scenario unpacking, atc_gym.py:45-58. */
 int atc_scenario_create(const float* blob_host, size_t n_words, int device, atc_scenario_t** out);
 int atc_scenario_destroy(atc_scenario_t* s);
+
+/* Zero-copy for latency-bound callers (the single-env AtcGym, atc_gym.py:128-192, whose step is one aircraft): every
+ * state / action / output pointer may also address pinned host memory (hipHostMalloc, e.g. a torch tensor with
+ * pin_memory()) that is mapped into the device's address space; the kernels then read and write it over the host link
+ * and no copy is launched around the step.  *dev receives the device address of such a buffer; fails (-2) if `host`
+ * is not mapped pinned memory. */
+int atc_host_mapped_ptr(const void* host, void** dev);
 
 /* -- batched queries (same device functions as the step kernel) -------------------------------- */
 /* Airspace.get_mva_height, model.py:282-292.  out_h[i] = MVA height [ft] or -1 (outside airspace).
