@@ -11,7 +11,7 @@
 #include "../../include/atc_step.h"
 
 #ifndef ATC_MVA_BATCH
-#define ATC_MVA_BATCH 4  // edge records fetched per L2 round trip in dirty lookup cells (8 VGPRs each)
+#define ATC_MVA_BATCH 2  // edge records fetched per L2 round trip in dirty lookup cells (8 VGPRs each)
 #endif
 
 namespace atc {

@@ -70,6 +70,15 @@ constexpr int kBlock = ATC_BLOCK;
 #ifndef ATC_ABLATE
 #define ATC_ABLATE 0  // developer-only timing ablations (bit mask, see uses); the shipped build always uses 0
 #endif
+#ifndef ATC_STAGGER_WG_PER_CU
+#define ATC_STAGGER_WG_PER_CU (1024 / ATC_BLOCK)
+#endif
+#ifndef ATC_STAGGER_MIN_ROUNDS
+#define ATC_STAGGER_MIN_ROUNDS 3
+#endif
+#ifndef ATC_LOOP_OPAQUE
+#define ATC_LOOP_OPAQUE 1
+#endif
 #ifndef ATC_TRACE
 #define ATC_TRACE 0  // developer-only: per-wavefront s_memtime stamps at phase boundaries (pointer smuggled in params)
 #endif
@@ -79,9 +88,9 @@ constexpr int kBlock = ATC_BLOCK;
 #define ATC_STAMP(n) do {} while (0)
 #endif
 #ifndef ATC_STAGGER
-// first-round workgroups sleep hash(blockIdx) in 0..31 times ATC_STAGGER * 64 cycles before starting (see k_step);
-// measured: 5 -> 31.1 us vs 31.8 us without (8: 31.9 us, 12: 33.1 us)
-#define ATC_STAGGER 5
+// n > 0: first-round workgroups sleep hash(blockIdx) in 0..31 times n * 64 cycles before starting (see k_step).  It paid
+// while the kernel ran 4 wavefronts per SIMD (5 -> 31.1 us vs 31.8 us); at 6-7 per SIMD it costs (25.8 vs 24.8 us): off.
+#define ATC_STAGGER 0
 #endif
 #ifndef ATC_GRID_CAP
 #define ATC_GRID_CAP 8   // workgroups per CU before the reset / observe / query kernels grid-stride
@@ -592,7 +601,7 @@ __device__ __forceinline__ void store_env_state(const atc_state_t& st, const Lan
     }
 }
 
-template <int W, bool FULL>
+template <int W, bool FULL, bool ONE>  // ONE: single-step launch (T == 1)
 __global__ void __launch_bounds__(kBlock, ATC_MIN_WAVES)
 k_step(const float* __restrict__ blob, int first_round, int off_grid, int B, int N, int T, atc_state_t st,
        const float* __restrict__ actions, atc_out_t out, atc_params_t p) {
@@ -611,7 +620,7 @@ k_step(const float* __restrict__ blob, int first_round, int off_grid, int B, int
     // the memory system and the SIMDs take turns idling.  De-phase the first round (first_round = workgroups resident at
     // launch, n_cu * 4) once; later rounds inherit the spread.  Only worth it when the launch runs for several rounds
     // (small launches would just start late).
-    if (blockIdx.x < (unsigned)first_round && gridDim.x >= 3u * (unsigned)first_round) {
+    if (blockIdx.x < (unsigned)first_round && gridDim.x >= (unsigned)ATC_STAGGER_MIN_ROUNDS * (unsigned)first_round) {
         const unsigned dly = ((blockIdx.x * 2654435761u) >> 27);
         for (unsigned q = 0; q < dly; ++q) __builtin_amdgcn_s_sleep(ATC_STAGGER);
     }
@@ -630,7 +639,11 @@ k_step(const float* __restrict__ blob, int first_round, int off_grid, int B, int
     const float2 lv = *at<float2>(st.last_vh, d.i * 8u);
     LaneState ls = {{ps.x, ps.y, kn.x, kn.y, kn.z}, lv.x, lv.y, kn.w, false};
 
-    for (int step = 0; step < T; ++step) {
+    // A single step is its own instantiation: with the step count a run-time value everything the loop carries (aircraft
+    // and env records, output bases, hoisted sector constants) stays live across the whole body — 122 VGPRs and 28 spilled
+    // SGPRs (4 wavefronts per SIMD) against 78 and none (6 per SIMD) for the straight-line form.
+    const int n_steps = ONE ? 1 : T;
+    for (int step = 0; step < n_steps; ++step) {
         const size_t sBN = (size_t)step * BN, sB = (size_t)step * (uint32_t)B;  // uniform (scalar) per-step bases
         const float* act_t = actions + sBN * 3;
         StepOut so = {out.obs + sBN * ATC_OBS_DIM, out.flags + sBN, out.reward + sB, out.done + sB,
@@ -641,9 +654,20 @@ k_step(const float* __restrict__ blob, int first_round, int off_grid, int B, int
         const float a_v = stream_load(at<float>(act_t, d.i * 12u)), a_h = stream_load(at<float>(act_t, d.i * 12u + 4u)),
                     a_p = stream_load(at<float>(act_t, d.i * 12u + 8u));
         ATC_STAMP(1);
-        const Mid m = step_part_a(K, grid, p, d, a_v, a_h, a_p, ls, es);
+#if ATC_LOOP_OPAQUE
+        // multi-step launches: re-derive the sector base from an opaque zero in every iteration so that the scalar loads
+        // of the body are not hoisted out of the loop (where they would sit in spilled SGPRs across all of it)
+        int zk = 0;
+        if (!ONE) asm volatile("s_mov_b32 %0, 0" : "=s"(zk));
+        const float* __restrict__ Kt = K + zk;
+        const float* __restrict__ gt = grid ? grid + zk : nullptr;
+#else
+        const float* __restrict__ Kt = K;
+        const float* __restrict__ gt = grid;
+#endif
+        const Mid m = step_part_a(Kt, gt, p, d, a_v, a_h, a_p, ls, es);
         ATC_STAMP(3);
-        step_part_b<W, FULL>(K, grid, p, N, d, m, ls, es, so, pos, obs_stage);
+        step_part_b<W, FULL>(Kt, gt, p, N, d, m, ls, es, so, pos, obs_stage);
         ATC_STAMP(5);
     }
     ATC_STAMP(6);
@@ -837,16 +861,16 @@ static size_t lds_bytes(const atc_scenario*, bool pair_scan, bool step_kernel = 
     return w * sizeof(float);
 }
 
-template <int W, bool FULL>
+template <int W, bool FULL, bool ONE>
 static int launch_step2(const atc_scenario* s, int B, int N, int T, const atc_state_t* st, const float* actions,
                         const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
     const size_t lds = lds_bytes(s, W > 1 && W != 16, true);
     if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<W, FULL>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<W, FULL, ONE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long long slots = (long long)B * W;
     const int grid = (int)((slots + kBlock - 1) / kBlock);  // one workgroup per 256 slots, no grid-stride loop
-    hipLaunchKernelGGL((k_step<W, FULL>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->n_cu * (1024 / kBlock),
+    hipLaunchKernelGGL((k_step<W, FULL, ONE>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->n_cu * ATC_STAGGER_WG_PER_CU,
                        s->off_grid, B, N, T, *st, actions, *out, *p);
     HIP_TRY(hipGetLastError());
     return ATC_OK;
@@ -871,8 +895,11 @@ static int launch_step(const atc_scenario* s, int B, int N, int T, const atc_sta
         }
     }
 #endif
-    return full ? launch_step2<W, true>(s, B, N, T, st, actions, out, p, stream)
-                : launch_step2<W, false>(s, B, N, T, st, actions, out, p, stream);
+    if (full)
+        return T == 1 ? launch_step2<W, true, true>(s, B, N, T, st, actions, out, p, stream)
+                      : launch_step2<W, true, false>(s, B, N, T, st, actions, out, p, stream);
+    return T == 1 ? launch_step2<W, false, true>(s, B, N, T, st, actions, out, p, stream)
+                  : launch_step2<W, false, false>(s, B, N, T, st, actions, out, p, stream);
 }
 
 static int step_common(const atc_scenario_t* s, int B, int N, int T, const atc_state_t* st, const float* actions,
