@@ -76,9 +76,6 @@ constexpr int kBlock = ATC_BLOCK;
 #ifndef ATC_STAGGER_MIN_ROUNDS
 #define ATC_STAGGER_MIN_ROUNDS 3
 #endif
-#ifndef ATC_LOOP_OPAQUE
-#define ATC_LOOP_OPAQUE 1
-#endif
 #ifndef ATC_TRACE
 #define ATC_TRACE 0  // developer-only: per-wavefront s_memtime stamps at phase boundaries (pointer smuggled in params)
 #endif
@@ -654,20 +651,9 @@ k_step(const float* __restrict__ blob, int first_round, int off_grid, int B, int
         const float a_v = stream_load(at<float>(act_t, d.i * 12u)), a_h = stream_load(at<float>(act_t, d.i * 12u + 4u)),
                     a_p = stream_load(at<float>(act_t, d.i * 12u + 8u));
         ATC_STAMP(1);
-#if ATC_LOOP_OPAQUE
-        // multi-step launches: re-derive the sector base from an opaque zero in every iteration so that the scalar loads
-        // of the body are not hoisted out of the loop (where they would sit in spilled SGPRs across all of it)
-        int zk = 0;
-        if (!ONE) asm volatile("s_mov_b32 %0, 0" : "=s"(zk));
-        const float* __restrict__ Kt = K + zk;
-        const float* __restrict__ gt = grid ? grid + zk : nullptr;
-#else
-        const float* __restrict__ Kt = K;
-        const float* __restrict__ gt = grid;
-#endif
-        const Mid m = step_part_a(Kt, gt, p, d, a_v, a_h, a_p, ls, es);
+        const Mid m = step_part_a(K, grid, p, d, a_v, a_h, a_p, ls, es);
         ATC_STAMP(3);
-        step_part_b<W, FULL>(Kt, gt, p, N, d, m, ls, es, so, pos, obs_stage);
+        step_part_b<W, FULL>(K, grid, p, N, d, m, ls, es, so, pos, obs_stage);
         ATC_STAMP(5);
     }
     ATC_STAMP(6);
@@ -895,11 +881,14 @@ static int launch_step(const atc_scenario* s, int B, int N, int T, const atc_sta
         }
     }
 #endif
-    if (full)
-        return T == 1 ? launch_step2<W, true, true>(s, B, N, T, st, actions, out, p, stream)
-                      : launch_step2<W, true, false>(s, B, N, T, st, actions, out, p, stream);
-    return T == 1 ? launch_step2<W, false, true>(s, B, N, T, st, actions, out, p, stream)
-                  : launch_step2<W, false, false>(s, B, N, T, st, actions, out, p, stream);
+    // Multi-step launches keep the state in registers across the steps; the run-time step loop costs the kernel its
+    // occupancy (4 wavefronts per SIMD against 5-7 for the straight-line single step) but issuing T single-step launches
+    // instead is slower at every size (65 536 x 16, T = 20, [T, ...] outputs: 35.0 vs 27.1 us per step).
+    if (T > 1)
+        return full ? launch_step2<W, true, false>(s, B, N, T, st, actions, out, p, stream)
+                    : launch_step2<W, false, false>(s, B, N, T, st, actions, out, p, stream);
+    return full ? launch_step2<W, true, true>(s, B, N, 1, st, actions, out, p, stream)
+                : launch_step2<W, false, true>(s, B, N, 1, st, actions, out, p, stream);
 }
 
 static int step_common(const atc_scenario_t* s, int B, int N, int T, const atc_state_t* st, const float* actions,
