@@ -16,7 +16,9 @@
 //   LDS and read partners in batches.  Per-env reward / action count / minimum separation are reduced with DPP butterflies
 //   (wavefront shuffles beyond a row), done / won masks with a ballot — no block barrier, no atomics, no MFMA (there is no
 //   dense contraction on this path).
-//   Workgroup = 256 threads = 256 consecutive slots; one workgroup per tile (no grid-stride loop in the step kernel).
+//   Workgroup = 256 threads = 256 consecutive slots; one workgroup per tile.  The single-step kernel has NO loop around
+//   the step body (neither grid-stride nor the step loop of multi-step launches): it is its own instantiation
+//   k_step<W, FULL, ONE = true>, 71 VGPRs / 7 wavefronts per SIMD against 109-128 / 4 for the loop form.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared   (see build.py)
 #include <hip/hip_runtime.h>
@@ -70,12 +72,6 @@ constexpr int kBlock = ATC_BLOCK;
 #ifndef ATC_ABLATE
 #define ATC_ABLATE 0  // developer-only timing ablations (bit mask, see uses); the shipped build always uses 0
 #endif
-#ifndef ATC_STAGGER_WG_PER_CU
-#define ATC_STAGGER_WG_PER_CU (1024 / ATC_BLOCK)
-#endif
-#ifndef ATC_STAGGER_MIN_ROUNDS
-#define ATC_STAGGER_MIN_ROUNDS 3
-#endif
 #ifndef ATC_TRACE
 #define ATC_TRACE 0  // developer-only: per-wavefront s_memtime stamps at phase boundaries (pointer smuggled in params)
 #endif
@@ -83,11 +79,6 @@ constexpr int kBlock = ATC_BLOCK;
 #define ATC_STAMP(n) do { if (lane == 0 && trace) trace[(size_t)(blockIdx.x * (kBlock / 64) + (tid >> 6)) * 8 + (n)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define ATC_STAMP(n) do {} while (0)
-#endif
-#ifndef ATC_STAGGER
-// n > 0: first-round workgroups sleep hash(blockIdx) in 0..31 times n * 64 cycles before starting (see k_step).  It paid
-// while the kernel ran 4 wavefronts per SIMD (5 -> 31.1 us vs 31.8 us); at 6-7 per SIMD it costs (25.8 vs 24.8 us): off.
-#define ATC_STAGGER 0
 #endif
 #ifndef ATC_GRID_CAP
 #define ATC_GRID_CAP 8   // workgroups per CU before the reset / observe / query kernels grid-stride
@@ -600,7 +591,7 @@ __device__ __forceinline__ void store_env_state(const atc_state_t& st, const Lan
 
 template <int W, bool FULL, bool ONE>  // ONE: single-step launch (T == 1)
 __global__ void __launch_bounds__(kBlock, ATC_MIN_WAVES)
-k_step(const float* __restrict__ blob, int first_round, int off_grid, int B, int N, int T, atc_state_t st,
+k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, atc_state_t st,
        const float* __restrict__ actions, atc_out_t out, atc_params_t p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4* pos = reinterpret_cast<float4*>(smem);                    // [kBlock] pair-scan staging (W != 1, 16)
@@ -611,16 +602,6 @@ k_step(const float* __restrict__ blob, int first_round, int off_grid, int B, int
     const int tid = threadIdx.x, lane = tid & 63;
     unsigned long long* trace = reinterpret_cast<unsigned long long*>(
         ((unsigned long long)p.reserved0) | ((unsigned long long)__float_as_uint(p.reserved1) << 32));
-#endif
-#if ATC_STAGGER
-    // All resident wavefronts of a launch start together and then move through load -> compute -> store in lockstep, so
-    // the memory system and the SIMDs take turns idling.  De-phase the first round (first_round = workgroups resident at
-    // launch, n_cu * 4) once; later rounds inherit the spread.  Only worth it when the launch runs for several rounds
-    // (small launches would just start late).
-    if (blockIdx.x < (unsigned)first_round && gridDim.x >= (unsigned)ATC_STAGGER_MIN_ROUNDS * (unsigned)first_round) {
-        const unsigned dly = ((blockIdx.x * 2654435761u) >> 27);
-        for (unsigned q = 0; q < dly; ++q) __builtin_amdgcn_s_sleep(ATC_STAGGER);
-    }
 #endif
     ATC_STAMP(0);
     const uint32_t BN = (uint32_t)B * (uint32_t)N;      // host guarantees B*N*40 bytes < 4 GiB: 32-bit lane offsets
@@ -661,78 +642,6 @@ k_step(const float* __restrict__ blob, int first_round, int off_grid, int B, int
     store_lane_state(st, d, ls);
     store_env_state(st, d, es);
     ATC_STAMP(7);
-}
-
-#ifndef ATC_PIPE_WAVES
-#define ATC_PIPE_WAVES 3  // wavefronts per SIMD the pipelined kernel is register-budgeted for
-#endif
-// ---------------------------------------------------------------------------------------------------------------
-// Software-pipelined single-step kernel for large launches (fast variant only, T = 1): persistent workgroups walk the
-// tiles of 256 slots with stride gridDim.x and PREFETCH the next tile's aircraft state and actions (16 registers) right
-// after the current tile's last dependent gather (the MVA lookup), so those loads are in flight during the second half of
-// the step instead of stalling the next tile's first instruction.
-// ---------------------------------------------------------------------------------------------------------------
-struct Prefetch {
-    double2 ps;
-    float4 kn;
-    float2 lv;
-    float a_v, a_h, a_p;
-    int t;
-    int2 mask;
-};
-template <int W>
-__device__ __forceinline__ Prefetch prefetch_tile(const atc_state_t& st, const float* __restrict__ actions, uint32_t tile,
-                                                  int B, int N) {
-    const LaneIds d = make_ids<W>(tile * kBlock, B, N);
-    Prefetch f;
-    f.ps = *at<double2>(st.pos, d.i * 16u);
-    f.kn = *at<float4>(st.kin, d.i * 16u);
-    f.lv = *at<float2>(st.last_vh, d.i * 8u);
-    f.a_v = *at<float>(actions, d.i * 12u);
-    f.a_h = *at<float>(actions, d.i * 12u + 4u);
-    f.a_p = *at<float>(actions, d.i * 12u + 8u);
-    const int* er = at<int>(st.env, (uint32_t)d.e * (ATC_ENV_WORDS * 4u));
-    f.t = er[ATC_ENV_TIMESTEPS];
-    f.mask = *reinterpret_cast<const int2*>(er + ATC_ENV_MASK_LO);
-    return f;
-}
-template <int W>
-__global__ void __launch_bounds__(kBlock, ATC_PIPE_WAVES)
-k_step_pipe(const float* __restrict__ blob, int off_grid, int B, int N, atc_state_t st, const float* __restrict__ actions,
-            atc_out_t out, atc_params_t p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float4* pos = reinterpret_cast<float4*>(smem);
-    float* obs_stage = smem + ((W > 1 && W != 16) ? kBlock * 4 : 0);
-    const float* __restrict__ K = blob;
-    const float* __restrict__ grid = off_grid ? blob + off_grid : nullptr;
-    const uint32_t n_tiles = ((uint32_t)B * (uint32_t)W + kBlock - 1) / kBlock;
-    uint32_t tile = blockIdx.x;
-    if (tile >= n_tiles) return;
-    Prefetch f = prefetch_tile<W>(st, actions, tile, B, N);
-    const StepOut so = {out.obs, out.flags, out.reward, out.done, nullptr, nullptr, nullptr, nullptr};
-    for (; tile < n_tiles; tile += gridDim.x) {
-        const LaneIds d = make_ids<W>(tile * kBlock, B, N);
-        LaneState ls = {{f.ps.x, f.ps.y, f.kn.x, f.kn.y, f.kn.z}, f.lv.x, f.lv.y, f.kn.w, false};
-        EnvState es;
-        es.t = f.t;
-        es.amask = (uint64_t)(uint32_t)f.mask.x | ((uint64_t)(uint32_t)f.mask.y << 32);
-        const Mid m = step_part_a(K, grid, p, d, f.a_v, f.a_h, f.a_p, ls, es);
-        // bookkeeping words of this tile's env record (needed only by the reductions at the end of the step) ...
-        const int4* erp = at<int4>(st.env, (uint32_t)d.e * (ATC_ENV_WORDS * 4u));
-        const int4 e0 = erp[0], e1 = erp[1];
-        // ... and the next tile's state: both are in flight during the second half of this step
-        const uint32_t next = tile + gridDim.x;
-        if (next < n_tiles) f = prefetch_tile<W>(st, actions, next, B, N);
-        es.n_actions = e0.y;
-        es.episode = e0.z;
-        es.ep_length = e0.w;
-        es.total_reward = __int_as_float(e1.x);
-        es.ep_return = __int_as_float(e1.y);
-        es.win_bits = (uint32_t)e1.z;
-        step_part_b<W, false>(K, grid, p, N, d, m, ls, es, so, pos, obs_stage);
-        store_lane_state(st, d, ls);
-        store_env_state(st, d, es);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -856,31 +765,14 @@ static int launch_step2(const atc_scenario* s, int B, int N, int T, const atc_st
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long long slots = (long long)B * W;
     const int grid = (int)((slots + kBlock - 1) / kBlock);  // one workgroup per 256 slots, no grid-stride loop
-    hipLaunchKernelGGL((k_step<W, FULL, ONE>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->n_cu * ATC_STAGGER_WG_PER_CU,
-                       s->off_grid, B, N, T, *st, actions, *out, *p);
+    hipLaunchKernelGGL((k_step<W, FULL, ONE>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->off_grid, B, N, T, *st, actions, *out, *p);
     HIP_TRY(hipGetLastError());
     return ATC_OK;
 }
-#ifndef ATC_PIPE
-#define ATC_PIPE 0  // 1: large single-step launches use the software-pipelined persistent kernel
-#endif
 template <int W>
 static int launch_step(const atc_scenario* s, int B, int N, int T, const atc_state_t* st, const float* actions,
                        const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
     const bool full = out->raw_obs || out->ac_reward || out->min_sep || out->term_obs;
-#if ATC_PIPE
-    {
-        const long long tiles = ((long long)B * W + kBlock - 1) / kBlock;
-        const int resident = s->n_cu * ATC_PIPE_WAVES * (256 / kBlock);
-        if (T == 1 && !full && tiles >= 3LL * resident) {
-            const size_t lds = lds_bytes(s, W > 1 && W != 16, true);
-            hipLaunchKernelGGL((k_step_pipe<W>), dim3(resident), dim3(kBlock), lds, stream, s->d_blob, s->off_grid, B, N, *st,
-                               actions, *out, *p);
-            HIP_TRY(hipGetLastError());
-            return ATC_OK;
-        }
-    }
-#endif
     // Multi-step launches keep the state in registers across the steps; the run-time step loop costs the kernel its
     // occupancy (4 wavefronts per SIMD against 5-7 for the straight-line single step) but issuing T single-step launches
     // instead is slower at every size (65 536 x 16, T = 20, [T, ...] outputs: 35.0 vs 27.1 us per step).
