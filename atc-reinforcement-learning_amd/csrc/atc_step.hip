@@ -397,7 +397,9 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const int gbase = tid & ~(W - 1);
-            constexpr int U = (W >= 32) ? 3 : (W >= 8 ? 7 : (W > 1 ? W - 1 : 1));  // per batch: 63 = 21x3, 31 = 10x3+1
+            // partners per LDS batch.  7 for every width since the single-step instantiation freed the registers
+            // (N = 64: 63 = 9 x 7; measured 11.7 vs 12.3 us at 4 096 x 64, 60.6 vs 62.8 us at 32 768 x 64 against batches of 3)
+            constexpr int U = (W >= 8) ? 7 : (W > 1 ? W - 1 : 1);
 #pragma unroll 1
             for (int d0 = 1; d0 < W; d0 += U) {
                 float4 q[U];
