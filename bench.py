@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU")
     ap.add_argument("--aircraft", type=int, default=AIRCRAFT)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grid-cell", type=float, default=0.5, help="cell size [nm] of the MVA lookup grid")
     ap.add_argument("--rollout", type=int, default=0, help="fuse this many steps per launch (0 = one launch per step)")
     ap.add_argument("--sep-nm", type=float, default=3.0, help="developer knob: separation minimum (0 disables conflicts)")
     ap.add_argument("--graph", action="store_true", help="replay the %d-step action-hold block as one captured HIP graph "
@@ -126,7 +127,7 @@ def main():
     B, N, K, W = args.envs, args.aircraft, args.steps, args.warmup
 
     scn = scenarios.LOWWDense() if N > 16 else scenarios.LOWW(random_entrypoints=N > 1)
-    env = AtcVecEnv(B, N, scenario=scn, device=local, auto_reset=True, seed=D.rank_seed(0, rank), grid_cell=0.5,
+    env = AtcVecEnv(B, N, scenario=scn, device=local, auto_reset=True, seed=D.rank_seed(0, rank), grid_cell=args.grid_cell,
                     sep_nm=args.sep_nm)
 
     # action ring resident in HBM before timing (Philox, seed 0 + rank)
@@ -216,7 +217,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%d envs x %d aircraft per GPU (%d envs total), sector %s, dt=1 s, reward shaping + "
                                    "normalisation on, continuous actions U(-1,1) re-sampled every %d steps, auto-reset, "
-                                   "O(N^2) separation scan, MVA lookup grid 0.5 nm" % (B, N, B * ws, type(scn).__name__, HOLD),
+                                   "O(N^2) separation scan, MVA lookup grid %g nm" % (B, N, B * ws, type(scn).__name__, HOLD, args.grid_cell),
                        "envs_per_gpu": B, "aircraft_per_env": N, "launch": "rollout T=%d" % args.rollout if args.rollout
                        else ("one atc_step launch per step, %d-step blocks replayed as a captured HIP graph" % HOLD
                              if args.graph else "one atc_step launch per step"), "parallelism": "env-sharded x%d, no step-path collective, "
