@@ -29,10 +29,16 @@ def build_lib(force=False, verbose=False, extra=()):
     if not force and not needs_build():
         return OUT
     extra = list(extra) + os.environ.get("ATC_HIPCC_EXTRA", "").split()
-    cmd = [HIPCC] + FLAGS + extra + ["-o", OUT, SRC]
+    tmp = OUT + ".tmp%d" % os.getpid()  # link under a private name, publish atomically (other ranks may be waiting)
+    cmd = [HIPCC] + FLAGS + extra + ["-o", tmp, SRC]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, OUT)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return OUT
 
 

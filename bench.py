@@ -113,6 +113,16 @@ def main():
         cmd += sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    # a fresh checkout has no native pieces yet: local rank 0 compiles them, the other ranks wait for the files
+    import __graft_entry__ as entry
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        entry.ensure_built()
+    else:
+        lib_path = os.path.join(ROOT, "atc-reinforcement-learning_amd", "atc_hip", "libatcstep.so")
+        t_wait = time.time()
+        while not os.path.exists(lib_path) and time.time() - t_wait < 600:
+            time.sleep(1.0)
+
     import torch
     from atc_hip import dist as D
     from atc_hip.vec_env import AtcVecEnv
