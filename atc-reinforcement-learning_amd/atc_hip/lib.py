@@ -33,10 +33,16 @@ class AtcOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in OUT_FIELDS]
 
 
+class AtcStepCall(C.Structure):
+    """atc_step_call_t"""
+    _fields_ = [("s", C.c_void_p), ("B", C.c_int32), ("N", C.c_int32), ("st", C.POINTER(AtcState)), ("actions", C.c_void_p),
+                ("out", C.POINTER(AtcOut)), ("p", C.POINTER(AtcParams)), ("stream", C.c_void_p)]
+
+
 EXPORTS = ("atc_abi_version", "atc_last_error", "atc_host_mapped_ptr", "atc_scenario_create", "atc_scenario_destroy",
            "atc_query_mva",
            "atc_query_mva_index", "atc_query_corridor", "atc_query_shaping", "atc_reset", "atc_observe", "atc_step",
-           "atc_rollout")
+           "atc_step_multi", "atc_rollout")
 
 _lib = None
 
@@ -64,6 +70,7 @@ def load():
     lib.atc_reset.argtypes = [vp, ci, ci, C.POINTER(AtcState), vp, vp, C.POINTER(AtcParams), ci, vp]
     lib.atc_observe.argtypes = [vp, ci, ci, C.POINTER(AtcState), vp, vp, C.POINTER(AtcParams), vp]
     lib.atc_step.argtypes = [vp, ci, ci, C.POINTER(AtcState), vp, C.POINTER(AtcOut), C.POINTER(AtcParams), vp]
+    lib.atc_step_multi.argtypes = [ci, C.POINTER(AtcStepCall)]
     lib.atc_rollout.argtypes = [vp, ci, ci, ci, C.POINTER(AtcState), vp, C.POINTER(AtcOut), C.POINTER(AtcParams), vp]
     for name in EXPORTS:
         if name not in ("atc_abi_version", "atc_last_error"):

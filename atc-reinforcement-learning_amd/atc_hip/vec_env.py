@@ -189,6 +189,34 @@ class AtcVecEnv:
         self._finish()
         return self.obs, self.reward, self.done, self._info()
 
+    def make_launcher(self, actions, stream=None):
+        """Pre-bound `atc_step` call for FIXED buffers (this env's state / outputs, the given device action tensor, the
+        given torch stream or the current one): returns a no-argument callable that only launches — host cost of a few
+        microseconds instead of the argument handling of step().  Meant for pipelined actors that keep several
+        independent sub-batches in flight on separate streams (tools/multi_stream.py, bench.py --streams): a sub-batch's
+        launch ramp and tail then overlap the others' bodies.  Results are in self.obs / reward / done / flags once the
+        stream has reached the launch."""
+        torch = self.torch
+        a = self._as_actions(actions)
+        q = C.c_void_p((stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream)
+        args = (self.sector.handle, self.B, self.N, C.byref(self._state), C.c_void_p(self._ptr(a)), C.byref(self._out),
+                C.byref(self.params), q)
+        fn, check = self._lib.atc_step, _lib.check
+
+        def launch(_keep=(a, stream)):
+            rc = fn(*args)
+            if rc:
+                check(rc)
+        return launch
+
+    def step_call(self, actions, stream=None):
+        """The arguments of one atc_step of this env as an `atc_step_call_t` (+ the objects that must outlive it)."""
+        a = self._as_actions(actions)
+        q = (stream if stream is not None else self.torch.cuda.current_stream(self.device)).cuda_stream
+        call = _lib.AtcStepCall(self.sector.handle, self.B, self.N, C.pointer(self._state), self._ptr(a),
+                                C.pointer(self._out), C.pointer(self.params), q)
+        return call, (a, stream, self)
+
     def step_async(self, actions):
         self._pending = actions
 
@@ -277,3 +305,21 @@ class AtcVecEnv:
 
     def close(self):
         self.sector.close()
+
+
+def make_multi_launcher(envs, actions, streams):
+    """One step of several INDEPENDENT sub-batch envs with a single foreign call (`atc_step_multi`): envs[i] steps with
+    the device tensor actions[i] on streams[i].  Returns a no-argument callable that only launches.  With no join between
+    steps the sub-batches run decoupled: the launch ramp and tail of one overlap the body of the others (bench.py
+    --streams, tools/multi_stream.py)."""
+    n = len(envs)
+    assert n == len(actions) == len(streams) and n >= 1
+    built = [e.step_call(a, q) for e, a, q in zip(envs, actions, streams)]
+    arr = (_lib.AtcStepCall * n)(*[b[0] for b in built])
+    fn, check = _lib.load().atc_step_multi, _lib.check
+
+    def launch(_keep=(built, arr)):
+        rc = fn(n, arr)
+        if rc:
+            check(rc)
+    return launch

@@ -933,6 +933,16 @@ int atc_step(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const
     return step_common(s, B, N, 1, st, actions, out, p, stream);
 }
 
+int atc_step_multi(int n, const atc_step_call_t* calls) {
+    if (n < 0 || (n > 0 && !calls)) return fail_arg("null pointer");
+    for (int i = 0; i < n; ++i) {
+        const atc_step_call_t& c = calls[i];
+        const int rc = step_common(c.s, c.B, c.N, 1, c.st, c.actions, c.out, c.p, c.stream);
+        if (rc != ATC_OK) return rc;
+    }
+    return ATC_OK;
+}
+
 int atc_rollout(const atc_scenario_t* s, int B, int N, int T, const atc_state_t* st, const float* actions,
                 const atc_out_t* out, const atc_params_t* p, void* stream) {
     return step_common(s, B, N, T, st, actions, out, p, stream);

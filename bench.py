@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--grid-cell", type=float, default=0.5, help="cell size [nm] of the MVA lookup grid")
     ap.add_argument("--rollout", type=int, default=0, help="fuse this many steps per launch (0 = one launch per step)")
     ap.add_argument("--sep-nm", type=float, default=3.0, help="developer knob: separation minimum (0 disables conflicts)")
+    ap.add_argument("--streams", type=int, default=1, help="step the batch as this many independent sub-batches on "
+                    "separate HIP streams (no join between steps): launch ramp / tail of one overlaps the others")
     ap.add_argument("--graph", action="store_true", help="replay the %d-step action-hold block as one captured HIP graph "
                     "(removes per-launch host overhead; matters for the small launch-bound configs)" % HOLD)
     args = ap.parse_args()
@@ -137,14 +139,24 @@ def main():
     B, N, K, W = args.envs, args.aircraft, args.steps, args.warmup
 
     scn = scenarios.LOWWDense() if N > 16 else scenarios.LOWW(random_entrypoints=N > 1)
-    env = AtcVecEnv(B, N, scenario=scn, device=local, auto_reset=True, seed=D.rank_seed(0, rank), grid_cell=args.grid_cell,
-                    sep_nm=args.sep_nm)
+    S = args.streams
+    assert S >= 1 and B % S == 0 and not (S > 1 and (args.graph or args.rollout)), "--streams: B % S == 0, no --graph/--rollout"
+    subs = [AtcVecEnv(B // S, N, scenario=scn, device=local, auto_reset=True, seed=D.rank_seed(0, rank) + 7919 * s,
+                      grid_cell=args.grid_cell, sep_nm=args.sep_nm) for s in range(S)]
+    env = subs[0]
 
     # action ring resident in HBM before timing (Philox, seed 0 + rank)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     n_ring = max(2, min(64, (K + W) // HOLD + 1))
     ring = [torch.rand((B, N, 3), generator=g, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(n_ring)]
+
+    launchers = None
+    if S > 1:  # sub-batch s owns envs [s B/S, (s+1) B/S) of every ring tensor and its own stream
+        streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+        Bs = B // S
+        from atc_hip.vec_env import make_multi_launcher
+        launchers = [make_multi_launcher(subs, [a[s * Bs:(s + 1) * Bs] for s in range(S)], streams) for a in ring]
 
     graph = None
     act_buf = None
@@ -162,6 +174,10 @@ def main():
                 env.step(act_buf)
 
     def run(n_steps, t_base):
+        if launchers is not None:
+            for s in range(n_steps):
+                launchers[((t_base + s) // HOLD) % n_ring]()   # one foreign call = one step of every sub-batch
+            return
         if graph is not None:
             for s in range(0, n_steps, HOLD):
                 act_buf.copy_(ring[((t_base + s) // HOLD) % n_ring], non_blocking=True)
@@ -185,36 +201,49 @@ def main():
                     "done": torch.empty((T, B), dtype=torch.uint8, device=dev),
                     "flags": torch.empty((T, B, N), dtype=torch.int32, device=dev)}
 
+    def stats():
+        if S == 1:
+            return env.ep_return, env.ep_length
+        return torch.cat([e.ep_return for e in subs]), torch.cat([e.ep_length for e in subs])
+
     run(W, 0)
-    D.all_gather_stats(env.ep_return, env.ep_length)  # untimed: creates the RCCL communicator / channels (N > 1)
+    torch.cuda.synchronize(dev)
+    D.all_gather_stats(*stats())  # untimed: creates the RCCL communicator / channels (N > 1)
     torch.cuda.synchronize(dev)
     D.barrier()
     torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # HIP events on the stream(s) the kernels are launched on (torch's current stream, or one per sub-batch)
+    qs = streams if S > 1 else [torch.cuda.current_stream(dev)]
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in qs]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in qs]
     t0 = time.perf_counter()
-    ev0.record()               # torch's current stream == the stream atc_step is launched on
+    for e, q in zip(ev0, qs):
+        e.record(q)
     run(K, W)
-    ev1.record()
-    returns, lengths = D.all_gather_stats(env.ep_return, env.ep_length)  # the path's only exchange (RCCL, N > 1)
+    for e, q in zip(ev1, qs):
+        e.record(q)
+    torch.cuda.synchronize(dev)  # (sub-batch streams are joined here, before the statistics are gathered)
+    returns, lengths = D.all_gather_stats(*stats())  # the path's only exchange (RCCL, N > 1)
     torch.cuda.synchronize(dev)
     D.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms_total = ev0.elapsed_time(ev1)
+    kernel_ms_total = max(a.elapsed_time(b) for a, b in zip(ev0, ev1))
     elapsed = D.max_over_ranks(elapsed, dev)
     T = args.rollout or 1
     n_launches = K // T
     launch_ms = D.max_over_ranks(kernel_ms_total, dev) / n_launches   # average launch duration (HIP events)
 
-    episodes = D.sum_over_ranks(float(env.episodes.sum().item()) - B, dev)
+    episodes = D.sum_over_ranks(float(sum(e.episodes.sum().item() for e in subs)) - B, dev)
     value = ws * B * K / elapsed
-    bytes_launch = algorithmic_bytes_per_env_step(N) * B * T
-    achieved = bytes_launch / (launch_ms * 1e-3) / 1e9
+    bytes_launch = algorithmic_bytes_per_env_step(N) * (B // S) * T
+    # S > 1: launch_ms is the wall duration of ONE sub-batch launch while S - 1 others are in flight
+    achieved = S * bytes_launch / (launch_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("envs") == B and tj.get("aircraft") == N:
+            if tj.get("envs") == B and tj.get("aircraft") == N and S == 1:
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -230,20 +259,23 @@ def main():
                                    "O(N^2) separation scan, MVA lookup grid %g nm" % (B, N, B * ws, type(scn).__name__, HOLD, args.grid_cell),
                        "envs_per_gpu": B, "aircraft_per_env": N, "launch": "rollout T=%d" % args.rollout if args.rollout
                        else ("one atc_step launch per step, %d-step blocks replayed as a captured HIP graph" % HOLD
-                             if args.graph else "one atc_step launch per step"), "parallelism": "env-sharded x%d, no step-path collective, "
+                             if args.graph else ("%d sub-batches of %d envs on %d HIP streams, one launch per sub-batch per step "
+                                                "(atc_step_multi), no join between steps" % (S, B // S, S) if S > 1 else "one atc_step launch per step")), "parallelism": "env-sharded x%d, no step-path collective, "
                        "1 all-gather of episode returns per rollout" % ws,
                        "episodes_finished": int(episodes), "positions": "f64 accumulators"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_step<%d>" % (1 << max(0, (N - 1).bit_length())),
                          "avg_launch_ms": launch_ms, "algorithmic_bytes_per_launch": bytes_launch,
+                         "concurrent_launches": S,
                          "note": "HIP events on the launch stream around the %d timed launches (includes inter-launch "
                                  "gaps)" % n_launches},
         }
         if ws == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N)
         print(json.dumps(line))
-    env.close()
+    for e in subs:
+        e.close()
     if ws > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

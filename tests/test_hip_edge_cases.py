@@ -207,6 +207,47 @@ def test_fast_and_full_kernel_variants_agree(N):
         e.close()
 
 
+def test_sub_batches_on_streams_equal_one_batch():
+    """atc_step_multi: a batch stepped as 3 independent sub-batches on 3 streams (one foreign call per step, no join
+    between steps) gives exactly the results of the same envs stepped as one batch; launch errors are reported."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv, make_multi_launcher
+    from atc_hip import lib as binding
+    from envs.atc import scenarios
+    scn = scenarios.LOWW(random_entrypoints=True)
+    N, sizes = 16, [700, 300, 1048]
+    B = sum(sizes)
+    kw = dict(scenario=scn, auto_reset=True, spawn="lattice")
+    whole = AtcVecEnv(B, N, **kw)
+    subs = [AtcVecEnv(b, N, **kw) for b in sizes]
+    streams = [torch.cuda.Stream() for _ in sizes]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    ring = [(torch.rand((B, N, 3), generator=g) * 2.1 - 1.05).cuda() for _ in range(3)]
+    lo = [0, sizes[0], sizes[0] + sizes[1], B]
+    calls = [make_multi_launcher(subs, [a[lo[i]:lo[i + 1]] for i in range(3)], streams) for a in ring]
+    torch.cuda.synchronize()
+    for t in range(120):
+        calls[(t // 7) % 3]()          # runs ahead on the three streams, never joined inside the loop
+    for t in range(120):
+        whole.step(ring[(t // 7) % 3])
+    torch.cuda.synchronize()
+    for i, e in enumerate(subs):
+        sl = slice(lo[i], lo[i + 1])
+        assert torch.equal(e.obs, whole.obs[sl]) and torch.equal(e.reward, whole.reward[sl])
+        assert torch.equal(e.done, whole.done[sl]) and torch.equal(e.flags, whole.flags[sl])
+        assert torch.equal(e.env, whole.env[sl])
+        assert torch.equal(e.pos, whole.pos[lo[i] * N:lo[i + 1] * N]) and torch.equal(e.kin, whole.kin[lo[i] * N:lo[i + 1] * N])
+    assert int(whole.episodes.sum()) > B
+    # a bad call in the list is reported (second call has B = 0), the ones before it were issued
+    bad = (binding.AtcStepCall * 2)(subs[0].step_call(ring[0][:sizes[0]])[0], subs[1].step_call(ring[0][lo[1]:lo[2]])[0])
+    bad[1].B = 0
+    assert binding.load().atc_step_multi(2, bad) == -1
+    assert b"B >= 1" in binding.load().atc_last_error()
+    torch.cuda.synchronize()
+    for e in subs + [whole]:
+        e.close()
+
+
 @pytest.mark.parametrize("B,N", [(1, 1), (5, 3), (70, 16)])
 def test_host_mapped_buffers_match_device_buffers(B, N):
     """Zero-copy mode (state, actions and outputs in pinned host memory mapped into the device, atc_host_mapped_ptr):
