@@ -288,17 +288,19 @@ def test_golden_rollouts_batched(fixture):
 
 # ------------------------------------------------------------------------------------------------ batched vs fp32 oracle
 def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, spawn="lattice", hold=20, grid_cell=0.5,
-                   use_rollout=0, timestep_limit=6000):
+                   use_rollout=0, timestep_limit=6000, full=True, shaping=True, normalize=True, sep_nm=3.0):
+    """full=False drives the fast kernel variant (obs / reward / done / flags only), full=True the one with every optional
+    output; everything the variant produces is compared with the fp32 oracle."""
     torch = _torch()
     from atc_hip.vec_env import AtcVecEnv
     from envs.atc import model
     from oracle import oracle as O
-    sp = model.SimParameters(dt, discrete_action_space=discrete)
+    sp = model.SimParameters(dt, discrete_action_space=discrete, reward_shaping=shaping, normalize_state=normalize)
     env = AtcVecEnv(B, N, sim_parameters=sp, scenario=scen_obj, auto_reset=True, spawn=spawn, seed=seed,
-                    grid_cell=grid_cell, want_raw_obs=True, want_ac_reward=True, want_min_sep=True, want_term_obs=True,
-                    timestep_limit=timestep_limit)
+                    grid_cell=grid_cell, want_raw_obs=full, want_ac_reward=full, want_min_sep=full, want_term_obs=full,
+                    timestep_limit=timestep_limit, sep_nm=sep_nm)
     p = O.make_params(dt=dt, discrete=discrete, auto_reset=True, random_entry=(spawn == "random"), seed=seed,
-                      timestep_limit=timestep_limit)
+                      timestep_limit=timestep_limit, shaping=shaping, normalize=normalize, sep_nm=sep_nm)
     orc = O.OracleEnv(comp, B, N, p, np.float32)
     o0 = env.obs.cpu().numpy().reshape(B, N, 10)
     assert np.all(np.abs(o0 - orc.obs) <= 1e-5 * np.maximum(1.0, np.abs(orc.obs)))
@@ -333,13 +335,19 @@ def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, sp
             assert np.array_equal(fl, orc.flags), ("flags", t + c, np.argwhere(fl != orc.flags)[:5])
             assert np.array_equal(d.cpu().numpy(), orc.done), ("done", t + c)
             on = o.cpu().numpy().reshape(B, N, 10)
-            # envs that were auto-reset return RAW obs (large values): compare relative to magnitude
-            assert np.all(np.abs(on - orc.obs) <= 1e-5 * np.maximum(1.0, np.abs(orc.obs))), ("obs", t + c)
+            # envs that were auto-reset return RAW obs (large values): compare relative to magnitude; without
+            # normalisation every obs is raw and 1e-5 in obs units is 1e-5 of the component's normalisation half-range
+            scale = np.maximum(1.0, np.abs(orc.obs))
+            if not normalize:
+                scale = np.maximum(scale, half_range.astype(np.float32))
+            assert np.all(np.abs(on - orc.obs) <= 1e-5 * scale), ("obs", t + c)
             rr = r.cpu().numpy()
-            assert np.all(np.abs(rr - orc.reward) <= 1e-5 * np.maximum(1.0, np.abs(orc.reward)) * max(1, N // 4)), ("rew", t + c)
+            # 2e-5: within ~0.2 nm of the FAF the approach-angle term of the shaping is ill-conditioned (atan2 of a tiny
+            # offset): positions that differ by 1e-6 nm (last-ulp sin/cos differences, accumulated) move it by 1.2e-5
+            assert np.all(np.abs(rr - orc.reward) <= 2e-5 * np.maximum(1.0, np.abs(orc.reward)) * max(1, N // 4)), ("rew", t + c)
             n_done += int(orc.done.sum())
             seen |= int(np.bitwise_or.reduce(orc.flags.ravel()))
-        if not use_rollout:
+        if not use_rollout and full:
             # optional outputs and persistent state
             # heading arithmetic is exact in both implementations -> relative_angle (raw[9]) must be bit-identical
             # (checks the division-free Python-modulo of csrc/atc_device.h against the fmodf-based oracle)
@@ -349,13 +357,18 @@ def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, sp
             assert np.all(np.abs(info["original_state"].cpu().numpy().reshape(B, N, 10) - orc.raw_obs)
                           <= 1e-5 * half_range), t
             assert np.all(np.abs(info["aircraft_reward"].cpu().numpy() - orc.ac_reward)
-                          <= 1e-5 * np.maximum(1.0, np.abs(orc.ac_reward))), t
+                          <= 2e-5 * np.maximum(1.0, np.abs(orc.ac_reward))), t   # 2e-5: see the env reward above
             ms, oms = info["min_separation"].cpu().numpy(), orc.min_sep
-            assert np.all(np.abs(ms - oms) <= 1e-5 * np.maximum(1.0, np.abs(oms))), t
+            # distances are evaluated on the fp32 copies of the positions (ulp 7.6e-6 nm at x = 64): two implementations whose
+            # fp64 positions differ by 1e-7 can round a coordinate to neighbouring floats -> allow 4e-5 nm (4e-7 of the sector)
+            assert np.all(np.abs(ms - oms) <= 4e-5 * np.maximum(1.0, np.abs(oms))), t
             dn = orc.done.astype(bool)
             if dn.any():
                 tob = info["terminal_observation"].cpu().numpy().reshape(B, N, 10)
-                assert np.all(np.abs(tob[dn] - orc.term_obs[dn]) <= 1e-5 * np.maximum(1.0, np.abs(orc.term_obs[dn]))), t
+                tscale = np.maximum(1.0, np.abs(orc.term_obs[dn]))
+                if not normalize:
+                    tscale = np.maximum(tscale, half_range.astype(np.float32))
+                assert np.all(np.abs(tob[dn] - orc.term_obs[dn]) <= 1e-5 * tscale), t
         t += chunk
     # persistent state after the run: integer state exact, float state within tolerance
     assert np.array_equal(env.timesteps.cpu().numpy(), orc.timesteps)
