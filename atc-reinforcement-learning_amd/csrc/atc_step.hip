@@ -462,7 +462,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
             r += sh.ang;
             r += sh.gs;
         }
-        const int n_noise = (int)K[ATC_H_N_NOISE];
+        const int n_noise = (ATC_ABLATE & 256) ? 0 : (int)K[ATC_H_N_NOISE];
         for (int q = 0; q < n_noise; ++q) {  // extension (README.md:62): noise-abatement areas
             const float* rec = K + (int)K[ATC_H_OFF_POLY] + ((int)K[ATC_H_N_MVA] + q) * ATC_P_WORDS;
             if (in_bounds(rec, x32, y32) && a.h < rec[ATC_P_HEIGHT] &&
