@@ -72,6 +72,9 @@ constexpr int kBlock = ATC_BLOCK;
 #ifndef ATC_ABLATE
 #define ATC_ABLATE 0  // developer-only timing ablations (bit mask, see uses); the shipped build always uses 0
 #endif
+#ifndef ATC_LOOP_OPAQUE
+#define ATC_LOOP_OPAQUE 1  // see the step loop of k_step
+#endif
 #ifndef ATC_TRACE
 #define ATC_TRACE 0  // developer-only: per-wavefront s_memtime stamps at phase boundaries (pointer smuggled in params)
 #endif
@@ -625,18 +628,33 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, atc_st
     const int n_steps = ONE ? 1 : T;
     for (int step = 0; step < n_steps; ++step) {
         const size_t sBN = (size_t)step * BN, sB = (size_t)step * (uint32_t)B;  // uniform (scalar) per-step bases
+        // Multi-step launches: everything that is invariant across steps (lane ids and the address arithmetic on them, the
+        // sector base) is re-derived from an opaque zero inside the body, so that LICM cannot hoist it and keep it alive
+        // around the loop: 91 instead of 109 VGPRs (5 wavefronts per SIMD instead of 4) for N = 16.
+        LaneIds dl = d;
+        const float* Kl = K;
+        const float* gl = grid;
+        if (!ONE && ATC_LOOP_OPAQUE) {
+            uint32_t zv;
+            int zs;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(zv));
+            asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
+            dl.i += zv; dl.e += (int)zv; dl.k += (int)zv; dl.tid += (int)zv; dl.lane += (int)zv; dl.slot0 += (uint32_t)zs;
+            Kl = K + zs;
+            gl = grid ? grid + zs : nullptr;
+        }
         const float* act_t = actions + sBN * 3;
         StepOut so = {out.obs + sBN * ATC_OBS_DIM, out.flags + sBN, out.reward + sB, out.done + sB,
                       FULL && out.raw_obs ? out.raw_obs + sBN * ATC_OBS_DIM : nullptr,
                       FULL && out.ac_reward ? out.ac_reward + sBN : nullptr,
                       FULL && out.min_sep ? out.min_sep + sB : nullptr,
                       FULL && out.term_obs ? out.term_obs + sBN * ATC_OBS_DIM : nullptr};
-        const float a_v = stream_load(at<float>(act_t, d.i * 12u)), a_h = stream_load(at<float>(act_t, d.i * 12u + 4u)),
-                    a_p = stream_load(at<float>(act_t, d.i * 12u + 8u));
+        const float a_v = stream_load(at<float>(act_t, dl.i * 12u)), a_h = stream_load(at<float>(act_t, dl.i * 12u + 4u)),
+                    a_p = stream_load(at<float>(act_t, dl.i * 12u + 8u));
         ATC_STAMP(1);
-        const Mid m = step_part_a(K, grid, p, d, a_v, a_h, a_p, ls, es);
+        const Mid m = step_part_a(Kl, gl, p, dl, a_v, a_h, a_p, ls, es);
         ATC_STAMP(3);
-        step_part_b<W, FULL>(K, grid, p, N, d, m, ls, es, so, pos, obs_stage);
+        step_part_b<W, FULL>(Kl, gl, p, N, dl, m, ls, es, so, pos, obs_stage);
         ATC_STAMP(5);
     }
     ATC_STAMP(6);
