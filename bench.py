@@ -265,7 +265,7 @@ def main():
                        "episodes_finished": int(episodes), "positions": "f64 accumulators"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_step<%d>" % (1 << max(0, (N - 1).bit_length())),
+                         "kernel": "k_step<%d, false, %s>" % (1 << max(0, (N - 1).bit_length()), "false" if args.rollout else "true"),
                          "avg_launch_ms": launch_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "concurrent_launches": S,
                          "note": "HIP events on the launch stream around the %d timed launches (includes inter-launch "
