@@ -183,6 +183,40 @@ struct PairScan16<9, WANT_MIN> {
     static __device__ __forceinline__ void run(float, float, float, float, float, float&, float&) {}
 };
 
+// Separation scan for N <= 8 (W = 2, 4, 8): the partners of lane k are the lanes k ^ m, m = 1..W-1, of its aligned group,
+// all reachable with DPP operand modifiers — quad_perm for m = 1, 2, 3, row_half_mirror for m = 7 (= 7 - k within 8 lanes)
+// and quad_perm applied to the half-mirrored copy for m = 4, 5, 6 (7 ^ 3, 7 ^ 2, 7 ^ 1).  No LDS, no waits.  Both lanes of
+// a pair evaluate it (bit-identical: d^2 and |dh| are symmetric), so no hand-back is needed.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <bool WANT_MIN>
+__device__ __forceinline__ void pair_eval(float xs, float y, float h, float px, float py, float ph, float sep2, float sep_ft,
+                                          float& min_d2, float& margin) {
+    const float dx = xs - px, dy = y - py;
+    const float d2 = fmaf(dx, dx, dy * dy);
+    margin = fminf(margin, fmaxf(d2 - sep2, fabsf(h - ph) - sep_ft));
+    if (WANT_MIN) min_d2 = fminf(min_d2, d2);
+}
+template <int W, bool WANT_MIN>
+__device__ __forceinline__ void pair_scan_xor(float xs, float y, float h, float sep2, float sep_ft, float& min_d2,
+                                              float& margin) {
+    constexpr int X1 = 0xB1, X2 = 0x4E, X3 = 0x1B, HALF_MIRROR = 0x141;  // quad_perm [1,0,3,2] [2,3,0,1] [3,2,1,0]
+    pair_eval<WANT_MIN>(xs, y, h, dpp_f<X1>(xs), dpp_f<X1>(y), dpp_f<X1>(h), sep2, sep_ft, min_d2, margin);
+    if (W >= 4) {
+        pair_eval<WANT_MIN>(xs, y, h, dpp_f<X2>(xs), dpp_f<X2>(y), dpp_f<X2>(h), sep2, sep_ft, min_d2, margin);
+        pair_eval<WANT_MIN>(xs, y, h, dpp_f<X3>(xs), dpp_f<X3>(y), dpp_f<X3>(h), sep2, sep_ft, min_d2, margin);
+    }
+    if (W >= 8) {
+        const float mx = dpp_f<HALF_MIRROR>(xs), my = dpp_f<HALF_MIRROR>(y), mh = dpp_f<HALF_MIRROR>(h);
+        pair_eval<WANT_MIN>(xs, y, h, mx, my, mh, sep2, sep_ft, min_d2, margin);                                      // k ^ 7
+        pair_eval<WANT_MIN>(xs, y, h, dpp_f<X3>(mx), dpp_f<X3>(my), dpp_f<X3>(mh), sep2, sep_ft, min_d2, margin);   // k ^ 4
+        pair_eval<WANT_MIN>(xs, y, h, dpp_f<X2>(mx), dpp_f<X2>(my), dpp_f<X2>(mh), sep2, sep_ft, min_d2, margin);   // k ^ 5
+        pair_eval<WANT_MIN>(xs, y, h, dpp_f<X1>(mx), dpp_f<X1>(my), dpp_f<X1>(mh), sep2, sep_ft, min_d2, margin);   // k ^ 6
+    }
+}
+
 // Per-lane addressing = uniform 64-bit base + 32-bit BYTE offset (the host guarantees B*N*40 < 4 GiB): the compiler can
 // then use the scalar-base addressing form and does not keep a 64-bit address pair per array alive in VGPRs.
 template <typename T>
@@ -376,10 +410,10 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     // ---- separation scan (extension; README.md:51): 3 nm / 1000 ft among aircraft active at step start ---------------
     // Every lane visits its env's other W-1 slots (never itself); aircraft that are not under control are staged
     // at x = 1e18 so that they neither conflict nor enter the minimum — branch-free.
-    // Where the MVA cell (gather issued in the first half) is resolved: after the separation scan, so that the L2 round
-    // trip overlaps the scan — except for W = 16, where the unrolled DPP scan already uses the whole register budget and
-    // keeping the cell in flight across it costs scratch spills (measured: 30.8 vs 28.1 us).
-    constexpr bool kResolveAfterScan = (W != 16);
+    // Where the MVA cell (gather issued in the first half) is resolved: after the separation scan for the LDS-staged
+    // widths, so that the L2 round trip overlaps the scan; before it for the DPP widths (W <= 16), where keeping the cell
+    // in flight across the unrolled scan only costs registers (W = 8: 88 vs 71 VGPRs, i.e. 5 vs 7 wavefronts per SIMD).
+    constexpr bool kResolveAfterScan = (W >= 32);
     float mva = 0.0f;
     int pi = 0;
     if (!kResolveAfterScan) {
@@ -394,6 +428,8 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
         const float sep2 = p.sep_nm * p.sep_nm;
         if (W == 16) {
             PairScan16<1, FULL>::run(xs, y32, a.h, sep2, p.sep_ft, min_d2, margin);
+        } else if (W <= 8) {
+            pair_scan_xor<W, FULL>(xs, y32, a.h, sep2, p.sep_ft, min_d2, margin);
         } else {
             pos[tid] = make_float4(xs, y32, a.h, 0.0f);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -599,8 +635,8 @@ __global__ void __launch_bounds__(kBlock, ATC_MIN_WAVES)
 k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, atc_state_t st,
        const float* __restrict__ actions, atc_out_t out, atc_params_t p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float4* pos = reinterpret_cast<float4*>(smem);                    // [kBlock] pair-scan staging (W != 1, 16)
-    float* obs_stage = smem + ((W > 1 && W != 16) ? kBlock * 4 : 0);  // [4 waves][64 x 10] obs transpose
+    float4* pos = reinterpret_cast<float4*>(smem);                    // [kBlock] pair-scan staging (W >= 32)
+    float* obs_stage = smem + (W >= 32 ? kBlock * 4 : 0);  // [4 waves][64 x 10] obs transpose
     const float* __restrict__ K = blob;  // the sector: uniform-index reads -> scalar loads
     const float* __restrict__ grid = off_grid ? blob + off_grid : nullptr;
 #if ATC_TRACE
@@ -779,7 +815,7 @@ static size_t lds_bytes(const atc_scenario*, bool pair_scan, bool step_kernel = 
 template <int W, bool FULL, bool ONE>
 static int launch_step2(const atc_scenario* s, int B, int N, int T, const atc_state_t* st, const float* actions,
                         const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
-    const size_t lds = lds_bytes(s, W > 1 && W != 16, true);
+    const size_t lds = lds_bytes(s, W >= 32, true);
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<W, FULL, ONE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
