@@ -22,7 +22,10 @@ def init(backend=None):
     if backend is None:  # ATC_DIST_BACKEND=gloo lets the multi-rank control flow be exercised on a box with one GPU
         backend = os.environ.get("ATC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
-        torch.cuda.set_device(local)  # one process per GPU: bind before the communicator is created
+        # one process per GPU: bind before the communicator is created.  If the launcher narrowed the visible devices to one
+        # per rank (HIP_VISIBLE_DEVICES), LOCAL_RANK exceeds the device count and the rank's GPU is device 0.
+        local = local % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local)
     if ws > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
