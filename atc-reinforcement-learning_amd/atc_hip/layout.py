@@ -2,8 +2,8 @@
 
 tests/test_abi.py parses the header and checks that every constant here matches it.
 """
-ABI_VERSION = 10
-BLOB_VERSION = 1008.0
+ABI_VERSION = 11
+BLOB_VERSION = 1009.0
 
 H_VERSION, H_NWORDS, H_N_MVA, H_N_NOISE, H_N_ENTRY, H_OFF_POLY, H_OFF_VERT, H_OFF_ENTRY, H_OFF_GRID, H_N_VERTW = range(10)
 H_OFF_SLOT = 10
@@ -15,6 +15,9 @@ C_TRI_H, C_TRI_1, C_TRI_2 = 40, 48, 56
 C_NORM_MIN, C_NORM_MAX, C_ACT_DISCR, C_BBOX = 64, 74, 84, 87
 C_DIR_RWY_X, C_DIR_RWY_Y = 91, 92
 C_ALIGNED_OK = 93
+C_POS_X0, C_POS_Y0, C_POS_SCALE, C_POS_INV = 94, 95, 100, 101   # fixed-point position grid: nm = X0 + fix * 2^-k
+C_FAF_FIX = 124                                                 # FAF on the grid: x (hi, lo), y (hi, lo); fix = hi * 65536 + lo
+POS_MAX_K = 27
 C_TRI_BBOX = 96
 C_NORM_A, C_NORM_B = 104, 114
 C_END = 128
@@ -34,8 +37,10 @@ F_BELOW_MVA, F_OUTSIDE, F_WON, F_TIMEOUT = 1, 2, 4, 8
 F_INVALID_V, F_INVALID_H, F_CONFLICT, F_NOISE, F_INACTIVE = 16, 32, 64, 128, 256
 F_TERMINAL = F_BELOW_MVA | F_OUTSIDE | F_TIMEOUT | F_CONFLICT  # episode-ending on their own (WON: when all handed over)
 
-M_REWARD_SHAPING, M_NORMALIZE, M_DISCRETE, M_AUTO_RESET, M_RANDOM_ENTRY = 1, 2, 4, 8, 16
+M_REWARD_SHAPING, M_NORMALIZE, M_DISCRETE, M_AUTO_RESET, M_RANDOM_ENTRY, M_KEEP_ACTIVE = 1, 2, 4, 8, 16, 32
 
-# per-env record (atc_state_t.env): 12 x 32-bit words, float fields by bit pattern
-ENV_TIMESTEPS, ENV_ACTIONS_TAKEN, ENV_EPISODES, ENV_EP_LENGTH, ENV_TOTAL_REWARD, ENV_EP_RETURN, ENV_WIN_BITS = range(7)
-ENV_MASK_LO, ENV_MASK_HI, ENV_WORDS = 8, 9, 12
+# per-step env record (atc_state_t.env): 4 x 32-bit words, float fields by bit pattern
+ENV_TIMESTEPS, ENV_ACTIONS_TAKEN, ENV_TOTAL_REWARD, ENV_MASK_LO, ENV_WORDS = range(5)
+# per-episode env record (atc_state_t.stats): 8 x 32-bit words
+STAT_EPISODES, STAT_EP_LENGTH, STAT_EP_RETURN, STAT_WIN_BITS, STAT_EP_ACTIONS, STAT_MASK_HI = range(6)
+STAT_WORDS = 8

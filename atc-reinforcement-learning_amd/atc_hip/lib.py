@@ -8,8 +8,17 @@ import numpy as np
 from . import layout as L
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# ATC_LIBATCSTEP: developer override used only to A/B kernel build variants (tools/); default is the in-tree build
-LIB_PATH = os.environ.get("ATC_LIBATCSTEP") or os.path.join(HERE, "libatcstep.so")
+_lib = None
+LIB_PATH = os.path.join(HERE, "libatcstep.so")  # the in-tree build; nothing in the environment can redirect it
+
+
+def use_library(path):
+    """Developer tools that A/B kernel build variants (bench.py --lib, tools/) name the variant explicitly, before the first
+    load; the product never calls this."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("libatcstep.so is already loaded")
+    LIB_PATH = os.path.abspath(path)
 
 
 class AtcParams(C.Structure):
@@ -19,7 +28,7 @@ class AtcParams(C.Structure):
                 ("reserved1", C.c_float)]
 
 
-STATE_FIELDS = ("pos", "kin", "last_vh", "env")
+STATE_FIELDS = ("pos_hp", "v", "last_act", "env", "stats")
 OUT_FIELDS = ("obs", "raw_obs", "reward", "ac_reward", "done", "flags", "min_sep", "term_obs")
 
 
@@ -43,9 +52,6 @@ EXPORTS = ("atc_abi_version", "atc_last_error", "atc_host_mapped_ptr", "atc_scen
            "atc_query_mva",
            "atc_query_mva_index", "atc_query_corridor", "atc_query_shaping", "atc_reset", "atc_observe", "atc_step",
            "atc_step_multi", "atc_rollout")
-
-_lib = None
-
 
 def load():
     """Loads libatcstep.so; raises (never falls back) when it has not been built."""
@@ -106,10 +112,10 @@ def current_stream_ptr(device):
 
 
 def make_params(dt=1.0, shaping=True, normalize=True, discrete=False, auto_reset=False, random_entry=False, seed=0,
-                timestep_limit=6000, sep_nm=3.0, sep_ft=1000.0, conflict_reward=-200.0):
+                timestep_limit=6000, sep_nm=3.0, sep_ft=1000.0, conflict_reward=-200.0, keep_active=False):
     mode = (L.M_REWARD_SHAPING if shaping else 0) | (L.M_NORMALIZE if normalize else 0) | \
            (L.M_DISCRETE if discrete else 0) | (L.M_AUTO_RESET if auto_reset else 0) | \
-           (L.M_RANDOM_ENTRY if random_entry else 0)
+           (L.M_RANDOM_ENTRY if random_entry else 0) | (L.M_KEEP_ACTIVE if keep_active else 0)
     return AtcParams(float(dt), int(timestep_limit), mode, 0, int(seed) & (2 ** 64 - 1), sep_nm, sep_ft, conflict_reward,
                      0.0)
 

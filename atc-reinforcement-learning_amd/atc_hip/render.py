@@ -65,8 +65,8 @@ def rgb_array(vec, env=0, size=800):
     img = bg.copy()
     n = vec.N
     lo, hi = env * n, (env + 1) * n
-    pos = vec.pos[lo:hi].cpu().numpy()
-    kin = vec.kin[lo:hi].cpu().numpy()
+    pos = np.stack([vec.x[lo:hi].cpu().numpy(), vec.y[lo:hi].cpu().numpy()], 1)
+    heading = vec.phi[lo:hi].cpu().numpy()
     mask = int(vec.active_mask[env])
     p = view.px(pos)
     for k in range(n):
@@ -76,6 +76,6 @@ def rgb_array(vec, env=0, size=800):
             continue
         u0, v0 = int(round(u)), int(round(v))
         img[max(v0 - 2, 0):v0 + 3, max(u0 - 2, 0):u0 + 3] = color
-        phi = np.radians(kin[k, 1])  # compass heading: 0 = +y, clockwise (model.py:345-348)
+        phi = np.radians(heading[k])  # compass heading: 0 = +y, clockwise (model.py:345-348)
         _line(img, u, v, u + 12 * np.sin(phi), v - 12 * np.cos(phi), color)
     return img

@@ -205,6 +205,28 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None):
     return np.concatenate([hdr, cells.ravel(), pad, pool_arr.ravel()])
 
 
+def position_grid(points):
+    """Fixed-point position grid of the fp32 path (include/atc_step.h, "Aircraft positions"): integer-valued origin at the
+    centre of `points` and the largest k <= POS_MAX_K with 2^(31-k) nm >= 1.5 x the half extent.  Returns (x0, y0, k)."""
+    pts = np.asarray(points, dtype=np.float64).reshape(-1, 2)
+    x0 = float(np.rint(0.5 * (pts[:, 0].min() + pts[:, 0].max())))
+    y0 = float(np.rint(0.5 * (pts[:, 1].min() + pts[:, 1].max())))
+    half = max(1e-6, float(np.abs(pts - np.array([x0, y0])).max()))
+    k = int(min(L.POS_MAX_K, math.floor(31 - math.log2(1.5 * half))))
+    return x0, y0, k
+
+
+def to_fix(value, origin, k):
+    """nm -> grid counts (host placement of an aircraft: float64 arithmetic, round half even, saturating)."""
+    c = np.rint((np.asarray(value, dtype=np.float64) - origin) * 2.0 ** k)
+    return np.clip(c, -2.0 ** 31, 2.0 ** 31 - 1).astype(np.int64).astype(np.int32)
+
+
+def from_fix(fix, origin, k):
+    """grid counts -> nm (float64, exact)."""
+    return np.asarray(fix, dtype=np.float64) * 2.0 ** -k + origin
+
+
 class CompiledSector:
     """Result of compile_sector: `.blob64` (float64 master), `.blob32` (device copy) and the derived constants."""
 
@@ -301,6 +323,14 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
     d = np.dot(rot_matrix(cg["phi_to_runway"]), np.array([[0], [1]]))
     min_angle = cg["faf_angle"] - (cg["faf_angle"] - np.arccos(np.dot(np.transpose(d), d))[0][0])
     b[L.C_ALIGNED_OK] = 1.0 if min_angle <= 0.0 else 0.0
+    # fixed-point position grid: covers the airspace, the corridor and every entry point
+    gpts = [(bbox[0], bbox[1]), (bbox[2], bbox[3]), cg["faf"], cg["iaf"], cg["corner1"], cg["corner2"], (cg["x"], cg["y"])]
+    gpts += [(e[0], e[1]) for e in entrypoints]
+    px0, py0, pk = position_grid(gpts)
+    b[L.C_POS_X0], b[L.C_POS_Y0], b[L.C_POS_SCALE], b[L.C_POS_INV] = px0, py0, 2.0 ** pk, 2.0 ** -pk
+    for axis, (val, org) in enumerate(((cg["faf"][0], px0), (cg["faf"][1], py0))):
+        fix = int(to_fix(val, org, pk))
+        b[L.C_FAF_FIX + 2 * axis], b[L.C_FAF_FIX + 2 * axis + 1] = fix >> 16, fix & 0xffff
     voff = off_vert
     for i, ring in enumerate(rings):
         rec = off_poly + i * L.P_WORDS
@@ -328,6 +358,6 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
         bbox=bbox, world_diag=world_diag, faf_mva=faf_mva, corridor=cg, norm_min=norm_min, norm_max=norm_max,
         entrypoints=[(float(a), float(b_), float(c), [int(l) for l in lv]) for a, b_, c, lv in entrypoints],
         n_mva=len(mva_rings), n_noise=len(noise_rings), n_entry=n_entry, has_grid=grid is not None,
-        v_min=v_min, v_max=v_max, h_min=h_min, h_max=h_max,
+        v_min=v_min, v_max=v_max, h_min=h_min, h_max=h_max, pos_origin=(px0, py0), pos_k=pk,
     )
     return CompiledSector(b, meta)

@@ -18,10 +18,12 @@ class AtcVecEnv:
     def __init__(self, num_envs, num_aircraft=1, sim_parameters=None, scenario=None, device=0, auto_reset=True,
                  spawn="auto", seed=0, grid_cell=0.5, want_raw_obs=False, want_ac_reward=False, want_min_sep=False,
                  want_term_obs=False, timestep_limit=6000, sep_nm=3.0, sep_ft=1000.0, conflict_reward=-200.0,
-                 host_mapped=False):
+                 host_mapped=False, keep_active=False):
         """host_mapped=True keeps state and outputs in pinned host memory mapped into the device (zero-copy): the kernels
         read / write it over the host link, every call ends with a stream synchronisation, and what is returned are CPU
-        tensors.  Meant for tiny latency-bound batches (the single-env AtcGym); large batches belong in HBM."""
+        tensors.  Meant for tiny latency-bound batches (the single-env AtcGym); large batches belong in HBM.
+        keep_active=True is the reference's single-aircraft rule (ATC_M_KEEP_ACTIVE): an aircraft that reaches the corridor
+        ends the episode and stays under control instead of being handed over."""
         torch = _lib._torch_cuda()
         self.torch = torch
         self.host_mapped = bool(host_mapped)
@@ -46,37 +48,41 @@ class AtcVecEnv:
         self.params = _lib.make_params(dt=sp.timestep, shaping=sp.reward_shaping, normalize=sp.normalize_state,
                                        discrete=sp.discrete_action_space, auto_reset=auto_reset,
                                        random_entry=(spawn == "random"), seed=seed, timestep_limit=timestep_limit,
-                                       sep_nm=sep_nm, sep_ft=sep_ft, conflict_reward=conflict_reward)
+                                       sep_nm=sep_nm, sep_ft=sep_ft, conflict_reward=conflict_reward,
+                                       keep_active=keep_active)
         self.timestep_limit = timestep_limit
         B, N, BN, dev = self.B, self.N, self.B * self.N, self.device
         if self.host_mapped:
             z = lambda shape, dt: torch.zeros(shape, dtype=dt).pin_memory()  # noqa: E731
         else:
             z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
-        f32, f64, i32 = torch.float32, torch.float64, torch.int32
+        f32, i32 = torch.float32, torch.int32
         # persistent state (atc_state_t): packed records, see include/atc_step.h
-        self.pos = z((BN, 2), f64)            # x, y
-        self.kin = z((BN, 4), f32)            # h, phi, v, last accepted phi target
-        self.last_vh = z((BN, 2), f32)        # last accepted v / h targets
-        self.env = z((B, L.ENV_WORDS), i32)   # per-env record
+        self.pos_hp = z((BN, 4), i32)         # x, y (position-grid counts), h, phi (float bit patterns)
+        self.v = z(BN, f32)                   # speed
+        self.last_act = z((BN, 3), f32)       # last accepted v / h / phi targets
+        self.env = z((B, L.ENV_WORDS), i32)   # per-step env record
+        self.stats = z((B, L.STAT_WORDS), i32)  # per-episode env record
         self._state = _lib.AtcState(*[self._ptr(getattr(self, n)) for n in _lib.STATE_FIELDS])
-        # named views into the records (live device memory, usable for reads and in-place writes)
-        self.x, self.y = self.pos[:, 0], self.pos[:, 1]
-        self.h, self.phi, self.v = self.kin[:, 0], self.kin[:, 1], self.kin[:, 2]
+        self.pos_origin, self.pos_k = self.compiled.pos_origin, self.compiled.pos_k
+        # named views into the records (live memory, usable for reads and in-place writes)
+        self.h = self.pos_hp[:, 2:3].view(f32).squeeze(1)
+        self.phi = self.pos_hp[:, 3:4].view(f32).squeeze(1)
         self.timesteps = self.env[:, L.ENV_TIMESTEPS]
         self.actions_taken = self.env[:, L.ENV_ACTIONS_TAKEN]
-        self.episodes = self.env[:, L.ENV_EPISODES]
-        self.ep_length = self.env[:, L.ENV_EP_LENGTH]
         self.total_reward = self.env[:, L.ENV_TOTAL_REWARD:L.ENV_TOTAL_REWARD + 1].view(f32).squeeze(1)
-        self.ep_return = self.env[:, L.ENV_EP_RETURN:L.ENV_EP_RETURN + 1].view(f32).squeeze(1)
-        self.win_bits = self.env[:, L.ENV_WIN_BITS]
+        self.episodes = self.stats[:, L.STAT_EPISODES]
+        self.ep_length = self.stats[:, L.STAT_EP_LENGTH]
+        self.ep_return = self.stats[:, L.STAT_EP_RETURN:L.STAT_EP_RETURN + 1].view(f32).squeeze(1)
+        self.win_bits = self.stats[:, L.STAT_WIN_BITS]
+        self.ep_actions = self.stats[:, L.STAT_EP_ACTIONS]
         # per-step outputs (atc_out_t)
         self.obs = z((B, N * L.OBS_DIM), f32)
         self.raw_obs = z((B, N * L.OBS_DIM), f32) if want_raw_obs else None
         self.reward = z(B, f32)
         self.ac_reward = z((B, N), f32) if want_ac_reward else None
         self.done = z(B, torch.uint8)
-        self.flags = z((B, N), i32)
+        self.flags = z((B, N), torch.int16)
         self.min_sep = z(B, f32) if want_min_sep else None
         self.term_obs = z((B, N * L.OBS_DIM), f32) if want_term_obs else None
         self._out = self._make_out(self.obs, self.raw_obs, self.reward, self.ac_reward, self.done, self.flags,
@@ -94,7 +100,7 @@ class AtcVecEnv:
         assert self.raw_obs is not None
         B, N = self.B, self.N
         sizes = [("obs", B * N * L.OBS_DIM * 4), ("raw_obs", B * N * L.OBS_DIM * 4), ("reward", B * 4),
-                 ("flags", B * N * 4), ("done", B)]
+                 ("flags", B * N * 2), ("done", B)]
         layout, off = {}, 0
         for name, nb in sizes:
             layout[name] = (off, nb)
@@ -105,7 +111,7 @@ class AtcVecEnv:
         self.obs = view("obs", torch.float32, (B, N * L.OBS_DIM))
         self.raw_obs = view("raw_obs", torch.float32, (B, N * L.OBS_DIM))
         self.reward = view("reward", torch.float32, (B,))
-        self.flags = view("flags", torch.int32, (B, N))
+        self.flags = view("flags", torch.int16, (B, N))
         self.done = view("done", torch.uint8, (B,))
         self._out = self._make_out(self.obs, self.raw_obs, self.reward, self.ac_reward, self.done, self.flags,
                                    self.min_sep, self.term_obs)
@@ -247,7 +253,7 @@ class AtcVecEnv:
                 "obs": torch.empty((T, B, N * L.OBS_DIM), dtype=torch.float32, device=dev),
                 "reward": torch.empty((T, B), dtype=torch.float32, device=dev),
                 "done": torch.empty((T, B), dtype=torch.uint8, device=dev),
-                "flags": torch.empty((T, B, N), dtype=torch.int32, device=dev),
+                "flags": torch.empty((T, B, N), dtype=torch.int16, device=dev),
             }
         o = self._make_out(out["obs"], out.get("raw_obs"), out["reward"], out.get("ac_reward"), out["done"],
                            out["flags"], out.get("min_sep"), out.get("term_obs"))
@@ -262,12 +268,16 @@ class AtcVecEnv:
         """VecEnv.get_attr for the attributes the reference's trainer reads (learning/atc-gym-stable-baselines.py:34,36)
         and the episode counters."""
         torch = self.torch
-        if name == "actions_per_timestep":  # atc_gym.py:197
-            t = self.actions_taken.to(torch.float64) / self.timesteps.clamp(min=1).to(torch.float64)
+        if name == "actions_per_timestep":
+            # atc_gym.py:197 sets it on every step and reset() leaves it alone: an env that has just been (auto-)reset still
+            # reports the value of its last episode's final step
+            live = self.actions_taken.to(torch.float64) / self.timesteps.clamp(min=1).to(torch.float64)
+            last = self.ep_actions.to(torch.float64) / self.ep_length.clamp(min=1).to(torch.float64)
+            t = torch.where(self.timesteps > 0, live, last)
         elif name == "winning_ratio":  # atc_gym.py:362-363: mean of the last 10 episode outcomes
             bits = self.win_bits.to(torch.int64)
             t = sum(((bits >> k) & 1) for k in range(10)).to(torch.float64) / 10.0
-        elif name in ("timesteps", "actions_taken", "total_reward", "episodes", "ep_return", "ep_length"):
+        elif name in ("timesteps", "actions_taken", "total_reward", "episodes", "ep_return", "ep_length", "ep_actions"):
             t = getattr(self, name)
         else:
             raise AttributeError(name)
@@ -280,21 +290,43 @@ class AtcVecEnv:
     def active_mask(self):
         """u64 mask per env (bit k = aircraft k still under control) as an int64 tensor."""
         lo = self.env[:, L.ENV_MASK_LO].to(self.torch.int64) & 0xffffffff
-        hi = self.env[:, L.ENV_MASK_HI].to(self.torch.int64) & 0xffffffff
+        hi = self.stats[:, L.STAT_MASK_HI].to(self.torch.int64) & 0xffffffff
         return lo | (hi << 32)
+
+    # positions live on the sector's 32-bit fixed-point grid (include/atc_step.h "Aircraft positions"):
+    # nm = origin + counts * 2^-k.  `x` / `y` are float64 COPIES in nautical miles; write through set_state / set_xy.
+    @property
+    def x(self):
+        return self.pos_hp[:, 0].to(self.torch.float64) * 2.0 ** -self.pos_k + self.pos_origin[0]
+
+    @property
+    def y(self):
+        return self.pos_hp[:, 1].to(self.torch.float64) * 2.0 ** -self.pos_k + self.pos_origin[1]
+
+    def _to_fix(self, value, axis):
+        from .scenario import to_fix
+        return int(to_fix(float(value), self.pos_origin[axis], self.pos_k))
+
+    def set_xy(self, i, x=None, y=None):
+        if x is not None:
+            self.pos_hp[i, 0] = self._to_fix(x, 0)
+        if y is not None:
+            self.pos_hp[i, 1] = self._to_fix(y, 1)
 
     def set_state(self, env, slot, x, y, h, phi, v):
         i = env * self.N + slot
-        self.x[i], self.y[i], self.h[i], self.phi[i], self.v[i] = float(x), float(y), float(h), float(phi), float(v)
+        self.set_xy(i, x, y)
+        self.h[i], self.phi[i], self.v[i] = float(h), float(phi), float(v)
 
     def get_last_action(self, env, slot):
         """AtcGym.last_action (atc_gym.py:86,311) of one aircraft: [v, h, phi] targets last accepted."""
         i = env * self.N + slot
-        return [float(self.last_vh[i, 0]), float(self.last_vh[i, 1]), float(self.kin[i, 3])]
+        return [float(c) for c in self.last_act[i]]
 
     def set_last_action(self, env, slot, value):
         i = env * self.N + slot
-        self.last_vh[i, 0], self.last_vh[i, 1], self.kin[i, 3] = float(value[0]), float(value[1]), float(value[2])
+        for c in range(3):
+            self.last_act[i, c] = float(value[c])
 
     def get_state(self, env, slot):
         i = env * self.N + slot

@@ -1,4 +1,4 @@
-// atc_device.h — gfx950 device functions of the batched AtcGym.step() path (fp32 arithmetic, fp64 position state).
+// atc_device.h — gfx950 device functions of the batched AtcGym.step() path (fp32 arithmetic, fixed-point position state).
 //
 // Every function cites the reference lines it implements (path:line in fvalka/atc-reinforcement-learning).
 // Integer outputs (done / flag words / counters / MVA index) are required to match the fp32 CPU oracle bit-for-bit,
@@ -32,19 +32,19 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }  // v_sqrt_f32, 1 ulp
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
-// sin/cos of a heading in DEGREES.  The reduction is exact: k = rint(phi/90), t = phi - 90 k is computed by one fma and is
-// exactly representable (|t| <= 45 + slop, a multiple of ulp(phi)); the polynomials (fitted on |t| <= 46.4 deg) have
-// 8.5e-8 / 8.3e-8 max abs error in fp32 — the accuracy class of libm's sinf/cosf, at ~1/4 of the instructions of a generic
-// radian sincosf (no Payne-Hanek path, no division).  Used for the kinematics (model.py:122-129, 345-348).
+// sin/cos of a heading in DEGREES — the fp32 heading kinematics of include/atc_step.h (shared with the fp32 instantiation
+// of the test oracle, so that positions are bit-identical).  The reduction is exact: k = rint(phi/90), t = phi - 90 k is
+// computed by one fma and is exactly representable (|t| <= 45 + slop, a multiple of ulp(phi)); the polynomials (fitted on
+// |t| <= 46.4 deg) have 8.5e-8 / 8.3e-8 max abs error in fp32 — the accuracy class of libm's sinf/cosf, at ~1/4 of the
+// instructions of a generic radian sincosf (no Payne-Hanek path, no division).  Kinematics: model.py:122-129, 345-348.
 __device__ __forceinline__ void sincos_deg(float phi, float* sn, float* cs) {
     const float k = rintf(phi * (1.0f / 90.0f));
     const float t = fmaf(-90.0f, k, phi);
     const float r = t * kDegToRad;
     const float r2 = r * r;
-    const float sp = fmaf(fmaf(fmaf(-0.00019439239986240864f, r2, 0.008331366814672947f), r2, -0.16666631400585175f), r2, 1.0f);
+    const float sp = fmaf(fmaf(fmaf(ATC_SIN_C3, r2, ATC_SIN_C2), r2, ATC_SIN_C1), r2, 1.0f);
     const float s = sp * r;
-    const float c = fmaf(fmaf(fmaf(fmaf(2.436429167573806e-05f, r2, -0.001388648059219122f), r2, 0.04166661575436592f), r2,
-                              -0.5f), r2, 1.0f);
+    const float c = fmaf(fmaf(fmaf(fmaf(ATC_COS_C4, r2, ATC_COS_C3), r2, ATC_COS_C2), r2, ATC_COS_C1), r2, 1.0f);
     const int q = (int)k & 3;
     const float s1 = (q & 1) ? c : s;
     const float c1 = (q & 1) ? s : c;
@@ -230,9 +230,10 @@ __device__ __forceinline__ bool angle_window(const float* __restrict__ K, float 
     return (rel > 0.0f && rel <= K[ATC_C_FAF_ANGLE]) || (rel == 0.0f && K[ATC_C_ALIGNED_OK] != 0.0f);
 }
 __device__ __forceinline__ bool inside_corridor_angle(const float* __restrict__ K, float x, float y, float phi) {
+    // model.py:224-229: `if tri1 and window: True / elif tri2 and window: True / False`
     const float to_runway = K[ATC_C_PHI_TO_RWY];
-    if (ray_tracing(x, y, K + ATC_C_TRI_1, 4)) return angle_window(K, relative_angle(to_runway, phi));
-    if (ray_tracing(x, y, K + ATC_C_TRI_2, 4)) return angle_window(K, relative_angle(phi, to_runway));
+    if (ray_tracing(x, y, K + ATC_C_TRI_1, 4) && angle_window(K, relative_angle(to_runway, phi))) return true;
+    if (ray_tracing(x, y, K + ATC_C_TRI_2, 4) && angle_window(K, relative_angle(phi, to_runway))) return true;
     return false;
 }
 
@@ -295,8 +296,33 @@ __device__ __forceinline__ uint64_t draw(uint64_t seed, uint32_t env, uint32_t e
     return mix64(z ^ (uint64_t)slot);
 }
 
+// ---- aircraft positions: 32-bit fixed point on the sector's position grid (include/atc_step.h "Aircraft positions") ----
+__device__ __forceinline__ int sat_add(int a, int b) { return __builtin_elementwise_add_sat(a, b); }
+__device__ __forceinline__ int sat_sub(int a, int b) { return __builtin_elementwise_sub_sat(a, b); }
+// the fp32 position every formula of the reference sees: (float)(origin + fix * 2^-k), ONE rounding
+__device__ __forceinline__ float pos_to_real(const float* __restrict__ K, int axis, int p) {
+    return (float)fma((double)p, (double)K[ATC_C_POS_INV], (double)K[ATC_C_POS_X0 + axis]);
+}
+// model.py:122-129: x += d with d computed in fp32; the grid advances by rint(d 2^k) counts, saturating
+__device__ __forceinline__ int pos_advance(const float* __restrict__ K, int p, float d) {
+    float c = d * K[ATC_C_POS_SCALE];
+    c = fminf(fmaxf(c, -1073741824.0f), 1073741824.0f);
+    return sat_add(p, (int)rintf(c));
+}
+// entry point (fp32 nm) -> grid
+__device__ __forceinline__ int pos_spawn(const float* __restrict__ K, int axis, float v) {
+    float c = (v - K[ATC_C_POS_X0 + axis]) * K[ATC_C_POS_SCALE];
+    c = fminf(fmaxf(c, -2147483648.0f), 2147483520.0f);
+    return (int)rintf(c);
+}
+// faf - position (atc_gym.py:289-297): exact integer difference on the grid -> fp32 relative precision near the FAF
+__device__ __forceinline__ float pos_to_faf(const float* __restrict__ K, int axis, int p) {
+    const int faf = (int)K[ATC_C_FAF_FIX + 2 * axis] * 65536 + (int)K[ATC_C_FAF_FIX + 2 * axis + 1];
+    return (float)sat_sub(faf, p) * K[ATC_C_POS_INV];
+}
+
 struct Aircraft {
-    double x, y;      // positions accumulate in fp64 (fp32 accumulation drifts 0.5 ulp/step on straight legs)
+    int x, y;         // position grid counts
     float h, phi, v;
 };
 
@@ -308,8 +334,8 @@ __device__ __forceinline__ Aircraft spawn(const float* __restrict__ K, const atc
     a.v = kVInit;
     if (!(p.mode & ATC_M_RANDOM_ENTRY)) {
         const float4 rec = *reinterpret_cast<const float4*>(K + (int)K[ATC_H_OFF_SLOT] + 4 * k);
-        a.x = (double)rec.x;
-        a.y = (double)rec.y;
+        a.x = pos_spawn(K, 0, rec.x);
+        a.y = pos_spawn(K, 1, rec.y);
         a.phi = rec.z;
         a.h = rec.w;
         return a;
@@ -319,8 +345,8 @@ __device__ __forceinline__ Aircraft spawn(const float* __restrict__ K, const atc
     const int ei = (int)__umulhi((uint32_t)(u & 0xffffffffu), n_entry);
     const float* rec = K + (int)K[ATC_H_OFF_ENTRY] + ei * ATC_E_WORDS;
     const int li = (int)__umulhi((uint32_t)(u >> 32), (uint32_t)(int)rec[ATC_E_NLEV]);
-    a.x = (double)rec[ATC_E_X];
-    a.y = (double)rec[ATC_E_Y];
+    a.x = pos_spawn(K, 0, rec[ATC_E_X]);
+    a.y = pos_spawn(K, 1, rec[ATC_E_Y]);
     a.phi = rec[ATC_E_PHI];
     a.h = rec[ATC_E_LEV0 + li] * 100.0f;
     return a;
@@ -330,11 +356,12 @@ struct Obs {
     float o[ATC_OBS_DIM];
     float d_faf, phi_rel_faf, on_gp;
 };
-// atc_gym.py:262-297 _get_state
-__device__ __forceinline__ Obs get_state(const float* __restrict__ K, float x, float y, float h, float phi, float v, float mva) {
+// atc_gym.py:262-297 _get_state.  (px, py) = grid position, (x, y) = its fp32 value
+__device__ __forceinline__ Obs get_state(const float* __restrict__ K, int px, int py, float x, float y, float h, float phi,
+                                         float v, float mva) {
     Obs r;
-    const float to_faf_x = K[ATC_C_FAF_X] - x;
-    const float to_faf_y = K[ATC_C_FAF_Y] - y;
+    const float to_faf_x = pos_to_faf(K, 0, px);
+    const float to_faf_y = pos_to_faf(K, 1, py);
     r.d_faf = fast_sqrt(fmaf(to_faf_x, to_faf_x, to_faf_y * to_faf_y));   // np.hypot (value-only)
     r.phi_rel_faf = atan2_deg(to_faf_y, to_faf_x);                        // np.degrees(np.arctan2) (value-only)
     r.on_gp = 318.4f * r.d_faf + K[ATC_C_FAF_MVA] - 200.0f;

@@ -3,10 +3,11 @@
 // Work decomposition (one wavefront = 64 lanes):
 //   lane  = one aircraft slot;  W = next_pow2(N) consecutive lanes = one env;  64/W envs per wavefront
 //   (N = 64: one wavefront per env, N = 16: 4 envs per wavefront, N = 1: 64 envs per wavefront).
-//   Aircraft state lives in HBM as packed records indexed env*N + k: pos = double2 (x, y), kin = float4 (h, phi, v, last
-//   phi target), last_vh = float2 — a wavefront moves each array with ONE 16-byte (8-byte) access per lane, consecutive
-//   lanes on consecutive records (1 KiB per wave-instruction); the per-env record (12 words) is read with three 16-byte
-//   loads that the W lanes of an env share.  All per-lane indices are 32-bit offsets from uniform base pointers.
+//   Aircraft state lives in HBM as packed records indexed env*N + k: pos_hp = (x, y on the 32-bit fixed-point position
+//   grid, h, phi) 16 B, v 4 B, last_act = the three last accepted targets 12 B (written back only when one changed) — a
+//   wavefront moves each array with ONE access per lane on consecutive addresses; the per-step env record (4 words) is one
+//   16-byte load that the W lanes of an env share, the per-episode record is touched only when an episode ends.
+//   All per-lane indices are 32-bit offsets from uniform base pointers.
 //   The sector blob (constants, polygons, lookup grid) stays in global memory: constants are read with uniform indices
 //   (scalar loads -> SGPRs), the MVA lookup is one 8-byte L2 gather per aircraft (+ a few 16-byte edge records in cells
 //   that touch a polygon border).  There is no per-workgroup staging prologue and no block barrier: the first thing a
@@ -268,13 +269,15 @@ struct LaneIds {        // who this lane is (one aircraft slot of one env)
 struct LaneState {      // persistent per-aircraft state held in registers
     Aircraft a;
     float la_v, la_h, la_p;
-    bool la_changed;
+    bool la_changed, v_changed;
 };
-struct EnvState {       // persistent per-env record (replicated in the W lanes of the env)
-    int t, n_actions, episode, ep_length;
-    float total_reward, ep_return;
-    uint32_t win_bits;
-    uint64_t amask;
+struct EnvState {       // per-step env record (replicated in the W lanes of the env)
+    int t, n_actions;
+    float total_reward;
+    uint64_t amask;     // bits 32..63 live in the per-episode record and exist only for envs of more than 32 aircraft
+};
+struct Float3 {
+    float a, b, c;
 };
 struct Mid {            // what the first half of a step hands to the second
     bool active;
@@ -286,7 +289,7 @@ struct Mid {            // what the first half of a step hands to the second
 };
 struct StepOut {        // per-step output bases (uniform pointers)
     float* obs;
-    uint32_t* flags;
+    uint16_t* flags;
     float* reward;
     uint8_t* done;
     float *raw_obs, *ac_reward, *min_sep, *term_obs;
@@ -345,7 +348,9 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
             float dd = tv - a.v;
             dd = fminf(dd, kAMax * dt);
             dd = fmaxf(dd, kAMin * dt);
-            a.v = ok ? a.v + dd : a.v;
+            const float v_new = ok ? a.v + dd : a.v;
+            ls.v_changed = ls.v_changed || v_new != a.v;
+            a.v = v_new;
             acts += (ok && !(fabsf(tv - ls.la_v) < kDiscrV)) ? 1 : 0;
             ls.la_changed = ls.la_changed || (ok && tv != ls.la_v);
             ls.la_v = ok ? tv : ls.la_v;
@@ -371,6 +376,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
             dd = fmaxf(dd, kPhiDotMin * dt);
             a.phi = active ? a.phi + dd : a.phi;
             acts += (active && !(fabsf(tp - ls.la_p) < kDiscrPhi)) ? 1 : 0;
+            ls.la_changed = ls.la_changed || (active && tp != ls.la_p);
             ls.la_p = active ? tp : ls.la_p;
         }
     }
@@ -379,11 +385,11 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
         const float dist = active ? (a.v / 3600.0f) * dt : 0.0f;
         float sn, cs;
         if (ATC_ABLATE & 32) { sn = 0.6f; cs = 0.8f; } else sincos_deg(a.phi, &sn, &cs);
-        a.x += (double)(sn * dist);
-        a.y += (double)(cs * dist);
+        a.x = pos_advance(K, a.x, sn * dist);
+        a.y = pos_advance(K, a.y, cs * dist);
     }
-    m.x32 = (float)a.x;
-    m.y32 = (float)a.y;
+    m.x32 = pos_to_real(K, 0, a.x);
+    m.y32 = pos_to_real(K, 1, a.y);
     // MVA floor, first half: only ISSUE the lookup-cell gather here; nothing until the override chain needs its result
     m.cell = mva_cell_load(grid, m.x32, m.y32);
     m.active = active;
@@ -397,7 +403,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
 template <int W, bool FULL>
 __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const float* __restrict__ grid,
                                             const atc_params_t& p, int N, const LaneIds& d, const Mid& m, LaneState& ls,
-                                            EnvState& es, const StepOut& so, float4* pos, float* obs_stage) {
+                                            EnvState& es, const StepOut& so, int32_t* stp, float4* pos, float* obs_stage) {
     Aircraft& a = ls.a;
     const bool active = m.active;
     const float x32 = m.x32, y32 = m.y32;
@@ -493,7 +499,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
             for (int c = 0; c < ATC_OBS_DIM; ++c) ob.o[c] = x32;
             ob.d_faf = ob.phi_rel_faf = ob.on_gp = y32;
         } else {
-            ob = get_state(K, x32, y32, a.h, a.phi, a.v, mva);
+            ob = get_state(K, a.x, a.y, x32, y32, a.h, a.phi, a.v, mva);
         }
         if ((p.mode & ATC_M_REWARD_SHAPING) && !(ATC_ABLATE & 8)) {
             const Shaping sh = shaping_rewards(K, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp);
@@ -541,13 +547,17 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     const uint64_t won = group_ballot<W>((fl & ATC_F_WON) != 0, lane);
     const uint64_t term = group_ballot<W>(
         (fl & (ATC_F_BELOW_MVA | ATC_F_OUTSIDE | ATC_F_CONFLICT | ATC_F_TIMEOUT)) != 0, lane);
-    es.amask &= ~won;
-    const bool done = d.env_valid && (term != 0 || es.amask == 0);
+    // extension: an aircraft that reaches the corridor is handed over; the episode is won when all are.
+    // ATC_M_KEEP_ACTIVE: the reference's rule (atc_gym.py:163-169) — any win ends the episode, nobody is handed over.
+    const bool keep_active = (p.mode & ATC_M_KEEP_ACTIVE) != 0;
+    if (!keep_active) es.amask &= ~won;
+    const bool env_won = keep_active ? won != 0 : es.amask == 0;
+    const bool done = d.env_valid && (term != 0 || env_won);
     es.total_reward += env_r;  // atc_gym.py:194-197
     es.n_actions += env_acts;
 
     if (d.lane_valid) {
-        stream_store(at<uint32_t>(so.flags, i * 4u), fl);
+        stream_store(at<uint16_t>(so.flags, i * 2u), (uint16_t)fl);
         if (FULL && so.ac_reward) *at<float>(so.ac_reward, i * 4u) = r;
     }
     if (d.env_valid && k == 0) {
@@ -562,20 +572,30 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     if (done && (p.mode & ATC_M_AUTO_RESET)) {
         // VecEnv semantics: the env restarts inside the step; the returned obs is the RAW reset state
         // (atc_gym.py:351,365: reset() returns the un-normalised state computed with mva = 0).
-        es.ep_return = es.total_reward;
-        es.ep_length = es.t;
-        es.win_bits = ((es.win_bits << 1) | (es.amask == 0 ? 1u : 0u)) & 0x3ffu;
+        // The per-episode record is read, updated and written here and nowhere else on the step path.  In a multi-step launch
+        // an earlier step of this wavefront may have written it (lane k == 0 writes, all lanes of the env read): wavefront-
+        // scope fences order those accesses (they compile to nothing — a wavefront's memory operations are issued in order).
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int4* sr = at<int4>(stp, (uint32_t)e * (ATC_STAT_WORDS * 4u));
+        const int4 s0 = sr[0];  // episodes, ep_length, ep_return, win_bits
+        const int episode = s0.x;
+        if (d.env_valid && k == 0) {
+            const uint32_t win_bits = (((uint32_t)s0.w << 1) | (env_won ? 1u : 0u)) & 0x3ffu;
+            sr[0] = make_int4(episode + 1, es.t, __float_as_int(es.total_reward), (int)win_bits);
+            *at<int>(stp, (uint32_t)e * (ATC_STAT_WORDS * 4u) + ATC_STAT_EP_ACTIONS * 4u) = es.n_actions;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if (d.lane_valid) {
             if (FULL && so.term_obs) store_obs(at<float>(so.term_obs, i * 40u), o);
-            a = spawn(K, p, e, k, es.episode);
-            const Obs ob = get_state(K, (float)a.x, (float)a.y, a.h, a.phi, a.v, 0.0f);
+            a = spawn(K, p, e, k, episode);
+            ls.v_changed = true;
+            const Obs ob = get_state(K, a.x, a.y, pos_to_real(K, 0, a.x), pos_to_real(K, 1, a.y), a.h, a.phi, a.v, 0.0f);
 #pragma unroll
             for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = ob.o[c];
         }
         es.total_reward = 0.0f;
         es.n_actions = 0;
         es.t = 0;
-        es.episode += 1;
         es.amask = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
     }
 
@@ -614,19 +634,23 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
 }
 
 __device__ __forceinline__ void store_lane_state(const atc_state_t& st, const LaneIds& d, const LaneState& ls) {
-    if (d.lane_valid) {
-        *at<double2>(st.pos, d.i * 16u) = make_double2(ls.a.x, ls.a.y);
-        *at<float4>(st.kin, d.i * 16u) = make_float4(ls.a.h, ls.a.phi, ls.a.v, ls.la_p);
-        // actions are typically held for many steps: write last v/h targets back only where they changed
-        if (ls.la_changed) *at<float2>(st.last_vh, d.i * 8u) = make_float2(ls.la_v, ls.la_h);
+    if (d.lane_valid)
+        *at<int4>(st.pos_hp, d.i * 16u) = make_int4(ls.a.x, ls.a.y, __float_as_int(ls.a.h), __float_as_int(ls.a.phi));
+    // speed and last-action targets are typically constant for many steps (actions are held, the speed reaches its target):
+    // written back only by wavefronts in which one of them changed
+    if (__ballot(ls.v_changed) != 0ull && d.lane_valid) *at<float>(st.v, d.i * 4u) = ls.a.v;
+    if (__ballot(ls.la_changed) != 0ull && d.lane_valid) {
+        Float3 la = {ls.la_v, ls.la_h, ls.la_p};
+        *at<Float3>(st.last_act, d.i * 12u) = la;
     }
 }
-__device__ __forceinline__ void store_env_state(const atc_state_t& st, const LaneIds& d, const EnvState& es) {
+template <int W>
+__device__ __forceinline__ void store_env_state(const atc_state_t& st, const LaneIds& d, const EnvState& es, uint32_t hi0) {
     if (d.env_valid && d.k == 0) {
-        int4* er = at<int4>(st.env, (uint32_t)d.e * (ATC_ENV_WORDS * 4u));
-        er[0] = make_int4(es.t, es.n_actions, es.episode, es.ep_length);
-        er[1] = make_int4(__float_as_int(es.total_reward), __float_as_int(es.ep_return), (int)es.win_bits, 0);
-        er[2] = make_int4((int)(uint32_t)(es.amask & 0xffffffffu), (int)(uint32_t)(es.amask >> 32), 0, 0);
+        *at<int4>(st.env, (uint32_t)d.e * (ATC_ENV_WORDS * 4u)) =
+            make_int4(es.t, es.n_actions, __float_as_int(es.total_reward), (int)(uint32_t)(es.amask & 0xffffffffu));
+        if (W == 64 && (uint32_t)(es.amask >> 32) != hi0)
+            *at<uint32_t>(st.stats, (uint32_t)d.e * (ATC_STAT_WORDS * 4u) + ATC_STAT_MASK_HI * 4u) = (uint32_t)(es.amask >> 32);
     }
 }
 
@@ -649,14 +673,13 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, atc_st
     const LaneIds d = make_ids<W>(blockIdx.x * kBlock, B, N);
 
     // ---- load persistent state (16-byte records; the W lanes of an env share the env record) -------------------------
-    const int4* erp = at<int4>(st.env, (uint32_t)d.e * (ATC_ENV_WORDS * 4u));
-    const int4 e0 = erp[0], e1 = erp[1], e2 = erp[2];
-    EnvState es = {e0.x, e0.y, e0.z, e0.w, __int_as_float(e1.x), __int_as_float(e1.y), (uint32_t)e1.z,
-                   (uint64_t)(uint32_t)e2.x | ((uint64_t)(uint32_t)e2.y << 32)};
-    const double2 ps = *at<double2>(st.pos, d.i * 16u);
-    const float4 kn = *at<float4>(st.kin, d.i * 16u);
-    const float2 lv = *at<float2>(st.last_vh, d.i * 8u);
-    LaneState ls = {{ps.x, ps.y, kn.x, kn.y, kn.z}, lv.x, lv.y, kn.w, false};
+    const int4 e0 = *at<int4>(st.env, (uint32_t)d.e * (ATC_ENV_WORDS * 4u));
+    const uint32_t hi0 = (W == 64) ? *at<uint32_t>(st.stats, (uint32_t)d.e * (ATC_STAT_WORDS * 4u) + ATC_STAT_MASK_HI * 4u) : 0u;
+    EnvState es = {e0.x, e0.y, __int_as_float(e0.z), (uint64_t)(uint32_t)e0.w | ((uint64_t)hi0 << 32)};
+    const int4 ps = *at<int4>(st.pos_hp, d.i * 16u);
+    const float v0 = *at<float>(st.v, d.i * 4u);
+    const Float3 la0 = *at<Float3>(st.last_act, d.i * 12u);
+    LaneState ls = {{ps.x, ps.y, __int_as_float(ps.z), __int_as_float(ps.w), v0}, la0.a, la0.b, la0.c, false, false};
 
     // A single step is its own instantiation: with the step count a run-time value everything the loop carries (aircraft
     // and env records, output bases, hoisted sector constants) stays live across the whole body — 122 VGPRs and 28 spilled
@@ -690,13 +713,13 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, atc_st
         ATC_STAMP(1);
         const Mid m = step_part_a(Kl, gl, p, dl, a_v, a_h, a_p, ls, es);
         ATC_STAMP(3);
-        step_part_b<W, FULL>(Kl, gl, p, N, dl, m, ls, es, so, pos, obs_stage);
+        step_part_b<W, FULL>(Kl, gl, p, N, dl, m, ls, es, so, st.stats, pos, obs_stage);
         ATC_STAMP(5);
     }
     ATC_STAMP(6);
     // ---- write back persistent state -----------------------------------------------------------------------------------
     store_lane_state(st, d, ls);
-    store_env_state(st, d, es);
+    store_env_state<W>(st, d, es, hi0);
     ATC_STAMP(7);
 }
 
@@ -710,15 +733,14 @@ k_reset(const float* __restrict__ blob, int B, int N, atc_state_t st, const uint
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < BN; i += gridDim.x * kBlock) {
         const int e = (int)(i / (uint32_t)N), k = (int)(i % (uint32_t)N);
         if (mask && !mask[e]) continue;
-        const int episode = first ? 0 : st.env[(size_t)e * ATC_ENV_WORDS + ATC_ENV_EPISODES];
+        const int episode = first ? 0 : st.stats[(size_t)e * ATC_STAT_WORDS + ATC_STAT_EPISODES];
         const Aircraft a = spawn(blob, p, e, k, episode);
-        reinterpret_cast<double2*>(st.pos)[i] = make_double2(a.x, a.y);
+        reinterpret_cast<int4*>(st.pos_hp)[i] = make_int4(a.x, a.y, __float_as_int(a.h), __float_as_int(a.phi));
+        st.v[i] = a.v;
         // atc_gym.py:86: last_action = [0,0,0] once, in __init__ — never on reset (quirk Q7)
-        const float la_p = first ? 0.0f : st.kin[(size_t)i * 4 + 3];
-        reinterpret_cast<float4*>(st.kin)[i] = make_float4(a.h, a.phi, a.v, la_p);
-        if (first) reinterpret_cast<float2*>(st.last_vh)[i] = make_float2(0.0f, 0.0f);
-        if (obs) {
-            const Obs ob = get_state(blob, (float)a.x, (float)a.y, a.h, a.phi, a.v, 0.0f);  // mva = 0, atc_gym.py:351
+        if (first) st.last_act[3 * (size_t)i] = st.last_act[3 * (size_t)i + 1] = st.last_act[3 * (size_t)i + 2] = 0.0f;
+        if (obs) {  // mva = 0, atc_gym.py:351
+            const Obs ob = get_state(blob, a.x, a.y, pos_to_real(blob, 0, a.x), pos_to_real(blob, 1, a.y), a.h, a.phi, a.v, 0.0f);
             store_obs(obs + (size_t)i * ATC_OBS_DIM, ob.o);
         }
     }
@@ -731,9 +753,9 @@ k_observe(const float* __restrict__ blob, int B, int N, atc_state_t st, const ui
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < BN; i += gridDim.x * kBlock) {
         const int e = (int)(i / (uint32_t)N);
         if (mask && !mask[e]) continue;
-        const double2 ps = reinterpret_cast<const double2*>(st.pos)[i];
-        const float4 kn = reinterpret_cast<const float4*>(st.kin)[i];
-        const Obs ob = get_state(blob, (float)ps.x, (float)ps.y, kn.x, kn.y, kn.z, 0.0f);
+        const int4 ps = reinterpret_cast<const int4*>(st.pos_hp)[i];
+        const Obs ob = get_state(blob, ps.x, ps.y, pos_to_real(blob, 0, ps.x), pos_to_real(blob, 1, ps.y),
+                                 __int_as_float(ps.z), __int_as_float(ps.w), st.v[i], 0.0f);
         store_obs(obs + (size_t)i * ATC_OBS_DIM, ob.o);
     }
 }
@@ -744,20 +766,22 @@ k_reset_env(int B, int N, atc_state_t st, const uint8_t* __restrict__ mask, int 
     if (e >= B) return;
     if (mask && !mask[e]) return;
     int32_t* er = st.env + (size_t)e * ATC_ENV_WORDS;
+    int32_t* sr = st.stats + (size_t)e * ATC_STAT_WORDS;
     if (first) {
-        er[ATC_ENV_WIN_BITS] = 0;
-        er[ATC_ENV_EPISODES] = 0;
-        er[ATC_ENV_EP_RETURN] = __float_as_int(0.0f);
-        er[ATC_ENV_EP_LENGTH] = 0;
-        er[7] = er[10] = er[11] = 0;
+        sr[ATC_STAT_WIN_BITS] = 0;
+        sr[ATC_STAT_EPISODES] = 0;
+        sr[ATC_STAT_EP_RETURN] = __float_as_int(0.0f);
+        sr[ATC_STAT_EP_LENGTH] = 0;
+        sr[ATC_STAT_EP_ACTIONS] = 0;
+        sr[6] = sr[7] = 0;
     }
     er[ATC_ENV_TOTAL_REWARD] = __float_as_int(0.0f);
     er[ATC_ENV_ACTIONS_TAKEN] = 0;
     er[ATC_ENV_TIMESTEPS] = 0;
-    er[ATC_ENV_EPISODES] = er[ATC_ENV_EPISODES] + 1;
+    sr[ATC_STAT_EPISODES] = sr[ATC_STAT_EPISODES] + 1;
     const uint64_t full = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
     er[ATC_ENV_MASK_LO] = (int)(uint32_t)(full & 0xffffffffu);
-    er[ATC_ENV_MASK_HI] = (int)(uint32_t)(full >> 32);
+    sr[ATC_STAT_MASK_HI] = (int)(uint32_t)(full >> 32);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -839,13 +863,21 @@ static int launch_step(const atc_scenario* s, int B, int N, int T, const atc_sta
                 : launch_step2<W, false, true>(s, B, N, 1, st, actions, out, p, stream);
 }
 
-static int step_common(const atc_scenario_t* s, int B, int N, int T, const atc_state_t* st, const float* actions,
-                       const atc_out_t* out, const atc_params_t* p, void* stream) {
-    if (!s || !st || !actions || !out || !p) return fail_arg("null pointer");
-    if (B < 1 || N < 1 || N > ATC_MAX_AIRCRAFT || T < 1) return fail_arg("need B >= 1, 1 <= N <= 64, T >= 1");
-    if (!st->pos || !st->kin || !st->last_vh || !st->env) return fail_arg("atc_state_t has a null field");
+// argument checks shared by every entry point that touches the env state
+static int check_env_args(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const atc_params_t* p) {
+    if (!s || !st || !p) return fail_arg("null pointer");
+    if (B < 1 || N < 1 || N > ATC_MAX_AIRCRAFT) return fail_arg("need B >= 1, 1 <= N <= 64");
+    if (!st->pos_hp || !st->v || !st->last_act || !st->env || !st->stats) return fail_arg("atc_state_t has a null field");
     if ((unsigned long long)B * N * ATC_OBS_DIM * 4ull >= (1ull << 32) || (unsigned long long)B * 64ull >= (1ull << 32))
         return fail_arg("B*N too large for one launch (B*N*40 bytes must stay below 4 GiB): split the batch");
+    return ATC_OK;
+}
+
+static int step_common(const atc_scenario_t* s, int B, int N, int T, const atc_state_t* st, const float* actions,
+                       const atc_out_t* out, const atc_params_t* p, void* stream) {
+    if (!actions || !out) return fail_arg("null pointer");
+    if (const int rc = check_env_args(s, B, N, st, p)) return rc;
+    if (T < 1) return fail_arg("need T >= 1");
     if (!out->obs || !out->reward || !out->done || !out->flags) return fail_arg("obs/reward/done/flags are required");
     if (!(p->dt > 0.0f)) return fail_arg("dt must be > 0");
     hipStream_t q = (hipStream_t)stream;
@@ -959,10 +991,7 @@ int atc_query_shaping(const atc_scenario_t* s, int n, const float* d_faf, const 
 
 int atc_reset(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const uint8_t* mask, float* obs,
               const atc_params_t* p, int first, void* stream) {
-    if (!s || !st || !p) return fail_arg("null pointer");
-    if (B < 1 || N < 1 || N > ATC_MAX_AIRCRAFT) return fail_arg("need B >= 1, 1 <= N <= 64");
-    if (!st->pos || !st->kin || !st->last_vh || !st->env) return fail_arg("atc_state_t has a null field");
-    if ((unsigned long long)B * N * ATC_OBS_DIM * 4ull >= (1ull << 32)) return fail_arg("B*N too large for one launch");
+    if (const int rc = check_env_args(s, B, N, st, p)) return rc;
     hipStream_t q = (hipStream_t)stream;
     hipLaunchKernelGGL(k_reset, dim3(grid_for(s, (long long)B * N)), dim3(kBlock), lds_bytes(s, false), q, s->d_blob,
                        B, N, *st, mask, obs, *p, first);
@@ -974,8 +1003,8 @@ int atc_reset(const atc_scenario_t* s, int B, int N, const atc_state_t* st, cons
 
 int atc_observe(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const uint8_t* mask, float* obs,
                 const atc_params_t* p, void* stream) {
-    if (!s || !st || !obs || !p) return fail_arg("null pointer");
-    if (B < 1 || N < 1 || N > ATC_MAX_AIRCRAFT) return fail_arg("need B >= 1, 1 <= N <= 64");
+    if (!obs) return fail_arg("null pointer");
+    if (const int rc = check_env_args(s, B, N, st, p)) return rc;
     hipLaunchKernelGGL(k_observe, dim3(grid_for(s, (long long)B * N)), dim3(kBlock), lds_bytes(s, false),
                        (hipStream_t)stream, s->d_blob, B, N, *st, mask, obs);
     HIP_TRY(hipGetLastError());

@@ -37,7 +37,9 @@ class _AirplaneView:
         raise AttributeError(key)
 
     def __setattr__(self, key, value):
-        if key in ("x", "y", "h", "phi", "v"):
+        if key in ("x", "y"):   # positions live on the device's fixed-point grid (include/atc_step.h)
+            self._vec.set_xy(0, **{key: float(value)})
+        elif key in ("h", "phi", "v"):
             getattr(self._vec, key)[0] = float(value)
         else:
             object.__setattr__(self, key, value)
@@ -84,7 +86,7 @@ class AtcGym(Env):
         lay = self._out_layout
         f32 = lambda name: self._out_np[lay[name][0]:lay[name][0] + lay[name][1]].view(np.float32)  # noqa: E731
         self._obs_np, self._raw_np, self._rew_np = f32("obs"), f32("raw_obs"), f32("reward")
-        self._flags_np = self._out_np[lay["flags"][0]:lay["flags"][0] + 4].view(np.int32)
+        self._flags_np = self._out_np[lay["flags"][0]:lay["flags"][0] + 2].view(np.uint16)
         self._done_np = self._out_np[lay["done"][0]:lay["done"][0] + 1]
         import ctypes as C
         from atc_hip import lib as _lib
@@ -123,8 +125,10 @@ class AtcGym(Env):
     @staticmethod
     def _make_backend(sim_parameters, scenario, device):
         from atc_hip.vec_env import AtcVecEnv
+        # keep_active: the reference's aircraft is never handed over — after a win it keeps flying (and can win again) if
+        # the caller steps on without reset (atc_gym.py:128-192 has no inactive state)
         return AtcVecEnv(1, 1, sim_parameters=sim_parameters, scenario=scenario, device=device, auto_reset=False,
-                         spawn="lattice", want_raw_obs=True, host_mapped=True)
+                         spawn="lattice", want_raw_obs=True, host_mapped=True, keep_active=True)
 
     @property
     def last_action(self):

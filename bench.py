@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--sep-nm", type=float, default=3.0, help="developer knob: separation minimum (0 disables conflicts)")
     ap.add_argument("--streams", type=int, default=1, help="step the batch as this many independent sub-batches on "
                     "separate HIP streams (no join between steps): launch ramp / tail of one overlaps the others")
+    ap.add_argument("--lib", default=None, help="developer knob: path of a libatcstep.so build variant to A/B (default: the "
+                    "in-tree build)")
     ap.add_argument("--graph", action="store_true", help="replay the %d-step action-hold block as one captured HIP graph "
                     "(removes per-launch host overhead; matters for the small launch-bound configs)" % HOLD)
     args = ap.parse_args()
@@ -127,6 +129,9 @@ def main():
 
     import torch
     from atc_hip import dist as D
+    if args.lib:
+        from atc_hip import lib as _binding
+        _binding.use_library(args.lib)
     from atc_hip.vec_env import AtcVecEnv
     from envs.atc import scenarios
 
@@ -262,7 +267,7 @@ def main():
                              if args.graph else ("%d sub-batches of %d envs on %d HIP streams, one launch per sub-batch per step "
                                                 "(atc_step_multi), no join between steps" % (S, B // S, S) if S > 1 else "one atc_step launch per step")), "parallelism": "env-sharded x%d, no step-path collective, "
                        "1 all-gather of episode returns per rollout" % ws,
-                       "episodes_finished": int(episodes), "positions": "f64 accumulators"},
+                       "episodes_finished": int(episodes), "positions": "32-bit fixed point (2^-25 nm grid)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_step<%d, false, %s>" % (1 << max(0, (N - 1).bit_length()), "false" if args.rollout else "true"),

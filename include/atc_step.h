@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ATC_ABI_VERSION 10
+#define ATC_ABI_VERSION 11
 
 /* ---------------------------------------------------------------------------------------------
  * Scenario blob: one flat array of 32-bit floats (device copy) compiled on the host from the sector
@@ -35,7 +35,7 @@ extern "C" {
  * envs/atc/atc_gym.py:45-58,88-110).  Integer fields are stored as exactly representable floats.
  * The float64 master (used by the f64 oracle) has the identical word layout.
  * ------------------------------------------------------------------------------------------- */
-#define ATC_BLOB_VERSION 1008.0f
+#define ATC_BLOB_VERSION 1009.0f
 enum {
     ATC_H_VERSION = 0,   /* ATC_BLOB_VERSION */
     ATC_H_NWORDS = 1,    /* total words */
@@ -72,9 +72,15 @@ enum {
     ATC_C_DIR_RWY_X = 91, ATC_C_DIR_RWY_Y = 92, /* rot_matrix(phi_to_runway) . [0,1], model.py:219 */
     ATC_C_ALIGNED_OK = 93, /* 1 if the reference's angle window (model.py:216-229) accepts phi == phi_to_runway exactly,
                               evaluated on the host with the reference's own expression (np.dot / arccos) */
+    /* fixed-point position grid of the fp32 path (see "Aircraft positions" below): nm = X0 + fix * 2^-k */
+    ATC_C_POS_X0 = 94, ATC_C_POS_Y0 = 95, /* grid origin [nm], integer-valued */
+    ATC_C_POS_SCALE = 100,                /* 2^k  (counts per nm) */
+    ATC_C_POS_INV = 101,                  /* 2^-k (nm per count) */
     ATC_C_TRI_BBOX = 96,  /* x0,y0,x1,y1 of the corridor_horizontal triangle (exact early-out for model.py:198) */
     ATC_C_NORM_A = 104,   /* 10 words: 1 / (0.5 max)              — normalisation (atc_gym.py:187-189) as one fma:  */
     ATC_C_NORM_B = 114,   /* 10 words: -(min + 0.5 max) / (0.5 max)                  obs = raw * A + B (float32) */
+    ATC_C_FAF_FIX = 124,  /* 4 words: the FAF on the position grid, x then y, each as (hi, lo) with fix = hi * 65536 + lo,
+                             lo in [0, 65536) — two exactly representable floats per 32-bit integer */
     ATC_C_END = 128
 };
 /* polygon table record (8 words) */
@@ -105,7 +111,7 @@ enum { ATC_G_X0 = 0, ATC_G_Y0 = 1, ATC_G_INV = 2, ATC_G_NX = 3, ATC_G_NY = 4, AT
 #define ATC_OBS_DIM 10 /* atc_gym.py:262-277 */
 #define ATC_ACT_DIM 3  /* v, h, phi  (atc_gym.py:70,79) */
 
-/* per-aircraft flag word (outputs `flags`) */
+/* per-aircraft flag word (outputs `flags`, 16 bits) */
 enum {
     ATC_F_BELOW_MVA = 1u << 0, /* atc_gym.py:149-153 */
     ATC_F_OUTSIDE = 1u << 1,   /* atc_gym.py:156-161 */
@@ -124,7 +130,10 @@ enum {
     ATC_M_NORMALIZE = 1u << 1,       /* SimParameters.normalize_state, model.py:144 */
     ATC_M_DISCRETE = 1u << 2,        /* SimParameters.discrete_action_space, model.py:145 */
     ATC_M_AUTO_RESET = 1u << 3,      /* VecEnv semantics: done envs are reset inside the step, obs := raw reset obs */
-    ATC_M_RANDOM_ENTRY = 1u << 4     /* reset draws (entry, level) from the counter-based RNG; else slot lattice */
+    ATC_M_RANDOM_ENTRY = 1u << 4,    /* reset draws (entry, level) from the counter-based RNG; else slot lattice */
+    ATC_M_KEEP_ACTIVE = 1u << 5      /* the reference's single-aircraft rule (atc_gym.py:163-169): an aircraft that reaches the
+                                        corridor ends the episode and STAYS under control (no hand-over), so stepping on
+                                        without reset keeps simulating it (learning/atc-gym-compute-performance.py:14-16) */
 };
 
 typedef struct atc_params {
@@ -139,27 +148,64 @@ typedef struct atc_params {
     float reserved1;
 } atc_params_t;
 
+/* Aircraft positions (model.py:33-34) on the fp32 path.
+ * The reference accumulates x, y in float64.  An fp32 accumulator drifts by up to half an ulp PER STEP on a straight leg
+ * (1e-4 nm after 100 steps, measured) — beyond the 1e-5 bar.  Positions are therefore kept as 32-bit FIXED POINT on a
+ * per-sector grid: nm = origin + fix * 2^-k, origin integer-valued, k the largest exponent (<= 27) whose range
+ * +-2^(31-k) nm covers 1.5 x the sector's half extent (LOWW: origin (36, 42), k = 25: 3e-8 nm = 55 um steps, +-64 nm).
+ *   - per-step displacement d (fp32, model.py:122-129) advances the position by rint(d * 2^k) counts, saturating;
+ *   - the fp32 position every formula of the reference sees is  (float)(origin + fix * 2^-k)  — ONE rounding (evaluated
+ *     in float64, exact before the final conversion);
+ *   - differences of positions are exact integers: the vector to the FAF (atc_gym.py:289-297) is
+ *     (float)(faf_fix - fix) * 2^-k, accurate to fp32 RELATIVE precision however close the aircraft is to the FAF.
+ * Worst-case accumulated rounding over a 6 000-step episode: 6 000 * 2^-26 nm = 9e-5 nm (3e-6 in normalised units);
+ * half the bytes of a float64 pair.  An aircraft that is flown on, without reset, beyond the grid range (>= 24 nm outside
+ * the LOWW bounding box) is pinned at the range limit: it stays "outside the airspace" exactly like the reference's
+ * (model.py:289), only its x / y observation stops growing.
+ *
+ * fp32 heading kinematics (model.py:122-129, 345-348) — part of the fp32 spec so that every fp32 implementation (the HIP
+ * kernels, the fp32 instantiation of the test oracle) produces bit-identical positions:
+ *   k = rint(phi / 90) [phi * (1/90) in fp32], t = fma(-90, k, phi) (exact), r = t * (pi/180),
+ *   sin r = r * S(r^2), cos r = C(r^2) with the polynomials below (Horner, fmaf), quadrant fix-up by k mod 4.
+ *   Max abs error 8.5e-8 (the accuracy class of libm sinf/cosf). */
+#define ATC_SIN_C1 (-0.16666631400585175f)
+#define ATC_SIN_C2 (0.008331366814672947f)
+#define ATC_SIN_C3 (-0.00019439239986240864f)
+#define ATC_COS_C1 (-0.5f)
+#define ATC_COS_C2 (0.04166661575436592f)
+#define ATC_COS_C3 (-0.001388648059219122f)
+#define ATC_COS_C4 (2.436429167573806e-05f)
+#define ATC_POS_MAX_K 27
+
 /* Persistent environment state (all device pointers).  Aircraft arrays are indexed env * N + k and packed so that a
- * wavefront moves them with 16-byte (pos, kin) / 8-byte (last_vh) accesses, fully coalesced. */
+ * wavefront moves each with one access per lane on consecutive addresses.  Per aircraft-step the step kernel reads
+ * 16 + 4 + 12 B and writes 16 + 4 B (+ 12 B only when a last-action target changed). */
 typedef struct atc_state {
-    double* pos;      /* [B*N][2]  x, y [nm] (model.py:33-34).  float64 accumulators: fp32 accumulation drifts by up to
-                         0.5 ulp/step on straight legs (1e-4 nm after 100 steps), beyond the 1e-5 bar */
-    float* kin;       /* [B*N][4]  h [ft], phi [deg, never wrapped], v [kt] (model.py:35-38), last accepted phi target */
-    float* last_vh;   /* [B*N][2]  last accepted v and h targets; with kin[3] = AtcGym.last_action (atc_gym.py:86,311) */
-    int32_t* env;     /* [B][ATC_ENV_WORDS] per-env record, see ATC_ENV_* */
+    int32_t* pos_hp;  /* [B*N][4]  x_fix, y_fix (position grid counts, see above), h [ft] and phi [deg, never wrapped]
+                         (model.py:35-36) as float bit patterns — one 16-byte record */
+    float* v;         /* [B*N]     speed [kt] (model.py:37) */
+    float* last_act;  /* [B*N][3]  last accepted v / h / phi targets = AtcGym.last_action (atc_gym.py:86,311) */
+    int32_t* env;     /* [B][ATC_ENV_WORDS]  per-step env record, see ATC_ENV_* */
+    int32_t* stats;   /* [B][ATC_STAT_WORDS] per-episode env record, see ATC_STAT_* (touched only when an episode ends) */
 } atc_state_t;
-/* per-env record (12 x 32-bit words; float fields are stored by bit pattern) */
+/* per-step env record (4 x 32-bit words; float fields are stored by bit pattern) */
 enum {
     ATC_ENV_TIMESTEPS = 0,     /* i32  atc_gym.py:39 */
     ATC_ENV_ACTIONS_TAKEN = 1, /* i32  atc_gym.py:31 */
-    ATC_ENV_EPISODES = 2,      /* i32  atc_gym.py:33 (_episodes_run) */
-    ATC_ENV_EP_LENGTH = 3,     /* i32  length of the last finished episode (Monitor 'l') */
-    ATC_ENV_TOTAL_REWARD = 4,  /* f32  atc_gym.py:30 */
-    ATC_ENV_EP_RETURN = 5,     /* f32  return of the last finished episode (Monitor 'r') */
-    ATC_ENV_WIN_BITS = 6,      /* u32  last 10 episode outcomes, bit0 = most recent (atc_gym.py:36-37,359-363) */
-    ATC_ENV_MASK_LO = 8,       /* u32  active mask bits 0..31: bit k = aircraft k still under control (extension) */
-    ATC_ENV_MASK_HI = 9,       /* u32  active mask bits 32..63 */
-    ATC_ENV_WORDS = 12
+    ATC_ENV_TOTAL_REWARD = 2,  /* f32  atc_gym.py:30 */
+    ATC_ENV_MASK_LO = 3,       /* u32  active mask bits 0..31: bit k = aircraft k still under control (extension) */
+    ATC_ENV_WORDS = 4
+};
+/* per-episode env record (8 x 32-bit words) */
+enum {
+    ATC_STAT_EPISODES = 0,     /* i32  atc_gym.py:33 (_episodes_run) */
+    ATC_STAT_EP_LENGTH = 1,    /* i32  length of the last finished episode (Monitor 'l') */
+    ATC_STAT_EP_RETURN = 2,    /* f32  return of the last finished episode (Monitor 'r') */
+    ATC_STAT_WIN_BITS = 3,     /* u32  last 10 episode outcomes, bit0 = most recent (atc_gym.py:36-37,359-363) */
+    ATC_STAT_EP_ACTIONS = 4,   /* i32  actions_taken of the last finished episode: actions_per_timestep (atc_gym.py:197)
+                                       keeps its last value across reset() = EP_ACTIONS / EP_LENGTH */
+    ATC_STAT_MASK_HI = 5,      /* u32  active mask bits 32..63 (read / written per step only by envs of more than 32 aircraft) */
+    ATC_STAT_WORDS = 8
 };
 
 /* Per-step outputs (device pointers; nullable ones may be NULL). */
@@ -169,7 +215,7 @@ typedef struct atc_out {
     float* reward;     /* [B] env reward = sum over aircraft */
     float* ac_reward;  /* nullable [B*N] per-aircraft reward */
     uint8_t* done;     /* [B] */
-    uint32_t* flags;   /* [B*N] ATC_F_* */
+    uint16_t* flags;   /* [B*N] ATC_F_* */
     float* min_sep;    /* nullable [B] minimum horizontal separation among active pairs [nm] (diagnostic) */
     float* term_obs;   /* nullable [B*N*10] terminal observation of envs that were auto-reset this step */
 } atc_out_t;

@@ -11,6 +11,7 @@
 
 #define REAL double
 #define SUFFIX _f64
+#define ORC_FIXED_POS 0
 #define R_FMOD fmod
 #define R_FMA fma
 #define R_SIN sin
@@ -27,6 +28,7 @@
 #include "atc_oracle_impl.h"
 #undef REAL
 #undef SUFFIX
+#undef ORC_FIXED_POS
 #undef R_FMOD
 #undef R_FMA
 #undef R_SIN
@@ -41,6 +43,7 @@
 
 #define REAL float
 #define SUFFIX _f32
+#define ORC_FIXED_POS 1
 #define R_FMOD fmodf
 #define R_FMA fmaf
 #define R_SIN sinf

@@ -21,6 +21,66 @@
 
 /* ---- elementary helpers --------------------------------------------------------------------------------------- */
 
+/* Aircraft positions (model.py:33-34).
+ *   float64 instantiation: Python floats, x += d  — the reference as it is.
+ *   float32 instantiation: the fp32 spec of include/atc_step.h ("Aircraft positions"): 32-bit fixed point on the sector's
+ *   position grid, saturating; the fp32 value the reference's formulas see is (float)(origin + fix * 2^-k); the vector
+ *   to the FAF is an exact integer difference.  The HIP kernels implement the same spec, so their positions are
+ *   bit-identical to this instantiation's. */
+#if ORC_FIXED_POS
+typedef int32_t FN(pos_t);
+static int32_t FN(sat32)(int64_t v) { return v > INT32_MAX ? INT32_MAX : (v < INT32_MIN ? INT32_MIN : (int32_t)v); }
+static int32_t FN(pos_from_real)(const REAL* S, int axis, double v) { /* placing an aircraft (reset / set_state) */
+    double c = rint((v - (double)S[ATC_C_POS_X0 + axis]) * (double)S[ATC_C_POS_SCALE]);
+    return FN(sat32)((int64_t)(c > 4e18 ? 4e18 : (c < -4e18 ? -4e18 : c)));
+}
+static int32_t FN(pos_spawn)(const REAL* S, int axis, REAL v) { /* entry point -> grid, in fp32 like the device */
+    REAL c = (v - S[ATC_C_POS_X0 + axis]) * S[ATC_C_POS_SCALE];
+    c = c > (REAL)2147483520.0 ? (REAL)2147483520.0 : (c < (REAL)-2147483648.0 ? (REAL)-2147483648.0 : c); /* int32 range */
+    return (int32_t)rintf(c);
+}
+static REAL FN(pos_to_real)(const REAL* S, int axis, int32_t p) {
+    return (REAL)((double)p * (double)S[ATC_C_POS_INV] + (double)S[ATC_C_POS_X0 + axis]);
+}
+static int32_t FN(pos_advance)(const REAL* S, int32_t p, REAL d) {
+    REAL c = d * S[ATC_C_POS_SCALE];
+    c = c > (REAL)1073741824.0 ? (REAL)1073741824.0 : (c < (REAL)-1073741824.0 ? (REAL)-1073741824.0 : c); /* +-2^30 */
+    return FN(sat32)((int64_t)p + (int64_t)rintf(c));
+}
+static REAL FN(pos_to_faf)(const REAL* S, int axis, int32_t p) {
+    int64_t faf = (int64_t)S[ATC_C_FAF_FIX + 2 * axis] * 65536 + (int64_t)S[ATC_C_FAF_FIX + 2 * axis + 1];
+    return (REAL)FN(sat32)(faf - (int64_t)p) * S[ATC_C_POS_INV];
+}
+/* fp32 heading kinematics of include/atc_step.h: exact reduction in degrees + two short polynomials */
+static void FN(sincos_heading)(REAL phi, REAL* sn, REAL* cs) {
+    const float k = rintf(phi * (1.0f / 90.0f));
+    const float t = fmaf(-90.0f, k, phi);
+    const float r = t * (float)(3.14159265358979323846 / 180.0);
+    const float r2 = r * r;
+    const float sp = fmaf(fmaf(fmaf(ATC_SIN_C3, r2, ATC_SIN_C2), r2, ATC_SIN_C1), r2, 1.0f);
+    const float s = sp * r;
+    const float c = fmaf(fmaf(fmaf(fmaf(ATC_COS_C4, r2, ATC_COS_C3), r2, ATC_COS_C2), r2, ATC_COS_C1), r2, 1.0f);
+    const int q = (int)k & 3;
+    const float s1 = (q & 1) ? c : s;
+    const float c1 = (q & 1) ? s : c;
+    *sn = (q & 2) ? -s1 : s1;
+    *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+#else
+typedef double FN(pos_t);
+static double FN(pos_from_real)(const REAL* S, int axis, double v) { (void)S; (void)axis; return v; }
+static double FN(pos_spawn)(const REAL* S, int axis, REAL v) { (void)S; (void)axis; return v; }
+static REAL FN(pos_to_real)(const REAL* S, int axis, double p) { (void)S; (void)axis; return (REAL)p; }
+static double FN(pos_advance)(const REAL* S, double p, REAL d) { (void)S; return p + (double)d; }
+static REAL FN(pos_to_faf)(const REAL* S, int axis, double p) { return S[ATC_C_FAF_X + axis] - (REAL)p; }
+/* model.py:345-348 rot_matrix: sin / cos of math.radians(phi) */
+static void FN(sincos_heading)(REAL phi, REAL* sn, REAL* cs) {
+    REAL pr = phi * (REAL)(3.14159265358979323846 / 180.0);
+    *sn = R_SIN(pr);
+    *cs = R_COS(pr);
+}
+#endif
+
 /* Python float modulo: result takes the sign of the divisor (used by relative_angle, model.py:340-342). */
 static REAL FN(py_mod)(REAL a, REAL b) {
     REAL r = R_FMOD(a, b);
@@ -33,8 +93,6 @@ static REAL FN(relative_angle)(REAL a1, REAL a2) {
     return FN(py_mod)(a2 - a1 + (REAL)180, (REAL)360) - (REAL)180;
 }
 
-/* math.radians: x * (pi / 180)  (CPython mathmodule.c degToRad) */
-static REAL FN(radians)(REAL x) { return x * (REAL)(3.14159265358979323846 / 180.0); }
 /* np.degrees: x * (180 / pi) */
 static REAL FN(degrees)(REAL x) { return x * (REAL)(180.0 / 3.14159265358979323846); }
 
@@ -91,10 +149,10 @@ static int FN(inside_corridor_angle)(const REAL* S, REAL x, REAL y, REAL phi) {
     double dot = fma(cos(tr), cos(pr), sin(tr) * sin(pr));
     REAL beta = faf_angle - (REAL)acos(dot);
     REAL min_angle = faf_angle - beta;
+    /* model.py:224-229: `if tri1 and window: True / elif tri2 and window: True / False` */
     if (FN(ray_tracing)(x, y, S + ATC_C_TRI_1, 4)) {
         REAL ra = FN(relative_angle)(to_runway, phi);
         if (min_angle <= ra && ra <= faf_angle) return 1;
-        return 0; /* python `elif`: corridor2 is only evaluated when ray_tracing(corridor1) is false */
     }
     if (FN(ray_tracing)(x, y, S + ATC_C_TRI_2, 4)) {
         REAL ra = FN(relative_angle)(phi, to_runway);
@@ -159,8 +217,7 @@ static uint64_t FN(draw)(uint64_t seed, uint32_t env, uint32_t episode, uint32_t
 
 /* ---- structures (host pointers; same field meaning as include/atc_step.h) ----------------------------------------- */
 typedef struct FN(orc_state) {
-    double *x, *y;             /* [B*N] positions are ALWAYS accumulated in float64 (fp32 accumulation drifts by up to
-                                  0.5 ulp per step on straight legs: 1e-4 nm after 100 steps, measured) */
+    FN(pos_t) *x, *y;          /* [B*N] positions: float64 (reference) | 32-bit fixed point (fp32 spec), see pos_t above */
     REAL *h, *phi, *v;         /* [B*N] */
     REAL* last_act;            /* [3][B*N] */
     int32_t* timesteps;
@@ -171,6 +228,7 @@ typedef struct FN(orc_state) {
     int32_t* episodes;
     REAL* ep_return;
     int32_t* ep_length;
+    int32_t* ep_actions;       /* actions_taken of the last finished episode */
 } FN(orc_state_t);
 
 typedef struct FN(orc_out) {
@@ -179,7 +237,7 @@ typedef struct FN(orc_out) {
     REAL* reward;   /* [B] */
     REAL* ac_reward;/* nullable [B*N] */
     uint8_t* done;  /* [B] */
-    uint32_t* flags;/* [B*N] */
+    uint16_t* flags;/* [B*N] */
     REAL* min_sep;  /* nullable [B] */
     float* term_obs;/* nullable */
     int32_t* mva;   /* nullable [B*N] MVA height used for the observation (-1 outside) — oracle-only diagnostic */
@@ -187,10 +245,11 @@ typedef struct FN(orc_out) {
 
 /* atc_gym.py:262-277 _get_state -> float32[10]; also returns the full-precision d_faf / phi_rel_faf / on_gp used by the
  * shaping rewards (atc_gym.py:179-185 read self._d_faf etc., which are not rounded to float32). */
-static void FN(get_state)(const REAL* S, REAL x, REAL y, REAL h, REAL phi, REAL v, REAL mva, float* obs10, REAL* d_faf,
-                          REAL* phi_rel_faf, REAL* on_gp) {
-    REAL to_faf_x = S[ATC_C_FAF_X] - x;
-    REAL to_faf_y = S[ATC_C_FAF_Y] - y;
+static void FN(get_state)(const REAL* S, FN(pos_t) px, FN(pos_t) py, REAL h, REAL phi, REAL v, REAL mva, float* obs10,
+                          REAL* d_faf, REAL* phi_rel_faf, REAL* on_gp) {
+    REAL x = FN(pos_to_real)(S, 0, px), y = FN(pos_to_real)(S, 1, py);
+    REAL to_faf_x = FN(pos_to_faf)(S, 0, px);  /* faf - position, atc_gym.py:289-297 */
+    REAL to_faf_y = FN(pos_to_faf)(S, 1, py);
     REAL phi_rel_runway = FN(relative_angle)(S[ATC_C_PHI_TO_RWY], phi); /* atc_gym.py:284-287 */
     *d_faf = R_HYPOT(to_faf_x, to_faf_y);                               /* atc_gym.py:294-297 */
     *phi_rel_faf = FN(degrees)(R_ATAN2(to_faf_y, to_faf_x));            /* atc_gym.py:289-292 */
@@ -253,17 +312,18 @@ static void FN(reset_env)(const REAL* S, int N, const FN(orc_state_t) * st, cons
         st->episodes[e] = 0;
         st->ep_return[e] = 0;
         st->ep_length[e] = 0;
+        st->ep_actions[e] = 0;
     }
     int episode = st->episodes[e];
     for (int k = 0; k < N; ++k) {
         int i = e * N + k;
         REAL sx, sy;
         FN(spawn)(S, p, e, k, episode, &sx, &sy, &st->h[i], &st->phi[i], &st->v[i]);
-        st->x[i] = (double)sx;
-        st->y[i] = (double)sy;
+        st->x[i] = FN(pos_spawn)(S, 0, sx);
+        st->y[i] = FN(pos_spawn)(S, 1, sy);
         if (obs) {
             REAL d, pr, gp;
-            FN(get_state)(S, (REAL)st->x[i], (REAL)st->y[i], st->h[i], st->phi[i], st->v[i], (REAL)0, obs + (size_t)i * 10, &d, &pr, &gp);
+            FN(get_state)(S, st->x[i], st->y[i], st->h[i], st->phi[i], st->v[i], (REAL)0, obs + (size_t)i * 10, &d, &pr, &gp);
         }
     }
     st->total_reward[e] = 0;
@@ -312,7 +372,7 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
         const int t = st->timesteps[e];
         const uint64_t act0 = st->active_mask[e];
         REAL r[ATC_MAX_AIRCRAFT];
-        uint32_t fl[ATC_MAX_AIRCRAFT];
+        uint16_t fl[ATC_MAX_AIRCRAFT];
         REAL mva_h[ATC_MAX_AIRCRAFT];
         int mva_i[ATC_MAX_AIRCRAFT];
 
@@ -367,9 +427,10 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
             }
             /* model.py:122-129 Airplane.step: rot_matrix(phi) . [0, (v/3600)*dt] */
             REAL dist = (st->v[i] / (REAL)3600) * dt;
-            REAL pr = FN(radians)(st->phi[i]);
-            st->x[i] += (double)(R_SIN(pr) * dist); /* increment in REAL, accumulation in float64 */
-            st->y[i] += (double)(R_COS(pr) * dist);
+            REAL sn, cs;
+            FN(sincos_heading)(st->phi[i], &sn, &cs);
+            st->x[i] = FN(pos_advance)(S, st->x[i], sn * dist);
+            st->y[i] = FN(pos_advance)(S, st->y[i], cs * dist);
             r[k] = reward;
         }
 
@@ -378,7 +439,7 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
         for (int k = 0; k < N; ++k) {
             if (fl[k] & ATC_F_INACTIVE) continue;
             const size_t i = (size_t)e * N + k;
-            int pi = FN(find_mva)(S, (REAL)st->x[i], (REAL)st->y[i]);
+            int pi = FN(find_mva)(S, FN(pos_to_real)(S, 0, st->x[i]), FN(pos_to_real)(S, 1, st->y[i]));
             mva_i[k] = pi;
             if (pi >= 0) {
                 REAL mva = S[off_poly + pi * ATC_P_WORDS + ATC_P_HEIGHT];
@@ -401,7 +462,8 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
             for (int b = a + 1; b < N; ++b) {
                 if (fl[b] & ATC_F_INACTIVE) continue;
                 const size_t ia = (size_t)e * N + a, ib = (size_t)e * N + b;
-                REAL dx = (REAL)st->x[ia] - (REAL)st->x[ib], dy = (REAL)st->y[ia] - (REAL)st->y[ib];
+                REAL dx = FN(pos_to_real)(S, 0, st->x[ia]) - FN(pos_to_real)(S, 0, st->x[ib]);
+                REAL dy = FN(pos_to_real)(S, 1, st->y[ia]) - FN(pos_to_real)(S, 1, st->y[ib]);
                 REAL d2 = R_FMA(dx, dx, dy * dy); /* fused: the definition shared with the device kernel */
                 REAL dh = R_ABS(st->h[ia] - st->h[ib]);
                 REAL d = R_SQRT(d2);
@@ -417,6 +479,8 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
         /* pass 4: remaining override chain, observation, shaping (atc_gym.py:163-189) */
         REAL env_reward = 0;
         uint64_t act1 = act0;
+        int any_won = 0;
+        const int keep_active = (p->mode & ATC_M_KEEP_ACTIVE) != 0;
         for (int k = 0; k < N; ++k) {
             const size_t i = (size_t)e * N + k;
             float raw[10], nrm[10];
@@ -430,20 +494,21 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
                 continue;
             }
             if (fl[k] & ATC_F_CONFLICT) r[k] = (REAL)p->conflict_reward;
-            const REAL px = (REAL)st->x[i], py = (REAL)st->y[i];
+            const REAL px = FN(pos_to_real)(S, 0, st->x[i]), py = FN(pos_to_real)(S, 1, st->y[i]);
             if (FN(inside_corridor)(S, px, py, st->h[i], st->phi[i])) { /* atc_gym.py:163-169 */
                 int bonus = (p->timestep_limit - t) * 5;
                 if (bonus < 0) bonus = 0;
                 r[k] = (REAL)(10000 + bonus);
                 fl[k] |= ATC_F_WON;
-                act1 &= ~(1ull << k);
+                any_won = 1;
+                if (!keep_active) act1 &= ~(1ull << k); /* extension: handed over.  KEEP_ACTIVE: the reference's rule */
             }
             if (t > p->timestep_limit) { /* atc_gym.py:171-173 */
                 r[k] = (REAL)-200;
                 fl[k] |= ATC_F_TIMEOUT;
             }
             REAL d_faf, phi_rel_faf, on_gp;
-            FN(get_state)(S, px, py, st->h[i], st->phi[i], st->v[i], mva_h[k], raw, &d_faf, &phi_rel_faf, &on_gp);
+            FN(get_state)(S, st->x[i], st->y[i], st->h[i], st->phi[i], st->v[i], mva_h[k], raw, &d_faf, &phi_rel_faf, &on_gp);
             if (p->mode & ATC_M_REWARD_SHAPING) { /* atc_gym.py:179-185 */
                 REAL pos = FN(reward_approach_position)(d_faf, S[ATC_C_PHI_TO_RWY], phi_rel_faf, S[ATC_C_WORLD_DIAG]);
                 r[k] += pos;
@@ -470,7 +535,9 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
             env_reward += r[k];
             if (fl[k] & (ATC_F_BELOW_MVA | ATC_F_OUTSIDE | ATC_F_CONFLICT | ATC_F_TIMEOUT)) env_done = 1;
         }
-        if (act1 == 0) env_done = 1; /* every aircraft handed over (N = 1: the reference's win, atc_gym.py:169) */
+        /* every aircraft handed over (N = 1: the reference's win, atc_gym.py:169); KEEP_ACTIVE: any win ends the episode */
+        const int env_won = keep_active ? any_won : (act1 == 0);
+        if (env_won) env_done = 1;
         st->active_mask[e] = act1;
         st->total_reward[e] += env_reward; /* atc_gym.py:194-197 */
         out->reward[e] = env_reward;
@@ -479,8 +546,9 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
         if (env_done && (p->mode & ATC_M_AUTO_RESET)) {
             st->ep_return[e] = st->total_reward[e];
             st->ep_length[e] = t;
-            int won_all = (act1 == 0); /* every aircraft reached the corridor (N = 1: win_buffer.append(1), atc_gym.py:165) */
-            st->win_bits[e] = ((st->win_bits[e] << 1) | (uint32_t)won_all) & 0x3ffu;
+            st->ep_actions[e] = st->actions_taken[e];
+            /* every aircraft reached the corridor (N = 1: win_buffer.append(1), atc_gym.py:165) */
+            st->win_bits[e] = ((st->win_bits[e] << 1) | (uint32_t)env_won) & 0x3ffu;
             if (out->term_obs) memcpy(out->term_obs + (size_t)e * N * 10, out->obs + (size_t)e * N * 10, sizeof(float) * 10 * N);
             FN(reset_env)(S, N, st, p, e, out->obs, 0);
         }

@@ -12,7 +12,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liboracle_atc.so")
 
-M_REWARD_SHAPING, M_NORMALIZE, M_DISCRETE, M_AUTO_RESET, M_RANDOM_ENTRY = 1, 2, 4, 8, 16
+M_REWARD_SHAPING, M_NORMALIZE, M_DISCRETE, M_AUTO_RESET, M_RANDOM_ENTRY, M_KEEP_ACTIVE = 1, 2, 4, 8, 16, 32
 
 
 class Params(C.Structure):
@@ -23,9 +23,10 @@ class Params(C.Structure):
 
 
 def make_params(dt=1.0, shaping=True, normalize=True, discrete=False, auto_reset=False, random_entry=False, seed=0,
-                timestep_limit=6000, sep_nm=3.0, sep_ft=1000.0, conflict_reward=-200.0):
+                timestep_limit=6000, sep_nm=3.0, sep_ft=1000.0, conflict_reward=-200.0, keep_active=False):
     mode = (M_REWARD_SHAPING if shaping else 0) | (M_NORMALIZE if normalize else 0) | (M_DISCRETE if discrete else 0) | \
-           (M_AUTO_RESET if auto_reset else 0) | (M_RANDOM_ENTRY if random_entry else 0)
+           (M_AUTO_RESET if auto_reset else 0) | (M_RANDOM_ENTRY if random_entry else 0) | \
+           (M_KEEP_ACTIVE if keep_active else 0)
     return Params(dt, timestep_limit, mode, 0, seed, sep_nm, sep_ft, conflict_reward, 0.0)
 
 
@@ -70,7 +71,12 @@ class OracleEnv:
         self.params = params or make_params()
         r = self.dtype
         BN = B * N
-        self.x, self.y = np.zeros(BN, np.float64), np.zeros(BN, np.float64)  # positions: always float64
+        # positions: float64 in the reference-faithful instantiation, 32-bit fixed point on the sector's position grid in
+        # the fp32 one (include/atc_step.h "Aircraft positions"); `.x` / `.y` give nautical miles either way
+        self.fixed = self.dtype == np.float32
+        self.pos_origin, self.pos_k = compiled.pos_origin, compiled.pos_k
+        pdt = np.int32 if self.fixed else np.float64
+        self.px, self.py = np.zeros(BN, pdt), np.zeros(BN, pdt)
         self.h, self.phi, self.v = (np.zeros(BN, r) for _ in range(3))
         self.last_act = np.zeros((3, BN), r)
         self.timesteps = np.zeros(B, np.int32)
@@ -81,18 +87,20 @@ class OracleEnv:
         self.episodes = np.zeros(B, np.int32)
         self.ep_return = np.zeros(B, r)
         self.ep_length = np.zeros(B, np.int32)
+        self.ep_actions = np.zeros(B, np.int32)
         self.obs = np.zeros((B, N, 10), np.float32)
         self.raw_obs = np.zeros((B, N, 10), np.float32)
         self.reward = np.zeros(B, r)
         self.ac_reward = np.zeros((B, N), r)
         self.done = np.zeros(B, np.uint8)
-        self.flags = np.zeros((B, N), np.uint32)
+        self.flags = np.zeros((B, N), np.uint16)
         self.min_sep = np.zeros(B, r)
         self.term_obs = np.zeros((B, N, 10), np.float32)
         self.mva = np.zeros((B, N), np.int32)
-        self._st = (C.c_void_p * 14)(*[_ptr(a) for a in (
-            self.x, self.y, self.h, self.phi, self.v, self.last_act, self.timesteps, self.actions_taken,
-            self.total_reward, self.active_mask, self.win_bits, self.episodes, self.ep_return, self.ep_length)])
+        self._st = (C.c_void_p * 15)(*[_ptr(a) for a in (
+            self.px, self.py, self.h, self.phi, self.v, self.last_act, self.timesteps, self.actions_taken,
+            self.total_reward, self.active_mask, self.win_bits, self.episodes, self.ep_return, self.ep_length,
+            self.ep_actions)])
         self._out = (C.c_void_p * 9)(*[_ptr(a) for a in (
             self.obs, self.raw_obs, self.reward, self.ac_reward, self.done, self.flags, self.min_sep, self.term_obs,
             self.mva)])
@@ -105,9 +113,30 @@ class OracleEnv:
         assert rc == 0
         return self.obs.copy()
 
+    def _nm(self, p, axis):
+        if not self.fixed:
+            return p
+        return p.astype(np.float64) * 2.0 ** -self.pos_k + self.pos_origin[axis]
+
+    @property
+    def x(self):
+        """positions in nautical miles (float64 view of whatever the instantiation stores)"""
+        return self._nm(self.px, 0)
+
+    @property
+    def y(self):
+        return self._nm(self.py, 1)
+
+    def _to_pos(self, v, axis):
+        if not self.fixed:
+            return v
+        c = np.rint((float(v) - self.pos_origin[axis]) * 2.0 ** self.pos_k)
+        return np.int32(min(max(c, -2.0 ** 31), 2.0 ** 31 - 1))
+
     def set_state(self, e, k, x, y, h, phi, v):
         i = e * self.N + k
-        self.x[i], self.y[i], self.h[i], self.phi[i], self.v[i] = x, y, h, phi, v
+        self.px[i], self.py[i] = self._to_pos(x, 0), self._to_pos(y, 1)
+        self.h[i], self.phi[i], self.v[i] = h, phi, v
 
     def step(self, actions):
         a = np.ascontiguousarray(np.asarray(actions, dtype=self.dtype).reshape(self.B * self.N * 3))

@@ -342,9 +342,10 @@ def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, sp
                 scale = np.maximum(scale, half_range.astype(np.float32))
             assert np.all(np.abs(on - orc.obs) <= 1e-5 * scale), ("obs", t + c)
             rr = r.cpu().numpy()
-            # 2e-5: within ~0.2 nm of the FAF the approach-angle term of the shaping is ill-conditioned (atan2 of a tiny
-            # offset): positions that differ by 1e-6 nm (last-ulp sin/cos differences, accumulated) move it by 1.2e-5
-            assert np.all(np.abs(rr - orc.reward) <= 2e-5 * np.maximum(1.0, np.abs(orc.reward)) * max(1, N // 4)), ("rew", t + c)
+            # env reward = sum over the env's aircraft of per-aircraft rewards that each meet 1e-5 (checked below when the
+            # variant outputs them); the fp32 sum of N terms adds at most N/2 ulps of the running sum
+            rtol = 1e-5 * np.maximum(1.0, np.abs(orc.reward)) + 6e-8 * N * np.abs(orc.ac_reward).sum(1)
+            assert np.all(np.abs(rr - orc.reward) <= rtol), ("rew", t + c, np.abs(rr - orc.reward).max())
             n_done += int(orc.done.sum())
             seen |= int(np.bitwise_or.reduce(orc.flags.ravel()))
         if not use_rollout and full:
@@ -357,11 +358,9 @@ def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, sp
             assert np.all(np.abs(info["original_state"].cpu().numpy().reshape(B, N, 10) - orc.raw_obs)
                           <= 1e-5 * half_range), t
             assert np.all(np.abs(info["aircraft_reward"].cpu().numpy() - orc.ac_reward)
-                          <= 2e-5 * np.maximum(1.0, np.abs(orc.ac_reward))), t   # 2e-5: see the env reward above
-            ms, oms = info["min_separation"].cpu().numpy(), orc.min_sep
-            # distances are evaluated on the fp32 copies of the positions (ulp 7.6e-6 nm at x = 64): two implementations whose
-            # fp64 positions differ by 1e-7 can round a coordinate to neighbouring floats -> allow 4e-5 nm (4e-7 of the sector)
-            assert np.all(np.abs(ms - oms) <= 4e-5 * np.maximum(1.0, np.abs(oms))), t
+                          <= 1e-5 * np.maximum(1.0, np.abs(orc.ac_reward))), t
+            # positions are bit-identical and d^2 is the same fma on both sides: the minimum separation is too
+            assert np.array_equal(info["min_separation"].cpu().numpy(), orc.min_sep), t
             dn = orc.done.astype(bool)
             if dn.any():
                 tob = info["terminal_observation"].cpu().numpy().reshape(B, N, 10)
@@ -377,9 +376,14 @@ def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, sp
     assert np.array_equal(env.win_bits.cpu().numpy().astype(np.uint32), orc.win_bits)
     assert np.array_equal(env.active_mask.cpu().numpy().astype(np.uint64), orc.active_mask)
     assert np.array_equal(env.ep_length.cpu().numpy(), orc.ep_length)
-    assert np.allclose(env.x.cpu().numpy(), orc.x, rtol=0, atol=2e-5)
-    assert np.allclose(env.h.cpu().numpy(), orc.h, rtol=1e-6, atol=1e-3)
-    assert np.allclose(env.ep_return.cpu().numpy(), orc.ep_return, rtol=2e-5, atol=1e-3)
+    # the fp32 spec (include/atc_step.h: fixed-point position grid, shared heading kinematics, exact rate-limit
+    # arithmetic) makes the whole aircraft state BIT-IDENTICAL to the fp32 oracle's
+    assert np.array_equal(env.pos_hp[:, 0].cpu().numpy(), orc.px) and np.array_equal(env.pos_hp[:, 1].cpu().numpy(), orc.py)
+    assert np.array_equal(env.h.cpu().numpy(), orc.h) and np.array_equal(env.phi.cpu().numpy(), orc.phi)
+    assert np.array_equal(env.v.cpu().numpy(), orc.v)
+    assert np.array_equal(env.last_act.cpu().numpy(), orc.last_act.T)
+    assert np.array_equal(env.ep_actions.cpu().numpy(), orc.ep_actions)
+    assert np.allclose(env.ep_return.cpu().numpy(), orc.ep_return, rtol=1e-5, atol=1e-3)
     env.close()
     return n_done, seen
 
@@ -533,7 +537,7 @@ def test_metrics_sequence_g7():
         f = ep["final"]
         assert env.timesteps == f["timesteps"] and env.actions_taken == f["actions_taken"]
         assert env._win_buffer == f["win_buffer"]
-        assert abs(env.total_reward - f["total_reward"]) <= 2e-5 * max(1.0, abs(f["total_reward"]))
+        assert abs(env.total_reward - f["total_reward"]) <= 1e-5 * max(1.0, abs(f["total_reward"]))
         assert abs(env.last_reward - f["last_reward"]) <= 1e-5 * max(1.0, abs(f["last_reward"]))
     env.reset()
     assert abs(env.winning_ratio - g["after_last_reset"]["winning_ratio"]) < 1e-9

@@ -107,7 +107,7 @@ def test_full_step_on_random_sector_vs_oracle(seed, N):
         assert np.array_equal(done.cpu().numpy(), orc.done), t
         o = obs.cpu().numpy().reshape(B, N, 10)
         assert np.all(np.abs(o - orc.obs) <= 1e-5 * np.maximum(1.0, np.abs(orc.obs))), t
-        assert np.all(np.abs(rew.cpu().numpy() - orc.reward) <= 2e-5 * np.maximum(1.0, np.abs(orc.reward)) * max(1, N // 4)), t
+        assert np.all(np.abs(rew.cpu().numpy() - orc.reward) <= 1e-5 * np.maximum(1.0, np.abs(orc.reward)) + 6e-8 * N * np.abs(orc.ac_reward).sum(1)), t
         n_done += int(orc.done.sum())
     assert n_done > 5
     env.close()
