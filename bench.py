@@ -204,7 +204,7 @@ def main():
         roll_out = {"obs": torch.empty((T, B, N * 10), dtype=torch.float32, device=dev),
                     "reward": torch.empty((T, B), dtype=torch.float32, device=dev),
                     "done": torch.empty((T, B), dtype=torch.uint8, device=dev),
-                    "flags": torch.empty((T, B, N), dtype=torch.int32, device=dev)}
+                    "flags": torch.empty((T, B, N), dtype=torch.int16, device=dev)}
 
     def stats():
         if S == 1:

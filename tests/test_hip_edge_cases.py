@@ -188,7 +188,7 @@ def test_fast_and_full_kernel_variants_agree(N):
         acts = (torch.rand((T, B, N, 3), generator=g) * 2.1 - 1.05).cuda()
         out = {k: torch.empty((T,) + tuple(shape), dtype=dt, device="cuda") for k, shape, dt in (
             ("obs", (B, N * 10), torch.float32), ("reward", (B,), torch.float32), ("done", (B,), torch.uint8),
-            ("flags", (B, N), torch.int32), ("raw_obs", (B, N * 10), torch.float32), ("ac_reward", (B, N), torch.float32),
+            ("flags", (B, N), torch.int16), ("raw_obs", (B, N * 10), torch.float32), ("ac_reward", (B, N), torch.float32),
             ("min_sep", (B,), torch.float32), ("term_obs", (B, N * 10), torch.float32))}
         roll.rollout(acts, out=out)
         for t in range(T):
