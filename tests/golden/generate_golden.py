@@ -13,6 +13,13 @@ inputs + expected outputs of the AtcGym.step() hot path as small fixtures:
   g6_rollouts.npz     seeded random-action rollouts (continuous + discrete, random entry points, injected
                       win / timeout cases)
   g7_metrics.json     reset / metrics sequence over consecutive episodes
+  g8_tiebreak.npz     Airspace.get_mva_height on a sector with integer / dyadic vertices (exactly representable in fp32):
+                      vertices, edge midpoints, shared borders, overlapping polygons (list-order priority), points a few
+                      2^-10 nm either side of every edge — the tie-break rules of model.py:282-289,318-337
+  g9_wide.npz         >= 500 000 reference steps in compact form (per step: flags, done, actions_taken, reward; observation
+                      and state every 16th step and on the last step of every episode): LOWW / LOWW_random / Simple /
+                      UnitTest, dt 1/2/5, continuous and discrete, shaping x normalisation off, >= 50 each of win /
+                      below-MVA / timeout terminals, episodes stepped on past `done` (incl. past a win)
   model_test_known_answers.json  the 8 known answers of the reference's own envs/atc/model_test.py
 
 Usage:
@@ -65,7 +72,9 @@ SCENARIOS = {
     "LOWW_random": lambda: ref_scen.LOWW(random_entrypoints=True),
     "Simple": lambda: ref_scen.SimpleScenario(),
     "UnitTest": lambda: UnitTestScenario(),
+    "Dyadic": lambda: DyadicScenario(),
 }
+G1_SCENARIOS = ("LOWW", "LOWW_random", "Simple", "UnitTest")   # g1_constants.json (unchanged since round 1)
 
 
 def make_env(scen="LOWW", dt=1, shaping=True, normalize=True, discrete=False):
@@ -83,7 +92,7 @@ def mva_or_neg(airspace, x, y):
 # ----------------------------------------------------------------------------------------------- G1
 def gen_g1():
     out = {}
-    for name in SCENARIOS:
+    for name in G1_SCENARIOS:
         env = make_env(name)
         c = env._runway.corridor
         d = {
@@ -487,6 +496,210 @@ def gen_g7():
         json.dump({"episodes": episodes, "after_last_reset": tail}, f)
 
 
+# ----------------------------------------------------------------------------------------------- G8
+DYADIC_MVAS = [
+    # list order = lookup priority (model.py:283).  Polygon 0 overlaps the partition below: it must win inside its ring.
+    ([(16, 4), (28, 16), (16, 28), (4, 16)], 2500),
+    ([(0, 0), (16, 0), (16, 16), (0, 16)], 3000),
+    ([(16, 0), (32, 0), (32, 16), (16, 16)], 4000),
+    ([(0, 16), (16, 16), (24, 32), (0, 32)], 5000),
+    ([(16, 16), (32, 16), (32, 32), (24, 32)], 6000),
+    ([(32, 8), (40, 8), (40, 24.5), (32, 24.5)], 7000),   # shares part of the x = 32 border of two polygons
+]
+
+
+def dyadic_world():
+    mvas = [ref_model.MinimumVectoringAltitude(shape.Polygon(p), h) for p, h in DYADIC_MVAS]
+    runway = ref_model.Runway(16, 10, 0, 180)
+    return mvas, runway, ref_model.Airspace(mvas, runway)
+
+
+def gen_g8():
+    mvas, runway, asp = dyadic_world()
+    pts = []
+    eps = [0.0, 2.0 ** -10, -2.0 ** -10, 3 * 2.0 ** -10, -3 * 2.0 ** -10]
+    for m in mvas:
+        ring = np.asarray(m.area_as_list)
+        for k in range(len(ring) - 1):
+            a, b = ring[k], ring[k + 1]
+            for t in (0.0, 0.25, 0.5, 0.75):
+                p = a * (1 - t) + b * t
+                for dx in eps:
+                    for dy in eps:
+                        pts.append([p[0] + dx, p[1] + dy])
+    for x in np.arange(-1.0, 41.5, 0.5):
+        for y in np.arange(-1.0, 33.5, 0.5):
+            pts.append([x, y])
+    pts = np.asarray(pts, dtype=np.float64)
+    assert np.array_equal(pts, pts.astype(np.float32).astype(np.float64))  # every input is exactly representable in fp32
+    h = np.array([mva_or_neg(asp, float(p[0]), float(p[1])) for p in pts], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "g8_tiebreak.npz"), pts=pts, h=h,
+                        rings=json.dumps([[list(map(float, q)) for q in p] for p, _ in DYADIC_MVAS]),
+                        heights=np.array([hh for _, hh in DYADIC_MVAS], dtype=np.int32),
+                        runway=np.array([16.0, 10.0, 0.0, 180.0]))
+    return pts, h
+
+
+# ----------------------------------------------------------------------------------------------- G9
+class DyadicScenario(ref_scen.Scenario):
+    def __init__(self):
+        self.mvas, self.runway, self.airspace = dyadic_world()
+        self.entrypoints = [ref_model.EntryPoint(2, 30, 90, [150])]
+
+
+class WideRecorder:
+    """Compact recorder: every step keeps flags / done / actions_taken / reward, every `stride`-th step and the last step of
+    an episode also keep the observation and the float64 state."""
+
+    def __init__(self, stride=16):
+        self.stride = stride
+        self.ep = []
+        self.flags, self.done, self.acts, self.reward = [], [], [], []
+        self.samp_rows, self.obs, self.state = [], [], []
+        self.act_rows, self.act_vals = [], []
+
+    def run(self, env, actions, scen, dt, shaping, normalize, discrete, init_state=None, init_timesteps=None,
+            extra_after_done=0):
+        env.reset()
+        ap = env._airplane
+        if init_state is not None:
+            ap.x, ap.y, ap.h, ap.phi, ap.v = [float(v) for v in init_state]
+        if init_timesteps is not None:
+            env.timesteps = int(init_timesteps)
+        start = len(self.flags)
+        ep = dict(scen=scen, dt=float(dt), shaping=bool(shaping), normalize=bool(normalize), discrete=bool(discrete),
+                  init_state=[float(ap.x), float(ap.y), float(ap.h), float(ap.phi), float(ap.v)],
+                  init_timesteps=int(env.timesteps), init_last_action=[float(v) for v in env.last_action], start=start)
+        n, after, prev = 0, -1, None
+        for a in actions:
+            a64 = np.asarray(a, dtype=np.float64)
+            den = [env._denormalized_action(float(a64[i]), i) for i in range(3)]
+            flags = 0
+            if den[0] < ap.v_min or den[0] > ap.v_max:
+                flags |= F_INVALID_V
+            if den[1] < ap.h_min or den[1] > ap.h_max:
+                flags |= F_INVALID_H
+            obs, rew, done, info = env.step(a64)
+            m = mva_or_neg(env._airspace, ap.x, ap.y)
+            if m < 0:
+                flags |= F_OUTSIDE
+            elif ap.h < m:
+                flags |= F_BELOW_MVA
+            if env._runway.inside_corridor(ap.x, ap.y, ap.h, ap.phi):
+                flags |= F_WON
+            if env.timesteps > env.timestep_limit:
+                flags |= F_TIMEOUT
+            assert bool(flags & (F_OUTSIDE | F_BELOW_MVA | F_WON | F_TIMEOUT)) == bool(done)
+            row = start + n
+            if prev is None or not np.array_equal(prev, a64):
+                self.act_rows.append(row)
+                self.act_vals.append(a64.copy())
+                prev = a64
+            self.flags.append(flags)
+            self.done.append(int(done))
+            self.acts.append(int(env.actions_taken))
+            self.reward.append(float(rew))
+            n += 1
+            if done and after < 0:
+                after = extra_after_done
+            last = (after == 0)
+            if n % self.stride == 0 or done or last:
+                self.samp_rows.append(row)
+                self.obs.append(np.asarray(obs, dtype=np.float32))
+                self.state.append([ap.x, ap.y, ap.h, ap.phi, ap.v])
+            if after == 0:
+                break
+            if after > 0:
+                after -= 1
+        ep["steps"] = n
+        ep["total_reward"] = float(env.total_reward)
+        self.ep.append(ep)
+        return n
+
+    def save(self, path):
+        np.savez_compressed(
+            path, episodes=json.dumps(self.ep), flags=np.asarray(self.flags, dtype=np.uint8),
+            done=np.asarray(self.done, dtype=np.uint8), actions_taken=np.asarray(self.acts, dtype=np.int32),
+            reward=np.asarray(self.reward, dtype=np.float64).astype(np.float32),
+            samp_rows=np.asarray(self.samp_rows, dtype=np.int64), obs=np.asarray(self.obs, dtype=np.float32),
+            state=np.asarray(self.state, dtype=np.float64), act_rows=np.asarray(self.act_rows, dtype=np.int64),
+            act_vals=np.asarray(self.act_vals, dtype=np.float64).astype(np.float32))
+
+
+def interior_states(rng, scen_env, n, h_lo, h_hi):
+    """Random aircraft states strictly inside the airspace (rejection sampling against the reference's own lookup)."""
+    x0, y0, x1, y1 = scen_env._airspace.get_bounding_box()
+    out = []
+    while len(out) < n:
+        x, y = float(np.float32(rng.uniform(x0, x1))), float(np.float32(rng.uniform(y0, y1)))
+        m = mva_or_neg(scen_env._airspace, x, y)
+        if m < 0:
+            continue
+        out.append((x, y, float(np.float32(max(m + 500.0, rng.uniform(h_lo, h_hi)))), float(rng.integers(0, 360)),
+                    float(rng.integers(150, 280))))
+    return out
+
+
+def gen_g9():
+    rec = WideRecorder()
+    nvec = np.array([20, 380, 360])
+
+    def batch(scen, n_eps, seed0, horizon, hold, dt=1, shaping=True, normalize=True, discrete=False, tweak=None,
+              inits=None, init_t=None, extra=0):
+        env = make_env(scen, dt=dt, shaping=shaping, normalize=normalize, discrete=discrete)
+        for k in range(n_eps):
+            rng = np.random.default_rng(seed0 + k)
+            acts = hold_actions(rng, horizon, hold, discrete, nvec)
+            if tweak is not None:
+                acts = tweak(acts, rng)
+            rec.run(env, acts, scen, dt, shaping, normalize, discrete,
+                    init_state=None if inits is None else inits[k], init_timesteps=None if init_t is None else init_t(k),
+                    extra_after_done=extra)
+
+    random.seed(11)
+    batch("LOWW", 260, 10000, 6100, 20)
+    batch("LOWW_random", 260, 20000, 6100, 20)
+    batch("LOWW_random", 60, 21000, 3100, 10, dt=2, discrete=True)
+    batch("LOWW_random", 60, 22000, 1300, 4, dt=5, discrete=True)
+    batch("LOWW", 80, 23000, 6100, 20, discrete=True)
+    batch("LOWW_random", 80, 24000, 6100, 20, shaping=False, normalize=False)
+    batch("LOWW_random", 40, 24500, 6100, 20, shaping=False)
+    batch("LOWW_random", 40, 24600, 6100, 20, normalize=False)
+
+    def low(acts, rng):   # low altitude targets -> below-MVA terminals
+        acts = acts.copy()
+        acts[:, 1] = f32(-1.0 + 0.14 * (acts[:, 1] + 1.0) * 0.5)
+        return acts
+    batch("LOWW_random", 90, 25000, 6100, 20, tweak=low)
+    batch("LOWW", 40, 26000, 6100, 20, tweak=lambda a, r: f32(a * 1.06))   # invalid targets now and then
+
+    # wins: randomised starts on the LOWW intercept, heading held, descending through the glide path; some of them are
+    # stepped on past `done` (the aircraft keeps flying and can win again, quirk Q9)
+    base = [(48.9, 31.9, 3300.0, 345.0, 200.0), (47.0, 32.0, 3400.0, 10.0, 220.0), (50.6, 33.2, 3200.0, 310.0, 180.0),
+            (49.2, 30.5, 5000.0, 340.0, 250.0), (46.2, 31.8, 3600.0, 20.0, 250.0), (51.3, 33.0, 2900.0, 300.0, 160.0)]
+    env = make_env()
+    rng = np.random.default_rng(27000)
+    for k in range(120):
+        b = base[k % len(base)]
+        st = (float(np.float32(b[0] + rng.uniform(-0.25, 0.25))), float(np.float32(b[1] + rng.uniform(-0.25, 0.25))),
+              float(np.float32(b[2] + rng.uniform(-150, 150))), float(np.round(b[3] + rng.uniform(-4, 4))),
+              float(np.round(b[4] + rng.uniform(-20, 20))))
+        a = f32([2.0 * (st[4] - 100.0) / 200.0 - 1.0, 2.0 * 2700.0 / 38000.0 - 1.0, 2.0 * st[3] / 360.0 - 1.0])
+        rec.run(env, np.tile(a, (700, 1)), "LOWW", 1, True, True, False, init_state=st,
+                init_timesteps=int(rng.integers(0, 5800)), extra_after_done=(25 if k % 4 == 0 else 0))
+    # timeouts (timestep counter close to the limit)
+    batch("LOWW_random", 70, 28000, 60, 5, init_t=lambda k: 5975 + (k % 25))
+    # stepping on past other terminals
+    batch("LOWW", 12, 28500, 6100, 20, extra=40)
+    # SimpleScenario / the reference's unit-test world / the dyadic tie-break sector, from interior states
+    for scen, seed0 in (("Simple", 29000), ("UnitTest", 30000), ("Dyadic", 31000)):
+        env0 = make_env(scen)
+        inits = interior_states(np.random.default_rng(seed0), env0, 90, 8500.0, 12000.0)
+        batch(scen, 90, seed0 + 100, 3000, 20, inits=inits)
+    rec.save(os.path.join(HERE, "g9_wide.npz"))
+    return rec
+
+
 # ------------------------------------------------------------------------- reference unit-test known answers
 def gen_model_test():
     """Inputs and expected outputs of envs/atc/model_test.py:10-92, re-evaluated here against the reference."""
@@ -519,7 +732,7 @@ def gen_model_test():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "mt"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "mt", "g8", "g9"]
     if "g1" in which:
         gen_g1()
     if "mt" in which:
@@ -542,4 +755,13 @@ if __name__ == "__main__":
             print(name, int(((fl & bit) != 0).sum()), "terminal:", int((((fl & bit) != 0) & (dn != 0)).sum()))
     if "g7" in which:
         gen_g7()
+    if "g8" in which:
+        pts, h = gen_g8()
+        print("g8 points", len(pts), "heights", sorted(set(h.tolist())))
+    if "g9" in which:
+        r = gen_g9()
+        fl, dn = np.asarray(r.flags), np.asarray(r.done)
+        print("g9 episodes", len(r.ep), "steps", len(fl), "sampled rows", len(r.samp_rows))
+        for name, bit in (("below", 1), ("outside", 2), ("won", 4), ("timeout", 8), ("inv_v", 16), ("inv_h", 32)):
+            print(name, int(((fl & bit) != 0).sum()), "terminal:", int((((fl & bit) != 0) & (dn != 0)).sum()))
     print("done")

@@ -45,6 +45,16 @@ def make_scenario(name):
         s.runway = model.Runway(20, 20, 0, 180)
         s.airspace = model.Airspace(s.mvas, s.runway)
         return s
+    if name == "Dyadic":  # tie-break sector of tests/golden/g8_tiebreak.npz (integer / dyadic vertices, shared borders)
+        g = golden_npz("g8_tiebreak.npz")
+        s = scenarios.Scenario()
+        rings, heights = json.loads(str(g["rings"])), g["heights"]
+        s.mvas = [model.MinimumVectoringAltitude([tuple(p) for p in ring], int(h)) for ring, h in zip(rings, heights)]
+        s.runway = model.Runway(*[float(v) for v in g["runway"]])
+        s.airspace = model.Airspace(s.mvas, s.runway)
+        s.entrypoints = [model.EntryPoint(2, 30, 90, [150])]
+        s.noise_areas = []
+        return s
     raise KeyError(name)
 
 
@@ -76,3 +86,86 @@ def replay_episode(adapter, npz, ep, check, max_steps=None):
         rec = adapter.step(npz["action"][s + t])
         check(t, s + t, rec)
     return n
+
+
+# ---------------------------------------------------------------------------------------------- compact wide fixture (g9)
+class WideFixture:
+    """tests/golden/g9_wide.npz: per-step flags / done / actions_taken / reward of every reference step, observation and
+    float64 state on sampled rows, actions stored at their change points."""
+
+    def __init__(self, name="g9_wide.npz"):
+        z = golden_npz(name)
+        self.episodes = json.loads(str(z["episodes"]))
+        self.flags, self.done, self.actions_taken = z["flags"], z["done"], z["actions_taken"]
+        self.reward = z["reward"].astype(np.float64)
+        self.samp_rows, self.obs, self.state = z["samp_rows"], z["obs"], z["state"]
+        n = len(self.flags)
+        idx = np.zeros(n, np.int64)          # forward-fill the action change points
+        idx[z["act_rows"]] = np.arange(len(z["act_rows"]))
+        idx = np.maximum.accumulate(idx)
+        self.action = z["act_vals"][idx]
+        self.samp_index = np.full(n, -1, np.int64)
+        self.samp_index[self.samp_rows] = np.arange(len(self.samp_rows))
+
+    def groups(self):
+        out = {}
+        for ep in self.episodes:
+            out.setdefault((ep["scen"], ep["dt"], ep["shaping"], ep["normalize"], ep["discrete"]), []).append(ep)
+        return out
+
+
+FAF_RADIUS = 0.25   # [nm] see replay_wide
+
+
+def replay_wide(fx, make_backend, obs_tol, state_tol, rew_tol, max_envs=4096):
+    """Runs every episode of the wide fixture through a lock-step backend (the episodes of one configuration side by
+    side as the envs of one batch).  make_backend(scen, dt, shaping, normalize, discrete, B) returns an object with
+    place(b, init_state, init_timesteps, init_last_action) and step(actions[B,1,3]) -> (obs[B,10], reward[B], done[B],
+    flags[B], actions_taken[B], state[B,5]).  Integer outputs are compared exactly on EVERY reference step.
+
+    Stated exception to the 1e-5 bar (fp32 backends only; the float64 oracle never needs it): the bearing to the FAF
+    (obs[8], atc_gym.py:289-292) and the shaping terms built on it are ILL-CONDITIONED next to the FAF — a position error e
+    moves the bearing by e / d_faf radians.  Any fp32 displacement path is ~1e-6 nm off the float64 reference after a
+    few hundred steps, i.e. beyond 1e-5 once d_faf < ~0.1 nm.  Inside FAF_RADIUS the tolerance of the reward and of obs[8]
+    is scaled by FAF_RADIUS / d_faf; everywhere else it is the plain bar.  Returns (steps, steps inside the radius)."""
+    total, near = 0, 0
+    for (scen, dt, shaping, normalize, discrete), eps in fx.groups().items():
+        half = 0.5 * compiled(scen).norm_max.astype(np.float64)
+        faf = np.asarray(compiled(scen).corridor["faf"], dtype=np.float64)
+        for lo in range(0, len(eps), max_envs):
+            ge = eps[lo:lo + max_envs]
+            B = len(ge)
+            be = make_backend(scen, dt, shaping, normalize, discrete, B)
+            for b, ep in enumerate(ge):
+                be.place(b, ep["init_state"], ep["init_timesteps"], ep["init_last_action"])
+            steps = np.array([ep["steps"] for ep in ge])
+            starts = np.array([ep["start"] for ep in ge])
+            for t in range(int(steps.max())):
+                live = t < steps
+                rows = np.where(live, starts + t, starts)
+                obs, rew, done, flags, acts, state = be.step(fx.action[rows].astype(np.float32).reshape(B, 1, 3))
+                lr = rows[live]
+                assert np.array_equal(np.asarray(flags)[live].astype(np.uint8), fx.flags[lr]), (scen, t)
+                assert np.array_equal(np.asarray(done)[live].astype(np.uint8), fx.done[lr]), (scen, t)
+                assert np.array_equal(np.asarray(acts)[live], fx.actions_taken[lr]), (scen, t)
+                gw = fx.reward[lr]
+                st = np.asarray(state, dtype=np.float64)[live]
+                d_faf = np.hypot(faf[0] - st[:, 0], faf[1] - st[:, 1])
+                cond = np.maximum(1.0, FAF_RADIUS / np.maximum(d_faf, 1e-9))   # 1 outside the radius
+                near += int((cond > 1.0).sum())
+                # the fixture stores rewards as float32 (6e-8 relative)
+                assert np.all(np.abs(np.asarray(rew, dtype=np.float64)[live] - gw)
+                              <= (rew_tol * cond + 1e-7) * np.maximum(1.0, np.abs(gw))), (scen, t)
+                si = fx.samp_index[lr]
+                has = si >= 0
+                if has.any():
+                    go = fx.obs[si[has]].astype(np.float64)
+                    tol = (obs_tol if normalize else obs_tol * half) * np.ones((int(has.sum()), 10))
+                    tol[:, 8] *= cond[has]
+                    assert np.all(np.abs(np.asarray(obs, dtype=np.float64)[live][has] - go) <= tol), (scen, t)
+                    gs = fx.state[si[has]]
+                    assert np.all(np.abs(st[has] - gs) <= state_tol * np.maximum(1.0, np.abs(gs))), (scen, t)
+                total += int(live.sum())
+            be.close()
+    assert total == len(fx.flags)
+    return total, near

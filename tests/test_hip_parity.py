@@ -157,6 +157,17 @@ def test_shaping_golden():
     assert np.max(np.abs(out[:, 2] - g["gs"])) <= 1e-5
 
 
+@pytest.mark.parametrize("grid_cell", [None, 0.25, 0.5, 1.0])
+def test_tiebreak_points_exact(grid_cell):
+    """G8: sector with integer / dyadic vertices (the fp32 blob holds exactly the reference's polygons): vertices, edge
+    points, shared borders, overlapping polygons and points 2^-10 nm either side of every edge must get the REFERENCE's
+    answer (model.py:282-289,318-337), with the ordered scan and through every lookup grid."""
+    g = H.golden_npz("g8_tiebreak.npz")
+    s = _sector("Dyadic", grid_cell)
+    got = s.query_mva(g["pts"][:, 0], g["pts"][:, 1], use_grid=grid_cell is not None)
+    assert np.array_equal(got, g["h"])
+
+
 # ------------------------------------------------------------------------------------------------ trajectories (G2, G6)
 class HipGymAdapter:
     """Replays golden episodes through the single-env AtcGym mirror (what a user of the reference would call)."""
@@ -251,7 +262,7 @@ def test_golden_rollouts_batched(fixture):
         B = len(geps)
         sp = model.SimParameters(dt, reward_shaping=shaping, normalize_state=normalize, discrete_action_space=discrete)
         env = AtcVecEnv(B, 1, sim_parameters=sp, scenario=H.make_scenario(scen), auto_reset=False, spawn="lattice",
-                        want_raw_obs=True)
+                        want_raw_obs=True, keep_active=True)   # the reference's aircraft is never handed over
         half_range = torch.as_tensor(0.5 * H.compiled(scen).norm_max.astype(np.float64))
         for b, ep in enumerate(geps):
             env.set_state(b, 0, *ep["init_state"])
@@ -284,6 +295,71 @@ def test_golden_rollouts_batched(fixture):
             total += int(live.sum())
         env.close()
     assert total == len(npz["reward"])
+
+
+class _HipLockstep:
+    def __init__(self, scen, dt, shaping, normalize, discrete, B):
+        from atc_hip.vec_env import AtcVecEnv
+        from envs.atc import model
+        sp = model.SimParameters(dt, reward_shaping=shaping, normalize_state=normalize, discrete_action_space=discrete)
+        self.env = AtcVecEnv(B, 1, sim_parameters=sp, scenario=H.make_scenario(scen), auto_reset=False, spawn="lattice",
+                             keep_active=True)
+
+    def place(self, b, init_state, init_timesteps, init_last_action):
+        self.env.set_state(b, 0, *init_state)
+        self.env.timesteps[b] = init_timesteps
+        self.env.set_last_action(b, 0, init_last_action)
+
+    def step(self, actions):
+        e = self.env
+        torch = e.torch
+        obs, rew, done, info = e.step(actions)
+        pack = torch.cat([obs.double(), rew.double()[:, None], done.double()[:, None], info["flags"].double(),
+                          e.actions_taken.double()[:, None], e.x[:, None], e.y[:, None], e.h.double()[:, None],
+                          e.phi.double()[:, None], e.v.double()[:, None]], dim=1).cpu().numpy()   # one device->host hop
+        return pack[:, :10], pack[:, 10], pack[:, 11], pack[:, 12], pack[:, 13].astype(np.int64), pack[:, 14:19]
+
+    def close(self):
+        self.env.close()
+
+
+def test_wide_fixture_batched():
+    """G9: 650 963 reference steps (LOWW / random entries / Simple / UnitTest / Dyadic, dt 1-2-5, discrete, shaping and
+    normalisation off, >= 50 wins / MVA busts / timeouts, episodes stepped on past done) replayed through the batched
+    kernel: every integer output of every step exact, rewards and sampled observations within 1e-5 (stated near-FAF
+    exception: helpers.replay_wide)."""
+    fx = H.WideFixture()
+    n, near = H.replay_wide(fx, _HipLockstep, obs_tol=1e-5, state_tol=2e-5, rew_tol=1e-5)
+    assert n == len(fx.flags) > 500000 and near < 2e-3 * n
+
+
+def test_atcgym_keeps_flying_after_a_win():
+    """The reference has no inactive state (atc_gym.py:128-192): stepping on after a win without reset keeps simulating
+    the aircraft, which can win again (learning/atc-gym-compute-performance.py never resets).  Checked against the g9
+    episodes that were stepped on past a win."""
+    from envs.atc import atc_gym
+    fx = H.WideFixture()
+    eps = [ep for ep in fx.episodes if ep["scen"] == "LOWW" and ep["normalize"] and not ep["discrete"] and ep["dt"] == 1.0
+           and ep["shaping"] and fx.done[ep["start"]:ep["start"] + ep["steps"] - 1].any()
+           and (fx.flags[ep["start"]:ep["start"] + ep["steps"]] & H.F_WON).any()][:6]
+    assert len(eps) >= 3
+    env = atc_gym.AtcGym()
+    for ep in eps:
+        env.reset()
+        ap = env._airplane
+        ap.x, ap.y, ap.h, ap.phi, ap.v = ep["init_state"]
+        env._vec.timesteps[0] = ep["init_timesteps"]
+        env.timesteps = ep["init_timesteps"]
+        wins = 0
+        for t in range(ep["steps"]):
+            row = ep["start"] + t
+            obs, rew, done, info = env.step(fx.action[row])
+            assert done == bool(fx.done[row]) and env.actions_taken == int(fx.actions_taken[row]), (t, done)
+            gw = float(fx.reward[row])
+            assert abs(rew - gw) <= 2e-5 * max(1.0, abs(gw)), (t, rew, gw)   # 1e-5 + the fixture's float32 storage
+            wins += int(done and rew > 9000)
+        assert wins >= 2          # it won, kept flying inside the corridor and won again
+    env.close()
 
 
 # ------------------------------------------------------------------------------------------------ batched vs fp32 oracle
