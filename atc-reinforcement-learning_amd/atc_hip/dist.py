@@ -24,7 +24,11 @@ def init(backend=None):
     if backend == "nccl":
         # one process per GPU: bind before the communicator is created.  If the launcher narrowed the visible devices to one
         # per rank (HIP_VISIBLE_DEVICES), LOCAL_RANK exceeds the device count and the rank's GPU is device 0.
-        local = local % max(1, torch.cuda.device_count())
+        n_dev = torch.cuda.device_count()
+        if local >= n_dev:
+            if n_dev != 1:
+                raise RuntimeError("LOCAL_RANK %d but only %d visible devices: one process per GPU" % (local, n_dev))
+            local = 0
         torch.cuda.set_device(local)
     if ws > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -49,6 +53,9 @@ def rank_seed(seed, rank):
     return (int(seed) + 0x9E3779B97F4A7C15 * (rank + 1)) & (2 ** 64 - 1) if rank else int(seed)
 
 
+_equal_shards_checked = set()
+
+
 def all_gather_stats(*tensors):
     """All-gathers equally-shaped per-env tensors from every rank into [world, ...] tensors (one collective each).
     Identity (with a leading axis of 1) when not distributed."""
@@ -59,6 +66,15 @@ def all_gather_stats(*tensors):
     out = []
     for t in tensors:
         src = t.contiguous()
+        if src.shape[0] not in _equal_shards_checked:
+            # all_gather_into_tensor needs equal shards (shard_range() gives them only when ws divides the env count):
+            # checked once per shard size, not on every gather
+            _equal_shards_checked.add(src.shape[0])
+            n = torch.tensor([src.shape[0]], dtype=torch.int64, device="cpu" if host_staged else src.device)
+            lo, hi = n.clone(), n.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert int(lo) == int(hi), "all_gather_stats needs equally sized shards on every rank (%d..%d)" % (int(lo), int(hi))
         if host_staged and src.is_cuda:
             src = src.cpu()
         g = torch.empty((ws * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)

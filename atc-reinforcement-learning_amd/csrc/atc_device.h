@@ -163,6 +163,10 @@ __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const fl
             *height = cell.y;
             return -n - 1;
         }
+#ifdef ATC_ABLATE_WALK
+        *height = 3000.0f;  // developer-only timing ablation: dirty cells answered without walking their edge list
+        return 1;
+#endif
         // Records are fetched in batches of kBatch (both 16-byte halves of each, all loads issued before the first use):
         // one L2 round trip per batch instead of one per record.  Indices past the list are clamped (loads stay in
         // bounds) and their records ignored.

@@ -92,6 +92,97 @@ def cpu_baseline(n_aircraft, seconds_target=12.0):
     return out
 
 
+def parity_gate(scn, N, grid_cell, sep_nm, device):
+    """correctness gate of every timed run, executed BEFORE the timed region on rank 0.
+    (a) reference fixtures: the scripted LOWW episodes of tests/golden/g2_scripted.npz (captured from the imported reference)
+        replayed through the batched kernel — flags / done / counters exact, obs and rewards within 1e-5;
+    (b) this run's own workload: its first 256 envs x 40 steps against the fp32 CPU oracle (the checker, never the thing
+        measured) — flags / done exact, obs and rewards within 1e-5.
+    Raises if the gate fails: a number measured on wrong results is not a number."""
+    import numpy as np
+    import torch
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import model, scenarios
+    from oracle import oracle as O
+    out = {}
+    # (a) golden fixture
+    z = np.load(os.path.join(ROOT, "tests", "golden", "g2_scripted.npz"), allow_pickle=False)
+    eps = [e for e in json.loads(str(z["episodes"])) if e["scen"] == "LOWW" and e["dt"] == 1.0 and e["shaping"]
+           and e["normalize"] and not e["discrete"]]
+    env = AtcVecEnv(len(eps), 1, sim_parameters=model.SimParameters(1), scenario=scenarios.LOWW(), device=device,
+                    auto_reset=False, spawn="lattice", keep_active=True, grid_cell=grid_cell)
+    for b, e in enumerate(eps):
+        env.set_state(b, 0, *e["init_state"])
+        env.timesteps[b] = e["init_timesteps"]
+        env.set_last_action(b, 0, e["init_last_action"])
+    steps = np.array([e["steps"] for e in eps])
+    starts = np.array([e["start"] for e in eps])
+    n_steps, worst_o, worst_r = 0, 0.0, 0.0
+    for t in range(int(steps.max())):
+        live = t < steps
+        rows = np.where(live, starts + t, starts)
+        obs, rew, done, info = env.step(z["action"][rows].astype(np.float32).reshape(-1, 1, 3))
+        lr = rows[live]
+        ok = (np.array_equal(info["flags"].cpu().numpy()[live, 0].astype(np.uint32), z["flags"][lr])
+              and np.array_equal(done.cpu().numpy()[live], z["done"][lr])
+              and np.array_equal(env.actions_taken.cpu().numpy()[live], z["actions_taken"][lr]))
+        if not ok:
+            raise RuntimeError("parity gate (a): integer outputs differ from the reference fixture at step %d" % t)
+        worst_o = max(worst_o, float(np.abs(obs.cpu().numpy()[live].astype(np.float64) - z["obs"][lr]).max()))
+        gw = z["reward"][lr]
+        worst_r = max(worst_r, float((np.abs(rew.cpu().numpy()[live] - gw) / np.maximum(1.0, np.abs(gw))).max()))
+        n_steps += int(live.sum())
+    env.close()
+    if worst_o > 1e-5 or worst_r > 1e-5:
+        raise RuntimeError("parity gate (a): obs %.2e / reward %.2e beyond 1e-5" % (worst_o, worst_r))
+    out["reference_fixture"] = {"fixture": "tests/golden/g2_scripted.npz", "episodes": len(eps), "steps": n_steps,
+                                "integer_outputs_exact": True, "max_obs_err": worst_o, "max_rel_reward_err": worst_r}
+    # (b) this workload vs the fp32 oracle
+    B, T = 256, 40
+    comp = scenarios.compile_scenario(scn, grid_cell=grid_cell)
+    env = AtcVecEnv(B, N, scenario=scn, device=device, auto_reset=True, seed=0, grid_cell=grid_cell, sep_nm=sep_nm)
+    orc = O.OracleEnv(comp, B, N, O.make_params(auto_reset=True, seed=0, random_entry=bool(env.params.mode & 16),
+                                                sep_nm=sep_nm), np.float32)
+    g = torch.Generator(device="cpu").manual_seed(99)
+    worst_o = worst_r = 0.0
+    for t in range(T):
+        if t % HOLD == 0:
+            a = (torch.rand((B, N, 3), generator=g) * 2 - 1).numpy()
+        obs, rew, done, info = env.step(a)
+        orc.step(a)
+        if not (np.array_equal(info["flags"].cpu().numpy().astype(np.uint16), orc.flags)
+                and np.array_equal(done.cpu().numpy(), orc.done)):
+            raise RuntimeError("parity gate (b): flags / done differ from the fp32 oracle at step %d" % t)
+        o = obs.cpu().numpy().reshape(B, N, 10)
+        worst_o = max(worst_o, float((np.abs(o - orc.obs) / np.maximum(1.0, np.abs(orc.obs))).max()))
+        worst_r = max(worst_r, float((np.abs(rew.cpu().numpy() - orc.reward) / np.maximum(1.0, np.abs(orc.reward))).max()))
+    env.close()
+    if worst_o > 1e-5 or worst_r > 1e-5:
+        raise RuntimeError("parity gate (b): obs %.2e / reward %.2e beyond 1e-5" % (worst_o, worst_r))
+    out["fp32_oracle"] = {"envs": B, "aircraft": N, "steps": T, "flags_done_exact": True, "max_rel_obs_err": worst_o,
+                          "max_rel_reward_err": worst_r}
+    return out
+
+
+def single_env_protocol(n_steps=100000):
+    """The reference's own benchmark (learning/atc-gym-compute-performance.py:10-19): ONE env, 100 000 x step(one fixed
+    sampled action), no reset on done, FPS = N / wall time — through the drop-in envs.atc.atc_gym.AtcGym."""
+    import numpy as np
+    from envs.atc import atc_gym
+    env = atc_gym.AtcGym()
+    env.reset()
+    action = np.random.default_rng(0).uniform(-1, 1, 3).astype(np.float32)
+    for _ in range(200):
+        env.step(action)
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        env.step(action)
+    dt = time.perf_counter() - t0
+    env.close()
+    return {"protocol": "learning/atc-gym-compute-performance.py:10-19 (1 env x 1 aircraft, one fixed action, no reset)",
+            "steps": n_steps, "steps_per_s": n_steps / dt, "us_per_step": dt / n_steps * 1e6}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +191,9 @@ def main():
     ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU")
     ap.add_argument("--aircraft", type=int, default=AIRCRAFT)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-gate", action="store_true", help="developer knob: skip the pre-timing correctness gate")
+    ap.add_argument("--no-single-env", action="store_true", help="skip the single-env compute-performance.py protocol")
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; value = the median block")
     ap.add_argument("--grid-cell", type=float, default=0.5, help="cell size [nm] of the MVA lookup grid")
     ap.add_argument("--rollout", type=int, default=0, help="fuse this many steps per launch (0 = one launch per step)")
     ap.add_argument("--sep-nm", type=float, default=3.0, help="developer knob: separation minimum (0 disables conflicts)")
@@ -138,7 +232,9 @@ def main():
     rank, ws, local = D.init()
     assert ws == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (ws, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs the GPU (no CPU fallback)"
-    local = local % torch.cuda.device_count()  # == LOCAL_RANK on a real node; lets ATC_DIST_BACKEND=gloo share one GPU
+    if local >= torch.cuda.device_count():  # only when ATC_DIST_BACKEND=gloo lets several ranks share the one visible GPU
+        assert torch.cuda.device_count() == 1, "LOCAL_RANK %d >= %d visible devices" % (local, torch.cuda.device_count())
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     B, N, K, W = args.envs, args.aircraft, args.steps, args.warmup
@@ -211,32 +307,40 @@ def main():
             return env.ep_return, env.ep_length
         return torch.cat([e.ep_return for e in subs]), torch.cat([e.ep_length for e in subs])
 
+    gate = None
+    if rank == 0 and not args.no_parity_gate:
+        gate = parity_gate(scn, N, args.grid_cell, args.sep_nm, local)   # raises if results are wrong
+
     run(W, 0)
     torch.cuda.synchronize(dev)
     D.all_gather_stats(*stats())  # untimed: creates the RCCL communicator / channels (N > 1)
     torch.cuda.synchronize(dev)
-    D.barrier()
-    torch.cuda.synchronize(dev)
     # HIP events on the stream(s) the kernels are launched on (torch's current stream, or one per sub-batch)
     qs = streams if S > 1 else [torch.cuda.current_stream(dev)]
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in qs]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in qs]
-    t0 = time.perf_counter()
-    for e, q in zip(ev0, qs):
-        e.record(q)
-    run(K, W)
-    for e, q in zip(ev1, qs):
-        e.record(q)
-    torch.cuda.synchronize(dev)  # (sub-batch streams are joined here, before the statistics are gathered)
-    returns, lengths = D.all_gather_stats(*stats())  # the path's only exchange (RCCL, N > 1)
-    torch.cuda.synchronize(dev)
-    D.barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms_total = max(a.elapsed_time(b) for a, b in zip(ev0, ev1))
-    elapsed = D.max_over_ranks(elapsed, dev)
+    blocks = []   # (wall seconds, HIP-event milliseconds) of each timed block of K steps, max over ranks
+    for rep in range(max(1, args.repeats)):
+        D.barrier()
+        torch.cuda.synchronize(dev)
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in qs]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in qs]
+        t0 = time.perf_counter()
+        for e, q in zip(ev0, qs):
+            e.record(q)
+        run(K, W + rep * K)
+        for e, q in zip(ev1, qs):
+            e.record(q)
+        torch.cuda.synchronize(dev)  # (sub-batch streams are joined here, before the statistics are gathered)
+        returns, lengths = D.all_gather_stats(*stats())  # the path's only exchange (RCCL, N > 1)
+        torch.cuda.synchronize(dev)
+        D.barrier()
+        wall = time.perf_counter() - t0
+        blocks.append((D.max_over_ranks(wall, dev), D.max_over_ranks(max(a.elapsed_time(b) for a, b in zip(ev0, ev1)), dev)))
+    rank_seeds = D.all_gather_stats(torch.tensor([D.rank_seed(0, rank) & 0x7fffffffffffffff], dtype=torch.int64, device=dev))[0]
+    order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
+    elapsed, kernel_ms_total = blocks[order[len(order) // 2]]   # the median block
     T = args.rollout or 1
     n_launches = K // T
-    launch_ms = D.max_over_ranks(kernel_ms_total, dev) / n_launches   # average launch duration (HIP events)
+    launch_ms = kernel_ms_total / n_launches   # average launch duration (HIP events) of the median block
 
     episodes = D.sum_over_ranks(float(sum(e.episodes.sum().item() for e in subs)) - B, dev)
     value = ws * B * K / elapsed
@@ -267,7 +371,11 @@ def main():
                              if args.graph else ("%d sub-batches of %d envs on %d HIP streams, one launch per sub-batch per step "
                                                 "(atc_step_multi), no join between steps" % (S, B // S, S) if S > 1 else "one atc_step launch per step")), "parallelism": "env-sharded x%d, no step-path collective, "
                        "1 all-gather of episode returns per rollout" % ws,
-                       "episodes_finished": int(episodes), "positions": "32-bit fixed point (2^-25 nm grid)"},
+                       "episodes_finished": int(episodes), "positions": "32-bit fixed point (2^-25 nm grid)",
+                       "timed_blocks_ms_per_step": [b[0] / K * 1e3 for b in blocks], "timing": "median of %d timed blocks "
+                       "of %d steps, each bracketed by barrier + synchronize" % (len(blocks), K),
+                       "parity_gate": gate, "gathered_returns_shape": list(returns.shape),
+                       "rank_seeds": [int(v) for v in rank_seeds.reshape(-1).tolist()]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_step<%d, false, %s>" % (1 << max(0, (N - 1).bit_length()), "false" if args.rollout else "true"),
@@ -276,6 +384,8 @@ def main():
                          "note": "HIP events on the launch stream around the %d timed launches (includes inter-launch "
                                  "gaps)" % n_launches},
         }
+        if ws == 1 and not args.no_single_env:
+            line["config"]["single_env"] = single_env_protocol()
         if ws == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N)
         print(json.dumps(line))
