@@ -105,31 +105,39 @@ def _ring_edges(ring):
     return np.array([[a[0], a[1], b[0], b[1]] for a, b in e if a[1] != b[1]], dtype=np.float64).reshape(-1, 4)
 
 
-GRID_EDGE_WORDS = 8      # edge: p1x, p1y, p2x, p2y | min(p1y,p2y), max(p1y,p2y), max(p1x,p2x), 4 * polygon index + flags
-#                          terminator: polygon bounds x0, y0, x1, y1 | polygon height, 0, 0, 4 * polygon index + TERM
-GRID_F_TERM = 1.0        # terminator record of a polygon: evaluate the parity + bounds test now
+GRID_EDGE_WORDS = 8      # edge: p1x, p1y, p2x, p2y | min(p1y,p2y), max(p1y,p2y), polygon height, 16 * polygon index + flags
+#                          terminator: polygon bounds x0, y0, x1, y1 | 0, 0, polygon height, 16 * polygon index + flags
+GRID_F_TERM = 1.0        # terminator record: parity (+ base) and bounds test decide the polygon now
 GRID_F_CERTAIN = 2.0     # every point of the cell lies left of this edge: crossing needs no intersection test
+GRID_F_LAST = 4.0        # last edge of its polygon, whose bounds contain the whole cell: parity (+ base) decides now
+GRID_F_BASE = 8.0        # the polygon has an ODD number of edges that every point of the cell crosses (folded away)
+_BIG = 3.0e38
 
 
 def build_grid(rings, bounds, heights, bbox, cell, guard=None):
     """Uniform lookup grid for Airspace.find_mva (model.py:282-289) with IDENTICAL results to the ordered polygon scan.
 
-    * CLEAN cell: no edge of any MVA polygon comes within `guard` of it, so every point of the cell gets the answer of its
-      centre (evaluated here with the reference's rule); stored directly.
-    * DIRTY cell: an edge list.  The crossing test of the reference (y > min(p1y,p2y), y <= max(p1y,p2y),
-      x <= max(p1x,p2x), then x <= x-intersection) can only count an edge whose y-span meets the cell's y-span and whose
-      x-max is not left of the cell; all other edges contribute nothing for ANY point of the cell, so dropping them leaves
-      every crossing count — hence the result of ray_tracing — unchanged.  The device walks the listed edges polygon by
-      polygon (list order = priority) with the reference's own formula; each polygon's edges are followed by a terminator
-      record carrying its bounds (the inclusive bbox test of model.py:286) and its height, so the walk is self-contained.  Edges that lie entirely to the
-      right of the cell by more than 1e-3 nm are marked CERTAIN: x <= xints holds for every point of the cell whatever the
-      rounding of xints (which stays within a few ulps of [min(p1x,p2x), max(p1x,p2x)]), so the division is skipped.
+    * CLEAN cell: every point of the cell has the same answer; stored directly.
+    * DIRTY cell: an edge list, polygon by polygon in priority order.  For one polygon and one cell an edge of the ring is
+        - IRRELEVANT if one of the reference's three cheap tests (y > min(p1y,p2y), y <= max(p1y,p2y), x <= max(p1x,p2x),
+          model.py:328-330) fails for EVERY point of the cell: it can never be counted and is dropped;
+        - CONSTANT if all three hold for every point of the cell and the edge lies more than 1e-3 nm to the right of it
+          (then x <= x-intersection holds whatever the rounding): every point crosses it exactly once — only the PARITY of
+          the number of such edges matters and is folded into the polygon's BASE flag;
+        - CERTAIN if it lies more than 1e-3 nm to the right of the cell but its y-range covers the cell only partly: listed,
+          evaluated with the two y tests only;
+        - otherwise listed and evaluated with the reference's own formula (model.py:331-333).
+      Crossing parity of the listed edges xor BASE = result of ray_tracing over the full ring, for every point of the cell.
+      A polygon whose bounds (the inclusive test of model.py:286) contain the whole cell ends with its last edge (LAST);
+      otherwise a terminator record carries the bounds.  A polygon with no listed edge is dropped when BASE is even (no
+      point of the cell is inside it), and ends the list when BASE is odd and its bounds contain the cell (every point of
+      the cell is inside it: lower-priority polygons can never be reached) — if it is the first entry the cell is clean.
     Cell bounds are inflated by `slack` (guard + fp32 indexing error) so that a point the device bins into a neighbouring
     cell because of fp32 rounding is still covered.
 
     Layout (words): header[8] = x0, y0, inv_cell, nx, ny, offset of the edge pool (from grid start), n_records, 0;
     cells[ny*nx][2] = (n_records, first_record) for dirty cells, (-(polygon+1), MVA height) or (0, 0) for clean ones; pool of
-    8-word edge records."""
+    8-word records."""
     if guard is None:
         guard = 1e-3
     x0, y0, x1, y1 = bbox
@@ -156,7 +164,6 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None):
                         near[j, i] = True
     cells = np.zeros((ny, nx, 2), dtype=np.float64)
     pool = []
-    n_rec = 0
     for j in range(ny):
         cy0s = gy0 + j * cell - slack
         cy1s = gy0 + (j + 1) * cell + slack
@@ -169,7 +176,7 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None):
                 continue
             cx0s = gx0 + i * cell - slack
             cx1s = gx0 + (i + 1) * cell + slack
-            first = n_rec
+            recs = []
             for pi, (e, b) in enumerate(zip(edges, bounds)):
                 if b[2] < cx0s or b[0] > cx1s or b[3] < cy0s or b[1] > cy1s:
                     continue  # the (inclusive) bounds test of model.py:286 rejects every point of the cell
@@ -178,22 +185,37 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None):
                 xmin = np.minimum(e[:, 0], e[:, 2])
                 xmax = np.maximum(e[:, 0], e[:, 2])
                 rel = (cy1s > ymin) & (cy0s <= ymax) & (cx0s <= xmax)
-                idx = np.nonzero(rel)[0]
+                right = cx1s < xmin - 1e-3
+                const = rel & right & (cy0s > ymin) & (cy1s <= ymax)
+                base = GRID_F_BASE if int(const.sum()) & 1 else 0.0
+                idx = np.nonzero(rel & ~const)[0]
+                inside_bounds = b[0] <= cx0s and cx1s <= b[2] and b[1] <= cy0s and cy1s <= b[3]
                 if len(idx) == 0:
+                    if not base:
+                        continue              # no point of the cell is inside this polygon
+                    if inside_bounds:         # every point of the cell is inside it: nothing below it can be reached
+                        recs.append([-_BIG, -_BIG, _BIG, _BIG, 0.0, 0.0, heights[pi], 16.0 * pi + GRID_F_TERM + base])
+                        break
+                    recs.append([b[0], b[1], b[2], b[3], 0.0, 0.0, heights[pi], 16.0 * pi + GRID_F_TERM + base])
                     continue
-                certain = cx1s < xmin[idx] - 1e-3
+                certain = right[idx]
                 order = np.argsort(certain, kind="stable")  # intersection-test edges first: lanes diverge less
-                for k in order:
+                for pos, k in enumerate(order):
                     ek = e[idx[k]]
-                    pool.append([ek[0], ek[1], ek[2], ek[3], min(ek[1], ek[3]), max(ek[1], ek[3]), max(ek[0], ek[2]),
-                                 4.0 * pi + (GRID_F_CERTAIN if certain[k] else 0.0)])
-                    n_rec += 1
-                pool.append([b[0], b[1], b[2], b[3], heights[pi], 0.0, 0.0, 4.0 * pi + GRID_F_TERM])
-                n_rec += 1
-            cells[j, i, 0] = n_rec - first
-            cells[j, i, 1] = first
-            if n_rec == first:  # near an edge of a polygon whose bounds exclude the cell: nothing can match
-                cells[j, i, 1] = 0.0
+                    fl = GRID_F_CERTAIN if certain[k] else 0.0
+                    if inside_bounds and pos == len(order) - 1:
+                        fl += GRID_F_LAST + base
+                    recs.append([ek[0], ek[1], ek[2], ek[3], min(ek[1], ek[3]), max(ek[1], ek[3]), heights[pi], 16.0 * pi + fl])
+                if not inside_bounds:
+                    recs.append([b[0], b[1], b[2], b[3], 0.0, 0.0, heights[pi], 16.0 * pi + GRID_F_TERM + base])
+            if len(recs) == 1 and recs[0][0] == -_BIG:   # a single unconditional answer: the cell is clean after all
+                cells[j, i, 0] = -(recs[0][7] // 16 + 1.0)
+                cells[j, i, 1] = recs[0][6]
+                continue
+            cells[j, i, 0] = len(recs)
+            cells[j, i, 1] = len(pool) if recs else 0.0   # (0, 0): nothing can match = clean cell outside the airspace
+            pool.extend(recs)
+    n_rec = len(pool)
     hdr = np.zeros(L.G_HDR, dtype=np.float64)
     hdr[L.G_X0], hdr[L.G_Y0], hdr[L.G_INV], hdr[L.G_NX], hdr[L.G_NY] = gx0, gy0, inv, nx, ny
     off_pool = (L.G_HDR + cells.size + 3) & ~3  # edge records are read as 16-byte vectors

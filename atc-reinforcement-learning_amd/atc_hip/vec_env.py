@@ -241,12 +241,15 @@ class AtcVecEnv:
             info["terminal_observation"] = self.term_obs
         return info
 
-    def rollout(self, actions, out=None):
-        """T consecutive steps in one launch (state stays in registers).  actions: [T, B, N, 3].  Returns a dict of
-        [T, ...] device tensors (obs, reward, done, flags [+ optional outputs when `out` provides them])."""
+    def rollout(self, actions, out=None, hold=1):
+        """T consecutive steps in one launch (state stays in registers).  actions: [T / hold, B, N, 3]; each action block is
+        applied for `hold` consecutive steps (frame skip, learning/atc-gym-demo.py:18-19), so T = hold * actions.shape[0].
+        Returns a dict of [T, ...] device tensors (obs, reward, done, flags [+ optional outputs when `out` provides them])."""
         torch = self.torch
-        T = int(actions.shape[0])
-        a = self._as_actions(actions, lead=(T,))
+        hold = int(hold)
+        n_blocks = int(actions.shape[0])
+        T = n_blocks * hold
+        a = self._as_actions(actions, lead=(n_blocks,))
         B, N, dev = self.B, self.N, self.device
         if out is None:
             out = {
@@ -258,8 +261,8 @@ class AtcVecEnv:
         o = self._make_out(out["obs"], out.get("raw_obs"), out["reward"], out.get("ac_reward"), out["done"],
                            out["flags"], out.get("min_sep"), out.get("term_obs"))
         with torch.cuda.device(dev):
-            _lib.check(self._lib.atc_rollout(self.sector.handle, B, N, T, C.byref(self._state), self._ptr(a),
-                                             C.byref(o), C.byref(self.params), self._stream()))
+            _lib.check(self._lib.atc_rollout_hold(self.sector.handle, B, N, T, hold, C.byref(self._state), self._ptr(a),
+                                                  C.byref(o), C.byref(self.params), self._stream()))
         self._keep = a
         self._finish()
         return out

@@ -121,11 +121,12 @@ __device__ __forceinline__ bool ray_tracing(float x, float y, const float* ring,
 // below (polygon records, edge records) are L2/L1-resident gathers and sit on rare paths only.
 //
 // With the lookup grid (atc_hip/scenario.py:build_grid) a CLEAN cell answers directly (index + height in the cell) and
-// a DIRTY cell lists, polygon by polygon in priority order, exactly those edges the reference's crossing test could count
-// for some point of the cell; every other edge fails one of `y > min`, `y <= max`, `x <= max` for the whole cell, so
-// walking the list with the reference's formula yields the same crossing parity as ray_tracing over the full ring.
-// CERTAIN edges lie > 1e-3 nm to the right of the whole cell: x <= xints holds whatever the rounding of xints.
-// Each polygon's edges end with a terminator record holding its bounds (model.py:286) and height.
+// a DIRTY cell lists, polygon by polygon in priority order, those edges whose crossing depends on where in the cell the
+// point lies; edges that no point of the cell can cross are dropped, edges that every point of the cell crosses are
+// folded into the polygon's BASE parity — walking the list with the reference's formula and xor-ing BASE yields the
+// same parity as ray_tracing over the full ring.  CERTAIN edges lie > 1e-3 nm to the right of the whole cell:
+// x <= xints holds whatever the rounding of xints.  A polygon ends with its LAST edge (bounds contain the whole cell)
+// or with a terminator record holding its bounds (model.py:286).
 __device__ __forceinline__ bool in_bounds(const float* rec, float x, float y) {
     const float4 b = *reinterpret_cast<const float4*>(rec);  // minx, miny, maxx, maxy
     return b.x <= x && x <= b.z && b.y <= y && y <= b.w;
@@ -185,19 +186,28 @@ __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const fl
             for (int u = 0; u < kBatch; ++u) {
                 if (base + u < n) {
                     const int code = (int)m[u].w;
-                    if (code & ATC_GE_TERM) {  // g = polygon bounds, m.x = polygon height
-                        if (inside && g[u].x <= x && x <= g[u].z && g[u].y <= y && y <= g[u].w) {
-                            *height = m[u].x;
-                            return code >> 2;
+                    bool decide, ok = true;
+                    if (code & ATC_GE_TERM) {  // g = polygon bounds (model.py:286)
+                        decide = true;
+                        ok = g[u].x <= x && x <= g[u].z && g[u].y <= y && y <= g[u].w;
+                    } else {
+                        // the three cheap tests of model.py:328-330 (m.x / m.y = min / max of the edge's y, precomputed)
+                        if (y > m[u].x && y <= m[u].y && x <= fmaxf(g[u].x, g[u].z)) {
+                            bool cross = (code & ATC_GE_CERTAIN) != 0;
+                            if (!cross) {
+                                const float xints = (y - g[u].y) * (g[u].z - g[u].x) / (g[u].w - g[u].y) + g[u].x;
+                                cross = (g[u].x == g[u].z) || x <= xints;
+                            }
+                            inside = inside != cross;
+                        }
+                        decide = (code & ATC_GE_LAST) != 0;
+                    }
+                    if (decide) {
+                        if ((inside != ((code & ATC_GE_BASE) != 0)) && ok) {
+                            *height = m[u].z;
+                            return code >> 4;
                         }
                         inside = false;
-                    } else if (y > m[u].x && y <= m[u].y && x <= m[u].z) {  // the three cheap tests of model.py:328-330
-                        bool cross = (code & ATC_GE_CERTAIN) != 0;
-                        if (!cross) {
-                            const float xints = (y - g[u].y) * (g[u].z - g[u].x) / (g[u].w - g[u].y) + g[u].x;
-                            cross = (g[u].x == g[u].z) || x <= xints;
-                        }
-                        inside = inside != cross;
                     }
                 }
             }

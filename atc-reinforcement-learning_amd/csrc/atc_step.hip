@@ -81,15 +81,20 @@ constexpr int kBlock = ATC_BLOCK;
 #endif
 #if ATC_TRACE
 #define ATC_STAMP(n) do { if (lane == 0 && trace) trace[(size_t)(blockIdx.x * (kBlock / 64) + (tid >> 6)) * 8 + (n)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ATC_STAMP_B(n) do { unsigned long long* trace = so.trace; ATC_STAMP(n); } while (0)
 #else
 #define ATC_STAMP(n) do {} while (0)
+#define ATC_STAMP_B(n) do {} while (0)
 #endif
 #ifndef ATC_GRID_CAP
 #define ATC_GRID_CAP 8   // workgroups per CU before the reset / observe / query kernels grid-stride
 #endif
 #ifndef ATC_MIN_WAVES
-#define ATC_MIN_WAVES 4  // waves per SIMD the step kernel is register-budgeted for (<= 128 VGPRs)
+#define ATC_MIN_WAVES 4  // waves per SIMD the single-step kernel is register-budgeted for (<= 128 VGPRs; it needs 69-75)
 #endif
+#ifndef ATC_MIN_WAVES_LOOP
+#define ATC_MIN_WAVES_LOOP 6  // multi-step launches: <= 80 VGPRs.  Without the bound the allocator keeps literal constants and
+#endif                        // other loop invariants in registers across the step loop (86-99 VGPRs, 4-5 waves per SIMD)
 
 // ---------------------------------------------------------------------------------------------------------------
 // wavefront-group helpers (groups of W consecutive lanes, W a power of two <= 64)
@@ -287,12 +292,38 @@ struct Mid {            // what the first half of a step hands to the second
     float x32, y32;
     MvaCell cell;       // MVA lookup cell, gather issued in the first half, resolved after the separation scan
 };
+// Uniform products of the step parameters, evaluated ONCE on the host in fp32 (the same IEEE operations the kernel
+// would do) and passed as kernel arguments: gfx950 has no scalar float ALU, so computed in the kernel they would occupy
+// vector registers — and a multi-step launch would keep them there across its whole step loop.
+struct StepDerived {
+    float dv_hi, dv_lo;   // kAMax * dt, kAMin * dt           (model.py:47-48,75-78)
+    float dh_hi, dh_lo;   // kHDotMax * dt, kHDotMin * dt     (model.py:45-46,97-100)
+    float dp_hi, dp_lo;   // kPhiDotMax * dt, kPhiDotMin * dt (model.py:49-50,113-120)
+    float r_base;         // -0.05 * dt                       (atc_gym.py:137)
+    float sep2;           // sep_nm ^ 2
+};
+static StepDerived derive(const atc_params_t& p) {
+    StepDerived q;
+    q.dv_hi = kAMax * p.dt;
+    q.dv_lo = kAMin * p.dt;
+    q.dh_hi = kHDotMax * p.dt;
+    q.dh_lo = kHDotMin * p.dt;
+    q.dp_hi = kPhiDotMax * p.dt;
+    q.dp_lo = kPhiDotMin * p.dt;
+    q.r_base = -0.05f * p.dt;
+    q.sep2 = p.sep_nm * p.sep_nm;
+    return q;
+}
+
 struct StepOut {        // per-step output bases (uniform pointers)
     float* obs;
     uint16_t* flags;
     float* reward;
     uint8_t* done;
     float *raw_obs, *ac_reward, *min_sep, *term_obs;
+#if ATC_TRACE
+    unsigned long long* trace;
+#endif
 };
 
 template <int W>
@@ -319,8 +350,8 @@ __device__ __forceinline__ LaneIds make_ids(uint32_t slot0, int B, int N) {
 
 // ---- first half of AtcGym.step: timestep, action decode + rate limits, kinematics, MVA floor -----------------------
 __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const float* __restrict__ grid,
-                                           const atc_params_t& p, const LaneIds& d, float a_v, float a_h, float a_p,
-                                           LaneState& ls, EnvState& es) {
+                                           const atc_params_t& p, const StepDerived& q, const LaneIds& d, float a_v,
+                                           float a_h, float a_p, LaneState& ls, EnvState& es) {
     Mid m;
     Aircraft& a = ls.a;
     const float dt = p.dt;
@@ -328,7 +359,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
     es.t += 1;  // atc_gym.py:135
     const bool active = d.lane_valid && ((es.amask >> d.k) & 1ull);
     uint32_t fl = 0;
-    float r = -0.05f * dt;  // atc_gym.py:137
+    float r = q.r_base;  // -0.05 * dt, atc_gym.py:137
     int acts = 0;
     // ---- _action_with_reward x3 (atc_gym.py:139-141,299-335) -> Airplane.action_* (model.py:60-120) ------------------
     // branch-free form of: invalid target -> ValueError -> -1 reward, nothing applied, last_action kept
@@ -346,8 +377,8 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
             const bool valid = !(tv < v_min || tv > v_max);
             const bool ok = valid && active;
             float dd = tv - a.v;
-            dd = fminf(dd, kAMax * dt);
-            dd = fmaxf(dd, kAMin * dt);
+            dd = fminf(dd, q.dv_hi);
+            dd = fmaxf(dd, q.dv_lo);
             const float v_new = ok ? a.v + dd : a.v;
             ls.v_changed = ls.v_changed || v_new != a.v;
             a.v = v_new;
@@ -361,8 +392,8 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
             const bool valid = !(th < h_min || th > h_max);
             const bool ok = valid && active;
             float dd = th - a.h;
-            dd = fminf(dd, kHDotMax * dt);
-            dd = fmaxf(dd, kHDotMin * dt);
+            dd = fminf(dd, q.dh_hi);
+            dd = fmaxf(dd, q.dh_lo);
             a.h = ok ? a.h + dd : a.h;
             acts += (ok && !(fabsf(th - ls.la_h) < kDiscrH)) ? 1 : 0;
             ls.la_changed = ls.la_changed || (ok && th != ls.la_h);
@@ -372,8 +403,8 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
         }
         {
             float dd = tp - a.phi;
-            dd = fminf(dd, kPhiDotMax * dt);
-            dd = fmaxf(dd, kPhiDotMin * dt);
+            dd = fminf(dd, q.dp_hi);
+            dd = fmaxf(dd, q.dp_lo);
             a.phi = active ? a.phi + dd : a.phi;
             acts += (active && !(fabsf(tp - ls.la_p) < kDiscrPhi)) ? 1 : 0;
             ls.la_changed = ls.la_changed || (active && tp != ls.la_p);
@@ -402,8 +433,10 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
 // ---- second half: separation scan, win/timeout, observation, shaping, reductions, outputs, auto-reset --------------
 template <int W, bool FULL>
 __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const float* __restrict__ grid,
-                                            const atc_params_t& p, int N, const LaneIds& d, const Mid& m, LaneState& ls,
-                                            EnvState& es, const StepOut& so, int32_t* stp, float4* pos, float* obs_stage) {
+                                            const atc_params_t& p, const StepDerived& q, int N, const LaneIds& d,
+                                            const Mid& m, LaneState& ls,
+                                            EnvState& es, const StepOut& so, int32_t* stp, float4* pos, float* obs_stage,
+                                            const float* act_next, Float3& a_next) {
     Aircraft& a = ls.a;
     const bool active = m.active;
     const float x32 = m.x32, y32 = m.y32;
@@ -427,11 +460,19 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
         pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, m.cell, x32, y32, &hgt);
         mva = pi >= 0 ? hgt : 0.0f;
     }
+    // Multi-step launches: the NEXT step's action is requested here — behind the MVA gathers (loads return in order: issued
+    // earlier it would sit in front of them and its HBM latency would be paid at the MVA wait) and with the rest of the
+    // step body (scan, corridor, observation, shaping, stores) still ahead to cover it.
+    if (act_next) {
+        a_next.a = stream_load(at<float>(act_next, i * 12u));
+        a_next.b = stream_load(at<float>(act_next, i * 12u + 4u));
+        a_next.c = stream_load(at<float>(act_next, i * 12u + 8u));
+    }
     float min_d2 = 1e30f;
     float margin = 1e30f;  // min over partners of max(d^2 - sep^2, |dh| - sep_ft): conflict iff negative
     if (W > 1 && !(ATC_ABLATE & 2)) {
         const float xs = active ? x32 : 1e18f;
-        const float sep2 = p.sep_nm * p.sep_nm;
+        const float sep2 = q.sep2;
         if (W == 16) {
             PairScan16<1, FULL>::run(xs, y32, a.h, sep2, p.sep_ft, min_d2, margin);
         } else if (W <= 8) {
@@ -461,6 +502,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
             __builtin_amdgcn_wave_barrier();
         }
     }
+    ATC_STAMP_B(2);
     // ---- MVA floor (atc_gym.py:146-161), second half ---------------------------------------------------------------------
     {
         if (kResolveAfterScan) {
@@ -490,6 +532,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
         r = timeout ? -200.0f : r;
         fl |= timeout ? (uint32_t)ATC_F_TIMEOUT : 0u;
     }
+    ATC_STAMP_B(3);
     // ---- observation, shaping, noise areas, normalisation (atc_gym.py:175-189) ------------------------------------------
     float o[ATC_OBS_DIM];
     {
@@ -541,6 +584,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
         if (!active) min_d2 = 1e30f;
     }
 
+    ATC_STAMP_B(4);
     // ---- per-env reductions over the W lanes of the group ----------------------------------------------------------------
     const float env_r = group_sum<W>(r);
     const int env_acts = group_sum_i<W>(acts);
@@ -599,6 +643,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
         es.amask = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
     }
 
+    ATC_STAMP_B(5);
     // ---- observation store: [aircraft][10] rows are 40 B apart, so per-lane stores would scatter 8-byte pieces over 20
     //      cache lines per instruction; a full wavefront instead transposes its 64 x 10 block through LDS and writes 2 560
     //      contiguous bytes as 16-byte stores.
@@ -606,8 +651,9 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
         if (d.lane_valid && o[0] == 12345.678f) so.obs[i] = o[1];
     } else if (d.wave_full) {
         float* tb = obs_stage + (tid >> 6) * (64 * ATC_OBS_DIM);
+        float2* tb2 = reinterpret_cast<float2*>(tb) + lane * (ATC_OBS_DIM / 2);   // rows are 40 B: 8-byte aligned
 #pragma unroll
-        for (int c = 0; c < ATC_OBS_DIM; ++c) tb[lane * ATC_OBS_DIM + c] = o[c];
+        for (int c = 0; c < ATC_OBS_DIM / 2; ++c) tb2[c] = make_float2(o[2 * c], o[2 * c + 1]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -655,9 +701,9 @@ __device__ __forceinline__ void store_env_state(const atc_state_t& st, const Lan
 }
 
 template <int W, bool FULL, bool ONE>  // ONE: single-step launch (T == 1)
-__global__ void __launch_bounds__(kBlock, ATC_MIN_WAVES)
-k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, atc_state_t st,
-       const float* __restrict__ actions, atc_out_t out, atc_params_t p) {
+__global__ void __launch_bounds__(kBlock, (ONE ? ATC_MIN_WAVES : ((FULL || W < 8 || W == 64) ? ATC_MIN_WAVES_LOOP - 1 : ATC_MIN_WAVES_LOOP)))
+k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int hold, atc_state_t st,
+       const float* __restrict__ actions, atc_out_t out, atc_params_t p, StepDerived q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4* pos = reinterpret_cast<float4*>(smem);                    // [kBlock] pair-scan staging (W >= 32)
     float* obs_stage = smem + (W >= 32 ? kBlock * 4 : 0);  // [4 waves][64 x 10] obs transpose
@@ -685,6 +731,9 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, atc_st
     // and env records, output bases, hoisted sector constants) stays live across the whole body — 122 VGPRs and 28 spilled
     // SGPRs (4 wavefronts per SIMD) against 78 and none (6 per SIMD) for the straight-line form.
     const int n_steps = ONE ? 1 : T;
+    Float3 act = {0.0f, 0.0f, 0.0f};
+    const float* act_t = actions;   // action block of the current step; a block is held for `hold` steps
+    int held = 0;                   // steps the current block has been used for
     for (int step = 0; step < n_steps; ++step) {
         const size_t sBN = (size_t)step * BN, sB = (size_t)step * (uint32_t)B;  // uniform (scalar) per-step bases
         // Multi-step launches: everything that is invariant across steps (lane ids and the address arithmetic on them, the
@@ -702,21 +751,33 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, atc_st
             Kl = K + zs;
             gl = grid ? grid + zs : nullptr;
         }
-        const float* act_t = actions + sBN * 3;
         StepOut so = {out.obs + sBN * ATC_OBS_DIM, out.flags + sBN, out.reward + sB, out.done + sB,
                       FULL && out.raw_obs ? out.raw_obs + sBN * ATC_OBS_DIM : nullptr,
                       FULL && out.ac_reward ? out.ac_reward + sBN : nullptr,
                       FULL && out.min_sep ? out.min_sep + sB : nullptr,
-                      FULL && out.term_obs ? out.term_obs + sBN * ATC_OBS_DIM : nullptr};
-        const float a_v = stream_load(at<float>(act_t, dl.i * 12u)), a_h = stream_load(at<float>(act_t, dl.i * 12u + 4u)),
-                    a_p = stream_load(at<float>(act_t, dl.i * 12u + 8u));
+                      FULL && out.term_obs ? out.term_obs + sBN * ATC_OBS_DIM : nullptr
+#if ATC_TRACE
+                      , trace
+#endif
+        };
+        if (ONE || step == 0) {
+            act.a = stream_load(at<float>(act_t, dl.i * 12u));
+            act.b = stream_load(at<float>(act_t, dl.i * 12u + 4u));
+            act.c = stream_load(at<float>(act_t, dl.i * 12u + 8u));
+        }
+        const Mid m = step_part_a(Kl, gl, p, q, dl, act.a, act.b, act.c, ls, es);
         ATC_STAMP(1);
-        const Mid m = step_part_a(Kl, gl, p, dl, a_v, a_h, a_p, ls, es);
-        ATC_STAMP(3);
-        step_part_b<W, FULL>(Kl, gl, p, N, dl, m, ls, es, so, st.stats, pos, obs_stage);
-        ATC_STAMP(5);
+        Float3 nxt = act;
+        const float* act_next = nullptr;   // the next block is fetched during the last step of the current one
+        if (!ONE && ++held == hold) {
+            held = 0;
+            act_t += (size_t)BN * 3;
+            if (step + 1 < n_steps) act_next = act_t;
+        }
+        step_part_b<W, FULL>(Kl, gl, p, q, N, dl, m, ls, es, so, st.stats, pos, obs_stage, act_next, nxt);
+        act = nxt;
+        ATC_STAMP(6);
     }
-    ATC_STAMP(6);
     // ---- write back persistent state -----------------------------------------------------------------------------------
     store_lane_state(st, d, ls);
     store_env_state<W>(st, d, es, hi0);
@@ -837,7 +898,7 @@ static size_t lds_bytes(const atc_scenario*, bool pair_scan, bool step_kernel = 
 }
 
 template <int W, bool FULL, bool ONE>
-static int launch_step2(const atc_scenario* s, int B, int N, int T, const atc_state_t* st, const float* actions,
+static int launch_step2(const atc_scenario* s, int B, int N, int T, int hold, const atc_state_t* st, const float* actions,
                         const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
     const size_t lds = lds_bytes(s, W >= 32, true);
     if (lds > 48 * 1024)
@@ -845,22 +906,22 @@ static int launch_step2(const atc_scenario* s, int B, int N, int T, const atc_st
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long long slots = (long long)B * W;
     const int grid = (int)((slots + kBlock - 1) / kBlock);  // one workgroup per 256 slots, no grid-stride loop
-    hipLaunchKernelGGL((k_step<W, FULL, ONE>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->off_grid, B, N, T, *st, actions, *out, *p);
+    hipLaunchKernelGGL((k_step<W, FULL, ONE>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->off_grid, B, N, T, hold, *st, actions, *out, *p, derive(*p));
     HIP_TRY(hipGetLastError());
     return ATC_OK;
 }
 template <int W>
-static int launch_step(const atc_scenario* s, int B, int N, int T, const atc_state_t* st, const float* actions,
+static int launch_step(const atc_scenario* s, int B, int N, int T, int hold, const atc_state_t* st, const float* actions,
                        const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
     const bool full = out->raw_obs || out->ac_reward || out->min_sep || out->term_obs;
     // Multi-step launches keep the state in registers across the steps; the run-time step loop costs the kernel its
     // occupancy (4 wavefronts per SIMD against 5-7 for the straight-line single step) but issuing T single-step launches
     // instead is slower at every size (65 536 x 16, T = 20, [T, ...] outputs: 35.0 vs 27.1 us per step).
     if (T > 1)
-        return full ? launch_step2<W, true, false>(s, B, N, T, st, actions, out, p, stream)
-                    : launch_step2<W, false, false>(s, B, N, T, st, actions, out, p, stream);
-    return full ? launch_step2<W, true, true>(s, B, N, 1, st, actions, out, p, stream)
-                : launch_step2<W, false, true>(s, B, N, 1, st, actions, out, p, stream);
+        return full ? launch_step2<W, true, false>(s, B, N, T, hold, st, actions, out, p, stream)
+                    : launch_step2<W, false, false>(s, B, N, T, hold, st, actions, out, p, stream);
+    return full ? launch_step2<W, true, true>(s, B, N, 1, 1, st, actions, out, p, stream)
+                : launch_step2<W, false, true>(s, B, N, 1, 1, st, actions, out, p, stream);
 }
 
 // argument checks shared by every entry point that touches the env state
@@ -873,21 +934,21 @@ static int check_env_args(const atc_scenario_t* s, int B, int N, const atc_state
     return ATC_OK;
 }
 
-static int step_common(const atc_scenario_t* s, int B, int N, int T, const atc_state_t* st, const float* actions,
+static int step_common(const atc_scenario_t* s, int B, int N, int T, int hold, const atc_state_t* st, const float* actions,
                        const atc_out_t* out, const atc_params_t* p, void* stream) {
     if (!actions || !out) return fail_arg("null pointer");
     if (const int rc = check_env_args(s, B, N, st, p)) return rc;
-    if (T < 1) return fail_arg("need T >= 1");
+    if (T < 1 || hold < 1) return fail_arg("need T >= 1 and hold >= 1");
     if (!out->obs || !out->reward || !out->done || !out->flags) return fail_arg("obs/reward/done/flags are required");
     if (!(p->dt > 0.0f)) return fail_arg("dt must be > 0");
     hipStream_t q = (hipStream_t)stream;
-    if (N == 1) return launch_step<1>(s, B, N, T, st, actions, out, p, q);
-    if (N == 2) return launch_step<2>(s, B, N, T, st, actions, out, p, q);
-    if (N <= 4) return launch_step<4>(s, B, N, T, st, actions, out, p, q);
-    if (N <= 8) return launch_step<8>(s, B, N, T, st, actions, out, p, q);
-    if (N <= 16) return launch_step<16>(s, B, N, T, st, actions, out, p, q);
-    if (N <= 32) return launch_step<32>(s, B, N, T, st, actions, out, p, q);
-    return launch_step<64>(s, B, N, T, st, actions, out, p, q);
+    if (N == 1) return launch_step<1>(s, B, N, T, hold, st, actions, out, p, q);
+    if (N == 2) return launch_step<2>(s, B, N, T, hold, st, actions, out, p, q);
+    if (N <= 4) return launch_step<4>(s, B, N, T, hold, st, actions, out, p, q);
+    if (N <= 8) return launch_step<8>(s, B, N, T, hold, st, actions, out, p, q);
+    if (N <= 16) return launch_step<16>(s, B, N, T, hold, st, actions, out, p, q);
+    if (N <= 32) return launch_step<32>(s, B, N, T, hold, st, actions, out, p, q);
+    return launch_step<64>(s, B, N, T, hold, st, actions, out, p, q);
 }
 
 extern "C" {
@@ -1013,14 +1074,14 @@ int atc_observe(const atc_scenario_t* s, int B, int N, const atc_state_t* st, co
 
 int atc_step(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const float* actions, const atc_out_t* out,
              const atc_params_t* p, void* stream) {
-    return step_common(s, B, N, 1, st, actions, out, p, stream);
+    return step_common(s, B, N, 1, 1, st, actions, out, p, stream);
 }
 
 int atc_step_multi(int n, const atc_step_call_t* calls) {
     if (n < 0 || (n > 0 && !calls)) return fail_arg("null pointer");
     for (int i = 0; i < n; ++i) {
         const atc_step_call_t& c = calls[i];
-        const int rc = step_common(c.s, c.B, c.N, 1, c.st, c.actions, c.out, c.p, c.stream);
+        const int rc = step_common(c.s, c.B, c.N, 1, 1, c.st, c.actions, c.out, c.p, c.stream);
         if (rc != ATC_OK) return rc;
     }
     return ATC_OK;
@@ -1028,7 +1089,12 @@ int atc_step_multi(int n, const atc_step_call_t* calls) {
 
 int atc_rollout(const atc_scenario_t* s, int B, int N, int T, const atc_state_t* st, const float* actions,
                 const atc_out_t* out, const atc_params_t* p, void* stream) {
-    return step_common(s, B, N, T, st, actions, out, p, stream);
+    return step_common(s, B, N, T, 1, st, actions, out, p, stream);
+}
+
+int atc_rollout_hold(const atc_scenario_t* s, int B, int N, int T, int hold, const atc_state_t* st, const float* actions,
+                     const atc_out_t* out, const atc_params_t* p, void* stream) {
+    return step_common(s, B, N, T, hold, st, actions, out, p, stream);
 }
 
 }  // extern "C"

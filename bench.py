@@ -286,17 +286,22 @@ def main():
             return
         if args.rollout:
             T = args.rollout
-            assert n_steps % T == 0 and HOLD % T == 0 or T % HOLD == 0
             for s in range(0, n_steps, T):
-                a = torch.stack([ring[((t_base + s + c) // HOLD) % n_ring] for c in range(T)])
-                env.rollout(a, out=roll_out)
+                env.rollout(roll_actions[((t_base + s) // max(T, HOLD)) % len(roll_actions)], out=roll_out, hold=min(T, HOLD))
         else:
             for s in range(n_steps):
                 env.step(ring[((t_base + s) // HOLD) % n_ring])
 
     roll_out = None
+    roll_actions = None
     if args.rollout:
         T = args.rollout
+        assert (T <= HOLD and HOLD % T == 0) or T % HOLD == 0, "--rollout must divide or be a multiple of %d" % HOLD
+        assert K % T == 0 and W % T == 0, "--steps / --warmup must be multiples of --rollout"
+        # action blocks of one launch, resident before the timed region: [max(1, T / HOLD), B, N, 3], each held min(T, HOLD) steps
+        nb = max(1, T // HOLD)
+        roll_actions = [torch.stack([ring[(j * nb + c) % n_ring] for c in range(nb)]) if nb > 1 else ring[j % n_ring][None]
+                        for j in range(n_ring)]
         roll_out = {"obs": torch.empty((T, B, N * 10), dtype=torch.float32, device=dev),
                     "reward": torch.empty((T, B), dtype=torch.float32, device=dev),
                     "done": torch.empty((T, B), dtype=torch.uint8, device=dev),

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ATC_ABI_VERSION 11
+#define ATC_ABI_VERSION 12
 
 /* ---------------------------------------------------------------------------------------------
  * Scenario blob: one flat array of 32-bit floats (device copy) compiled on the host from the sector
@@ -35,7 +35,7 @@ extern "C" {
  * envs/atc/atc_gym.py:45-58,88-110).  Integer fields are stored as exactly representable floats.
  * The float64 master (used by the f64 oracle) has the identical word layout.
  * ------------------------------------------------------------------------------------------- */
-#define ATC_BLOB_VERSION 1009.0f
+#define ATC_BLOB_VERSION 1010.0f
 enum {
     ATC_H_VERSION = 0,   /* ATC_BLOB_VERSION */
     ATC_H_NWORDS = 1,    /* total words */
@@ -98,14 +98,16 @@ enum { ATC_E_X = 0, ATC_E_Y = 1, ATC_E_PHI = 2, ATC_E_NLEV = 3, ATC_E_LEV0 = 4, 
  *   cells  ny*nx*2 : (n_records >= 1, first_record)   -> dirty cell: walk that many edge records
  *                    (-(polygon + 1), MVA height)     -> clean cell: every point has this answer
  *                    (0, 0)                           -> clean cell outside the airspace
- *   pool           : 8-word records, two 16-byte halves G | M:
- *                    edge       G = p1x, p1y, p2x, p2y          M = min(p1y,p2y), max(p1y,p2y), max(p1x,p2x), code
- *                    terminator G = polygon bounds x0,y0,x1,y1  M = polygon height, 0, 0, code        (ends a polygon)
- *                    code = 4 * polygon index + flags                                                                 */
+ *   pool           : 8-word records, two 16-byte halves G | M (flags and folding rules: atc_hip/scenario.py:build_grid):
+ *                    edge       G = p1x, p1y, p2x, p2y          M = min(p1y,p2y), max(p1y,p2y), polygon height, code
+ *                    terminator G = polygon bounds x0,y0,x1,y1  M = 0, 0, polygon height, code
+ *                    code = 16 * polygon index + flags                                                                */
 enum { ATC_G_X0 = 0, ATC_G_Y0 = 1, ATC_G_INV = 2, ATC_G_NX = 3, ATC_G_NY = 4, ATC_G_OFF_POOL = 5, ATC_G_NREC = 6,
        ATC_G_HDR = 8, ATC_GE_WORDS = 8 };
-#define ATC_GE_TERM 1    /* terminator record of a polygon: evaluate parity + bounds test now (model.py:286-287) */
-#define ATC_GE_CERTAIN 2 /* the cell lies entirely left of this edge: crossing iff the y test passes */
+#define ATC_GE_TERM 1    /* terminator: (crossing parity xor BASE) and the bounds test (model.py:286-287) decide now */
+#define ATC_GE_CERTAIN 2 /* the cell lies entirely left of this edge: crossing iff the two y tests pass */
+#define ATC_GE_LAST 4    /* last edge of a polygon whose bounds contain the whole cell: parity xor BASE decides now */
+#define ATC_GE_BASE 8    /* an odd number of the polygon's edges is crossed by EVERY point of the cell (not listed) */
 
 #define ATC_MAX_AIRCRAFT 64
 #define ATC_OBS_DIM 10 /* atc_gym.py:262-277 */
@@ -296,6 +298,13 @@ int atc_step_multi(int n, const atc_step_call_t* calls);
  * Requires ATC_M_AUTO_RESET semantics to be meaningful for T > episode length. */
 int atc_rollout(const atc_scenario_t* s, int B, int N, int T, const atc_state_t* st, const float* actions,
                 const atc_out_t* out, const atc_params_t* p, void* stream);
+
+/* The same with every action HELD for `hold` consecutive steps (frame skip — the protocol of the reference's demo loop,
+ * learning/atc-gym-demo.py:18-19: one sampled action is applied 20 times): actions: [ceil(T / hold)][B*N*3], step t uses
+ * block t / hold.  Results are identical to atc_rollout with each block repeated `hold` times; the action tensor and its
+ * HBM traffic shrink by that factor. */
+int atc_rollout_hold(const atc_scenario_t* s, int B, int N, int T, int hold, const atc_state_t* st, const float* actions,
+                     const atc_out_t* out, const atc_params_t* p, void* stream);
 
 #ifdef __cplusplus
 }

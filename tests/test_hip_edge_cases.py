@@ -207,6 +207,32 @@ def test_fast_and_full_kernel_variants_agree(N):
         e.close()
 
 
+@pytest.mark.parametrize("N,T,hold", [(16, 20, 20), (16, 20, 5), (1, 12, 4), (64, 10, 10), (5, 9, 3)])
+def test_rollout_with_held_actions_equals_single_steps(N, T, hold):
+    """atc_rollout_hold (frame skip): T steps in one launch, every action block held for `hold` steps == the same steps
+    launched one by one with the action repeated; outputs and the whole persistent state bit-identical."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+    scn = scenarios.LOWWDense() if N > 16 else scenarios.LOWW(random_entrypoints=True)
+    B = 300
+    one = AtcVecEnv(B, N, scenario=scn, auto_reset=True, seed=5)
+    roll = AtcVecEnv(B, N, scenario=scn, auto_reset=True, seed=5)
+    g = torch.Generator(device="cpu").manual_seed(N * 100 + T)
+    for launch in range(4):
+        blocks = (torch.rand((T // hold, B, N, 3), generator=g) * 2.1 - 1.05).cuda()
+        out = roll.rollout(blocks, hold=hold)
+        for t in range(T):
+            o, r, d, info = one.step(blocks[t // hold])
+            assert torch.equal(out["obs"][t], o) and torch.equal(out["reward"][t], r), (launch, t)
+            assert torch.equal(out["done"][t], d) and torch.equal(out["flags"][t], info["flags"]), (launch, t)
+    for name in ("pos_hp", "v", "last_act", "env", "stats"):
+        assert torch.equal(getattr(one, name), getattr(roll, name)), name
+    assert N == 1 or int(one.episodes.sum()) > B
+    one.close()
+    roll.close()
+
+
 def test_sub_batches_on_streams_equal_one_batch():
     """atc_step_multi: a batch stepped as 3 independent sub-batches on 3 streams (one foreign call per step, no join
     between steps) gives exactly the results of the same envs stepped as one batch; launch errors are reported."""

@@ -81,21 +81,27 @@ def _walk_grid(b, g, tabs, tabs_h, x, y):
     inside = False
     for e in range(n):
         r = b[pool + (v + e) * L.GE_WORDS: pool + (v + e + 1) * L.GE_WORDS]
-        pi, fl = int(r[7]) // 4, int(r[7]) % 4
-        if fl & 1:  # terminator: bounds + height
-            assert tuple(r[0:4]) == tuple(tabs[pi]) and r[4] == tabs_h[pi]
-            if inside and r[0] <= x <= r[2] and r[1] <= y <= r[3]:
+        pi, fl = int(r[7]) // 16, int(r[7]) % 16
+        assert r[6] == tabs_h[pi]
+        ok = True
+        if fl & 1:  # terminator: bounds (or "always": +-3e38)
+            assert tuple(r[0:4]) == tuple(tabs[pi]) or r[0] == -3.0e38
+            ok = r[0] <= x <= r[2] and r[1] <= y <= r[3]
+            decide = True
+        else:
+            p1x, p1y, p2x, p2y = r[0], r[1], r[2], r[3]
+            assert (r[4], r[5]) == (min(p1y, p2y), max(p1y, p2y))
+            if y > r[4] and y <= r[5] and x <= max(p1x, p2x):
+                cross = bool(fl & 2)
+                if not cross:
+                    xints = (y - p1y) * (p2x - p1x) / (p2y - p1y) + p1x
+                    cross = p1x == p2x or x <= xints
+                inside = inside != cross
+            decide = bool(fl & 4)
+        if decide:
+            if (inside != bool(fl & 8)) and ok:
                 return pi
             inside = False
-            continue
-        p1x, p1y, p2x, p2y = r[0], r[1], r[2], r[3]
-        assert (r[4], r[5], r[6]) == (min(p1y, p2y), max(p1y, p2y), max(p1x, p2x))
-        if y > r[4] and y <= r[5] and x <= r[6]:
-            cross = bool(fl & 2)
-            if not cross:
-                xints = (y - p1y) * (p2x - p1x) / (p2y - p1y) + p1x
-                cross = p1x == p2x or x <= xints
-            inside = inside != cross
     return -1
 
 
@@ -125,3 +131,4 @@ def test_grid_matches_ordered_scan_on_host(scen, cell):
     n_dirty = int((cells[:, 0] > 0).sum())
     assert 0 < n_dirty < 0.45 * len(cells)
     assert cells[:, 0].max() <= 64
+    print(scen, cell, 'dirty cells', n_dirty, 'of', len(cells), 'records per dirty cell %.2f' % (cells[cells[:, 0] > 0, 0].mean()), 'max', cells[:, 0].max())

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: per-wavefront phase timing of k_step with the ATC_TRACE build (s_memtime stamps).
-  ATC_LIBATCSTEP=build_variants/libatcstep_trace.so python tools/trace_phases.py"""
+  hipcc ... -DATC_TRACE=1 -o build_variants/libatcstep_trace.so ; python tools/trace_phases.py [envs]"""
 import ctypes as C
 import os
 import struct
@@ -10,10 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "atc-reinforcement-learning_amd")]
 import numpy as np
 import torch
+from atc_hip import lib as _binding
+_binding.use_library(os.path.join(ROOT, "build_variants", "libatcstep_trace.so"))
 from atc_hip.vec_env import AtcVecEnv
 from envs.atc import scenarios
 
-B, N = 65536, 16
+B, N = (int(sys.argv[1]) if len(sys.argv) > 1 else 65536), 16
 env = AtcVecEnv(B, N, scenario=scenarios.LOWW(random_entrypoints=True), auto_reset=True)
 acts = [(torch.rand((B, N, 3), device="cuda") * 2 - 1) for _ in range(4)]
 for t in range(300):
@@ -26,13 +28,41 @@ env.params.reserved1 = struct.unpack("f", struct.pack("I", (ptr >> 32) & 0xfffff
 torch.cuda.synchronize()
 env.step(acts[0])
 torch.cuda.synchronize()
-tr = trace.cpu().numpy().astype(np.float64)
-t0 = tr[:, 0].min()
-names = ["loads+decode", "kinematics", "mva", "pair-scan", "corridor+obs+shaping", "reduce+flags+obs-store", "state-store"]
-d = np.diff(tr, axis=1)
-print("s_memtime ticks (100 MHz const clock?) per phase: mean / median / p90")
+raw = trace.cpu().numpy()
+good = (raw > 0).all(axis=1) & (np.diff(raw, axis=1) >= 0).all(axis=1)
+print("wavefronts traced: %d, usable rows: %d" % (len(raw), int(good.sum())))
+names = ["loads -> decode+kinematics", "mva resolve + pair scan", "overrides + corridor", "obs + shaping + normalise",
+         "reductions, flag/reward stores, auto-reset", "obs transpose + store", "state store"]
+# s_memtime counts a per-XCD clock (the counters of different XCDs are not aligned): workgroups are dealt round-robin to the
+# 8 XCDs, so the timeline is drawn per XCD and the tick is calibrated against the kernel time measured with HIP events
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ev0.record()
+for t in range(200):
+    env.step(acts[(t // 20) % 4])
+ev1.record()
+torch.cuda.synchronize()
+kernel_us = ev0.elapsed_time(ev1) / 200 * 1e3
+wave = np.arange(len(raw))
+xcd = (wave // 4) % 8
+span = np.median([raw[xcd == x, 7].max() - raw[xcd == x, 0].min() for x in range(8)])
+tick_us = kernel_us / span
+print("kernel %.2f us (HIP events), span %.0f ticks on one XCD -> %.3f ns per tick" % (kernel_us, span, tick_us * 1e3))
+d = np.diff(raw.astype(np.float64), axis=1) * tick_us
+print("phase durations per wavefront [us]: mean / median / p90 / share of lifetime")
+life = (raw[:, 7] - raw[:, 0]) * tick_us
 for k, nme in enumerate(names):
-    print("%-26s %9.1f %9.1f %9.1f" % (nme, d[:, k].mean(), np.median(d[:, k]), np.percentile(d[:, k], 90)))
-life = tr[:, 7] - tr[:, 0]
-print("wave lifetime: mean %.1f median %.1f p90 %.1f ; kernel span %.1f ticks" % (life.mean(), np.median(life), np.percentile(life, 90), tr[:, 7].max() - t0))
-print("start spread: p10 %.1f p50 %.1f p90 %.1f" % tuple(np.percentile(tr[:, 0] - t0, [10, 50, 90])))
+    print("%-44s %6.2f %6.2f %6.2f   %4.1f %%" % (nme, d[:, k].mean(), np.median(d[:, k]), np.percentile(d[:, k], 90),
+                                                  100 * d[:, k].sum() / life.sum()))
+print("wave lifetime [us]: mean %.2f median %.2f p90 %.2f" % (life.mean(), np.median(life), np.percentile(life, 90)))
+x = 0
+r = raw[xcd == x].astype(np.float64)
+t0 = r[:, 0].min()
+r = (r - t0) * tick_us
+print("XCD %d timeline (1 us bins): waves waiting for their loads / computing / in the store phases / started / finished" % x)
+for b in np.arange(0.0, r[:, 7].max(), 1.0):
+    mid = b + 0.5
+    loading = int(((r[:, 0] <= mid) & (mid < r[:, 1])).sum())
+    compute = int(((r[:, 1] <= mid) & (mid < r[:, 5])).sum())
+    storing = int(((r[:, 5] <= mid) & (mid < r[:, 7])).sum())
+    print("%5.0f us  load %4d  compute %4d  store %4d   +%4d -%4d" % (
+        b, loading, compute, storing, int(((r[:, 0] >= b) & (r[:, 0] < b + 1)).sum()), int(((r[:, 7] >= b) & (r[:, 7] < b + 1)).sum())))
