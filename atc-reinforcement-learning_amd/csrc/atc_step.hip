@@ -478,26 +478,56 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
         } else if (W <= 8) {
             pair_scan_xor<W, FULL>(xs, y32, a.h, sep2, p.sep_ft, min_d2, margin);
         } else {
-            pos[tid] = make_float4(xs, y32, a.h, 0.0f);
+            // W = 32 / 64: partners come from LDS and every unordered pair is evaluated ONCE — lane k visits the partners
+            // k + 1 .. k + W/2 (mod W) of its group (the pair at distance W/2 is visited from both ends, harmless).  The result
+            // has to reach the partner as well: the conflict test of distance d over the whole wavefront is one compare into
+            // a 64-bit lane mask, and "lane j is the PARTNER of a conflict at distance d" is that mask rotated by d inside
+            // each group — scalar-unit work (3-6 SALU operations per distance), no return traffic between lanes.
+            // Each group is staged TWICE back to back (slots k and W + k of its 2 W records), so that partner k + d is the record
+            // d places after the lane's own, whatever k: one address per lane, the distance is an offset — no wrap-around
+            // arithmetic per partner.
+            const int gbase = tid & ~(W - 1);
+            float4* own = pos + 2 * gbase + k;
+            own[0] = make_float4(xs, y32, a.h, 1e36f);
+            own[W] = make_float4(xs, y32, a.h, 1e36f);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int gbase = tid & ~(W - 1);
-            // partners per LDS batch.  7 for every width since the single-step instantiation freed the registers
-            // (N = 64: 63 = 9 x 7; measured 11.7 vs 12.3 us at 4 096 x 64, 60.6 vs 62.8 us at 32 768 x 64 against batches of 3)
-            constexpr int U = (W >= 8) ? 7 : (W > 1 ? W - 1 : 1);
+            constexpr int H = W / 2;   // distances 1 .. H
+            constexpr int U = 4;       // partners per LDS batch
+            uint64_t hit = 0;          // lanes that are the FIRST element of a conflicting pair ... or (rotated in) the second
 #pragma unroll 1
-            for (int d0 = 1; d0 < W; d0 += U) {
-                float4 q[U];
+            for (int d0 = 1; d0 <= H; d0 += U) {
+                float4 qv[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) q[u] = pos[gbase + ((k + d0 + u) & (W - 1))];
+                for (int u = 0; u < U; ++u) qv[u] = own[d0 + u];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const float dx = xs - q[u].x, dy = y32 - q[u].y;
-                    const float d2 = (d0 + u < W) ? fmaf(dx, dx, dy * dy) : 1e36f;  // tail of the last batch
-                    if (FULL) min_d2 = fminf(min_d2, d2);
-                    margin = fminf(margin, fmaxf(d2 - sep2, fabsf(a.h - q[u].z) - p.sep_ft));
+                    const int dd = d0 + u;   // uniform
+                    const float dx = xs - qv[u].x, dy = y32 - qv[u].y;
+                    const float d2 = fmaf(dx, dx, dy * dy);
+                    const float mg = fmaxf(d2 - sep2, fabsf(a.h - qv[u].z) - p.sep_ft);
+                    const uint64_t mk = __ballot(mg < 0.0f);   // (H is a multiple of U: no tail)
+                    if (W == 64) {
+                        hit |= mk | (mk << dd) | (mk >> (64 - dd));
+                    } else {  // two groups of 32 lanes: rotate inside each half
+                        const uint32_t lo = (uint32_t)mk, hi = (uint32_t)(mk >> 32);
+                        const uint32_t rlo = (lo << dd) | (lo >> (32 - dd)), rhi = (hi << dd) | (hi >> (32 - dd));
+                        hit |= mk | (uint64_t)rlo | ((uint64_t)rhi << 32);
+                    }
+                    if (FULL) {   // diagnostic minimum separation: the partner needs the VALUE -> LDS float minimum
+                        min_d2 = fminf(min_d2, d2);
+                        // d^2 >= 0: the IEEE order of non-negative floats is the order of their bit patterns
+                        atomicMin(reinterpret_cast<unsigned int*>(&pos[2 * gbase + ((k + dd) & (W - 1))].w), __float_as_uint(d2));
+                    }
                 }
+            }
+            if ((hit >> lane) & 1ull) margin = -1.0f;
+            if (FULL) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                min_d2 = fminf(min_d2, own[0].w);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -701,12 +731,12 @@ __device__ __forceinline__ void store_env_state(const atc_state_t& st, const Lan
 }
 
 template <int W, bool FULL, bool ONE>  // ONE: single-step launch (T == 1)
-__global__ void __launch_bounds__(kBlock, (ONE ? ATC_MIN_WAVES : ((FULL || W < 8 || W == 64) ? ATC_MIN_WAVES_LOOP - 1 : ATC_MIN_WAVES_LOOP)))
+__global__ void __launch_bounds__(kBlock, (ONE ? ATC_MIN_WAVES : ((FULL || W < 8 || W >= 32) ? ATC_MIN_WAVES_LOOP - 1 : ATC_MIN_WAVES_LOOP)))
 k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int hold, atc_state_t st,
        const float* __restrict__ actions, atc_out_t out, atc_params_t p, StepDerived q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float4* pos = reinterpret_cast<float4*>(smem);                    // [kBlock] pair-scan staging (W >= 32)
-    float* obs_stage = smem + (W >= 32 ? kBlock * 4 : 0);  // [4 waves][64 x 10] obs transpose
+    float4* pos = reinterpret_cast<float4*>(smem);                    // [2 kBlock] pair-scan staging (W >= 32)
+    float* obs_stage = smem + (W >= 32 ? 2 * kBlock * 4 : 0);  // [4 waves][64 x 10] obs transpose
     const float* __restrict__ K = blob;  // the sector: uniform-index reads -> scalar loads
     const float* __restrict__ grid = off_grid ? blob + off_grid : nullptr;
 #if ATC_TRACE
@@ -893,7 +923,7 @@ static int grid_for(const atc_scenario* s, long long threads) {
 static size_t lds_bytes(const atc_scenario*, bool pair_scan, bool step_kernel = false) {
     size_t w = 0;  // the sector is not staged: LDS only holds the obs transpose stage and the pair-scan staging
     if (step_kernel) w += (size_t)(kBlock / 64) * 64 * ATC_OBS_DIM;
-    if (pair_scan) w += (size_t)kBlock * 4;
+    if (pair_scan) w += (size_t)2 * kBlock * 4;
     return w * sizeof(float);
 }
 

@@ -228,7 +228,7 @@ def test_rollout_with_held_actions_equals_single_steps(N, T, hold):
             assert torch.equal(out["done"][t], d) and torch.equal(out["flags"][t], info["flags"]), (launch, t)
     for name in ("pos_hp", "v", "last_act", "env", "stats"):
         assert torch.equal(getattr(one, name), getattr(roll, name)), name
-    assert N == 1 or int(one.episodes.sum()) > B
+    assert N < 16 or int(one.episodes.sum()) > B
     one.close()
     roll.close()
 
