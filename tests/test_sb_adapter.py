@@ -60,6 +60,57 @@ def test_adapter_equals_loop_of_single_envs():
         e.close()
 
 
+def test_adapter_against_reference_episodes_with_wins():
+    """AtcSBVecEnv against the REFERENCE (g9 fixture), not against another HIP env: 24 recorded episodes — 16 that end in the
+    approach corridor, 8 that end outside / below the MVA — run side by side through the adapter's numpy surface.  Every
+    step's observation / reward / done, Monitor's episode record on done, the terminal observation, the raw reset
+    observation returned in its place (SB semantics + quirk Q1), and winning_ratio afterwards (atc_gym.py:359-363)."""
+    from atc_hip.sb_adapter import AtcSBVecEnv
+    fx = H.WideFixture()
+    std = [ep for ep in fx.episodes if ep["scen"] == "LOWW" and ep["dt"] == 1.0 and ep["shaping"] and ep["normalize"]
+           and not ep["discrete"] and int(fx.done[ep["start"]:ep["start"] + ep["steps"]].sum()) == 1 and 2 <= ep["steps"] <= 700]
+    last = lambda ep: ep["start"] + ep["steps"] - 1   # noqa: E731
+    wins = [ep for ep in std if fx.flags[last(ep)] & H.F_WON and not fx.flags[last(ep)] & H.F_TIMEOUT][:16]
+    lost = [ep for ep in std if not fx.flags[last(ep)] & H.F_WON][:8]
+    assert len(wins) == 16 and len(lost) == 8
+    eps = wins + lost
+    B = len(eps)
+    venv = AtcSBVecEnv(B)
+    venv.reset()
+    for b, ep in enumerate(eps):
+        venv.vec.set_state(b, 0, *ep["init_state"])
+        venv.set_attr("timesteps", ep["init_timesteps"], indices=[b])
+        venv.vec.set_last_action(b, 0, ep["init_last_action"])
+    steps = np.array([ep["steps"] for ep in eps])
+    starts = np.array([ep["start"] for ep in eps])
+    finished = np.zeros(B, bool)
+    for t in range(int(steps.max())):
+        live = (t < steps) & ~finished
+        rows = np.where(live, starts + t, starts)
+        obs, rew, done, infos = venv.step(fx.action[rows].astype(np.float32))
+        for b in np.nonzero(live)[0]:
+            row = rows[b]
+            gw = fx.reward[row]
+            assert bool(done[b]) == bool(fx.done[row]), (b, t)
+            assert abs(rew[b] - gw) <= 2e-5 * max(1.0, abs(gw)), (b, t, rew[b], gw)      # 1e-5 + float32 storage of the fixture
+            si = fx.samp_index[row]
+            if done[b]:
+                ep = eps[b]
+                assert si >= 0 and np.all(np.abs(infos[b]["terminal_observation"] - fx.obs[si]) <= 1e-5), (b, t)
+                assert infos[b]["episode"]["l"] == ep["init_timesteps"] + ep["steps"]     # Monitor 'l' = env.timesteps
+                gt = ep["total_reward"]                                                  # Monitor 'r' = sum of rewards
+                assert abs(infos[b]["episode"]["r"] - gt) <= (1e-5 + 6e-8 * ep["steps"]) * max(1.0, abs(gt)), (b, gt)
+                assert list(obs[b][:5]) == [10.0, 51.0, 15000.0, 90.0, 250.0]            # raw reset observation
+                finished[b] = True
+            elif si >= 0:
+                assert np.all(np.abs(obs[b] - fx.obs[si]) <= 1e-5), (b, t)
+    assert finished.all()
+    wr = venv.get_attr("winning_ratio")
+    assert wr[:16] == [0.1] * 16 and wr[16:] == [0.0] * 8
+    assert min(venv.get_attr("episodes")) >= 2
+    venv.close()
+
+
 def test_sparse_infos_for_large_batches():
     from atc_hip.sb_adapter import AtcSBVecEnv
     venv = AtcSBVecEnv(1024)
