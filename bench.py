@@ -28,10 +28,11 @@ HOLD = 20            # action re-sampling interval [steps]
 HBM_PEAK_GBS = 8000  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def algorithmic_bytes_per_env_step(n):
+def algorithmic_bytes_per_env_step(n, fused_steps=1, hold=1):
     """SURVEY.md §8(d) / BASELINE.md §3: 96 B per aircraft (32 read: state 20 + action 12; 64 write: state 20 + obs 40 +
-    reward 4) + 13 B per env (timesteps r/w 8, done 1, flags 4)."""
-    return 96 * n + 13
+    reward 4) + 13 B per env (timesteps r/w 8, done 1, flags 4).  "In a T-step fused rollout the state term (40 N) is paid
+    once per T" (SURVEY §8d); an action block held for `hold` steps is read once per `hold`."""
+    return (44 + 40.0 / fused_steps + 12.0 / hold) * n + 13
 
 
 def _time_oracle(n_aircraft, B, threads, seconds_target):
@@ -349,16 +350,19 @@ def main():
 
     episodes = D.sum_over_ranks(float(sum(e.episodes.sum().item() for e in subs)) - B, dev)
     value = ws * B * K / elapsed
-    bytes_launch = algorithmic_bytes_per_env_step(N) * (B // S) * T
+    bytes_launch = algorithmic_bytes_per_env_step(N, T, min(T, HOLD) if args.rollout else 1) * (B // S) * T
     # S > 1: launch_ms is the wall duration of ONE sub-batch launch while S - 1 others are in flight
     achieved = S * bytes_launch / (launch_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM traffic per launch from the PMC passes of THIS workload (tools/pmc_profile.sh: separate rocprofv3 --pmc runs,
+    # FETCH_SIZE / WRITE_SIZE with the gfx950 corrections) — PMC counters cannot be read from inside the process, so the
+    # figure comes from the committed summary of those passes and is null for any other workload.
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath))
-            if tj.get("envs") == B and tj.get("aircraft") == N and S == 1:
-                traffic = tj.get("hbm_bytes_per_launch")
+            for tj in json.load(open(tpath))["workloads"]:
+                if tj["envs"] == B and tj["aircraft"] == N and tj["rollout"] == (args.rollout or 0) and S == 1:
+                    traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
         except Exception:
             traffic = None
 
@@ -382,7 +386,7 @@ def main():
                        "parity_gate": gate, "gathered_returns_shape": list(returns.shape),
                        "rank_seeds": [int(v) for v in rank_seeds.reshape(-1).tolist()]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_step<%d, false, %s>" % (1 << max(0, (N - 1).bit_length()), "false" if args.rollout else "true"),
                          "avg_launch_ms": launch_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "concurrent_launches": S,
