@@ -92,6 +92,21 @@ __device__ __forceinline__ float py_mod360(float a) {
 
 // model.py:340-342
 __device__ __forceinline__ float relative_angle(float a1, float a2) { return py_mod360(a2 - a1 + 180.0f) - 180.0f; }
+// The same for angles whose difference is known to lie in [-360, 720) (a bearing from atan2 against a runway heading):
+// there CPython's fmod is the identity or one subtraction and only the sign fix-up remains — same result, half the work.
+__device__ __forceinline__ float relative_angle_near(float a1, float a2) {
+    float r = a2 - a1 + 180.0f;
+    r = (r < 0.0f) ? r + 360.0f : ((r >= 360.0f) ? r - 360.0f : r);
+    return r - 180.0f;
+}
+// v / 3600 (model.py:124), correctly rounded without the IEEE division sequence: q0 = v * RN(1/3600), one fma gives the
+// exact remainder v - 3600 q0, a second folds it back.  Bit-identical to v / 3600.0f for every float with
+// 2^-4 <= |v| < 2^16 and for 0 (checked exhaustively, 1.7e8 values; aircraft speeds are 100..300 kt).
+__device__ __forceinline__ float div3600(float v) {
+    constexpr float r = 1.0f / 3600.0f;
+    const float q0 = v * r;
+    return fmaf(fmaf(-q0, 3600.0f, v), r, q0);
+}
 
 // model.py:318-337 ray_tracing over a closed ring (x,y interleaved in LDS, n vertices, first == last).
 // Same inequality set and evaluation order; the reference's n+1-th iteration re-visits ring[0] from ring[n-1]
@@ -282,7 +297,7 @@ __device__ __forceinline__ Shaping shaping_rewards(const float* __restrict__ K, 
     // plane_to_runway = relative_angle(phi_to_runway, phi_plane): the caller already has it as obs[9]
     const float to_rwy = K[ATC_C_PHI_TO_RWY];
     Shaping r;
-    const float rel_faf = relative_angle(to_rwy, phi_rel_faf);
+    const float rel_faf = relative_angle_near(to_rwy, phi_rel_faf);  // phi_rel_faf = atan2 in [-180, 180], to_rwy in [0, 360)
     const float u = fabsf(rel_faf) * (1.0f / 180.0f);
     r.pos = sigmoid_distance(d_faf, fast_rcp(K[ATC_C_WORLD_DIAG])) * (u * fast_sqrt(u)) * 0.8f;  // u ** 1.5
     const float side = (rel_faf > 0.0f) ? 1.0f : ((rel_faf < 0.0f) ? -1.0f : 0.0f);  // np.sign

@@ -413,7 +413,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
     }
     // ---- Airplane.step (model.py:122-129): rot_matrix(phi) . [0, (v/3600) dt] ----------------------------------------
     {
-        const float dist = active ? (a.v / 3600.0f) * dt : 0.0f;
+        const float dist = active ? div3600(a.v) * dt : 0.0f;
         float sn, cs;
         if (ATC_ABLATE & 32) { sn = 0.6f; cs = 0.8f; } else sincos_deg(a.phi, &sn, &cs);
         a.x = pos_advance(K, a.x, sn * dist);
