@@ -114,7 +114,7 @@ GRID_F_BASE = 8.0        # the polygon has an ODD number of edges that every poi
 _BIG = 3.0e38
 
 
-def build_grid(rings, bounds, heights, bbox, cell, guard=None):
+def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=()):
     """Uniform lookup grid for Airspace.find_mva (model.py:282-289) with IDENTICAL results to the ordered polygon scan.
 
     * CLEAN cell: every point of the cell has the same answer; stored directly.
@@ -135,9 +135,12 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None):
     Cell bounds are inflated by `slack` (guard + fp32 indexing error) so that a point the device bins into a neighbouring
     cell because of fp32 rounding is still covered.
 
+    Noise-abatement areas (extension): every cell also carries the bit mask of the noise polygons whose bounds meet the
+    (inflated) cell — the step kernel tests an aircraft only against those (usually none) instead of every noise polygon.
+
     Layout (words): header[8] = x0, y0, inv_cell, nx, ny, offset of the edge pool (from grid start), n_records, 0;
-    cells[ny*nx][2] = (n_records, first_record) for dirty cells, (-(polygon+1), MVA height) or (0, 0) for clean ones; pool of
-    8-word records."""
+    cells[ny*nx][2] = (c, first_record | MVA height) with |c| = code + 64 * noise mask: c > 0 dirty cell, code = n_records
+    (< 64); c <= 0 clean cell, code = polygon + 1 (0 = outside the airspace); pool of 8-word records."""
     if guard is None:
         guard = 1e-3
     x0, y0, x1, y1 = bbox
@@ -215,6 +218,20 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None):
             cells[j, i, 0] = len(recs)
             cells[j, i, 1] = len(pool) if recs else 0.0   # (0, 0): nothing can match = clean cell outside the airspace
             pool.extend(recs)
+    assert len(noise_bounds) <= 16, "at most 16 noise-abatement areas"
+    assert cells[:, :, 0].max() < 64
+    for j in range(ny):
+        cy0s = gy0 + j * cell - slack
+        cy1s = gy0 + (j + 1) * cell + slack
+        for i in range(nx):
+            cx0s = gx0 + i * cell - slack
+            cx1s = gx0 + (i + 1) * cell + slack
+            mask = 0
+            for q, b in enumerate(noise_bounds):
+                if not (b[2] < cx0s or b[0] > cx1s or b[3] < cy0s or b[1] > cy1s):
+                    mask |= 1 << q
+            c = cells[j, i, 0]
+            cells[j, i, 0] = (c + 64.0 * mask) if c > 0 else (c - 64.0 * mask)
     n_rec = len(pool)
     hdr = np.zeros(L.G_HDR, dtype=np.float64)
     hdr[L.G_X0], hdr[L.G_Y0], hdr[L.G_INV], hdr[L.G_NX], hdr[L.G_NY] = gx0, gy0, inv, nx, ny
@@ -267,6 +284,7 @@ class CompiledSector:
 def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_guard=None):
     """mvas: [(points, height_ft)], runway: (x, y, h, phi_from_runway), entrypoints: [(x, y, phi, [levels])],
     noise: [(points, ceiling_ft, penalty_per_step)].  Returns CompiledSector."""
+    assert len(noise) <= 16, "at most 16 noise-abatement areas"
     mva_rings = [close_ring(p) for p, _ in mvas]
     mva_heights = [float(hh) for _, hh in mvas]
     noise_rings = [close_ring(p) for p, _, _ in noise]
@@ -302,7 +320,8 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
     grid = None
     off_grid = 0
     if grid_cell is not None and mva_rings:
-        grid = build_grid(mva_rings, bounds[:len(mva_rings)], mva_heights, bbox, float(grid_cell), grid_guard)
+        grid = build_grid(mva_rings, bounds[:len(mva_rings)], mva_heights, bbox, float(grid_cell), grid_guard,
+                          noise_bounds=bounds[len(mva_rings):])
         off_grid = (end + 3) & ~3  # 16-byte aligned: cells are read as 8-byte pairs, edge records as 16-byte vectors
         end = off_grid + len(grid)
 

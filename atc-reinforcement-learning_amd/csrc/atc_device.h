@@ -149,9 +149,14 @@ __device__ __forceinline__ bool in_bounds(const float* rec, float x, float y) {
 // The lookup is split so that the caller can issue the cell gather early and resolve it later: the L2 round trip then
 // overlaps independent work (in the step kernel: the whole separation scan) instead of stalling the wavefront.
 struct MvaCell {
-    float2 cell;   // (n_records | -(polygon + 1) | 0, first_record | height)
+    float2 cell;   // (+-(code + 64 noise mask), first_record | height): > 0 dirty, code = n_records; <= 0 clean, code = polygon + 1
     bool in_grid;  // false: beyond the padded bbox (also NaN) -> outside the airspace
 };
+// bit q set: the aircraft has to be tested against noise-abatement area q (all of them where there is no grid cell to ask)
+__device__ __forceinline__ uint32_t noise_candidates(const float* __restrict__ grid, const MvaCell& c) {
+    if (!grid || !c.in_grid) return 0xffffu;
+    return (uint32_t)(int)fabsf(c.cell.x) >> 6;
+}
 __device__ __forceinline__ MvaCell mva_cell_load(const float* __restrict__ grid, float x, float y) {
     MvaCell c;
     c.cell = make_float2(0.0f, 0.0f);
@@ -174,11 +179,12 @@ __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const fl
     if (grid) {
         if (!c.in_grid) return -1;
         const float2 cell = c.cell;
-        const int n = (int)cell.x;
-        if (n <= 0) {  // clean cell: (-(polygon + 1), height) or (0, 0) = outside
+        const int code = (int)fabsf(cell.x) & 63;
+        if (!(cell.x > 0.0f)) {  // clean cell: polygon + 1 (0 = outside the airspace), height
             *height = cell.y;
-            return -n - 1;
+            return code - 1;
         }
+        const int n = code;
 #ifdef ATC_ABLATE_WALK
         *height = 3000.0f;  // developer-only timing ablation: dirty cells answered without walking their edge list
         return 1;

@@ -430,6 +430,27 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
     return m;
 }
 
+// Extension (README.md:62): noise-abatement areas the aircraft is inside of and below the ceiling of — ATC_F_NOISE plus one
+// bit per area in bits 16.. (consumed by the reward stage).  Evaluated while the lookup-grid cell is at hand: the cell names
+// the areas whose bounds meet it, and almost every wavefront has no candidate at all.
+__device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, const float* __restrict__ grid, const MvaCell& c,
+                                               float x, float y, float h) {
+    const int n_noise = (ATC_ABLATE & 256) ? 0 : (int)K[ATC_H_N_NOISE];
+    uint32_t bits = 0;
+    if (n_noise > 0) {
+        const uint32_t cand = noise_candidates(grid, c);
+        if (__ballot(cand != 0u) != 0ull) {
+            for (int q = 0; q < n_noise; ++q) {
+                const float* rec = K + (int)K[ATC_H_OFF_POLY] + ((int)K[ATC_H_N_MVA] + q) * ATC_P_WORDS;
+                if (((cand >> q) & 1u) && in_bounds(rec, x, y) && h < rec[ATC_P_HEIGHT] &&
+                    ray_tracing(x, y, K + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT]))
+                    bits |= (uint32_t)ATC_F_NOISE | (0x10000u << q);
+            }
+        }
+    }
+    return bits;
+}
+
 // ---- second half: separation scan, win/timeout, observation, shaping, reductions, outputs, auto-reset --------------
 template <int W, bool FULL>
 __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const float* __restrict__ grid,
@@ -459,6 +480,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
         float hgt = 0.0f;
         pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, m.cell, x32, y32, &hgt);
         mva = pi >= 0 ? hgt : 0.0f;
+        fl |= noise_areas(K, grid, m.cell, x32, y32, a.h);
     }
     // Multi-step launches: the NEXT step's action is requested here — behind the MVA gathers (loads return in order: issued
     // earlier it would sit in front of them and its HBM latency would be paid at the MVA wait) and with the rest of the
@@ -539,6 +561,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
             float hgt = 0.0f;
             pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, m.cell, x32, y32, &hgt);
             mva = pi >= 0 ? hgt : 0.0f;                // atc_gym.py:161: mva = 0 outside
+            fl |= noise_areas(K, grid, m.cell, x32, y32, a.h);
         }
         const bool below = pi >= 0 && a.h < mva;
         r = pi < 0 ? -50.0f : (below ? -200.0f : r);
@@ -580,14 +603,13 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
             r += sh.ang;
             r += sh.gs;
         }
-        const int n_noise = (ATC_ABLATE & 256) ? 0 : (int)K[ATC_H_N_NOISE];
-        for (int q = 0; q < n_noise; ++q) {  // extension (README.md:62): noise-abatement areas
-            const float* rec = K + (int)K[ATC_H_OFF_POLY] + ((int)K[ATC_H_N_MVA] + q) * ATC_P_WORDS;
-            if (in_bounds(rec, x32, y32) && a.h < rec[ATC_P_HEIGHT] &&
-                ray_tracing(x32, y32, K + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT])) {
-                r -= rec[ATC_P_PENALTY];
-                fl |= ATC_F_NOISE;
-            }
+        // extension (README.md:62): noise-abatement areas — which ones the aircraft is in was decided next to the MVA lookup
+        // (bits 16.. of fl); the penalties are subtracted here, after the shaping terms, in area order.
+        if (__ballot((fl >> 16) != 0u) != 0ull) {
+            const int n_noise = (int)K[ATC_H_N_NOISE];
+            for (int q = 0; q < n_noise; ++q)
+                if ((fl >> (16 + q)) & 1u) r -= (K + (int)K[ATC_H_OFF_POLY] + ((int)K[ATC_H_N_MVA] + q) * ATC_P_WORDS)[ATC_P_PENALTY];
+            fl &= 0xffffu;
         }
         if (FULL && so.raw_obs && d.lane_valid) {
             float z[ATC_OBS_DIM];
@@ -997,6 +1019,7 @@ int atc_scenario_create(const float* blob_host, size_t n_words, int device, atc_
     if (n_words < ATC_C_END || blob_host[ATC_H_VERSION] != ATC_BLOB_VERSION || (size_t)blob_host[ATC_H_NWORDS] != n_words)
         return fail_arg("not a scenario blob of this ABI version");
     if ((int)blob_host[ATC_H_N_MVA] > 32) return fail_arg("at most 32 MVA polygons");
+    if ((int)blob_host[ATC_H_N_NOISE] > 16) return fail_arg("at most 16 noise-abatement areas");
     {   // compiled-in aircraft constants (csrc/atc_device.h) must match the blob
         const float want[] = {kVMin, kVMax, kHMin, kHMax, kAMin, kAMax, kHDotMin, kHDotMax, kPhiDotMin, kPhiDotMax, kVInit};
         for (int c = 0; c < 11; ++c)

@@ -35,7 +35,7 @@ extern "C" {
  * envs/atc/atc_gym.py:45-58,88-110).  Integer fields are stored as exactly representable floats.
  * The float64 master (used by the f64 oracle) has the identical word layout.
  * ------------------------------------------------------------------------------------------- */
-#define ATC_BLOB_VERSION 1010.0f
+#define ATC_BLOB_VERSION 1011.0f
 enum {
     ATC_H_VERSION = 0,   /* ATC_BLOB_VERSION */
     ATC_H_NWORDS = 1,    /* total words */
@@ -95,9 +95,10 @@ enum { ATC_E_X = 0, ATC_E_Y = 1, ATC_E_PHI = 2, ATC_E_NLEV = 3, ATC_E_LEV0 = 4, 
 /* lookup grid (optional acceleration structure for Airspace.find_mva, model.py:282-289; results identical to the
  * ordered polygon scan by construction — see atc_hip/scenario.py:build_grid).  16-byte aligned in the blob.
  *   header 8 words : x0, y0, 1/cell, nx, ny, offset of the edge pool (from grid start), number of edge records, 0
- *   cells  ny*nx*2 : (n_records >= 1, first_record)   -> dirty cell: walk that many edge records
- *                    (-(polygon + 1), MVA height)     -> clean cell: every point has this answer
- *                    (0, 0)                           -> clean cell outside the airspace
+ *   cells  ny*nx*2 : (c, v) with |c| = code + 64 * noise mask (bit q: the bounds of noise-abatement area q meet the cell)
+ *                    c > 0  : dirty cell, code = n_records (< 64), v = first record: walk that many edge records
+ *                    c <= 0 : clean cell, code = polygon + 1 and v = MVA height — every point has this answer;
+ *                             code = 0: outside the airspace
  *   pool           : 8-word records, two 16-byte halves G | M (flags and folding rules: atc_hip/scenario.py:build_grid):
  *                    edge       G = p1x, p1y, p2x, p2y          M = min(p1y,p2y), max(p1y,p2y), polygon height, code
  *                    terminator G = polygon bounds x0,y0,x1,y1  M = 0, 0, polygon height, code

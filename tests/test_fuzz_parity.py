@@ -37,7 +37,7 @@ def _case(seed):
               hold=int(rng.choice([1, 7, 20])), grid_cell=grid_cell, use_rollout=rollout,
               timestep_limit=int(rng.choice([6000, 6000, 40])), full=bool(rng.integers(2)),
               shaping=bool(rng.integers(4) > 0), normalize=bool(rng.integers(4) > 0),
-              sep_nm=float(rng.choice([3.0, 3.0, 0.0, 5.0])))
+              sep_nm=float(rng.choice([3.0, 3.0, 0.0, 5.0])), keep_active=bool(rng.integers(5) == 0))
     if rollout:
         kw["steps"] = (kw["steps"] // rollout) * rollout
     return scn, comp, kw

@@ -364,7 +364,8 @@ def test_atcgym_keeps_flying_after_a_win():
 
 # ------------------------------------------------------------------------------------------------ batched vs fp32 oracle
 def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, spawn="lattice", hold=20, grid_cell=0.5,
-                   use_rollout=0, timestep_limit=6000, full=True, shaping=True, normalize=True, sep_nm=3.0):
+                   use_rollout=0, timestep_limit=6000, full=True, shaping=True, normalize=True, sep_nm=3.0,
+                   keep_active=False):
     """full=False drives the fast kernel variant (obs / reward / done / flags only), full=True the one with every optional
     output; everything the variant produces is compared with the fp32 oracle."""
     torch = _torch()
@@ -374,9 +375,10 @@ def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, sp
     sp = model.SimParameters(dt, discrete_action_space=discrete, reward_shaping=shaping, normalize_state=normalize)
     env = AtcVecEnv(B, N, sim_parameters=sp, scenario=scen_obj, auto_reset=True, spawn=spawn, seed=seed,
                     grid_cell=grid_cell, want_raw_obs=full, want_ac_reward=full, want_min_sep=full, want_term_obs=full,
-                    timestep_limit=timestep_limit, sep_nm=sep_nm)
+                    timestep_limit=timestep_limit, sep_nm=sep_nm, keep_active=keep_active)
     p = O.make_params(dt=dt, discrete=discrete, auto_reset=True, random_entry=(spawn == "random"), seed=seed,
-                      timestep_limit=timestep_limit, shaping=shaping, normalize=normalize, sep_nm=sep_nm)
+                      timestep_limit=timestep_limit, shaping=shaping, normalize=normalize, sep_nm=sep_nm,
+                      keep_active=keep_active)
     orc = O.OracleEnv(comp, B, N, p, np.float32)
     o0 = env.obs.cpu().numpy().reshape(B, N, 10)
     assert np.all(np.abs(o0 - orc.obs) <= 1e-5 * np.maximum(1.0, np.abs(orc.obs)))
@@ -506,6 +508,36 @@ def test_rollout_equals_single_steps_vs_oracle():
     scn = scenarios.LOWW(random_entrypoints=True)
     _run_vs_oracle(scn, scenarios.compile_scenario(scn, grid_cell=0.5), B=256, N=16, steps=120, seed=8, use_rollout=24)
     _run_vs_oracle(scenarios.LOWW(), H.compiled("LOWW", 0.5), B=1000, N=1, steps=250, seed=2, use_rollout=50)
+
+
+def test_flying_on_beyond_the_position_grid():
+    """Documented limit of the fixed-point position grid (include/atc_step.h): an aircraft that is flown on without reset
+    beyond the grid range is pinned at the range limit — it stays OUTSIDE the airspace like the reference's, its x / y
+    observation stops growing, and HIP and the fp32 oracle still agree bit for bit."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+    from oracle import oracle as O
+    scn = scenarios.LOWW()
+    comp = H.compiled("LOWW", 0.5)
+    env = AtcVecEnv(4, 1, scenario=scn, auto_reset=False, keep_active=True)
+    orc = O.OracleEnv(comp, 4, 1, O.make_params(keep_active=True), np.float32)
+    a = np.zeros((4, 1, 3), np.float32)
+    a[:, 0, 0] = 1.0                                   # 300 kt
+    a[:, 0, 2] = [-1.0, -0.5, 0.0, 0.5]                 # headings 0 / 90 / 180 / 270: one aircraft per compass direction
+    lim_lo = np.array(comp.pos_origin) - 2.0 ** (31 - comp.pos_k)
+    lim_hi = np.array(comp.pos_origin) + 2.0 ** (31 - comp.pos_k)
+    for t in range(1400):                               # 1400 s x 300 kt = 117 nm: well past the +-64 nm grid
+        obs, rew, done, info = env.step(a)
+        orc.step(a)
+        if t % 50 == 0 or t > 1350:
+            assert np.array_equal(env.pos_hp[:, 0].cpu().numpy(), orc.px) and np.array_equal(env.pos_hp[:, 1].cpu().numpy(), orc.py)
+            assert np.array_equal(info["flags"].cpu().numpy().astype(np.uint16), orc.flags)
+    assert bool((info["flags"][:, 0] & H.F_OUTSIDE).all()) and bool(done.all())
+    x, y = env.x.cpu().numpy(), env.y.cpu().numpy()
+    assert y[0] == lim_hi[1] - 2.0 ** -comp.pos_k and x[1] == lim_hi[0] - 2.0 ** -comp.pos_k      # INT32_MAX counts
+    assert y[2] == lim_lo[1] and x[3] == lim_lo[0]                                                  # INT32_MIN counts
+    env.close()
 
 
 # ------------------------------------------------------------------------------------------------ extension known answers

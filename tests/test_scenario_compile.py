@@ -72,11 +72,12 @@ def _walk_grid(b, g, tabs, tabs_h, x, y):
     if not (0 <= fx < nx and 0 <= fy < ny):
         return -1
     c = g + L.G_HDR + 2 * (int(fy) * nx + int(fx))
-    n, v = int(b[c]), int(b[c + 1])
-    if n <= 0:
-        if n < 0:
-            assert b[c + 1] == tabs_h[-n - 1]
-        return -n - 1
+    code, v = int(abs(b[c])) & 63, int(b[c + 1])
+    if not b[c] > 0:
+        if code > 0:
+            assert b[c + 1] == tabs_h[code - 1]
+        return code - 1
+    n = code
     pool = g + int(b[g + L.G_OFF_POOL])
     inside = False
     for e in range(n):
@@ -130,5 +131,5 @@ def test_grid_matches_ordered_scan_on_host(scen, cell):
     cells = b[g + L.G_HDR: g + L.G_HDR + 2 * int(b[g + L.G_NX]) * int(b[g + L.G_NY])].reshape(-1, 2)
     n_dirty = int((cells[:, 0] > 0).sum())
     assert 0 < n_dirty < 0.45 * len(cells)
-    assert cells[:, 0].max() <= 64
+    assert cells[:, 0].max() < 64
     print(scen, cell, 'dirty cells', n_dirty, 'of', len(cells), 'records per dirty cell %.2f' % (cells[cells[:, 0] > 0, 0].mean()), 'max', cells[:, 0].max())
