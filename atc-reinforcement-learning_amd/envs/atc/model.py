@@ -143,6 +143,11 @@ class Airspace:
             raise ValueError('Outside of airspace')
         return self.mvas[idx]
 
+    def get_mva_heights(self, xs, ys):
+        """Batched get_mva_height: heights [ft] for arrays of points in ONE launch, -1 outside the airspace (build-own
+        convenience; the reference evaluates one point per call)."""
+        return self._dev.handle().query_mva(xs, ys)
+
     def get_mva_height(self, x, y):
         return self.find_mva(x, y).height
 
@@ -152,12 +157,23 @@ class Airspace:
         return (min(v[0] for v in b), min(v[1] for v in b), max(v[2] for v in b), max(v[3] for v in b))
 
 
+_ray_sectors = {}   # one-polygon device sectors of recent ray_tracing() calls, keyed by the ring's bytes
+
+
 def ray_tracing(x, y, poly):
-    """model.py:318-337 — evaluated on the device against a one-polygon sector."""
+    """model.py:318-337 — evaluated on the device against a one-polygon sector (compiled and uploaded once per polygon;
+    `x`, `y` may be arrays: one launch for all points)."""
     ring = _scn.close_ring(poly)
-    comp = _scn.compile_sector([(ring, 1)], (0.0, 0.0, 0.0, 0.0), [])
-    from atc_hip import lib
-    return bool(lib.Scenario(comp).query_mva_index([x], [y])[0] == 0)
+    key = ring.tobytes()
+    sector = _ray_sectors.get(key)
+    if sector is None:
+        from atc_hip import lib
+        if len(_ray_sectors) >= 64:
+            _ray_sectors.pop(next(iter(_ray_sectors))).close()
+        sector = _ray_sectors[key] = lib.Scenario(_scn.compile_sector([(ring, 1)], (0.0, 0.0, 0.0, 0.0), []))
+    xs, ys = np.atleast_1d(x), np.atleast_1d(y)
+    hit = sector.query_mva_index(xs, ys) == 0
+    return bool(hit[0]) if np.ndim(x) == 0 and np.ndim(y) == 0 else hit
 
 
 def relative_angle(angle1, angle2):

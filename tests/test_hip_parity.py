@@ -69,6 +69,11 @@ class TestReferenceModelTests:
     def test_ray_tracing_function(self):
         assert self.model.ray_tracing(30, 10, [(15, 0), (35, 0), (35, 26)]) is True
         assert self.model.ray_tracing(16, 20, [(15, 0), (35, 0), (35, 26)]) is False
+        # the polygon's device sector is compiled once and reused; arrays of points go in one launch
+        assert len(self.model._ray_sectors) == 1
+        hit = self.model.ray_tracing(np.array([30.0, 16.0, 34.9]), np.array([10.0, 20.0, 0.1]), [(15, 0), (35, 0), (35, 26)])
+        assert hit.tolist() == [True, False, True] and len(self.model._ray_sectors) == 1
+        assert self.airspace.get_mva_heights([34.0, -5.0], [1.0, -5.0]).tolist() == [3500, -1]
 
 
 # ------------------------------------------------------------------------------------------------ G3 / G4 / G5 lattices
