@@ -485,11 +485,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     // Multi-step launches: the NEXT step's action is requested here — behind the MVA gathers (loads return in order: issued
     // earlier it would sit in front of them and its HBM latency would be paid at the MVA wait) and with the rest of the
     // step body (scan, corridor, observation, shaping, stores) still ahead to cover it.
-    if (act_next) {
-        a_next.a = stream_load(at<float>(act_next, i * 12u));
-        a_next.b = stream_load(at<float>(act_next, i * 12u + 4u));
-        a_next.c = stream_load(at<float>(act_next, i * 12u + 8u));
-    }
+    if (act_next) a_next = *at<Float3>(act_next, i * 12u);
     float min_d2 = 1e30f;
     float margin = 1e30f;  // min over partners of max(d^2 - sep^2, |dh| - sep_ft): conflict iff negative
     if (W > 1 && !(ATC_ABLATE & 2)) {
@@ -812,11 +808,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
                       , trace
 #endif
         };
-        if (ONE || step == 0) {
-            act.a = stream_load(at<float>(act_t, dl.i * 12u));
-            act.b = stream_load(at<float>(act_t, dl.i * 12u + 4u));
-            act.c = stream_load(at<float>(act_t, dl.i * 12u + 8u));
-        }
+        if (ONE || step == 0) act = *at<Float3>(act_t, dl.i * 12u);   // one 12-byte load per lane
         const Mid m = step_part_a(Kl, gl, p, q, dl, act.a, act.b, act.c, ls, es);
         ATC_STAMP(1);
         Float3 nxt = act;
