@@ -30,6 +30,7 @@ class _AirplaneView:
         object.__setattr__(self, "_vec", vec)
         object.__setattr__(self, "name", name)
         object.__setattr__(self, "id", 0)
+        object.__setattr__(self, "position_history", [])   # model.py:51,123: (x, y) before every move, new list per reset
 
     def __getattr__(self, key):
         if key in ("x", "y", "h", "phi", "v"):
@@ -83,6 +84,8 @@ class AtcGym(Env):
         self._act_np = self._host_act.numpy()
         self._out_np = self._host_out.numpy()
         self._env_np = self._vec.env.numpy()
+        self._pos_np = self._vec.pos_hp.numpy()
+        self._pos_inv = 2.0 ** -self._vec.pos_k
         lay = self._out_layout
         f32 = lambda name: self._out_np[lay[name][0]:lay[name][0] + lay[name][1]].view(np.float32)  # noqa: E731
         self._obs_np, self._raw_np, self._rew_np = f32("obs"), f32("raw_obs"), f32("reward")
@@ -152,6 +155,10 @@ class AtcGym(Env):
         """atc_gym.py:128-192 — one launch of the HIP step kernel + the reference's Python-side bookkeeping."""
         a = np.asarray(action, dtype=np.float32).reshape(1, 1, 3)
         self._act_np[:] = a.reshape(3)
+        # model.py:123: Airplane.step first remembers where the aircraft IS (read by render() only), then moves it
+        px, py = self._pos_np[0, 0], self._pos_np[0, 1]
+        self._airplane.position_history.append((self._vec.pos_origin[0] + int(px) * self._pos_inv,
+                                                self._vec.pos_origin[1] + int(py) * self._pos_inv))
         state_out, raw, rew, dn, flags, self.timesteps, self.actions_taken = self._launch_and_fetch()
         self.done = False
         # one append per terminal cause, in the reference's order (atc_gym.py:151,158,165)
@@ -208,6 +215,7 @@ class AtcGym(Env):
         vec.reset()
         vec.set_state(0, 0, entry_point.x, entry_point.y, level * 100, entry_point.phi, 250)
         self._airplane.id = plane_id
+        self._airplane.position_history = []
         self.state = vec.observe().reshape(-1).numpy().astype(np.float32)  # host-mapped: synchronised, copied here
         self.total_reward = 0
         self.last_reward = 0
@@ -223,10 +231,12 @@ class AtcGym(Env):
 
     def render(self, mode='human'):
         """The pyglet window of the reference (atc_gym.py:367-552) is out of scope; `rgb_array` is served by
-        the headless numpy renderer (atc_hip/render.py) so recorders keep working, `human` is a no-op."""
+        the headless numpy renderer (atc_hip/render.py: the reference's geometry — pinned on tests/golden/g10 — drawn without
+        label text) so recorders keep working, `human` is a no-op."""
         if mode == 'rgb_array':
             from atc_hip import render
-            return render.rgb_array(self._vec, env=0)
+            return render.rgb_array(self._vec, env=0, history=self._airplane.position_history,
+                                    total_reward=self.total_reward, last_reward=self.last_reward)
         return None
 
     def close(self):

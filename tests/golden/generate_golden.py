@@ -16,6 +16,9 @@ inputs + expected outputs of the AtcGym.step() hot path as small fixtures:
   g8_tiebreak.npz     Airspace.get_mva_height on a sector with integer / dyadic vertices (exactly representable in fp32):
                       vertices, edge midpoints, shared borders, overlapping polygons (list-order priority), points a few
                       2^-10 nm either side of every edge — the tie-break rules of model.py:282-289,318-337
+  g10_render_geometry.json  the geometry the reference's render() builds (window size, MVA outlines, runway, FAF symbol,
+                      approach dashes, aircraft symbol / label anchors / history dots after a scripted flight), captured with
+                      the recording `rendering` stand-in of tests/oracle_shims
   g9_wide.npz         >= 500 000 reference steps in compact form (per step: flags, done, actions_taken, reward; observation
                       and state every 16th step and on the last step of every episode): LOWW / LOWW_random / Simple /
                       UnitTest, dt 1/2/5, continuous and discrete, shaping x normalisation off, >= 50 each of win /
@@ -700,6 +703,56 @@ def gen_g9():
     return rec
 
 
+# ----------------------------------------------------------------------------------------------- G10
+def gen_g10():
+    """What AtcGym.render() draws (atc_gym.py:367-552), as plain geometry in the reference's screen coordinates."""
+    def pts(v):
+        return [[float(np.asarray(p).ravel()[0]), float(np.asarray(p).ravel()[1])] for p in v]
+
+    def geom(g):
+        d = {"kind": type(g).__name__, "color": [float(c) for c in g.color] if g.color else None,
+             "linewidth": float(g.linewidth)}
+        if hasattr(g, "v"):
+            d["v"] = pts(g.v)
+        if hasattr(g, "close"):
+            d["close"] = bool(g.close)
+        if hasattr(g, "radius"):
+            d["radius"] = float(g.radius)
+            d["translation"] = [float(t) for t in g.attrs[0].translation]
+        if hasattr(g, "text"):
+            d["text"], d["x"], d["y"] = g.text, float(g.x), float(g.y)
+        return d
+
+    out = {}
+    for name in ("LOWW", "Simple"):
+        env = make_env(name)
+        frames = []
+        acts = [f32([0.0, -0.2, 0.5])] * 60
+        if name == "Simple":
+            ap = env._airplane
+            ap.x, ap.y, ap.h, ap.phi, ap.v = 5.0, 30.0, 9000.0, 90.0, 250.0
+        env.render(mode='rgb_array')
+        static = [geom(g) for g in env.viewer.geoms]
+        frames.append({"step": 0, "state": [float(v) for v in (env._airplane.x, env._airplane.y, env._airplane.h,
+                                                                 env._airplane.phi, env._airplane.v)],
+                       "geoms": [geom(g) for g in env.viewer.last_frame]})
+        for t, a in enumerate(acts):
+            env.step(np.asarray(a, dtype=np.float64))
+            if (t + 1) % 20 == 0:
+                env.render(mode='rgb_array')
+                frames.append({"step": t + 1, "state": [float(v) for v in (env._airplane.x, env._airplane.y, env._airplane.h,
+                                                                             env._airplane.phi, env._airplane.v)],
+                               "total_reward": float(env.total_reward), "last_reward": float(env.last_reward),
+                               "geoms": [geom(g) for g in env.viewer.last_frame]})
+        out[name] = {"width": int(env.viewer.width), "height": int(env.viewer.height), "scale": float(env._scale),
+                     "padding": int(env._padding), "static": static, "frames": frames,
+                     "actions": [[float(v) for v in a] for a in acts],
+                     "init_state": frames[0]["state"]}
+    with open(os.path.join(HERE, "g10_render_geometry.json"), "w") as f:
+        json.dump(out, f)
+    return out
+
+
 # ------------------------------------------------------------------------- reference unit-test known answers
 def gen_model_test():
     """Inputs and expected outputs of envs/atc/model_test.py:10-92, re-evaluated here against the reference."""
@@ -732,7 +785,7 @@ def gen_model_test():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "mt", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "mt", "g8", "g9", "g10"]
     if "g1" in which:
         gen_g1()
     if "mt" in which:
@@ -755,6 +808,9 @@ if __name__ == "__main__":
             print(name, int(((fl & bit) != 0).sum()), "terminal:", int((((fl & bit) != 0) & (dn != 0)).sum()))
     if "g7" in which:
         gen_g7()
+    if "g10" in which:
+        o = gen_g10()
+        print("g10", {k: (v["width"], v["height"], len(v["static"]), [len(f["geoms"]) for f in v["frames"]]) for k, v in o.items()})
     if "g8" in which:
         pts, h = gen_g8()
         print("g8 points", len(pts), "heights", sorted(set(h.tolist())))

@@ -131,19 +131,34 @@ def test_sparse_infos_for_large_batches():
     venv.close()
 
 
-def test_rgb_array_renders_aircraft():
+def test_render_frames_equal_reference_geometry():
+    """G10 on the GPU: AtcGym flies the scripted episode the reference flew; at steps 0 / 20 / 40 / 60 the frame geometry the
+    renderer builds from the DEVICE state (aircraft symbol, label anchors and texts, history dots, reward labels) equals what
+    the reference drew, and `render('rgb_array')` returns a frame of the reference's window size."""
+    from test_sector_io_render import _same_geoms
     from atc_hip import render
     from envs.atc import atc_gym
-    env = atc_gym.AtcGym()
-    img = env.render(mode='rgb_array')
-    assert img.shape == (800, 800, 3) and img.dtype == np.uint8
-    bg, view = render.background(env._vec.compiled, 800)
-    u, v = view.px([[10.0, 51.0]])[0]                      # the LOWW entry point (scenarios.py:205-207)
-    assert tuple(img[int(round(v)), int(round(u))]) == render.AIRCRAFT
-    assert (img != bg).any(axis=2).sum() >= 25             # marker + heading tick
-    assert env.render(mode='human') is None
-    for _ in range(50):
-        env.step(np.array([0.0, 0.0, -0.5]))
-    img2 = env.render(mode='rgb_array')
-    assert (img2 != img).any()
-    env.close()
+    for scen in ("LOWW", "Simple"):
+        g = H.golden_json("g10_render_geometry.json")[scen]
+        env = atc_gym.AtcGym(scenario=H.make_scenario(scen))
+        env.reset()
+        ap = env._airplane
+        ap.x, ap.y, ap.h, ap.phi, ap.v = g["init_state"]
+        frames = {f["step"]: f for f in g["frames"]}
+
+        def check(step):
+            f = frames[step]
+            got = render.frame_scene(env._vec.compiled, [{"x": ap.x, "y": ap.y, "h": ap.h, "v": ap.v, "name": ap.name,
+                                                          "history": ap.position_history}], env.total_reward, env.last_reward)
+            _same_geoms(got, f["geoms"], 2e-3)            # fp32 positions: 1e-4 nm x 9.4 px / nm
+            img = env.render(mode='rgb_array')
+            assert img.shape == (g["height"], g["width"], 3) and img.dtype == np.uint8
+            return img
+
+        img0 = check(0)
+        for t, a in enumerate(g["actions"]):
+            env.step(np.asarray(a))
+            if (t + 1) in frames:
+                img = check(t + 1)
+        assert (img != img0).any() and env.render(mode='human') is None
+        env.close()

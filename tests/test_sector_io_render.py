@@ -50,16 +50,57 @@ def test_custom_sector_compiles_and_matches_oracle_lookup():
     assert comp.faf_mva == 2000 and comp.n_entry == 1
 
 
-def test_render_background_layer():
+def _same_geoms(got, exp, tol):
+    assert len(got) == len(exp), (len(got), len(exp))
+    for g, e in zip(got, exp):
+        kind = "FilledPolygon" if (g["kind"] == "Circle") else g["kind"]
+        assert kind == e["kind"], (g["kind"], e["kind"])
+        if g["kind"] == "Label":
+            assert g["text"] == e["text"] and abs(g["x"] - e["x"]) <= tol and abs(g["y"] - e["y"]) <= tol, (g, e)
+            continue
+        if g["kind"] == "Circle":
+            assert g["radius"] == e["radius"] and np.allclose(g["translation"], e["translation"], rtol=0, atol=tol)
+        else:
+            assert np.allclose(np.asarray(g["v"], float), np.asarray(e["v"], float), rtol=0, atol=tol), (g["kind"], g["v"], e["v"])
+            assert g.get("close", None) == e.get("close", None)
+            assert float(g["linewidth"]) == e["linewidth"]
+        assert np.allclose(g["color"], e["color"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("scen", ["LOWW", "Simple"])
+def test_render_static_geometry_equals_reference(scen):
+    """G10: what the reference's render() draws once (atc_gym.py:384-398) — window size, background, filled MVA polygons,
+    their outlines, runway line, FAF triangle, approach dashes — captured from the imported reference with a recording
+    `rendering` stand-in; the headless renderer builds the same primitives in the same screen coordinates, in the same order,
+    with the same colours and line widths."""
+    g = H.golden_json("g10_render_geometry.json")[scen]
+    comp = H.compiled(scen)
+    sc = render.Screen(comp.bbox)
+    assert (sc.width, sc.height) == (g["width"], g["height"]) and abs(sc.scale - g["scale"]) < 1e-12
+    assert render.PADDING == g["padding"]
+    _same_geoms(render.static_scene(comp), g["static"], 1e-9)
+    # per-frame geometry from the recorded aircraft states (the GPU test produces the states itself)
+    for f in g["frames"]:
+        x, y, h, phi, v = f["state"]
+        got = render.frame_scene(comp, [{"x": x, "y": y, "h": h, "v": v}], f.get("total_reward", 0.0), f.get("last_reward", 0.0))
+        exp = [e for e in f["geoms"] if not (e["kind"] == "FilledPolygon" and "radius" in e)]   # history dots: GPU test
+        _same_geoms(got, exp, 1e-9)
+
+
+def test_render_rasterises_the_scene():
     comp = H.compiled("LOWW")
-    img, view = render.background(comp, size=400)
-    assert img.shape == (400, 400, 3) and img.dtype == np.uint8
-    lines = np.all(img == np.array(render.LINES, np.uint8), axis=2)
-    assert 1500 < lines.sum() < 20000                     # polygon outlines were drawn
-    # every polygon vertex lands on an outline pixel
-    for ring in comp.mva_rings:
-        for u, v in view.px(ring):
-            assert lines[int(round(v)), int(round(u))]
-    corr = np.all(img == np.array(render.CORRIDOR, np.uint8), axis=2)
-    u, v = view.px([comp.corridor["faf"]])[0]
-    assert corr[int(round(v)), int(round(u))]
+    img, sc = render.background(comp)
+    assert img.shape == (sc.height, sc.width, 3) == (768, 620, 3) and img.dtype == np.uint8
+    line = render._u8(render.LINES_INFO)
+    lines = np.all(img == line, axis=2)
+    assert 2000 < lines.sum() < 40000                     # outlines, runway, FAF symbol, approach dashes
+    for ring in comp.mva_rings:                           # every polygon vertex lands on an outline pixel
+        for u, v in sc.padded(ring):
+            assert lines[sc.height - 1 - int(round(v)), int(round(u))]
+    inside = np.all(img == render._u8(render.BACKGROUND_ACTIVE), axis=2)
+    outside = np.all(img == render._u8(render.BACKGROUND_INACTIVE), axis=2)
+    assert inside.sum() > 0.4 * img.shape[0] * img.shape[1] and outside.sum() > 0.1 * img.shape[0] * img.shape[1]
+    frame = render.rasterise(sc.width, sc.height, render.frame_scene(comp, [{"x": 30.0, "y": 40.0, "h": 9000.0, "v": 250.0,
+                                                                             "history": [(29.0 + 0.1 * i, 40.0) for i in range(30)]}]), img.copy())
+    plane = np.all(frame == render._u8(render.AIRPLANE), axis=2)
+    assert 20 < plane.sum() < 400
