@@ -4,11 +4,18 @@
  * This file is the parity oracle (checker) for the HIP product path.  Only tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg may load it.  It is never imported by the product package.
  *
- * Included twice by atc_oracle.c with REAL = double (suffix _f64; pinned against the golden vectors captured from the
- * reference, tests/golden/) and REAL = float (suffix _f32; the fp32 restatement the HIP kernel's integer outputs must
- * match bit-for-bit).  Scalar, same operation order as the reference, compiled with -ffp-contract=off.
+ * Included twice by atc_oracle.c:
+ *   REAL = double (suffix _f64): the reference as it is — Python floats, libm; pinned against the golden vectors captured
+ *     from the imported reference (integer outputs exact, state within 1e-11);
+ *   REAL = float (suffix _f32): the fp32 restatement — the same operation order in float with libm's float functions,
+ *     EXCEPT the two choices include/atc_step.h fixes for every fp32 implementation ("Aircraft positions": the fixed-point
+ *     position grid and the polynomial heading kinematics).  With those shared, the HIP kernels' aircraft state and every
+ *     integer output match this instantiation bit for bit; it is itself pinned against the same golden vectors (integer
+ *     outputs exact, fp32 values within 1e-5).
+ * Scalar, compiled with -ffp-contract=off.
  *
- * Pinned by: tests/golden/{g1..g7,model_test_known_answers} (see tests/test_oracle_golden.py).
+ * Pinned by: tests/golden/{g1..g9,model_test_known_answers} (see tests/test_oracle_golden.py): 48 080 + 650 963 reference
+ * steps, lattices, tie-break points, shaping grids, the reference's own 8 unit-test answers.
  * The multi-aircraft separation scan and noise-abatement areas have NO reference implementation
  * (README.md:51,60,62 are prose only): for those paths parity is UNPINNED and this file is the definition.
  *
