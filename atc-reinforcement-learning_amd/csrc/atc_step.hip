@@ -12,14 +12,16 @@
 //   (scalar loads -> SGPRs), the MVA lookup is one 8-byte L2 gather per aircraft (+ a few 16-byte edge records in cells
 //   that touch a polygon border).  There is no per-workgroup staging prologue and no block barrier: the first thing a
 //   wavefront does is issue its state loads.
-//   The O(N^2) separation scan: for N = 16 an env is one DPP row and partner state arrives by row rotation fused into
-//   the subtract (each pair evaluated once, the inverse rotation hands the result back); other widths stage (x, y, h) in
-//   LDS and read partners in batches.  Per-env reward / action count / minimum separation are reduced with DPP butterflies
-//   (wavefront shuffles beyond a row), done / won masks with a ballot — no block barrier, no atomics, no MFMA (there is no
-//   dense contraction on this path).
+//   The O(N^2) separation scan evaluates every unordered pair once: for N = 16 an env is one DPP row and partner state
+//   arrives by row rotation fused into the subtract (the inverse rotation hands the result back); N <= 8 pairs lanes by
+//   XOR through quad_perm / row_half_mirror; N > 16 stages (x, y, h) in LDS, visits the next W/2 partners and hands a
+//   conflict to the partner as the ballot mask rotated on the scalar unit.  Per-env reward / action count / minimum
+//   separation are reduced with DPP butterflies (wavefront shuffles beyond a row), done / won masks with a ballot — no
+//   block barrier, no atomics in the fast variant, no MFMA (there is no dense contraction on this path).
 //   Workgroup = 256 threads = 256 consecutive slots; one workgroup per tile.  The single-step kernel has NO loop around
 //   the step body (neither grid-stride nor the step loop of multi-step launches): it is its own instantiation
-//   k_step<W, FULL, ONE = true>, 71 VGPRs / 7 wavefronts per SIMD against 109-128 / 4 for the loop form.
+//   k_step<W, FULL, ONE = true> (N = 16: 63 VGPRs); multi-step launches keep the state in registers across a run-time step
+//   loop under an 80-VGPR launch bound (6 wavefronts per SIMD) and prefetch the next step's action.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared   (see build.py)
 #include <hip/hip_runtime.h>
@@ -472,7 +474,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     // at x = 1e18 so that they neither conflict nor enter the minimum — branch-free.
     // Where the MVA cell (gather issued in the first half) is resolved: after the separation scan for the LDS-staged
     // widths, so that the L2 round trip overlaps the scan; before it for the DPP widths (W <= 16), where keeping the cell
-    // in flight across the unrolled scan only costs registers (W = 8: 88 vs 71 VGPRs, i.e. 5 vs 7 wavefronts per SIMD).
+    // in flight across the unrolled scan only costs registers.
     constexpr bool kResolveAfterScan = (W >= 32);
     float mva = 0.0f;
     int pi = 0;
@@ -776,8 +778,8 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     LaneState ls = {{ps.x, ps.y, __int_as_float(ps.z), __int_as_float(ps.w), v0}, la0.a, la0.b, la0.c, false, false};
 
     // A single step is its own instantiation: with the step count a run-time value everything the loop carries (aircraft
-    // and env records, output bases, hoisted sector constants) stays live across the whole body — 122 VGPRs and 28 spilled
-    // SGPRs (4 wavefronts per SIMD) against 78 and none (6 per SIMD) for the straight-line form.
+    // and env records, output bases, hoisted sector constants) stays live across the whole body — the straight-line form
+    // needs 63 VGPRs (N = 16), the loop form 80 under its launch bound (94 without it).
     const int n_steps = ONE ? 1 : T;
     Float3 act = {0.0f, 0.0f, 0.0f};
     const float* act_t = actions;   // action block of the current step; a block is held for `hold` steps
@@ -786,7 +788,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         const size_t sBN = (size_t)step * BN, sB = (size_t)step * (uint32_t)B;  // uniform (scalar) per-step bases
         // Multi-step launches: everything that is invariant across steps (lane ids and the address arithmetic on them, the
         // sector base) is re-derived from an opaque zero inside the body, so that LICM cannot hoist it and keep it alive
-        // around the loop: 91 instead of 109 VGPRs (5 wavefronts per SIMD instead of 4) for N = 16.
+        // around the loop: under the 80-VGPR launch bound the loop form has no scratch with it and 88 B per lane without.
         LaneIds dl = d;
         const float* Kl = K;
         const float* gl = grid;
