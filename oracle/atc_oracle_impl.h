@@ -37,10 +37,6 @@
 #if ORC_FIXED_POS
 typedef int32_t FN(pos_t);
 static int32_t FN(sat32)(int64_t v) { return v > INT32_MAX ? INT32_MAX : (v < INT32_MIN ? INT32_MIN : (int32_t)v); }
-static int32_t FN(pos_from_real)(const REAL* S, int axis, double v) { /* placing an aircraft (reset / set_state) */
-    double c = rint((v - (double)S[ATC_C_POS_X0 + axis]) * (double)S[ATC_C_POS_SCALE]);
-    return FN(sat32)((int64_t)(c > 4e18 ? 4e18 : (c < -4e18 ? -4e18 : c)));
-}
 static int32_t FN(pos_spawn)(const REAL* S, int axis, REAL v) { /* entry point -> grid, in fp32 like the device */
     REAL c = (v - S[ATC_C_POS_X0 + axis]) * S[ATC_C_POS_SCALE];
     c = c > (REAL)2147483520.0 ? (REAL)2147483520.0 : (c < (REAL)-2147483648.0 ? (REAL)-2147483648.0 : c); /* int32 range */
@@ -75,7 +71,6 @@ static void FN(sincos_heading)(REAL phi, REAL* sn, REAL* cs) {
 }
 #else
 typedef double FN(pos_t);
-static double FN(pos_from_real)(const REAL* S, int axis, double v) { (void)S; (void)axis; return v; }
 static double FN(pos_spawn)(const REAL* S, int axis, REAL v) { (void)S; (void)axis; return v; }
 static REAL FN(pos_to_real)(const REAL* S, int axis, double p) { (void)S; (void)axis; return (REAL)p; }
 static double FN(pos_advance)(const REAL* S, double p, REAL d) { (void)S; return p + (double)d; }
