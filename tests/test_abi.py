@@ -89,3 +89,29 @@ def test_product_refuses_to_run_without_gpu():
     from envs.atc import atc_gym
     with pytest.raises(RuntimeError):
         atc_gym.AtcGym()
+
+
+@pytest.mark.gpu
+def test_integration_stub_runs():
+    """The binding a maintainer of the reference would write is executed as it stands in the
+    document and must reproduce the drop-in AtcGym step for step."""
+    import numpy as np
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text[text.index("## B."):]
+    code = re.search(r"```python\n(.*?)```", block, flags=re.S).group(1)
+    ns = {"LIBATCSTEP": LIB}
+    exec(compile(code, "INTEGRATION.md#B", "exec"), ns)
+    from envs.atc import atc_gym
+    env = atc_gym.AtcGym()
+    s0 = env.reset()
+    assert np.array_equal(ns["out"]["obs"].cpu().numpy(), s0)
+    rng = np.random.default_rng(2)
+    for t in range(200):
+        if t % 20 == 0:
+            a = rng.uniform(-1, 1, 3).astype(np.float32)
+        o1, r1, d1, i1 = ns["step"](a)
+        o2, r2, d2, i2 = env.step(a)
+        assert np.array_equal(o1, o2) and r1 == r2 and d1 == d2 and np.array_equal(i1["original_state"], i2["original_state"]), t
+        if d2:
+            break
+    env.close()
