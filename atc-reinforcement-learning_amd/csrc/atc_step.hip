@@ -39,6 +39,7 @@ struct atc_scenario {
     int off_grid;    // 0 = no grid
     int device;
     int n_cu;
+    float pos_inv, pos_x0, pos_y0;   // host copies of ATC_C_POS_INV / ATC_C_POS_X0 / ATC_C_POS_Y0
 };
 
 static thread_local char g_err[512] = "";
@@ -303,9 +304,13 @@ struct StepDerived {
     float dp_hi, dp_lo;   // kPhiDotMax * dt, kPhiDotMin * dt (model.py:49-50,113-120)
     float r_base;         // -0.05 * dt                       (atc_gym.py:137)
     float sep2;           // sep_nm ^ 2
+    double pos_inv, pos_x0, pos_y0;   // position grid (blob: ATC_C_POS_*) widened once for the fixed-point -> fp32 conversion
 };
-static StepDerived derive(const atc_params_t& p) {
+static StepDerived derive(const atc_params_t& p, const atc_scenario* s) {
     StepDerived q;
+    q.pos_inv = (double)s->pos_inv;
+    q.pos_x0 = (double)s->pos_x0;
+    q.pos_y0 = (double)s->pos_y0;
     q.dv_hi = kAMax * p.dt;
     q.dv_lo = kAMin * p.dt;
     q.dh_hi = kHDotMax * p.dt;
@@ -350,16 +355,36 @@ __device__ __forceinline__ LaneIds make_ids(uint32_t slot0, int B, int N) {
     return d;
 }
 
-// ---- first half of AtcGym.step: timestep, action decode + rate limits, kinematics, MVA floor -----------------------
+// max(min(d, hi), lo) for lo < hi (model.py:75-78,97-100,117-120) as ONE v_med3_f32.  fminf / fmaxf would each be preceded by a
+// canonicalisation of the uniform limit (IEEE mode: 4 instructions per clamp).  Identical for every non-NaN d; a NaN d (a NaN
+// action, outside the action space) yields lo here and hi there — unspecified input either way.
+__device__ __forceinline__ float clamp_rate(float d, float lo, float hi) { return __builtin_amdgcn_fmed3f(d, lo, hi); }
+
+// _denormalized_action (atc_gym.py:318-335): action -> (v, h, phi) targets.  offset (v_min, 0, 0); factor (10, 100, 1)
+// discrete | (v_max - v_min, h_max, 360) continuous (atc_gym.py:64-78), same operation order.
+__device__ __forceinline__ Float3 decode_targets(const atc_params_t& p, const Float3& act) {
+    constexpr float v_min = kVMin, v_max = kVMax, h_max = kHMax;
+    const bool discrete = (p.mode & ATC_M_DISCRETE) != 0;
+    const float a_v = act.a, a_h = act.b, a_p = act.c;
+    const float fac_v = discrete ? 10.0f : v_max - v_min;
+    const float fac_h = discrete ? 100.0f : h_max;
+    const float fac_p = discrete ? 1.0f : 360.0f;
+    Float3 t;
+    t.a = discrete ? a_v * fac_v + v_min : a_v * fac_v / 2.0f + fac_v / 2.0f + v_min;
+    t.b = discrete ? a_h * fac_h + 0.0f : a_h * fac_h / 2.0f + fac_h / 2.0f + 0.0f;
+    t.c = discrete ? a_p * fac_p + 0.0f : a_p * fac_p / 2.0f + fac_p / 2.0f + 0.0f;
+    return t;
+}
+
+// ---- first half of AtcGym.step: timestep, rate limits towards the targets, kinematics, MVA floor ---------------------
 __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const float* __restrict__ grid,
-                                           const atc_params_t& p, const StepDerived& q, const LaneIds& d, float a_v,
-                                           float a_h, float a_p, LaneState& ls, EnvState& es) {
+                                           const atc_params_t& p, const StepDerived& q, const LaneIds& d, float tv,
+                                           float th, float tp, LaneState& ls, EnvState& es) {
     Mid m;
     Aircraft& a = ls.a;
     const float dt = p.dt;
-    const bool discrete = (p.mode & ATC_M_DISCRETE) != 0;
     es.t += 1;  // atc_gym.py:135
-    const bool active = d.lane_valid && ((es.amask >> d.k) & 1ull);
+    const bool active = d.lane_valid && ((d.k < 32 ? ((uint32_t)es.amask >> d.k) : ((uint32_t)(es.amask >> 32) >> (d.k - 32))) & 1u);
     uint32_t fl = 0;
     float r = q.r_base;  // -0.05 * dt, atc_gym.py:137
     int acts = 0;
@@ -368,19 +393,11 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
     // (atc_gym.py:303-315); valid -> rate-limited move, actions_taken++ unless |target - last| < discriminator
     {
         constexpr float v_min = kVMin, v_max = kVMax, h_min = kHMin, h_max = kHMax;
-        // atc_gym.py:64-78: offset (v_min,0,0); factor (10,100,1) discrete | (v_max-v_min, h_max, 360) continuous
-        const float fac_v = discrete ? 10.0f : v_max - v_min;
-        const float fac_h = discrete ? 100.0f : h_max;
-        const float fac_p = discrete ? 1.0f : 360.0f;
-        const float tv = discrete ? a_v * fac_v + v_min : a_v * fac_v / 2.0f + fac_v / 2.0f + v_min;
-        const float th = discrete ? a_h * fac_h + 0.0f : a_h * fac_h / 2.0f + fac_h / 2.0f + 0.0f;
-        const float tp = discrete ? a_p * fac_p + 0.0f : a_p * fac_p / 2.0f + fac_p / 2.0f + 0.0f;
         {
             const bool valid = !(tv < v_min || tv > v_max);
             const bool ok = valid && active;
             float dd = tv - a.v;
-            dd = fminf(dd, q.dv_hi);
-            dd = fmaxf(dd, q.dv_lo);
+            dd = clamp_rate(dd, q.dv_lo, q.dv_hi);
             const float v_new = ok ? a.v + dd : a.v;
             ls.v_changed = ls.v_changed || v_new != a.v;
             a.v = v_new;
@@ -394,8 +411,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
             const bool valid = !(th < h_min || th > h_max);
             const bool ok = valid && active;
             float dd = th - a.h;
-            dd = fminf(dd, q.dh_hi);
-            dd = fmaxf(dd, q.dh_lo);
+            dd = clamp_rate(dd, q.dh_lo, q.dh_hi);
             a.h = ok ? a.h + dd : a.h;
             acts += (ok && !(fabsf(th - ls.la_h) < kDiscrH)) ? 1 : 0;
             ls.la_changed = ls.la_changed || (ok && th != ls.la_h);
@@ -405,8 +421,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
         }
         {
             float dd = tp - a.phi;
-            dd = fminf(dd, q.dp_hi);
-            dd = fmaxf(dd, q.dp_lo);
+            dd = clamp_rate(dd, q.dp_lo, q.dp_hi);
             a.phi = active ? a.phi + dd : a.phi;
             acts += (active && !(fabsf(tp - ls.la_p) < kDiscrPhi)) ? 1 : 0;
             ls.la_changed = ls.la_changed || (active && tp != ls.la_p);
@@ -421,8 +436,8 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
         a.x = pos_advance(K, a.x, sn * dist);
         a.y = pos_advance(K, a.y, cs * dist);
     }
-    m.x32 = pos_to_real(K, 0, a.x);
-    m.y32 = pos_to_real(K, 1, a.y);
+    m.x32 = (float)fma((double)a.x, q.pos_inv, q.pos_x0);   // atc::pos_to_real with the widened constants
+    m.y32 = (float)fma((double)a.y, q.pos_inv, q.pos_y0);
     // MVA floor, first half: only ISSUE the lookup-cell gather here; nothing until the override chain needs its result
     m.cell = mva_cell_load(grid, m.x32, m.y32);
     m.active = active;
@@ -781,7 +796,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     // and env records, output bases, hoisted sector constants) stays live across the whole body — the straight-line form
     // needs 63 VGPRs (N = 16), the loop form 80 under its launch bound (94 without it).
     const int n_steps = ONE ? 1 : T;
-    Float3 act = {0.0f, 0.0f, 0.0f};
+    Float3 act = {0.0f, 0.0f, 0.0f};   // action of the current block (held for `hold` steps)
     const float* act_t = actions;   // action block of the current step; a block is held for `hold` steps
     int held = 0;                   // steps the current block has been used for
     for (int step = 0; step < n_steps; ++step) {
@@ -811,7 +826,9 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
 #endif
         };
         if (ONE || step == 0) act = *at<Float3>(act_t, dl.i * 12u);   // one 12-byte load per lane
-        const Mid m = step_part_a(Kl, gl, p, q, dl, act.a, act.b, act.c, ls, es);
+        // (decoding a held block once per block instead of once per step was measured slower: 15.7 vs 15.1 us per step)
+        const Float3 tg = decode_targets(p, act);
+        const Mid m = step_part_a(Kl, gl, p, q, dl, tg.a, tg.b, tg.c, ls, es);
         ATC_STAMP(1);
         Float3 nxt = act;
         const float* act_next = nullptr;   // the next block is fetched during the last step of the current one
@@ -952,7 +969,7 @@ static int launch_step2(const atc_scenario* s, int B, int N, int T, int hold, co
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long long slots = (long long)B * W;
     const int grid = (int)((slots + kBlock - 1) / kBlock);  // one workgroup per 256 slots, no grid-stride loop
-    hipLaunchKernelGGL((k_step<W, FULL, ONE>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->off_grid, B, N, T, hold, *st, actions, *out, *p, derive(*p));
+    hipLaunchKernelGGL((k_step<W, FULL, ONE>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->off_grid, B, N, T, hold, *st, actions, *out, *p, derive(*p, s));
     HIP_TRY(hipGetLastError());
     return ATC_OK;
 }
@@ -1026,6 +1043,9 @@ int atc_scenario_create(const float* blob_host, size_t n_words, int device, atc_
     atc_scenario* s = new atc_scenario();
     s->n_words = (int)n_words;
     s->off_grid = (int)blob_host[ATC_H_OFF_GRID];
+    s->pos_inv = blob_host[ATC_C_POS_INV];
+    s->pos_x0 = blob_host[ATC_C_POS_X0];
+    s->pos_y0 = blob_host[ATC_C_POS_Y0];
     s->device = device;
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, device);
