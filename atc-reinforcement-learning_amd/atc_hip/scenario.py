@@ -313,6 +313,8 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
     off_poly = L.C_END
     off_vert = off_poly + n_poly * L.P_WORDS
     n_vertw = 2 * sum(len(r) for r in rings)
+    # alignment the device code relies on: polygon records are read as 16-byte vectors, ring vertices as 8-byte pairs
+    assert off_poly % 4 == 0 and L.P_WORDS % 4 == 0 and off_vert % 2 == 0
     off_entry = off_vert + n_vertw
     n_entry = len(entrypoints)
     off_slot = (off_entry + n_entry * L.E_WORDS + 3) & ~3  # 16-byte aligned float4 records
