@@ -85,8 +85,7 @@ class AtcVecEnv:
         self.flags = z((B, N), torch.int16)
         self.min_sep = z(B, f32) if want_min_sep else None
         self.term_obs = z((B, N * L.OBS_DIM), f32) if want_term_obs else None
-        self._out = self._make_out(self.obs, self.raw_obs, self.reward, self.ac_reward, self.done, self.flags,
-                                   self.min_sep, self.term_obs)
+        self._bind_outputs()
         self._lib = _lib.load()
         self.reset(first=True)
 
@@ -113,8 +112,7 @@ class AtcVecEnv:
         self.reward = view("reward", torch.float32, (B,))
         self.flags = view("flags", torch.int16, (B, N))
         self.done = view("done", torch.uint8, (B,))
-        self._out = self._make_out(self.obs, self.raw_obs, self.reward, self.ac_reward, self.done, self.flags,
-                                   self.min_sep, self.term_obs)
+        self._bind_outputs()
         return dev, host, layout
 
     def _ptr(self, t):
@@ -125,6 +123,16 @@ class AtcVecEnv:
 
     def _make_out(self, *tensors):
         return _lib.AtcOut(*[self._ptr(t) for t in tensors])
+
+    def _bind_outputs(self):
+        """(Re)builds atc_out_t for this env's own output tensors and everything step() reuses from call to call."""
+        self._out = self._make_out(self.obs, self.raw_obs, self.reward, self.ac_reward, self.done, self.flags,
+                                   self.min_sep, self.term_obs)
+        self._out_ref = C.byref(self._out)
+        self._state_ref = C.byref(self._state)
+        self._params_ref = C.byref(self.params)
+        self._n_act = self.B * self.N * L.ACT_DIM
+        self._info_cache = self._info()
 
     def _finish(self):
         if self.host_mapped:  # results live in host memory: valid only once the stream has drained
@@ -187,13 +195,25 @@ class AtcVecEnv:
         """AtcGym.step (atc_gym.py:128-192) for every env.  actions: [B, N, 3] (or [B, N*3]) float tensor / array:
         continuous in [-1, 1] or discrete indices (atc_gym.py:318-335).  Returns (obs [B,N*10], reward [B], done [B]
         uint8, info) — device tensors that are overwritten by the next step."""
+        torch = self.torch
+        # fast path: a float32 device tensor of the right size on this env's (current) device is handed over as it is —
+        # small batches are host-bound otherwise (8 192 x 16: 6.4 us on the GPU against 10.4 us of Python per call)
+        if (torch.is_tensor(actions) and actions.is_cuda and actions.dtype is torch.float32 and actions.is_contiguous()
+                and actions.numel() == self._n_act and actions.device == self.device
+                and torch.cuda.current_device() == self.device.index and not self.host_mapped):
+            rc = self._lib.atc_step(self.sector.handle, self.B, self.N, self._state_ref, actions.data_ptr(), self._out_ref,
+                                    self._params_ref, torch.cuda.current_stream().cuda_stream)
+            if rc:
+                _lib.check(rc)
+            self._keep = actions
+            return self.obs, self.reward, self.done, self._info_cache
         a = self._as_actions(actions)
-        with self.torch.cuda.device(self.device):
+        with torch.cuda.device(self.device):
             _lib.check(self._lib.atc_step(self.sector.handle, self.B, self.N, C.byref(self._state), self._ptr(a),
                                           C.byref(self._out), C.byref(self.params), self._stream()))
         self._keep = a
         self._finish()
-        return self.obs, self.reward, self.done, self._info()
+        return self.obs, self.reward, self.done, self._info_cache
 
     def make_launcher(self, actions, stream=None):
         """Pre-bound `atc_step` call for FIXED buffers (this env's state / outputs, the given device action tensor, the
