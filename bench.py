@@ -401,6 +401,31 @@ def main():
                          "note": "HIP events on the launch stream around the %d timed launches (includes inter-launch "
                                  "gaps)" % n_launches},
         }
+        if ws == 1 and not args.no_single_env and not args.rollout and S == 1 and graph is None:
+            # the same envs with 20 steps fused per launch (atc_rollout_hold, the action held like in the timed loop): a
+            # side record, not `value` — the headline stays one launch per step, what env.step() costs
+            Tf = HOLD
+            ro = {"obs": torch.empty((Tf, B, N * 10), dtype=torch.float32, device=dev),
+                  "reward": torch.empty((Tf, B), dtype=torch.float32, device=dev),
+                  "done": torch.empty((Tf, B), dtype=torch.uint8, device=dev),
+                  "flags": torch.empty((Tf, B, N), dtype=torch.int16, device=dev)}
+            for j in range(10):
+                env.rollout(ring[j % n_ring][None], out=ro, hold=Tf)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n_l = 50
+            e0.record()
+            for j in range(n_l):
+                env.rollout(ring[j % n_ring][None], out=ro, hold=Tf)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            us = e0.elapsed_time(e1) * 1e3 / (n_l * Tf)
+            fb = algorithmic_bytes_per_env_step(N, Tf, Tf)
+            line["config"]["fused_rollout"] = {"entry": "atc_rollout_hold", "T": Tf, "hold": Tf, "launches": n_l,
+                                               "us_per_step": us, "env_steps_per_s": B / (us * 1e-6),
+                                               "algorithmic_bytes_per_env_step": fb,
+                                               "hbm_frac": fb * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            del ro
         if ws == 1 and not args.no_single_env:
             line["config"]["single_env"] = single_env_protocol()
         if ws == 1 and not args.no_cpu_baseline:
