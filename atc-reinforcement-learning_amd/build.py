@@ -28,11 +28,11 @@ def needs_build():
 def build_lib(force=False, verbose=False, extra=()):
     if not force and not needs_build():
         return OUT
-    extra = list(extra) + os.environ.get("ATC_HIPCC_EXTRA", "").split()
+    extra = list(extra)   # explicit arguments only: nothing in the environment changes what the product is built from
     tmp = OUT + ".tmp%d" % os.getpid()  # link under a private name, publish atomically (other ranks may be waiting)
     cmd = [HIPCC] + FLAGS + extra + ["-o", tmp, SRC]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), file=sys.stderr)  # never on stdout: bench.py prints exactly one JSON line there
     try:
         subprocess.check_call(cmd)
         os.replace(tmp, OUT)
