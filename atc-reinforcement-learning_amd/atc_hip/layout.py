@@ -2,7 +2,7 @@
 
 tests/test_abi.py parses the header and checks that every constant here matches it.
 """
-ABI_VERSION = 12
+ABI_VERSION = 13
 BLOB_VERSION = 1011.0
 
 H_VERSION, H_NWORDS, H_N_MVA, H_N_NOISE, H_N_ENTRY, H_OFF_POLY, H_OFF_VERT, H_OFF_ENTRY, H_OFF_GRID, H_N_VERTW = range(10)
@@ -29,6 +29,7 @@ G_X0, G_Y0, G_INV, G_NX, G_NY, G_OFF_POOL, G_NREC = range(7)
 G_HDR = 8
 GE_WORDS = 8
 
+PKT_CHUNKS = 9
 MAX_AIRCRAFT = 64
 OBS_DIM = 10
 ACT_DIM = 3

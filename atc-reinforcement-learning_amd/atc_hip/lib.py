@@ -29,7 +29,7 @@ class AtcParams(C.Structure):
 
 
 STATE_FIELDS = ("pos_hp", "v", "last_act", "env", "stats")
-OUT_FIELDS = ("obs", "raw_obs", "reward", "ac_reward", "done", "flags", "min_sep", "term_obs")
+OUT_FIELDS = ("obs", "raw_obs", "reward", "ac_reward", "done", "flags", "min_sep", "term_obs", "packet")
 
 
 class AtcState(C.Structure):

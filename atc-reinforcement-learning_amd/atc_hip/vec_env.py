@@ -18,10 +18,12 @@ class AtcVecEnv:
     def __init__(self, num_envs, num_aircraft=1, sim_parameters=None, scenario=None, device=0, auto_reset=True,
                  spawn="auto", seed=0, grid_cell=0.5, want_raw_obs=False, want_ac_reward=False, want_min_sep=False,
                  want_term_obs=False, timestep_limit=6000, sep_nm=3.0, sep_ft=1000.0, conflict_reward=-200.0,
-                 host_mapped=False, keep_active=False):
+                 host_mapped=False, keep_active=False, want_packet=False):
         """host_mapped=True keeps state and outputs in pinned host memory mapped into the device (zero-copy): the kernels
         read / write it over the host link, every call ends with a stream synchronisation, and what is returned are CPU
         tensors.  Meant for tiny latency-bound batches (the single-env AtcGym); large batches belong in HBM.
+        want_packet=True (host_mapped, N == 1) adds atc_out_t.packet: the step result as self-validating 16-byte chunks that a
+        host can poll in mapped memory instead of synchronising the stream (see `poll_packet`).
         keep_active=True is the reference's single-aircraft rule (ATC_M_KEEP_ACTIVE): an aircraft that reaches the corridor
         ends the episode and stays under control instead of being handed over."""
         torch = _lib._torch_cuda()
@@ -85,6 +87,9 @@ class AtcVecEnv:
         self.flags = z((B, N), torch.int16)
         self.min_sep = z(B, f32) if want_min_sep else None
         self.term_obs = z((B, N * L.OBS_DIM), f32) if want_term_obs else None
+        if want_packet and not (self.host_mapped and N == 1):
+            raise ValueError("want_packet needs host_mapped=True and num_aircraft=1")
+        self.packet = z((B, L.PKT_CHUNKS, 4), i32) if want_packet else None
         self._bind_outputs()
         self._lib = _lib.load()
         self.reset(first=True)
@@ -127,7 +132,7 @@ class AtcVecEnv:
     def _bind_outputs(self):
         """(Re)builds atc_out_t for this env's own output tensors and everything step() reuses from call to call."""
         self._out = self._make_out(self.obs, self.raw_obs, self.reward, self.ac_reward, self.done, self.flags,
-                                   self.min_sep, self.term_obs)
+                                   self.min_sep, self.term_obs, getattr(self, "packet", None))
         self._out_ref = C.byref(self._out)
         self._state_ref = C.byref(self._state)
         self._params_ref = C.byref(self.params)
@@ -279,7 +284,7 @@ class AtcVecEnv:
                 "flags": torch.empty((T, B, N), dtype=torch.int16, device=dev),
             }
         o = self._make_out(out["obs"], out.get("raw_obs"), out["reward"], out.get("ac_reward"), out["done"],
-                           out["flags"], out.get("min_sep"), out.get("term_obs"))
+                           out["flags"], out.get("min_sep"), out.get("term_obs"), None)
         with torch.cuda.device(dev):
             _lib.check(self._lib.atc_rollout_hold(self.sector.handle, B, N, T, hold, C.byref(self._state), self._ptr(a),
                                                   C.byref(o), C.byref(self.params), self._stream()))

@@ -328,6 +328,7 @@ struct StepOut {        // per-step output bases (uniform pointers)
     float* reward;
     uint8_t* done;
     float *raw_obs, *ac_reward, *min_sep, *term_obs;
+    uint32_t* packet;
 #if ATC_TRACE
     unsigned long long* trace;
 #endif
@@ -469,7 +470,7 @@ __device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, con
 }
 
 // ---- second half: separation scan, win/timeout, observation, shaping, reductions, outputs, auto-reset --------------
-template <int W, bool FULL>
+template <int W, bool FULL, bool ONE>
 __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const float* __restrict__ grid,
                                             const atc_params_t& p, const StepDerived& q, int N, const LaneIds& d,
                                             const Mid& m, LaneState& ls,
@@ -601,6 +602,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     ATC_STAMP_B(3);
     // ---- observation, shaping, noise areas, normalisation (atc_gym.py:175-189) ------------------------------------------
     float o[ATC_OBS_DIM];
+    float zraw[ATC_OBS_DIM];   // FULL only: raw observation (zeros for handed-over aircraft)
     {
         Obs ob;
         if (ATC_ABLATE & 8) {
@@ -624,11 +626,10 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
                 if ((fl >> (16 + q)) & 1u) r -= (K + (int)K[ATC_H_OFF_POLY] + ((int)K[ATC_H_N_MVA] + q) * ATC_P_WORDS)[ATC_P_PENALTY];
             fl &= 0xffffu;
         }
-        if (FULL && so.raw_obs && d.lane_valid) {
-            float z[ATC_OBS_DIM];
+        if (FULL) {
 #pragma unroll
-            for (int c = 0; c < ATC_OBS_DIM; ++c) z[c] = active ? ob.o[c] : 0.0f;  // zeros for handed-over aircraft
-            store_obs(at<float>(so.raw_obs, i * 40u), z);
+            for (int c = 0; c < ATC_OBS_DIM; ++c) zraw[c] = active ? ob.o[c] : 0.0f;  // zeros for handed-over aircraft
+            if (so.raw_obs && d.lane_valid) store_obs(at<float>(so.raw_obs, i * 40u), zraw);
         }
         if (p.mode & ATC_M_NORMALIZE) {  // atc_gym.py:187-189: (s - min - max/2) / (max/2) as one fma
 #pragma unroll
@@ -672,6 +673,19 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     if (d.env_valid && k == 0) {
         *at<float>(so.reward, (uint32_t)e * 4u) = env_r;
         *at<uint8_t>(so.done, (uint32_t)e) = done ? 1 : 0;
+    }
+    if (FULL && ONE && W == 1 && so.packet && d.lane_valid) {
+        // The step result of a single-aircraft env as 9 self-validating 16-byte chunks (include/atc_step.h, atc_out_t.packet):
+        // each chunk is ONE store carrying the caller's sequence tag, so a host polling mapped memory never mixes steps.
+        const uint32_t tag = p.reserved0;
+        const float w[27] = {o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9], zraw[0], zraw[1], zraw[2], zraw[3],
+                             zraw[4], zraw[5], zraw[6], zraw[7], zraw[8], zraw[9], env_r,
+                             __uint_as_float((fl & 0xffffu) | (done ? 0x10000u : 0u)), __int_as_float(es.t),
+                             __int_as_float(es.n_actions), __int_as_float(a.x), __int_as_float(a.y), 0.0f};
+        uint4* pk = at<uint4>(so.packet, (uint32_t)e * (ATC_PKT_CHUNKS * 16u));
+#pragma unroll
+        for (int c = 0; c < ATC_PKT_CHUNKS; ++c)
+            pk[c] = make_uint4(__float_as_uint(w[3 * c]), __float_as_uint(w[3 * c + 1]), __float_as_uint(w[3 * c + 2]), tag);
     }
     if (FULL && so.min_sep) {
         const float m2 = (W > 1) ? group_min<W>(min_d2) : 1e30f;
@@ -820,7 +834,8 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
                       FULL && out.raw_obs ? out.raw_obs + sBN * ATC_OBS_DIM : nullptr,
                       FULL && out.ac_reward ? out.ac_reward + sBN : nullptr,
                       FULL && out.min_sep ? out.min_sep + sB : nullptr,
-                      FULL && out.term_obs ? out.term_obs + sBN * ATC_OBS_DIM : nullptr
+                      FULL && out.term_obs ? out.term_obs + sBN * ATC_OBS_DIM : nullptr,
+                      FULL && out.packet ? out.packet + sB * (ATC_PKT_CHUNKS * 4) : nullptr
 #if ATC_TRACE
                       , trace
 #endif
@@ -837,7 +852,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             act_t += (size_t)BN * 3;
             if (step + 1 < n_steps) act_next = act_t;
         }
-        step_part_b<W, FULL>(Kl, gl, p, q, N, dl, m, ls, es, so, st.stats, pos, obs_stage, act_next, nxt);
+        step_part_b<W, FULL, ONE>(Kl, gl, p, q, N, dl, m, ls, es, so, st.stats, pos, obs_stage, act_next, nxt);
         act = nxt;
         ATC_STAMP(6);
     }
@@ -976,7 +991,7 @@ static int launch_step2(const atc_scenario* s, int B, int N, int T, int hold, co
 template <int W>
 static int launch_step(const atc_scenario* s, int B, int N, int T, int hold, const atc_state_t* st, const float* actions,
                        const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
-    const bool full = out->raw_obs || out->ac_reward || out->min_sep || out->term_obs;
+    const bool full = out->raw_obs || out->ac_reward || out->min_sep || out->term_obs || out->packet;
     // Multi-step launches keep the state in registers across the steps; the run-time step loop costs the kernel its
     // occupancy (4 wavefronts per SIMD against 5-7 for the straight-line single step) but issuing T single-step launches
     // instead is slower at every size (65 536 x 16, T = 20, [T, ...] outputs: 35.0 vs 27.1 us per step).
@@ -1003,6 +1018,7 @@ static int step_common(const atc_scenario_t* s, int B, int N, int T, int hold, c
     if (const int rc = check_env_args(s, B, N, st, p)) return rc;
     if (T < 1 || hold < 1) return fail_arg("need T >= 1 and hold >= 1");
     if (!out->obs || !out->reward || !out->done || !out->flags) return fail_arg("obs/reward/done/flags are required");
+    if (out->packet && (N != 1 || T != 1)) return fail_arg("atc_out_t.packet is for single steps of single-aircraft envs");
     if (!(p->dt > 0.0f)) return fail_arg("dt must be > 0");
     hipStream_t q = (hipStream_t)stream;
     if (N == 1) return launch_step<1>(s, B, N, T, hold, st, actions, out, p, q);

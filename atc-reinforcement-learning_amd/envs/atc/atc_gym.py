@@ -26,22 +26,23 @@ class _AirplaneView:
     h_min, h_max, v_min, v_max = 0, 38000, 100, 300
     h_dot_min, h_dot_max, a_max, a_min, phi_dot_max, phi_dot_min = -41, 15, 5, -5, 3, -3
 
-    def __init__(self, vec, name="FLT01"):
-        object.__setattr__(self, "_vec", vec)
+    def __init__(self, env, name="FLT01"):
+        object.__setattr__(self, "_env", env)
         object.__setattr__(self, "name", name)
         object.__setattr__(self, "id", 0)
         object.__setattr__(self, "position_history", [])   # model.py:51,123: (x, y) before every move, new list per reset
 
     def __getattr__(self, key):
         if key in ("x", "y", "h", "phi", "v"):
-            return float(getattr(self._vec, key)[0])
+            return float(getattr(self._env._vec, key)[0])      # (env._vec drains the stream first)
         raise AttributeError(key)
 
     def __setattr__(self, key, value):
         if key in ("x", "y"):   # positions live on the device's fixed-point grid (include/atc_step.h)
-            self._vec.set_xy(0, **{key: float(value)})
+            self._env._vec.set_xy(0, **{key: float(value)})
+            self._env._pos_now = None
         elif key in ("h", "phi", "v"):
-            getattr(self._vec, key)[0] = float(value)
+            getattr(self._env._vec, key)[0] = float(value)
         else:
             object.__setattr__(self, key, value)
 
@@ -74,8 +75,9 @@ class AtcGym(Env):
         self._runway = scenario.runway
         self._airspace = scenario.airspace
 
-        self._vec = self._make_backend(sim_parameters, scenario, device)
-        torch = self._vec.torch
+        self._backend = self._make_backend(sim_parameters, scenario, device)
+        self._outstanding = False
+        torch = self._backend.torch
         # Zero-copy step: aircraft state, the action and everything step() returns live in pinned host memory that is
         # mapped into the device (AtcVecEnv(host_mapped=True)); one step = write 3 floats, one kernel launch, one stream
         # synchronisation, read the results in place.  No copy is launched around the step.
@@ -86,6 +88,7 @@ class AtcGym(Env):
         self._env_np = self._vec.env.numpy()
         self._pos_np = self._vec.pos_hp.numpy()
         self._pos_inv = 2.0 ** -self._vec.pos_k
+        self._pos_origin = tuple(self._vec.pos_origin)
         lay = self._out_layout
         f32 = lambda name: self._out_np[lay[name][0]:lay[name][0] + lay[name][1]].view(np.float32)  # noqa: E731
         self._obs_np, self._raw_np, self._rew_np = f32("obs"), f32("raw_obs"), f32("reward")
@@ -99,11 +102,22 @@ class AtcGym(Env):
             _a=C.c_void_p(_lib.mapped_ptr(self._host_act)), _o=C.byref(v._out), _p=C.byref(v.params): \
             _f(_h, 1, 1, _s, _a, _o, _p, stream)
         self._current_stream = torch.cuda.current_stream
+        # Completion without a stream synchronisation: the kernel also writes the step result as 9 self-validating 16-byte
+        # chunks (atc_out_t.packet), each ONE store tagged with this step's sequence number.  The host polls the tags in the
+        # mapped buffer; a chunk whose tag is current holds this step's payload whatever order the chunks arrived in (this is
+        # what makes polling safe — plain completion-word polling is not: stores to mapped memory are not ordered among
+        # themselves).  Anything else that touches device-side state first drains the stream (_settle).
+        self._pkt_i = self._vec.packet.numpy().reshape(L.PKT_CHUNKS, 4)
+        self._pkt_tags = self._pkt_i[:, 3]
+        self._pkt_f = self._pkt_i.view(np.float32)
+        self._seq = 0
+        self._outstanding = False
+        self._pos_now = None                   # grid position after the last step (None: read it from the state record)
         comp = self._vec.compiled
         self._faf_mva = int(comp.faf_mva)
         self._world_x_min, self._world_y_min, self._world_x_max, self._world_y_max = comp.bbox
         self._world_max_distance = comp.world_diag
-        self._airplane = _AirplaneView(self._vec)
+        self._airplane = _AirplaneView(self)
 
         self.done = True
         self.reset()
@@ -125,13 +139,20 @@ class AtcGym(Env):
         self.reward_range = (-3000.0, 23000.0)  # as declared by the reference (atc_gym.py:115)
 
     # -- backend ---------------------------------------------------------------------------------------------------
+    @property
+    def _vec(self):
+        """The batched backend (1 env x 1 aircraft).  Every access from outside step() first drains the stream: step()
+        returns as soon as the result packet has arrived, the kernel's trailing state stores may still be in flight."""
+        self._settle()
+        return self._backend
+
     @staticmethod
     def _make_backend(sim_parameters, scenario, device):
         from atc_hip.vec_env import AtcVecEnv
         # keep_active: the reference's aircraft is never handed over — after a win it keeps flying (and can win again) if
         # the caller steps on without reset (atc_gym.py:128-192 has no inactive state)
         return AtcVecEnv(1, 1, sim_parameters=sim_parameters, scenario=scenario, device=device, auto_reset=False,
-                         spawn="lattice", want_raw_obs=True, host_mapped=True, keep_active=True)
+                         spawn="lattice", want_raw_obs=True, host_mapped=True, keep_active=True, want_packet=True)
 
     @property
     def last_action(self):
@@ -156,9 +177,12 @@ class AtcGym(Env):
         a = np.asarray(action, dtype=np.float32).reshape(1, 1, 3)
         self._act_np[:] = a.reshape(3)
         # model.py:123: Airplane.step first remembers where the aircraft IS (read by render() only), then moves it
-        px, py = self._pos_np[0, 0], self._pos_np[0, 1]
-        self._airplane.position_history.append((self._vec.pos_origin[0] + int(px) * self._pos_inv,
-                                                self._vec.pos_origin[1] + int(py) * self._pos_inv))
+        if self._pos_now is None:
+            self._settle()
+            self._pos_now = (int(self._pos_np[0, 0]), int(self._pos_np[0, 1]))
+        px, py = self._pos_now
+        self._airplane.position_history.append((self._pos_origin[0] + px * self._pos_inv,
+                                                self._pos_origin[1] + py * self._pos_inv))
         state_out, raw, rew, dn, flags, self.timesteps, self.actions_taken = self._launch_and_fetch()
         self.done = False
         # one append per terminal cause, in the reference's order (atc_gym.py:151,158,165)
@@ -181,14 +205,33 @@ class AtcGym(Env):
 
     def _launch_and_fetch(self):
         """One launch of the step kernel on host-mapped buffers, one stream synchronisation, results read in place."""
-        stream = self._current_stream(self._vec.device)
+        stream = self._current_stream(self._backend.device)
+        self._seq = seq = (self._seq + 1) & 0x7fffffff
+        self._backend.params.reserved0 = seq
         rc = self._launch(stream.cuda_stream)
         if rc:
             self._check(rc)
-        stream.synchronize()
-        env = self._env_np[0]
-        return (self._obs_np.copy(), self._raw_np.copy(), float(self._rew_np[0]), bool(self._done_np[0]),
-                int(self._flags_np[0]), int(env[L.ENV_TIMESTEPS]), int(env[L.ENV_ACTIONS_TAKEN]))
+        self._outstanding = True
+        tags = self._pkt_tags
+        for _ in range(20000):                 # ~10 us of kernel + host link; a few hundred polls at most
+            if (tags == seq).all():
+                break
+        else:                                  # never expected: fall back to the blocking wait
+            stream.synchronize()
+            self._outstanding = False
+            assert (tags == seq).all()
+        w = self._pkt_f[:, :3].reshape(27).copy()      # read AFTER the tags were seen current
+        iw = self._pkt_i[:, :3].reshape(27)
+        fd = int(iw[21])
+        self._pos_now = (int(iw[24]), int(iw[25]))
+        return (w[0:10], w[10:20], float(w[20]), bool(fd >> 16), fd & 0xffff, int(iw[22]), int(iw[23]))
+
+    def _settle(self):
+        """Drains the stream before anything but step() looks at (or writes) memory the last kernel may still be writing:
+        the result packet arrives before the kernel's trailing state stores."""
+        if self._outstanding:
+            self._current_stream(self._backend.device).synchronize()
+            self._outstanding = False
 
     def _update_metrics(self, reward):
         """atc_gym.py:194-197"""
@@ -216,6 +259,7 @@ class AtcGym(Env):
         vec.set_state(0, 0, entry_point.x, entry_point.y, level * 100, entry_point.phi, 250)
         self._airplane.id = plane_id
         self._airplane.position_history = []
+        self._pos_now = None
         self.state = vec.observe().reshape(-1).numpy().astype(np.float32)  # host-mapped: synchronised, copied here
         self.total_reward = 0
         self.last_reward = 0
@@ -240,6 +284,7 @@ class AtcGym(Env):
         return None
 
     def close(self):
-        if getattr(self, "_vec", None) is not None:
-            self._vec.close()
-            self._vec = None
+        if getattr(self, "_backend", None) is not None:
+            self._settle()
+            self._backend.close()
+            self._backend = None

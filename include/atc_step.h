@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ATC_ABI_VERSION 12
+#define ATC_ABI_VERSION 13
 
 /* ---------------------------------------------------------------------------------------------
  * Scenario blob: one flat array of 32-bit floats (device copy) compiled on the host from the sector
@@ -143,7 +143,7 @@ typedef struct atc_params {
     float dt;               /* SimParameters.timestep [s], model.py:141 */
     int32_t timestep_limit; /* 6000, atc_gym.py:40 */
     uint32_t mode;          /* ATC_M_* */
-    uint32_t reserved0;
+    uint32_t reserved0;     /* tag written into every chunk of atc_out_t.packet (ignored without a packet) */
     uint64_t seed;          /* RNG key for ATC_M_RANDOM_ENTRY */
     float sep_nm;           /* 3.0  (extension) */
     float sep_ft;           /* 1000 (extension) */
@@ -221,7 +221,14 @@ typedef struct atc_out {
     uint16_t* flags;   /* [B*N] ATC_F_* */
     float* min_sep;    /* nullable [B] minimum horizontal separation among active pairs [nm] (diagnostic) */
     float* term_obs;   /* nullable [B*N*10] terminal observation of envs that were auto-reset this step */
+    uint32_t* packet;  /* nullable, N == 1 only: [B][ATC_PKT_CHUNKS][4] — the step result of one env as self-validating
+                          16-byte chunks, for a host that polls pinned mapped memory instead of synchronising the stream
+                          (the single-env AtcGym).  Every chunk = 3 payload words + params.reserved0 (the caller's step
+                          sequence number) and is written with ONE 16-byte store, so a reader that sees the expected tag in
+                          a chunk and THEN reads its payload has that step's values whatever order the chunks arrive in:
+                          obs[10], raw obs[10], reward | flags + (done << 16), timesteps, actions_taken | x, y grid counts */
 } atc_out_t;
+#define ATC_PKT_CHUNKS 9
 
 /* Opaque device-resident scenario (owned by the library). */
 typedef struct atc_scenario atc_scenario_t;
