@@ -16,10 +16,16 @@ from .vec_env import AtcVecEnv
 
 class AtcSBVecEnv:
     def __init__(self, num_envs, num_aircraft=1, sim_parameters=None, scenario=None, device=0, seed=0, sparse_infos=None,
-                 **kw):
+                 host_mapped=None, **kw):
         from envs.atc._spaces import Box, MultiDiscrete
+        # Small batches (the 8-16 envs stable-baselines users run) are latency-bound: their state and outputs live in pinned
+        # host memory mapped into the device, so a vector step is one launch + one synchronisation with the numpy results read
+        # in place — no device-to-host copy.  Large batches stay in HBM and cross PCIe once per step.
+        if host_mapped is None:
+            host_mapped = int(num_envs) * int(num_aircraft) <= 256
         self.vec = AtcVecEnv(num_envs, num_aircraft, sim_parameters=sim_parameters, scenario=scenario, device=device,
-                             auto_reset=True, seed=seed, want_raw_obs=True, want_term_obs=True, **kw)
+                             auto_reset=True, seed=seed, want_raw_obs=True, want_term_obs=True, host_mapped=host_mapped,
+                             **kw)
         self.num_envs = self.vec.B
         n = self.vec.N
         sp = self.vec.sim_parameters
@@ -32,6 +38,7 @@ class AtcSBVecEnv:
         self.metadata = {'render.modes': ['human', 'rgb_array'], 'video.frames_per_second': 50}
         self._t0 = time.time()
         self._actions = None
+        self._act_pinned = None
         # Building one dict per env per step is what bounds large batches.  With sparse infos only finished envs get their
         # own dict (terminal_observation + Monitor's episode record, which is all stable-baselines reads); the others share
         # one empty dict and the raw states of the whole batch are exposed as `self.original_state` [B, 10 N].
@@ -45,19 +52,33 @@ class AtcSBVecEnv:
         return self.vec.reset().cpu().numpy().copy()
 
     def step_async(self, actions):
-        self._actions = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.vec.N, L.ACT_DIM)
+        a = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.vec.N, L.ACT_DIM)
+        if self.vec.host_mapped:   # the kernel reads the actions in place from a pinned, mapped buffer
+            if self._act_pinned is None:
+                self._act_pinned = self.vec.torch.zeros((self.num_envs, self.vec.N, L.ACT_DIM)).pin_memory()
+                self._act_np = self._act_pinned.numpy()
+            self._act_np[...] = a
+            self._actions = self._act_pinned
+        else:
+            self._actions = a
 
     def step_wait(self):
         vec = self.vec
         obs, rew, done, info = vec.step(self._actions)
         torch = vec.torch
-        pack = torch.cat([obs, info["original_state"], info["terminal_observation"],
-                          rew[:, None], done[:, None].to(torch.float32), vec.ep_return[:, None],
-                          vec.ep_length[:, None].to(torch.float32)], dim=1).cpu().numpy()   # one device->host hop
         d = vec.obs_dim
-        obs_h, raw_h, term_h = pack[:, :d], pack[:, d:2 * d], pack[:, 2 * d:3 * d]
-        rew_h, done_h = pack[:, 3 * d], pack[:, 3 * d + 1] != 0
-        ep_r, ep_l = pack[:, 3 * d + 2], pack[:, 3 * d + 3]
+        if vec.host_mapped:   # results are host memory already (the step ended with a stream synchronisation)
+            obs_h, raw_h = obs.numpy().copy(), info["original_state"].numpy().copy()
+            term_h = info["terminal_observation"].numpy().copy()
+            rew_h, done_h = rew.numpy().copy(), done.numpy() != 0
+            ep_r, ep_l = vec.ep_return.numpy().copy(), vec.ep_length.numpy().copy()
+        else:
+            pack = torch.cat([obs, info["original_state"], info["terminal_observation"],
+                              rew[:, None], done[:, None].to(torch.float32), vec.ep_return[:, None],
+                              vec.ep_length[:, None].to(torch.float32)], dim=1).cpu().numpy()   # one device->host hop
+            obs_h, raw_h, term_h = pack[:, :d], pack[:, d:2 * d], pack[:, 2 * d:3 * d]
+            rew_h, done_h = pack[:, 3 * d], pack[:, 3 * d + 1] != 0
+            ep_r, ep_l = pack[:, 3 * d + 2], pack[:, 3 * d + 3]
         now = round(time.time() - self._t0, 6)
         self.original_state = raw_h
         if self.sparse_infos:
@@ -73,6 +94,8 @@ class AtcSBVecEnv:
                     item["terminal_observation"] = term_h[b]
                     item["episode"] = {"r": float(ep_r[b]), "l": int(ep_l[b]), "t": now}
                 infos.append(item)
+        if vec.host_mapped:
+            return obs_h, rew_h, done_h, infos
         return obs_h.copy(), rew_h.copy(), done_h.copy(), infos
 
     def step(self, actions):
