@@ -2,7 +2,7 @@
 
 tests/test_abi.py parses the header and checks that every constant here matches it.
 """
-ABI_VERSION = 13
+ABI_VERSION = 14
 BLOB_VERSION = 1011.0
 
 H_VERSION, H_NWORDS, H_N_MVA, H_N_NOISE, H_N_ENTRY, H_OFF_POLY, H_OFF_VERT, H_OFF_ENTRY, H_OFF_GRID, H_N_VERTW = range(10)
@@ -38,7 +38,7 @@ F_BELOW_MVA, F_OUTSIDE, F_WON, F_TIMEOUT = 1, 2, 4, 8
 F_INVALID_V, F_INVALID_H, F_CONFLICT, F_NOISE, F_INACTIVE = 16, 32, 64, 128, 256
 F_TERMINAL = F_BELOW_MVA | F_OUTSIDE | F_TIMEOUT | F_CONFLICT  # episode-ending on their own (WON: when all handed over)
 
-M_REWARD_SHAPING, M_NORMALIZE, M_DISCRETE, M_AUTO_RESET, M_RANDOM_ENTRY, M_KEEP_ACTIVE = 1, 2, 4, 8, 16, 32
+M_REWARD_SHAPING, M_NORMALIZE, M_DISCRETE, M_AUTO_RESET, M_RANDOM_ENTRY, M_KEEP_ACTIVE, M_ACTIONS_HELD = 1, 2, 4, 8, 16, 32, 64
 
 # per-step env record (atc_state_t.env): 4 x 32-bit words, float fields by bit pattern
 ENV_TIMESTEPS, ENV_ACTIONS_TAKEN, ENV_TOTAL_REWARD, ENV_MASK_LO, ENV_WORDS = range(5)

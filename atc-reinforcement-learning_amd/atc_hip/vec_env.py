@@ -196,10 +196,19 @@ class AtcVecEnv:
             raise ValueError("actions must have %d elements, got %d" % (want, a.numel()))
         return a
 
-    def step(self, actions):
+    def step(self, actions, held=False):
         """AtcGym.step (atc_gym.py:128-192) for every env.  actions: [B, N, 3] (or [B, N*3]) float tensor / array:
         continuous in [-1, 1] or discrete indices (atc_gym.py:318-335).  Returns (obs [B,N*10], reward [B], done [B]
-        uint8, info) — device tensors that are overwritten by the next step."""
+        uint8, info) — device tensors that are overwritten by the next step.
+        held=True is the caller's promise that `actions` holds the same values as in the previous step of these envs (a
+        held action block / frame skip, learning/atc-gym-demo.py:18-19; ATC_M_ACTIONS_HELD): same results, and the kernel
+        skips the last-action record."""
+        if held:
+            self.params.mode |= L.M_ACTIONS_HELD
+            try:
+                return self.step(actions)
+            finally:
+                self.params.mode &= ~L.M_ACTIONS_HELD
         torch = self.torch
         # fast path: a float32 device tensor of the right size on this env's (current) device is handed over as it is —
         # small batches are host-bound otherwise (8 192 x 16: 6.4 us on the GPU against 10.4 us of Python per call)
@@ -220,33 +229,42 @@ class AtcVecEnv:
         self._finish()
         return self.obs, self.reward, self.done, self._info_cache
 
-    def make_launcher(self, actions, stream=None):
+    def make_launcher(self, actions, stream=None, held=False):
         """Pre-bound `atc_step` call for FIXED buffers (this env's state / outputs, the given device action tensor, the
         given torch stream or the current one): returns a no-argument callable that only launches — host cost of a few
         microseconds instead of the argument handling of step().  Meant for pipelined actors that keep several
         independent sub-batches in flight on separate streams (tools/multi_stream.py, bench.py --streams): a sub-batch's
         launch ramp and tail then overlap the others' bodies.  Results are in self.obs / reward / done / flags once the
-        stream has reached the launch."""
+        stream has reached the launch.  held=True binds a snapshot of the current parameters with ATC_M_ACTIONS_HELD set:
+        for the launches of a held action block after its first (see step())."""
         torch = self.torch
         a = self._as_actions(actions)
         q = C.c_void_p((stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream)
+        params = self.params
+        if held:
+            params = type(self.params).from_buffer_copy(self.params)
+            params.mode |= L.M_ACTIONS_HELD
         args = (self.sector.handle, self.B, self.N, C.byref(self._state), C.c_void_p(self._ptr(a)), C.byref(self._out),
-                C.byref(self.params), q)
+                C.byref(params), q)
         fn, check = self._lib.atc_step, _lib.check
 
-        def launch(_keep=(a, stream)):
+        def launch(_keep=(a, stream, params)):
             rc = fn(*args)
             if rc:
                 check(rc)
         return launch
 
-    def step_call(self, actions, stream=None):
+    def step_call(self, actions, stream=None, held=False):
         """The arguments of one atc_step of this env as an `atc_step_call_t` (+ the objects that must outlive it)."""
         a = self._as_actions(actions)
         q = (stream if stream is not None else self.torch.cuda.current_stream(self.device)).cuda_stream
+        params = self.params
+        if held:   # snapshot with ATC_M_ACTIONS_HELD, see make_launcher
+            params = type(self.params).from_buffer_copy(self.params)
+            params.mode |= L.M_ACTIONS_HELD
         call = _lib.AtcStepCall(self.sector.handle, self.B, self.N, C.pointer(self._state), self._ptr(a),
-                                C.pointer(self._out), C.pointer(self.params), q)
-        return call, (a, stream, self)
+                                C.pointer(self._out), C.pointer(params), q)
+        return call, (a, stream, self, params)
 
     def step_async(self, actions):
         self._pending = actions
@@ -367,14 +385,14 @@ class AtcVecEnv:
         self.sector.close()
 
 
-def make_multi_launcher(envs, actions, streams):
+def make_multi_launcher(envs, actions, streams, held=False):
     """One step of several INDEPENDENT sub-batch envs with a single foreign call (`atc_step_multi`): envs[i] steps with
     the device tensor actions[i] on streams[i].  Returns a no-argument callable that only launches.  With no join between
     steps the sub-batches run decoupled: the launch ramp and tail of one overlap the body of the others (bench.py
     --streams, tools/multi_stream.py)."""
     n = len(envs)
     assert n == len(actions) == len(streams) and n >= 1
-    built = [e.step_call(a, q) for e, a, q in zip(envs, actions, streams)]
+    built = [e.step_call(a, q, held) for e, a, q in zip(envs, actions, streams)]
     arr = (_lib.AtcStepCall * n)(*[b[0] for b in built])
     fn, check = _lib.load().atc_step_multi, _lib.check
 

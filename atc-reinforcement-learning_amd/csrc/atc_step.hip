@@ -83,8 +83,9 @@ constexpr int kBlock = ATC_BLOCK;
 #define ATC_TRACE 0  // developer-only: per-wavefront s_memtime stamps at phase boundaries (pointer smuggled in params)
 #endif
 #if ATC_TRACE
-#define ATC_STAMP(n) do { if (lane == 0 && trace) trace[(size_t)(blockIdx.x * (kBlock / 64) + (tid >> 6)) * 8 + (n)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define ATC_STAMP_B(n) do { unsigned long long* trace = so.trace; ATC_STAMP(n); } while (0)
+// one row of 8 stamps per wavefront AND step (row = wavefront * steps + step)
+#define ATC_STAMP(n) do { if (lane == 0 && trow) trow[(n)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ATC_STAMP_B(n) do { unsigned long long* trow = so.trace; ATC_STAMP(n); } while (0)
 #else
 #define ATC_STAMP(n) do {} while (0)
 #define ATC_STAMP_B(n) do {} while (0)
@@ -758,13 +759,13 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     }
 }
 
-__device__ __forceinline__ void store_lane_state(const atc_state_t& st, const LaneIds& d, const LaneState& ls) {
+__device__ __forceinline__ void store_lane_state(const atc_state_t& st, const LaneIds& d, const LaneState& ls, bool la_live) {
     if (d.lane_valid)
         *at<int4>(st.pos_hp, d.i * 16u) = make_int4(ls.a.x, ls.a.y, __float_as_int(ls.a.h), __float_as_int(ls.a.phi));
     // speed and last-action targets are typically constant for many steps (actions are held, the speed reaches its target):
     // written back only by wavefronts in which one of them changed
     if (__ballot(ls.v_changed) != 0ull && d.lane_valid) *at<float>(st.v, d.i * 4u) = ls.a.v;
-    if (__ballot(ls.la_changed) != 0ull && d.lane_valid) {
+    if (__ballot(ls.la_changed) != 0ull && d.lane_valid && la_live) {
         Float3 la = {ls.la_v, ls.la_h, ls.la_p};
         *at<Float3>(st.last_act, d.i * 12u) = la;
     }
@@ -792,8 +793,8 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     const int tid = threadIdx.x, lane = tid & 63;
     unsigned long long* trace = reinterpret_cast<unsigned long long*>(
         ((unsigned long long)p.reserved0) | ((unsigned long long)__float_as_uint(p.reserved1) << 32));
+    const unsigned long long t_launch = __builtin_amdgcn_s_memtime();
 #endif
-    ATC_STAMP(0);
     const uint32_t BN = (uint32_t)B * (uint32_t)N;      // host guarantees B*N*40 bytes < 4 GiB: 32-bit lane offsets
     const LaneIds d = make_ids<W>(blockIdx.x * kBlock, B, N);
 
@@ -803,7 +804,14 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     EnvState es = {e0.x, e0.y, __int_as_float(e0.z), (uint64_t)(uint32_t)e0.w | ((uint64_t)hi0 << 32)};
     const int4 ps = *at<int4>(st.pos_hp, d.i * 16u);
     const float v0 = *at<float>(st.v, d.i * 4u);
-    const Float3 la0 = *at<Float3>(st.last_act, d.i * 12u);
+    // ATC_M_ACTIONS_HELD (single-step launches): the caller repeats the previous launch's actions, so an aircraft that was under
+    // control then has last_action == its accepted targets and cannot count an action or change the record — the 12-byte
+    // record is only read (and written) by envs that were reset since their last step (timesteps == 0), whose aircraft
+    // may have been handed over when the action block started and still carry an older record.
+    const bool same_actions = ONE && (p.mode & ATC_M_ACTIONS_HELD) != 0;
+    const bool la_live = !same_actions || e0.x == 0;
+    Float3 la0 = {0.0f, 0.0f, 0.0f};
+    if (la_live) la0 = *at<Float3>(st.last_act, d.i * 12u);
     LaneState ls = {{ps.x, ps.y, __int_as_float(ps.z), __int_as_float(ps.w), v0}, la0.a, la0.b, la0.c, false, false};
 
     // A single step is its own instantiation: with the step count a run-time value everything the loop carries (aircraft
@@ -814,6 +822,10 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     const float* act_t = actions;   // action block of the current step; a block is held for `hold` steps
     int held = 0;                   // steps the current block has been used for
     for (int step = 0; step < n_steps; ++step) {
+#if ATC_TRACE
+        unsigned long long* trow = trace ? trace + ((size_t)(blockIdx.x * (kBlock / 64) + (tid >> 6)) * n_steps + step) * 8 : nullptr;
+        if (lane == 0 && trow) trow[0] = step ? __builtin_amdgcn_s_memtime() : t_launch;
+#endif
         const size_t sBN = (size_t)step * BN, sB = (size_t)step * (uint32_t)B;  // uniform (scalar) per-step bases
         // Multi-step launches: everything that is invariant across steps (lane ids and the address arithmetic on them, the
         // sector base) is re-derived from an opaque zero inside the body, so that LICM cannot hoist it and keep it alive
@@ -837,12 +849,17 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
                       FULL && out.term_obs ? out.term_obs + sBN * ATC_OBS_DIM : nullptr,
                       FULL && out.packet ? out.packet + sB * (ATC_PKT_CHUNKS * 4) : nullptr
 #if ATC_TRACE
-                      , trace
+                      , trow
 #endif
         };
         if (ONE || step == 0) act = *at<Float3>(act_t, dl.i * 12u);   // one 12-byte load per lane
         // (decoding a held block once per block instead of once per step was measured slower: 15.7 vs 15.1 us per step)
         const Float3 tg = decode_targets(p, act);
+        if (ONE && !la_live) {   // held block: the record equals the accepted targets (components that are refused are not compared)
+            ls.la_v = tg.a;
+            ls.la_h = tg.b;
+            ls.la_p = tg.c;
+        }
         const Mid m = step_part_a(Kl, gl, p, q, dl, tg.a, tg.b, tg.c, ls, es);
         ATC_STAMP(1);
         Float3 nxt = act;
@@ -857,9 +874,11 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         ATC_STAMP(6);
     }
     // ---- write back persistent state -----------------------------------------------------------------------------------
-    store_lane_state(st, d, ls);
+    store_lane_state(st, d, ls, la_live);
     store_env_state<W>(st, d, es, hi0);
-    ATC_STAMP(7);
+#if ATC_TRACE
+    if (lane == 0 && trace) trace[((size_t)(blockIdx.x * (kBlock / 64) + (tid >> 6)) * n_steps + (n_steps - 1)) * 8 + 7] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -93,7 +93,7 @@ def cpu_baseline(n_aircraft, seconds_target=12.0):
     return out
 
 
-def parity_gate(scn, N, grid_cell, sep_nm, device):
+def parity_gate(scn, N, grid_cell, sep_nm, device, held_hint=False):
     """correctness gate of every timed run, executed BEFORE the timed region on rank 0.
     (a) reference fixtures: the scripted LOWW episodes of tests/golden/g2_scripted.npz (captured from the imported reference)
         replayed through the batched kernel — flags / done / counters exact, obs and rewards within 1e-5;
@@ -149,18 +149,23 @@ def parity_gate(scn, N, grid_cell, sep_nm, device):
     for t in range(T):
         if t % HOLD == 0:
             a = (torch.rand((B, N, 3), generator=g) * 2 - 1).numpy()
-        obs, rew, done, info = env.step(a)
+        obs, rew, done, info = env.step(a, held=held_hint and t % HOLD != 0)   # the launch mode of the timed loop
         orc.step(a)
         if not (np.array_equal(info["flags"].cpu().numpy().astype(np.uint16), orc.flags)
-                and np.array_equal(done.cpu().numpy(), orc.done)):
-            raise RuntimeError("parity gate (b): flags / done differ from the fp32 oracle at step %d" % t)
+                and np.array_equal(done.cpu().numpy(), orc.done)
+                and np.array_equal(env.actions_taken.cpu().numpy(), orc.actions_taken)):
+            raise RuntimeError("parity gate (b): flags / done / actions_taken differ from the fp32 oracle at step %d" % t)
         o = obs.cpu().numpy().reshape(B, N, 10)
         worst_o = max(worst_o, float((np.abs(o - orc.obs) / np.maximum(1.0, np.abs(orc.obs))).max()))
         worst_r = max(worst_r, float((np.abs(rew.cpu().numpy() - orc.reward) / np.maximum(1.0, np.abs(orc.reward))).max()))
+    env_last_act = env.last_act.cpu().numpy().reshape(B * N, 3)
     env.close()
     if worst_o > 1e-5 or worst_r > 1e-5:
         raise RuntimeError("parity gate (b): obs %.2e / reward %.2e beyond 1e-5" % (worst_o, worst_r))
-    out["fp32_oracle"] = {"envs": B, "aircraft": N, "steps": T, "flags_done_exact": True, "max_rel_obs_err": worst_o,
+    if not np.array_equal(env_last_act, orc.last_act.T.reshape(B * N, 3)):
+        raise RuntimeError("parity gate (b): last_action records differ from the fp32 oracle")
+    out["fp32_oracle"] = {"envs": B, "aircraft": N, "steps": T, "flags_done_exact": True, "actions_taken_exact": True,
+                          "last_action_exact": True, "held_hint": bool(held_hint), "max_rel_obs_err": worst_o,
                           "max_rel_reward_err": worst_r}
     return out
 
@@ -196,6 +201,10 @@ def main():
     ap.add_argument("--no-single-env", action="store_true", help="skip the single-env compute-performance.py protocol")
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; value = the median block")
     ap.add_argument("--grid-cell", type=float, default=0.5, help="cell size [nm] of the MVA lookup grid")
+    ap.add_argument("--no-held-hint", action="store_true", help="do not tell atc_step that launches 2..%d of an action block "
+                    "repeat the previous launch's actions (ATC_M_ACTIONS_HELD)" % HOLD)
+    ap.add_argument("--prewarm", type=int, default=-1, help="developer knob: untimed steps before the warm-up (default: "
+                    "6000 / 12000, the steady episode mix); profiling passes use fewer")
     ap.add_argument("--rollout", type=int, default=0, help="fuse this many steps per launch (0 = one launch per step)")
     ap.add_argument("--sep-nm", type=float, default=3.0, help="developer knob: separation minimum (0 disables conflicts)")
     ap.add_argument("--streams", type=int, default=1, help="step the batch as this many independent sub-batches on "
@@ -254,15 +263,21 @@ def main():
     ring = [torch.rand((B, N, 3), generator=g, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(n_ring)]
 
     launchers = None
+    held_launchers = None
+    last_block = [None]   # ring index of the previous launch (the held promise is only made for an immediate repeat)
     if S == 1 and not args.graph and not args.rollout:
         # one pre-bound atc_step call per ring tensor (AtcVecEnv.make_launcher): the timed loop then only launches — a few
         # microseconds of host time per step, so the GPU never waits for Python even in a 20-step timed block
         launchers = [env.make_launcher(a) for a in ring]
+        if not args.no_held_hint:   # launches 2..HOLD of a held block carry the promise "same actions as the previous launch"
+            held_launchers = [env.make_launcher(a, held=True) for a in ring]
     if S > 1:  # sub-batch s owns envs [s B/S, (s+1) B/S) of every ring tensor and its own stream
         streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
         Bs = B // S
         from atc_hip.vec_env import make_multi_launcher
         launchers = [make_multi_launcher(subs, [a[s * Bs:(s + 1) * Bs] for s in range(S)], streams) for a in ring]
+        if not args.no_held_hint:
+            held_launchers = [make_multi_launcher(subs, [a[s * Bs:(s + 1) * Bs] for s in range(S)], streams, held=True) for a in ring]
 
     graph = None
     act_buf = None
@@ -282,7 +297,12 @@ def main():
     def run(n_steps, t_base):
         if launchers is not None:
             for s in range(n_steps):
-                launchers[((t_base + s) // HOLD) % n_ring]()   # one foreign call = one step of every sub-batch
+                j = ((t_base + s) // HOLD) % n_ring
+                if held_launchers is not None and last_block[0] == j and (t_base + s) % HOLD:
+                    held_launchers[j]()
+                else:
+                    launchers[j]()   # one foreign call = one step of every sub-batch
+                last_block[0] = j
             return
         if graph is not None:
             for s in range(0, n_steps, HOLD):
@@ -319,11 +339,11 @@ def main():
 
     gate = None
     if rank == 0 and not args.no_parity_gate:
-        gate = parity_gate(scn, N, args.grid_cell, args.sep_nm, local)   # raises if results are wrong
+        gate = parity_gate(scn, N, args.grid_cell, args.sep_nm, local, held_hint=held_launchers is not None)   # raises if results are wrong
 
     # Untimed: bring every rank's GPU to its working clocks and the envs into their steady episode mix before the W warm-up
     # steps the caller asked for (the driver uses a handful; the first launches after start-up are not representative).
-    PREWARM = 6000 if N * B >= 1 << 18 else 12000
+    PREWARM = args.prewarm if args.prewarm >= 0 else (6000 if N * B >= 1 << 18 else 12000)
     run(PREWARM - PREWARM % max(1, args.rollout, HOLD if args.graph else 1), 0)
     run(W, 0)
     torch.cuda.synchronize(dev)
@@ -369,7 +389,8 @@ def main():
     if os.path.exists(tpath):
         try:
             for tj in json.load(open(tpath))["workloads"]:
-                if tj["envs"] == B and tj["aircraft"] == N and tj["rollout"] == (args.rollout or 0) and S == 1:
+                if (tj["envs"] == B and tj["aircraft"] == N and tj["rollout"] == (args.rollout or 0) and S == 1
+                        and bool(tj.get("held_hint", False)) == (held_launchers is not None)):
                     traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
         except Exception:
             traffic = None
@@ -391,6 +412,9 @@ def main():
                        "episodes_finished": int(episodes), "positions": "32-bit fixed point (2^-25 nm grid)",
                        "timed_blocks_ms_per_step": [b[0] / K * 1e3 for b in blocks], "timing": "median of %d timed blocks "
                        "of %d steps, each bracketed by barrier + synchronize" % (len(blocks), K),
+                       "actions_held_hint": ("launches 2..%d of every %d-step action block carry ATC_M_ACTIONS_HELD (the caller's "
+                                             "promise that the block is repeated; results identical, last_action record skipped)"
+                                             % (HOLD, HOLD)) if held_launchers is not None else None,
                        "prewarm_steps": PREWARM, "parity_gate": gate, "gathered_returns_shape": list(returns.shape),
                        "rank_seeds": [int(v) for v in rank_seeds.reshape(-1).tolist()]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ATC_ABI_VERSION 13
+#define ATC_ABI_VERSION 14
 
 /* ---------------------------------------------------------------------------------------------
  * Scenario blob: one flat array of 32-bit floats (device copy) compiled on the host from the sector
@@ -134,9 +134,17 @@ enum {
     ATC_M_DISCRETE = 1u << 2,        /* SimParameters.discrete_action_space, model.py:145 */
     ATC_M_AUTO_RESET = 1u << 3,      /* VecEnv semantics: done envs are reset inside the step, obs := raw reset obs */
     ATC_M_RANDOM_ENTRY = 1u << 4,    /* reset draws (entry, level) from the counter-based RNG; else slot lattice */
-    ATC_M_KEEP_ACTIVE = 1u << 5      /* the reference's single-aircraft rule (atc_gym.py:163-169): an aircraft that reaches the
+    ATC_M_KEEP_ACTIVE = 1u << 5,     /* the reference's single-aircraft rule (atc_gym.py:163-169): an aircraft that reaches the
                                         corridor ends the episode and STAYS under control (no hand-over), so stepping on
                                         without reset keeps simulating it (learning/atc-gym-compute-performance.py:14-16) */
+    ATC_M_ACTIONS_HELD = 1u << 6     /* atc_step only — a promise of the caller: `actions` holds, for every aircraft, the same
+                                        bits as in the previous atc_step of these envs (a held action block / frame skip,
+                                        learning/atc-gym-demo.py:18-19).  Results are identical to a launch without the bit;
+                                        the kernel then skips the last_action record (12 of 110 bytes per aircraft-step):
+                                        an aircraft under control in the previous step has last_action == its accepted
+                                        targets (atc_gym.py:305-311), so no action is counted and the record does not
+                                        change.  Envs reset since their last step (timesteps == 0) are handled in full.
+                                        Set on a launch whose actions DID change, actions_taken / last_action are wrong. */
 };
 
 typedef struct atc_params {

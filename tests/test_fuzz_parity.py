@@ -38,6 +38,7 @@ def _case(seed):
               timestep_limit=int(rng.choice([6000, 6000, 40])), full=bool(rng.integers(2)),
               shaping=bool(rng.integers(4) > 0), normalize=bool(rng.integers(4) > 0),
               sep_nm=float(rng.choice([3.0, 3.0, 0.0, 5.0])), keep_active=bool(rng.integers(5) == 0))
+    kw["held_hint"] = bool(rng.integers(2))   # drawn last: the cases of earlier sweeps keep their configurations
     if rollout:
         kw["steps"] = (kw["steps"] // rollout) * rollout
     return scn, comp, kw

@@ -373,3 +373,73 @@ def test_atcgym_packet_polling_equals_synchronised_reads():
     assert n_done > 20
     a_env.close()
     b_env.close()
+
+
+def _winning_state(scn):
+    """an (x, y, h, phi) well inside the final-approach corridor and above its MVA (found with the query kernels)"""
+    import numpy as np
+    c = scn.runway.corridor
+    fx, fy = float(np.ravel(c.faf)[0]), float(np.ravel(c.faf)[1])
+    ix, iy = float(np.ravel(c.iaf)[0]), float(np.ravel(c.iaf)[1])
+    for s in np.linspace(0.2, 0.8, 7):
+        for off in (0.15, -0.15, 0.3, -0.3):
+            x, y = fx + s * (ix - fx) + off, fy + s * (iy - fy)
+            for dphi in (8.0, -8.0, 15.0, -15.0):
+                phi = scn.runway.phi_to_runway + dphi
+                h = float(scn.airspace.get_mva_heights([x], [y])[0]) + 150.0
+                if all(scn.runway.inside_corridor(x + dx, y + dy, h, phi + dp)
+                       for dx in (-0.1, 0.0, 0.1) for dy in (-0.1, 0.0, 0.1) for dp in (-3.0, 0.0, 3.0)):
+                    return x, y, h, phi
+    raise AssertionError("no robust winning state found")
+
+
+@pytest.mark.parametrize("N,hold", [(16, 7), (1, 5), (64, 10), (5, 20)])
+def test_held_actions_hint_changes_nothing(N, hold):
+    """ATC_M_ACTIONS_HELD (step(..., held=True) / make_launcher(held=True)): a promise that the action block is repeated —
+    outputs and the whole persistent state (incl. last_action and the action counters) are bit-identical to plain steps,
+    also for envs that are auto-reset in the middle of a block while carrying aircraft handed over in an EARLIER block
+    (their last_action record is older than the block: the one case in which a held step can count an action)."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+    scn = scenarios.LOWWDense() if N > 16 else scenarios.LOWW(random_entrypoints=N > 1)
+    B = 400
+    plain = AtcVecEnv(B, N, scenario=scn, auto_reset=True, seed=11)
+    hint = AtcVecEnv(B, N, scenario=scn, auto_reset=True, seed=11)
+    if N > 1:   # slot 0 of every second env starts inside the corridor: handed over in the first step of the first block
+        x, y, h, phi = _winning_state(scn)
+        for env in (plain, hint):
+            for e in range(0, B, 2):
+                env.set_state(e, 0, x, y, h, phi, 180.0)
+    g = torch.Generator(device="cpu").manual_seed(N * 1000 + hold)
+    stale_resets = 0
+    handed_over = 0
+    t = 0
+    for block in range(8):
+        a = (torch.rand((B, N, 3), generator=g) * 2.1 - 1.05).cuda()
+        launch_first, launch_held = hint.make_launcher(a), hint.make_launcher(a, held=True)
+        for k in range(hold):
+            slot0_inactive = (plain.active_mask & 1) == 0
+            o, r, d, info = plain.step(a)
+            if block % 2:   # both ways of passing the promise
+                o2, r2, d2, i2 = hint.step(a, held=k > 0)
+            else:
+                (launch_held if k > 0 else launch_first)()
+                o2, r2, d2, i2 = hint.obs, hint.reward, hint.done, {"flags": hint.flags}
+            assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(d, d2), (block, k)
+            assert torch.equal(info["flags"], i2["flags"]), (block, k)
+            for name in ("pos_hp", "v", "last_act", "env", "stats"):
+                assert torch.equal(getattr(plain, name), getattr(hint, name)), (name, block, k)
+            handed_over += int(slot0_inactive.sum()) if t == 1 else 0
+            if k == 0:
+                stale = slot0_inactive.clone()   # slot 0 handed over before this block began: its record is older than the block
+            if k < hold - 1:                     # reset with a held step to follow
+                stale_resets += int((d.bool() & stale).sum())
+            stale &= ~d.bool()
+            t += 1
+    assert not (hint.params.mode & 64)          # step(held=True) leaves the parameters as they were
+    if N > 1:
+        assert handed_over >= B // 4, handed_over
+        assert stale_resets > 0, "the stale-record case did not occur"
+    plain.close()
+    hint.close()

@@ -370,9 +370,10 @@ def test_atcgym_keeps_flying_after_a_win():
 # ------------------------------------------------------------------------------------------------ batched vs fp32 oracle
 def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, spawn="lattice", hold=20, grid_cell=0.5,
                    use_rollout=0, timestep_limit=6000, full=True, shaping=True, normalize=True, sep_nm=3.0,
-                   keep_active=False):
+                   keep_active=False, held_hint=False):
     """full=False drives the fast kernel variant (obs / reward / done / flags only), full=True the one with every optional
-    output; everything the variant produces is compared with the fp32 oracle."""
+    output; everything the variant produces is compared with the fp32 oracle.  held_hint: single steps that repeat the
+    previous step's action array are launched with ATC_M_ACTIONS_HELD (must change nothing)."""
     torch = _torch()
     from atc_hip.vec_env import AtcVecEnv
     from envs.atc import model
@@ -398,6 +399,7 @@ def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, sp
     while t < steps:
         chunk = use_rollout or 1
         acts = []
+        repeated = act is not None and t % hold != 0
         for c in range(chunk):
             if (t + c) % hold == 0 or act is None:
                 if discrete:
@@ -409,7 +411,7 @@ def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, sp
             out = env.rollout(torch.as_tensor(np.stack(acts)))
             res = [(out["obs"][c], out["reward"][c], out["done"][c], out["flags"][c]) for c in range(chunk)]
         else:
-            o, r, d, info = env.step(acts[0])
+            o, r, d, info = env.step(acts[0], held=held_hint and repeated)
             res = [(o, r, d, info["flags"])]
         for c in range(chunk):
             orc.step(acts[c])
@@ -487,7 +489,7 @@ def test_batched_n1_random_entries_discrete_vs_oracle():
 def test_batched_n16_vs_oracle():
     from envs.atc import scenarios
     scn = scenarios.LOWW(random_entrypoints=True)
-    n_done, seen = _run_vs_oracle(scn, scenarios.compile_scenario(scn, grid_cell=0.5), B=512, N=16, steps=400, seed=21)
+    n_done, seen = _run_vs_oracle(scn, scenarios.compile_scenario(scn, grid_cell=0.5), B=512, N=16, steps=400, seed=21, held_hint=True)
     assert n_done > 50 and (seen & H.F_CONFLICT)
 
 

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Developer tool: per-wavefront, per-step phase timing of the multi-step launch (ATC_TRACE build, s_memtime stamps).
+  hipcc ... -DATC_TRACE=1 -o build_variants/libatcstep_trace.so ; python tools/trace_rollout.py [envs] [aircraft] [T]"""
+import os
+import struct
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "atc-reinforcement-learning_amd")]
+import numpy as np
+import torch
+from atc_hip import lib as _binding
+_binding.use_library(os.path.join(ROOT, "build_variants", "libatcstep_trace.so"))
+from atc_hip.vec_env import AtcVecEnv
+from envs.atc import scenarios
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+env = AtcVecEnv(B, N, scenario=scenarios.LOWW(random_entrypoints=True), auto_reset=True)
+acts = [(torch.rand((1, B, N, 3), device="cuda") * 2 - 1) for _ in range(4)]
+out = None
+for t in range(30):
+    out = env.rollout(acts[t % 4], out, hold=T)
+W = 1
+while W < N:
+    W *= 2
+n_waves = (B * W + 255) // 256 * 4
+trace = torch.zeros((n_waves, T, 8), dtype=torch.int64, device="cuda")
+ptr = trace.data_ptr()
+env.params.reserved0 = ptr & 0xffffffff
+env.params.reserved1 = struct.unpack("f", struct.pack("I", (ptr >> 32) & 0xffffffff))[0]
+torch.cuda.synchronize()
+env.rollout(acts[0], out, hold=T)
+torch.cuda.synchronize()
+raw = trace.cpu().numpy().astype(np.float64)
+env.params.reserved0 = 0
+env.params.reserved1 = 0.0
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ev0.record()
+for t in range(50):
+    env.rollout(acts[t % 4], out, hold=T)
+ev1.record()
+torch.cuda.synchronize()
+launch_us = ev0.elapsed_time(ev1) / 50 * 1e3
+xcd = (np.arange(n_waves) // 4) % 8
+span = np.median([raw[xcd == x, T - 1, 7].max() - raw[xcd == x, 0, 0].min() for x in range(8)])
+tick = launch_us / span   # upper bound for the tick: the period includes the launch floor
+print("launch %.1f us = %.2f us per step; span on one XCD %.0f ticks -> <= %.2f ns per tick" % (launch_us, launch_us / T, span, tick * 1e3))
+names = ["top: decode + kinematics (+ first loads in step 0)", "mva resolve + pair scan", "overrides + corridor",
+         "obs + shaping + normalise", "reductions, flag/reward stores, auto-reset (+ next action fetch)", "obs transpose + store"]
+life = (raw[:, T - 1, 7] - raw[:, 0, 0]) * tick
+print("wave lifetime: mean %.1f us, per step %.2f us" % (life.mean(), life.mean() / T))
+for label, sl in (("step 0", slice(0, 1)), ("steps 1..T-1", slice(1, T))):
+    r = raw[:, sl, :]
+    d = np.diff(r[:, :, :7], axis=2) * tick
+    print(label)
+    for k, nme in enumerate(names):
+        print("  %-70s mean %6.3f  median %6.3f  p90 %6.3f us" % (nme, d[:, :, k].mean(), np.median(d[:, :, k]), np.percentile(d[:, :, k], 90)))
+    print("  step total (stamp 0 -> 6): mean %.3f us" % ((r[:, :, 6] - r[:, :, 0]) * tick).mean())
+gap = (raw[:, 1:, 0] - raw[:, :-1, 6]) * tick
+print("between steps (stamp 6 -> next stamp 0): mean %.3f us" % gap.mean())
+print("state store (last stamp 6 -> 7): mean %.3f us" % ((raw[:, T - 1, 7] - raw[:, T - 1, 6]) * tick).mean())
