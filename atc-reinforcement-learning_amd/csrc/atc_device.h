@@ -157,18 +157,31 @@ __device__ __forceinline__ uint32_t noise_candidates(const float* __restrict__ g
     if (!grid || !c.in_grid) return 0xffffu;
     return (uint32_t)(int)fabsf(c.cell.x) >> 6;
 }
-__device__ __forceinline__ MvaCell mva_cell_load(const float* __restrict__ grid, float x, float y) {
+// the grid header (origin, 1 / cell, columns, rows): read EARLY by the caller — as part of mva_cell_load it was a scalar-load
+// round trip (plus a second one behind a short-circuit test) between the new position and the cell gather
+struct GridHdr {
+    float x0, y0, inv, nx, ny;
+};
+__device__ __forceinline__ GridHdr grid_header(const float* __restrict__ grid) {
+    GridHdr g = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (grid) {
+        const float4 a = *reinterpret_cast<const float4*>(grid);   // ATC_G_X0, ATC_G_Y0, ATC_G_INV, ATC_G_NX
+        g.x0 = a.x; g.y0 = a.y; g.inv = a.z; g.nx = a.w;
+        g.ny = grid[ATC_G_NY];
+    }
+    return g;
+}
+__device__ __forceinline__ MvaCell mva_cell_load(const float* __restrict__ grid, const GridHdr& g, float x, float y) {
     MvaCell c;
     c.cell = make_float2(0.0f, 0.0f);
     c.in_grid = false;
     if (grid) {
-        const float fx = (x - grid[ATC_G_X0]) * grid[ATC_G_INV];
-        const float fy = (y - grid[ATC_G_Y0]) * grid[ATC_G_INV];
-        const float nx = grid[ATC_G_NX], ny = grid[ATC_G_NY];
-        c.in_grid = fx >= 0.0f && fx < nx && fy >= 0.0f && fy < ny;
+        const float fx = (x - g.x0) * g.inv;
+        const float fy = (y - g.y0) * g.inv;
+        c.in_grid = (fx >= 0.0f) & (fx < g.nx) & (fy >= 0.0f) & (fy < g.ny);
         // clamped index: the load is unconditional (no branch in front of it), the result is ignored when !in_grid
         const int ix = c.in_grid ? (int)fx : 0, iy = c.in_grid ? (int)fy : 0;
-        c.cell = *reinterpret_cast<const float2*>(grid + ATC_G_HDR + 2 * (iy * (int)nx + ix));
+        c.cell = *reinterpret_cast<const float2*>(grid + ATC_G_HDR + 2 * (iy * (int)g.nx + ix));
     }
     return c;
 }
@@ -247,7 +260,7 @@ __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const fl
 }
 __device__ __forceinline__ int find_mva(const float* __restrict__ K, const float* __restrict__ grid, float x, float y,
                                         float* height) {
-    const MvaCell c = mva_cell_load(grid, x, y);
+    const MvaCell c = mva_cell_load(grid, grid_header(grid), x, y);
     return mva_resolve(K, grid, c, x, y, height);
 }
 
@@ -275,8 +288,10 @@ __device__ __forceinline__ bool inside_corridor_angle(const float* __restrict__ 
 // model.py:188-210 Corridor.inside_corridor
 __device__ __forceinline__ bool inside_corridor(const float* __restrict__ K, float x, float y, float h, float phi) {
     // exact early-out: a point the crossing test accepts lies within the ring's bounds (precomputed on the host)
-    if (!(x >= K[ATC_C_TRI_BBOX] && x <= K[ATC_C_TRI_BBOX + 2] && y >= K[ATC_C_TRI_BBOX + 1] && y <= K[ATC_C_TRI_BBOX + 3]))
-        return false;
+    // (one 16-byte scalar load and bitwise ands: four short-circuit tests were four dependent scalar-load round trips)
+    static_assert(ATC_C_TRI_BBOX % 4 == 0, "bounds must be 16-byte aligned");
+    const float4 bb = *reinterpret_cast<const float4*>(K + ATC_C_TRI_BBOX);
+    if (!((x >= bb.x) & (x <= bb.z) & (y >= bb.y) & (y <= bb.w))) return false;
     if (!ray_tracing(x, y, K + ATC_C_TRI_H, 4)) return false;
     const float fx = K[ATC_C_FAF_X], fy = K[ATC_C_FAF_Y], nx = K[ATC_C_NRM_X], ny = K[ATC_C_NRM_Y];
     const float t = (x - fx) * nx + (y - fy) * ny;

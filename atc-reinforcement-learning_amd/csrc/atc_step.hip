@@ -384,6 +384,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
                                            float th, float tp, LaneState& ls, EnvState& es) {
     Mid m;
     Aircraft& a = ls.a;
+    const GridHdr gh = grid_header(grid);   // requested here, needed after the kinematics
     const float dt = p.dt;
     es.t += 1;  // atc_gym.py:135
     const bool active = d.lane_valid && ((d.k < 32 ? ((uint32_t)es.amask >> d.k) : ((uint32_t)(es.amask >> 32) >> (d.k - 32))) & 1u);
@@ -441,7 +442,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
     m.x32 = (float)fma((double)a.x, q.pos_inv, q.pos_x0);   // atc::pos_to_real with the widened constants
     m.y32 = (float)fma((double)a.y, q.pos_inv, q.pos_y0);
     // MVA floor, first half: only ISSUE the lookup-cell gather here; nothing until the override chain needs its result
-    m.cell = mva_cell_load(grid, m.x32, m.y32);
+    m.cell = mva_cell_load(grid, gh, m.x32, m.y32);
     m.active = active;
     m.r = r;
     m.fl = fl;
@@ -808,6 +809,8 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     // control then has last_action == its accepted targets and cannot count an action or change the record — the 12-byte
     // record is only read (and written) by envs that were reset since their last step (timesteps == 0), whose aircraft
     // may have been handed over when the action block started and still carry an older record.
+    Float3 act = {0.0f, 0.0f, 0.0f};   // action of the current block (held for `hold` steps); one 12-byte load per lane
+    if (ONE) act = *at<Float3>(actions, d.i * 12u);   // requested before the env record is waited for below
     const bool same_actions = ONE && (p.mode & ATC_M_ACTIONS_HELD) != 0;
     const bool la_live = !same_actions || e0.x == 0;
     Float3 la0 = {0.0f, 0.0f, 0.0f};
@@ -818,7 +821,6 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     // and env records, output bases, hoisted sector constants) stays live across the whole body — the straight-line form
     // needs 63 VGPRs (N = 16), the loop form 80 under its launch bound (94 without it).
     const int n_steps = ONE ? 1 : T;
-    Float3 act = {0.0f, 0.0f, 0.0f};   // action of the current block (held for `hold` steps)
     const float* act_t = actions;   // action block of the current step; a block is held for `hold` steps
     int held = 0;                   // steps the current block has been used for
     for (int step = 0; step < n_steps; ++step) {
@@ -852,7 +854,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
                       , trow
 #endif
         };
-        if (ONE || step == 0) act = *at<Float3>(act_t, dl.i * 12u);   // one 12-byte load per lane
+        if (!ONE && step == 0) act = *at<Float3>(act_t, dl.i * 12u);
         // (decoding a held block once per block instead of once per step was measured slower: 15.7 vs 15.1 us per step)
         const Float3 tg = decode_targets(p, act);
         if (ONE && !la_live) {   // held block: the record equals the accepted targets (components that are refused are not compared)
