@@ -160,14 +160,15 @@ __device__ __forceinline__ uint32_t noise_candidates(const float* __restrict__ g
 // the grid header (origin, 1 / cell, columns, rows): read EARLY by the caller — as part of mva_cell_load it was a scalar-load
 // round trip (plus a second one behind a short-circuit test) between the new position and the cell gather
 struct GridHdr {
-    float x0, y0, inv, nx, ny;
+    float x0, y0, inv, nx, ny, off_pool;
 };
 __device__ __forceinline__ GridHdr grid_header(const float* __restrict__ grid) {
-    GridHdr g = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    GridHdr g = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (grid) {
         const float4 a = *reinterpret_cast<const float4*>(grid);   // ATC_G_X0, ATC_G_Y0, ATC_G_INV, ATC_G_NX
+        const float2 b = *reinterpret_cast<const float2*>(grid + ATC_G_NY);   // ATC_G_NY, ATC_G_OFF_POOL
         g.x0 = a.x; g.y0 = a.y; g.inv = a.z; g.nx = a.w;
-        g.ny = grid[ATC_G_NY];
+        g.ny = b.x; g.off_pool = b.y;
     }
     return g;
 }
@@ -185,9 +186,8 @@ __device__ __forceinline__ MvaCell mva_cell_load(const float* __restrict__ grid,
     }
     return c;
 }
-__device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const float* __restrict__ grid, const MvaCell& c,
-                                           float x, float y, float* height) {
-    const float* tab = K + (int)K[ATC_H_OFF_POLY];
+__device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const float* __restrict__ grid, const GridHdr& gh,
+                                           const MvaCell& c, float x, float y, float* height) {
     *height = 0.0f;
     if (grid) {
         if (!c.in_grid) return -1;
@@ -205,7 +205,7 @@ __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const fl
         // Records are fetched in batches of kBatch (both 16-byte halves of each, all loads issued before the first use):
         // one L2 round trip per batch instead of one per record.  Indices past the list are clamped (loads stay in
         // bounds) and their records ignored.
-        const float4* rec = reinterpret_cast<const float4*>(grid + (int)grid[ATC_G_OFF_POOL]) + 2 * (int)cell.y;
+        const float4* rec = reinterpret_cast<const float4*>(grid + (int)gh.off_pool) + 2 * (int)cell.y;
         constexpr int kBatch = ATC_MVA_BATCH;
         bool inside = false;
         for (int base = 0; base < n; base += kBatch) {
@@ -248,6 +248,7 @@ __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const fl
         }
         return -1;
     }
+    const float* tab = K + (int)K[ATC_H_OFF_POLY];
     const int n_mva = (int)K[ATC_H_N_MVA];
     for (int p = 0; p < n_mva; ++p) {
         const float* rec = tab + p * ATC_P_WORDS;
@@ -260,8 +261,9 @@ __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const fl
 }
 __device__ __forceinline__ int find_mva(const float* __restrict__ K, const float* __restrict__ grid, float x, float y,
                                         float* height) {
-    const MvaCell c = mva_cell_load(grid, grid_header(grid), x, y);
-    return mva_resolve(K, grid, c, x, y, height);
+    const GridHdr gh = grid_header(grid);
+    const MvaCell c = mva_cell_load(grid, gh, x, y);
+    return mva_resolve(K, grid, gh, c, x, y, height);
 }
 
 // model.py:212-231 Corridor._inside_corridor_angle.

@@ -295,6 +295,7 @@ struct Mid {            // what the first half of a step hands to the second
     int acts;
     float x32, y32;
     MvaCell cell;       // MVA lookup cell, gather issued in the first half, resolved after the separation scan
+    GridHdr gh;         // uniform: the lookup grid's header, read at the top of the step
 };
 // Uniform products of the step parameters, evaluated ONCE on the host in fp32 (the same IEEE operations the kernel
 // would do) and passed as kernel arguments: gfx950 has no scalar float ALU, so computed in the kernel they would occupy
@@ -443,6 +444,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
     m.y32 = (float)fma((double)a.y, q.pos_inv, q.pos_y0);
     // MVA floor, first half: only ISSUE the lookup-cell gather here; nothing until the override chain needs its result
     m.cell = mva_cell_load(grid, gh, m.x32, m.y32);
+    m.gh = gh;
     m.active = active;
     m.r = r;
     m.fl = fl;
@@ -498,7 +500,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     int pi = 0;
     if (!kResolveAfterScan) {
         float hgt = 0.0f;
-        pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, m.cell, x32, y32, &hgt);
+        pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, m.gh, m.cell, x32, y32, &hgt);
         mva = pi >= 0 ? hgt : 0.0f;
         fl |= noise_areas(K, grid, m.cell, x32, y32, a.h);
     }
@@ -575,7 +577,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     {
         if (kResolveAfterScan) {
             float hgt = 0.0f;
-            pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, m.cell, x32, y32, &hgt);
+            pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, m.gh, m.cell, x32, y32, &hgt);
             mva = pi >= 0 ? hgt : 0.0f;                // atc_gym.py:161: mva = 0 outside
             fl |= noise_areas(K, grid, m.cell, x32, y32, a.h);
         }
