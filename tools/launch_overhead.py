@@ -34,8 +34,9 @@ print("torch elementwise add on 64 floats: %.2f us per launch" % period(lambda: 
 for B in (4096, 16384, 32768, 65536, 131072, 262144, 524288):
     env = AtcVecEnv(B, 16, scenario=scn, auto_reset=True)
     acts = (torch.rand((B, 16, 3), device="cuda") * 2 - 1)
-    la = env.make_launcher(acts)
+    la, la_held = env.make_launcher(acts), env.make_launcher(acts, held=True)   # the one action tensor is repeated for ever
     for _ in range(3000 if B <= 65536 else 800):
         la()
-    print("%7d envs: %.2f us per step" % (B, period(la, 2000 if B <= 65536 else 500)))
+    n = 2000 if B <= 65536 else 500
+    print("%7d envs: %.2f us per step, %.2f with ATC_M_ACTIONS_HELD" % (B, period(la, n), period(la_held, n)))
     env.close()
