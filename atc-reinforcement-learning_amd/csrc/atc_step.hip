@@ -90,6 +90,9 @@ constexpr int kBlock = ATC_BLOCK;
 #define ATC_STAMP(n) do {} while (0)
 #define ATC_STAMP_B(n) do {} while (0)
 #endif
+#ifndef ATC_LOOP_SKIP_BOOK
+#define ATC_LOOP_SKIP_BOOK 1  // multi-step launches: no last-action bookkeeping on the steps that repeat an action block
+#endif
 #ifndef ATC_GRID_CAP
 #define ATC_GRID_CAP 8   // workgroups per CU before the reset / observe / query kernels grid-stride
 #endif
@@ -296,6 +299,7 @@ struct Mid {            // what the first half of a step hands to the second
     float x32, y32;
     MvaCell cell;       // MVA lookup cell, gather issued in the first half, resolved after the separation scan
     GridHdr gh;         // uniform: the lookup grid's header, read at the top of the step
+    bool repeated;      // uniform: no action bookkeeping in this step (acts == 0 in every lane)
 };
 // Uniform products of the step parameters, evaluated ONCE on the host in fp32 (the same IEEE operations the kernel
 // would do) and passed as kernel arguments: gfx950 has no scalar float ALU, so computed in the kernel they would occupy
@@ -382,11 +386,14 @@ __device__ __forceinline__ Float3 decode_targets(const atc_params_t& p, const Fl
 // ---- first half of AtcGym.step: timestep, rate limits towards the targets, kinematics, MVA floor ---------------------
 __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const float* __restrict__ grid,
                                            const atc_params_t& p, const StepDerived& q, const LaneIds& d, float tv,
-                                           float th, float tp, LaneState& ls, EnvState& es) {
+                                           float th, float tp, LaneState& ls, EnvState& es, bool repeated) {
     Mid m;
     Aircraft& a = ls.a;
     const GridHdr gh = grid_header(grid);   // requested here, needed after the kinematics
     const float dt = p.dt;
+    // `repeated` (wave-uniform): this step repeats the previous step's actions and no env of the wavefront was reset in
+    // between — last_action == the accepted targets, so nothing can be counted or changed (see ATC_M_ACTIONS_HELD)
+    const bool book = !repeated;
     es.t += 1;  // atc_gym.py:135
     const bool active = d.lane_valid && ((d.k < 32 ? ((uint32_t)es.amask >> d.k) : ((uint32_t)(es.amask >> 32) >> (d.k - 32))) & 1u);
     uint32_t fl = 0;
@@ -405,9 +412,11 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
             const float v_new = ok ? a.v + dd : a.v;
             ls.v_changed = ls.v_changed || v_new != a.v;
             a.v = v_new;
-            acts += (ok && !(fabsf(tv - ls.la_v) < kDiscrV)) ? 1 : 0;
-            ls.la_changed = ls.la_changed || (ok && tv != ls.la_v);
-            ls.la_v = ok ? tv : ls.la_v;
+            if (book) {
+                acts += (ok && !(fabsf(tv - ls.la_v) < kDiscrV)) ? 1 : 0;
+                ls.la_changed = ls.la_changed || (ok && tv != ls.la_v);
+                ls.la_v = ok ? tv : ls.la_v;
+            }
             r = valid ? r : r - 1.0f;
             fl |= valid ? 0u : (uint32_t)ATC_F_INVALID_V;
         }
@@ -417,9 +426,11 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
             float dd = th - a.h;
             dd = clamp_rate(dd, q.dh_lo, q.dh_hi);
             a.h = ok ? a.h + dd : a.h;
-            acts += (ok && !(fabsf(th - ls.la_h) < kDiscrH)) ? 1 : 0;
-            ls.la_changed = ls.la_changed || (ok && th != ls.la_h);
-            ls.la_h = ok ? th : ls.la_h;
+            if (book) {
+                acts += (ok && !(fabsf(th - ls.la_h) < kDiscrH)) ? 1 : 0;
+                ls.la_changed = ls.la_changed || (ok && th != ls.la_h);
+                ls.la_h = ok ? th : ls.la_h;
+            }
             r = valid ? r : r - 1.0f;
             fl |= valid ? 0u : (uint32_t)ATC_F_INVALID_H;
         }
@@ -427,9 +438,11 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
             float dd = tp - a.phi;
             dd = clamp_rate(dd, q.dp_lo, q.dp_hi);
             a.phi = active ? a.phi + dd : a.phi;
-            acts += (active && !(fabsf(tp - ls.la_p) < kDiscrPhi)) ? 1 : 0;
-            ls.la_changed = ls.la_changed || (active && tp != ls.la_p);
-            ls.la_p = active ? tp : ls.la_p;
+            if (book) {
+                acts += (active && !(fabsf(tp - ls.la_p) < kDiscrPhi)) ? 1 : 0;
+                ls.la_changed = ls.la_changed || (active && tp != ls.la_p);
+                ls.la_p = active ? tp : ls.la_p;
+            }
         }
     }
     // ---- Airplane.step (model.py:122-129): rot_matrix(phi) . [0, (v/3600) dt] ----------------------------------------
@@ -449,6 +462,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
     m.r = r;
     m.fl = fl;
     m.acts = acts;
+    m.repeated = repeated;
     return m;
 }
 
@@ -657,7 +671,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     ATC_STAMP_B(4);
     // ---- per-env reductions over the W lanes of the group ----------------------------------------------------------------
     const float env_r = group_sum<W>(r);
-    const int env_acts = group_sum_i<W>(acts);
+    const int env_acts = m.repeated ? 0 : group_sum_i<W>(acts);
     const uint64_t won = group_ballot<W>((fl & ATC_F_WON) != 0, lane);
     const uint64_t term = group_ballot<W>(
         (fl & (ATC_F_BELOW_MVA | ATC_F_OUTSIDE | ATC_F_CONFLICT | ATC_F_TIMEOUT)) != 0, lane);
@@ -864,7 +878,10 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             ls.la_h = tg.b;
             ls.la_p = tg.c;
         }
-        const Mid m = step_part_a(Kl, gl, p, q, dl, tg.a, tg.b, tg.c, ls, es);
+        // multi-step launches know structurally which steps repeat an action block
+        const bool repeated = ONE ? (same_actions && __ballot(la_live) == 0ull)
+                                  : (ATC_LOOP_SKIP_BOOK && held > 0 && __ballot(es.t == 0) == 0ull);
+        const Mid m = step_part_a(Kl, gl, p, q, dl, tg.a, tg.b, tg.c, ls, es, repeated);
         ATC_STAMP(1);
         Float3 nxt = act;
         const float* act_next = nullptr;   // the next block is fetched during the last step of the current one
