@@ -18,15 +18,17 @@ from envs.atc import scenarios
 B, N = (int(sys.argv[1]) if len(sys.argv) > 1 else 65536), 16
 env = AtcVecEnv(B, N, scenario=scenarios.LOWW(random_entrypoints=True), auto_reset=True)
 acts = [(torch.rand((B, N, 3), device="cuda") * 2 - 1) for _ in range(4)]
+HELD = os.environ.get("ATC_TRACE_HELD", "1") != "0"   # launches 2..20 of an action block carry ATC_M_ACTIONS_HELD
 for t in range(300):
-    env.step(acts[(t // 20) % 4])
+    env.step(acts[(t // 20) % 4], held=HELD and t % 20 != 0)
 n_waves = B * 16 // 64
 trace = torch.zeros((n_waves, 8), dtype=torch.int64, device="cuda")
 ptr = trace.data_ptr()
 env.params.reserved0 = ptr & 0xffffffff
 env.params.reserved1 = struct.unpack("f", struct.pack("I", (ptr >> 32) & 0xffffffff))[0]
 torch.cuda.synchronize()
-env.step(acts[0])
+env.step(acts[0])                 # first launch of a block
+env.step(acts[0], held=HELD)      # the traced launch: a repeat
 torch.cuda.synchronize()
 raw = trace.cpu().numpy()
 good = (raw > 0).all(axis=1) & (np.diff(raw, axis=1) >= 0).all(axis=1)
@@ -38,7 +40,7 @@ names = ["loads -> decode+kinematics", "mva resolve + pair scan", "overrides + c
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ev0.record()
 for t in range(200):
-    env.step(acts[(t // 20) % 4])
+    env.step(acts[(t // 20) % 4], held=HELD and t % 20 != 0)
 ev1.record()
 torch.cuda.synchronize()
 kernel_us = ev0.elapsed_time(ev1) / 200 * 1e3
