@@ -433,11 +433,11 @@ def main():
                   "reward": torch.empty((Tf, B), dtype=torch.float32, device=dev),
                   "done": torch.empty((Tf, B), dtype=torch.uint8, device=dev),
                   "flags": torch.empty((Tf, B, N), dtype=torch.int16, device=dev)}
-            for j in range(10):
+            for j in range(50):
                 env.rollout(ring[j % n_ring][None], out=ro, hold=Tf)
             torch.cuda.synchronize(dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            n_l = 50
+            n_l = 100
             e0.record()
             for j in range(n_l):
                 env.rollout(ring[j % n_ring][None], out=ro, hold=Tf)
@@ -450,6 +450,37 @@ def main():
                                                "algorithmic_bytes_per_env_step": fb,
                                                "hbm_frac": fb * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
             del ro
+            if B % 2 == 0 and B >= 8192:
+                # the same batch as two independent sub-batches of B / 2 envs on two HIP streams (atc_step_multi: one foreign call
+                # per step, no join between steps, so one sub-batch's launch floor overlaps the other's body): a side record too —
+                # `value` / `roofline` stay the single in-order launch whose rocprofv3 kernel duration can be compared
+                from atc_hip.vec_env import make_multi_launcher
+                halves = [AtcVecEnv(B // 2, N, scenario=scn, device=local, auto_reset=True, seed=7919 * (s + 1),
+                                    grid_cell=args.grid_cell, sep_nm=args.sep_nm) for s in range(2)]
+                qs2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
+                n_r = min(n_ring, 8)
+                first = [make_multi_launcher(halves, [a[s * (B // 2):(s + 1) * (B // 2)] for s in range(2)], qs2) for a in ring[:n_r]]
+                rest = first if args.no_held_hint else [
+                    make_multi_launcher(halves, [a[s * (B // 2):(s + 1) * (B // 2)] for s in range(2)], qs2, held=True)
+                    for a in ring[:n_r]]
+
+                def run2(n):
+                    for t in range(n):
+                        (rest if t % HOLD else first)[(t // HOLD) % n_r]()
+                run2(2000)
+                for q in qs2:
+                    q.synchronize()
+                n2 = 2000
+                t0 = time.perf_counter()
+                run2(n2)
+                for q in qs2:
+                    q.synchronize()
+                us2 = (time.perf_counter() - t0) / n2 * 1e6
+                line["config"]["two_streams"] = {"entry": "atc_step_multi", "sub_batches": 2, "envs_per_sub_batch": B // 2, "steps": n2,
+                                                 "us_per_step": us2, "env_steps_per_s": B / (us2 * 1e-6),
+                                                 "hbm_frac": algorithmic_bytes_per_env_step(N) * B / (us2 * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                for e in halves:
+                    e.close()
         if ws == 1 and not args.no_single_env:
             line["config"]["single_env"] = single_env_protocol()
         if ws == 1 and not args.no_cpu_baseline:
