@@ -450,6 +450,22 @@ def main():
                                                "algorithmic_bytes_per_env_step": fb,
                                                "hbm_frac": fb * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
             del ro
+            if held_launchers is not None:
+                # the same loop without the held-action promise (every launch reads the last-action record): a side record
+                def run_plain(n):
+                    for t in range(n):
+                        launchers[(t // HOLD) % n_ring]()
+                run_plain(400)
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                run_plain(2000)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                usp = e0.elapsed_time(e1) * 1e3 / 2000
+                line["config"]["without_held_hint"] = {"steps": 2000, "us_per_step": usp, "env_steps_per_s": B / (usp * 1e-6),
+                                                       "hbm_frac": algorithmic_bytes_per_env_step(N) * B / (usp * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                last_block[0] = None
             if B % 2 == 0 and B >= 8192:
                 # the same batch as two independent sub-batches of B / 2 envs on two HIP streams (atc_step_multi: one foreign call
                 # per step, no join between steps, so one sub-batch's launch floor overlaps the other's body): a side record too —
