@@ -18,16 +18,20 @@ class AtcVecEnv:
     def __init__(self, num_envs, num_aircraft=1, sim_parameters=None, scenario=None, device=0, auto_reset=True,
                  spawn="auto", seed=0, grid_cell=0.5, want_raw_obs=False, want_ac_reward=False, want_min_sep=False,
                  want_term_obs=False, timestep_limit=6000, sep_nm=3.0, sep_ft=1000.0, conflict_reward=-200.0,
-                 host_mapped=False, keep_active=False, want_packet=False):
+                 host_mapped=False, keep_active=False, want_packet=False, check_held=False):
         """host_mapped=True keeps state and outputs in pinned host memory mapped into the device (zero-copy): the kernels
         read / write it over the host link, every call ends with a stream synchronisation, and what is returned are CPU
         tensors.  Meant for tiny latency-bound batches (the single-env AtcGym); large batches belong in HBM.
         want_packet=True (host_mapped, N == 1) adds atc_out_t.packet: the step result as self-validating 16-byte chunks that a
         host can poll in mapped memory instead of synchronising the stream (see `poll_packet`).
         keep_active=True is the reference's single-aircraft rule (ATC_M_KEEP_ACTIVE): an aircraft that reaches the corridor
-        ends the episode and stays under control instead of being handed over."""
+        ends the episode and stays under control instead of being handed over.
+        check_held=True (debugging aid) verifies the promise of step(..., held=True) — the actions equal those of the previous
+        step — on every such call and raises if it is broken (costs a device comparison and a synchronisation per step)."""
         torch = _lib._torch_cuda()
         self.torch = torch
+        self._check_held = bool(check_held)
+        self._prev_actions = None
         self.host_mapped = bool(host_mapped)
         from envs.atc import model, scenarios
         self.sim_parameters = sim_parameters if sim_parameters is not None else model.SimParameters(1)
@@ -203,6 +207,12 @@ class AtcVecEnv:
         held=True is the caller's promise that `actions` holds the same values as in the previous step of these envs (a
         held action block / frame skip, learning/atc-gym-demo.py:18-19; ATC_M_ACTIONS_HELD): same results, and the kernel
         skips the last-action record."""
+        if self._check_held:
+            cur = self._as_actions(actions).reshape(-1).to("cpu", copy=True)
+            if held and (self._prev_actions is None or not self.torch.equal(cur.view(self.torch.int32),
+                                                                              self._prev_actions.view(self.torch.int32))):
+                raise ValueError("step(held=True): the actions differ from the previous step's (or there was none)")
+            self._prev_actions = cur
         if held:
             self.params.mode |= L.M_ACTIONS_HELD
             try:

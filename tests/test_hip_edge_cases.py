@@ -443,3 +443,22 @@ def test_held_actions_hint_changes_nothing(N, hold):
         assert stale_resets > 0, "the stale-record case did not occur"
     plain.close()
     hint.close()
+
+
+def test_check_held_catches_a_broken_promise():
+    """AtcVecEnv(check_held=True): the debugging aid for callers adopting step(..., held=True)."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    env = AtcVecEnv(8, 4, check_held=True)
+    a = torch.rand((8, 4, 3), device="cuda") * 2 - 1
+    with pytest.raises(ValueError):
+        env.step(a, held=True)            # nothing to repeat yet
+    env.step(a)
+    env.step(a.clone(), held=True)        # same values, another tensor: fine
+    b = a.clone()
+    b[3, 2, 1] += 0.25
+    with pytest.raises(ValueError):
+        env.step(b, held=True)
+    env.step(b)
+    env.step(b.cpu().numpy(), held=True)  # arrays count by value too
+    env.close()
