@@ -540,48 +540,74 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
             // Each group is staged TWICE back to back (slots k and W + k of its 2 W records), so that partner k + d is the record
             // d places after the lane's own, whatever k: one address per lane, the distance is an offset — no wrap-around
             // arithmetic per partner.
+            // The staging is one plane per coordinate (x | y | h | d^2 minimum): two neighbouring partners are then two
+            // neighbouring floats of a plane and arrive as a register pair (ds_read2_b32), which is what the packed fp32
+            // instructions want — differences, the product and the fma of TWO pairs per instruction (v_pk_add / mul / fma_f32,
+            // IEEE per component: bit-identical to the scalar forms).  Conflict = (d^2 < sep^2) & (|dh| < sep_ft), the
+            // oracle's expression: two compares per pair whose lane masks are anded on the scalar unit — 4.5 VALU per pair.
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            // Layout: each group owns 8 W floats — planes x | y | h | min of 2 W floats each — so that the plane offsets fit the
+            // instructions' offset fields and the scan loop advances one address register (two for W = 64).
             const int gbase = tid & ~(W - 1);
-            float4* own = pos + 2 * gbase + k;
-            own[0] = make_float4(xs, y32, a.h, 1e36f);
-            own[W] = make_float4(xs, y32, a.h, 1e36f);
+            constexpr int P = 2 * W;                   // floats per plane of a group
+            float* own = reinterpret_cast<float*>(pos) + 8 * gbase + k;
+            own[0] = xs;          own[W] = xs;
+            own[P] = y32;         own[P + W] = y32;
+            own[2 * P] = a.h;     own[2 * P + W] = a.h;
+            if (FULL) { own[3 * P] = 1e36f; own[3 * P + W] = 1e36f; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             constexpr int H = W / 2;   // distances 1 .. H
             constexpr int U = 4;       // partners per LDS batch
-            uint64_t hit = 0;          // lanes that are the FIRST element of a conflicting pair ... or (rotated in) the second
-#pragma unroll 1
-            for (int d0 = 1; d0 <= H; d0 += U) {
-                float4 qv[U];
+            // lanes that are the FIRST element of a conflicting pair (`first`) ... or the second: the mask of distance d rotated by
+            // d inside each group.  The distances are visited from H down to 1 and the rotations accumulated Horner-style —
+            // acc = rot1(acc | mask_d) — so every distance costs one rotation by ONE (constant shifts) instead of one by d.
+            uint64_t first = 0, acc = 0;
+            const v2f xs2 = {xs, xs}, ys2 = {y32, y32}, hs2 = {a.h, a.h};
+            const float sep_ft = p.sep_ft;
+#pragma unroll 1   // (fully unrolled, the 2 H compare masks stay live together: 140-220 spilled SGPRs)
+            for (int d0 = H - U + 1; d0 >= 1; d0 -= U) {
+                v2f qx[U / 2], qy[U / 2], qh[U / 2];
 #pragma unroll
-                for (int u = 0; u < U; ++u) qv[u] = own[d0 + u];
+                for (int u = 0; u < U / 2; ++u) {
+                    const float* q0 = own + d0 + 2 * u;
+                    qx[u] = v2f{q0[0], q0[1]};
+                    qy[u] = v2f{q0[P], q0[P + 1]};
+                    qh[u] = v2f{q0[2 * P], q0[2 * P + 1]};
+                }
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int dd = d0 + u;   // uniform
-                    const float dx = xs - qv[u].x, dy = y32 - qv[u].y;
-                    const float d2 = fmaf(dx, dx, dy * dy);
-                    const float mg = fmaxf(d2 - sep2, fabsf(a.h - qv[u].z) - p.sep_ft);
-                    const uint64_t mk = __ballot(mg < 0.0f);   // (H is a multiple of U: no tail)
-                    if (W == 64) {
-                        hit |= mk | (mk << dd) | (mk >> (64 - dd));
-                    } else {  // two groups of 32 lanes: rotate inside each half
-                        const uint32_t lo = (uint32_t)mk, hi = (uint32_t)(mk >> 32);
-                        const uint32_t rlo = (lo << dd) | (lo >> (32 - dd)), rhi = (hi << dd) | (hi >> (32 - dd));
-                        hit |= mk | (uint64_t)rlo | ((uint64_t)rhi << 32);
-                    }
-                    if (FULL) {   // diagnostic minimum separation: the partner needs the VALUE -> LDS float minimum
-                        min_d2 = fminf(min_d2, d2);
-                        // d^2 >= 0: the IEEE order of non-negative floats is the order of their bit patterns
-                        atomicMin(reinterpret_cast<unsigned int*>(&pos[2 * gbase + ((k + dd) & (W - 1))].w), __float_as_uint(d2));
+                for (int u = U / 2 - 1; u >= 0; --u) {
+                    const v2f dx = xs2 - qx[u], dy = ys2 - qy[u], dh = hs2 - qh[u];
+                    const v2f d2 = __builtin_elementwise_fma(dx, dx, dy * dy);
+#pragma unroll
+                    for (int w = 1; w >= 0; --w) {
+                        // (two ballots anded as scalars: the compare masks themselves — a ballot of the anded predicate is
+                        // materialised per lane and compared again)
+                        const uint64_t mk = __builtin_amdgcn_ballot_w64(d2[w] < sep2) & __builtin_amdgcn_ballot_w64(fabsf(dh[w]) < sep_ft);
+                        first |= mk;
+                        const uint64_t t = acc | mk;
+                        if (W == 64) {
+                            acc = (t << 1) | (t >> 63);
+                        } else {  // two groups of 32 lanes: rotate inside each half
+                            acc = ((t << 1) & 0xfffffffefffffffeull) | ((t >> 31) & 0x0000000100000001ull);
+                        }
+                        if (FULL) {   // diagnostic minimum separation: the partner needs the VALUE -> LDS float minimum
+                            const int dd = d0 + 2 * u + w;   // uniform (H is a multiple of U: no tail)
+                            min_d2 = fminf(min_d2, d2[w]);
+                            // d^2 >= 0: the IEEE order of non-negative floats is the order of their bit patterns
+                            atomicMin(reinterpret_cast<unsigned int*>(own - k + 3 * P + ((k + dd) & (W - 1))), __float_as_uint(d2[w]));
+                        }
                     }
                 }
             }
+            const uint64_t hit = first | acc;
             if ((hit >> lane) & 1ull) margin = -1.0f;
             if (FULL) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                min_d2 = fminf(min_d2, own[0].w);
+                min_d2 = fminf(min_d2, own[3 * P]);
             }
             __builtin_amdgcn_wave_barrier();
         }
