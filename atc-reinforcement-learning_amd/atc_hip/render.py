@@ -8,8 +8,9 @@ Two layers:
     aircraft symbol, label anchors and history dots (:411-452), reward labels (:402-409).  Including its quirk: MVA polygons
     are shifted by the padding, everything placed with `_screen_vector` (:542-552) is not.  This layer is pinned against the
     geometry captured from the reference (tests/golden/g10_render_geometry.json).
-  * `rasterise` turns a scene into an RGB array with a small numpy rasteriser (even-odd polygon fill, thick lines, dots; label
-    text is not drawn — there is no font renderer here — only its anchors are part of the scene).
+  * `rasterise` turns a scene into an RGB array with a small numpy rasteriser (even-odd polygon fill, thick lines, dots, and
+    label text in a built-in 5 x 7 bitmap font at the reference's anchors: left / top, rendering.py:7-23 — the reference
+    asks pyglet for 9 pt Arial, a font renderer that does not exist here).
 """
 import math
 
@@ -20,6 +21,7 @@ BACKGROUND_INACTIVE = (29 / 256, 69 / 256, 76 / 256)
 BACKGROUND_ACTIVE = (84 / 256, 121 / 256, 128 / 256)
 LINES_INFO = (69 / 256, 173 / 256, 168 / 256)
 AIRPLANE = (157 / 256, 224 / 256, 173 / 256)
+LABEL = (157 / 255, 224 / 255, 173 / 255)         # ColorScheme.label (157, 224, 173, 255)
 INACTIVE = (110 / 256, 120 / 256, 120 / 256)      # handed-over aircraft (extension; no reference counterpart)
 SCREEN_WIDTH, PADDING = 600, 10                   # atc_gym.py:373-374
 
@@ -145,6 +147,51 @@ def _line(img, a, b, color, width=1):
             img[v[ok], u[ok]] = color
 
 
+# 5 x 7 bitmap font: one string of 7 rows x 5 columns per glyph ('#' = ink); lower case is drawn as upper case
+_GLYPHS = {
+    "0": ".###. #...# #..## #.#.# ##..# #...# .###.", "1": "..#.. .##.. ..#.. ..#.. ..#.. ..#.. .###.",
+    "2": ".###. #...# ....# ...#. ..#.. .#... #####", "3": ".###. #...# ....# ..##. ....# #...# .###.",
+    "4": "...#. ..##. .#.#. #..#. ##### ...#. ...#.", "5": "##### #.... ####. ....# ....# #...# .###.",
+    "6": "..##. .#... #.... ####. #...# #...# .###.", "7": "##### ....# ...#. ..#.. .#... .#... .#...",
+    "8": ".###. #...# #...# .###. #...# #...# .###.", "9": ".###. #...# #...# .#### ....# ...#. .##..",
+    "A": ".###. #...# #...# ##### #...# #...# #...#", "B": "####. #...# #...# ####. #...# #...# ####.",
+    "C": ".###. #...# #.... #.... #.... #...# .###.", "D": "####. #...# #...# #...# #...# #...# ####.",
+    "E": "##### #.... #.... ####. #.... #.... #####", "F": "##### #.... #.... ####. #.... #.... #....",
+    "G": ".###. #...# #.... #.### #...# #...# .###.", "H": "#...# #...# #...# ##### #...# #...# #...#",
+    "I": ".###. ..#.. ..#.. ..#.. ..#.. ..#.. .###.", "J": "..### ...#. ...#. ...#. ...#. #..#. .##..",
+    "K": "#...# #..#. #.#.. ##... #.#.. #..#. #...#", "L": "#.... #.... #.... #.... #.... #.... #####",
+    "M": "#...# ##.## #.#.# #.#.# #...# #...# #...#", "N": "#...# ##..# #.#.# #..## #...# #...# #...#",
+    "O": ".###. #...# #...# #...# #...# #...# .###.", "P": "####. #...# #...# ####. #.... #.... #....",
+    "Q": ".###. #...# #...# #...# #.#.# #..#. .##.#", "R": "####. #...# #...# ####. #.#.. #..#. #...#",
+    "S": ".#### #.... #.... .###. ....# ....# ####.", "T": "##### ..#.. ..#.. ..#.. ..#.. ..#.. ..#..",
+    "U": "#...# #...# #...# #...# #...# #...# .###.", "V": "#...# #...# #...# #...# #...# .#.#. ..#..",
+    "W": "#...# #...# #...# #.#.# #.#.# ##.## #...#", "X": "#...# #...# .#.#. ..#.. .#.#. #...# #...#",
+    "Y": "#...# #...# .#.#. ..#.. ..#.. ..#.. ..#..", "Z": "##### ....# ...#. ..#.. .#... #.... #####",
+    ":": "..... ..#.. ..#.. ..... ..#.. ..#.. .....", ".": "..... ..... ..... ..... ..... .##.. .##..",
+    "-": "..... ..... ..... ##### ..... ..... .....", "+": "..... ..#.. ..#.. ##### ..#.. ..#.. .....",
+    " ": "..... ..... ..... ..... ..... ..... .....", "?": ".###. #...# ....# ...#. ..#.. ..... ..#..",
+}
+_GLYPH_MASKS = {c: np.array([[ch == "#" for ch in row] for row in g.split()], bool) for c, g in _GLYPHS.items()}
+GLYPH_W, GLYPH_H, GLYPH_ADVANCE = 5, 7, 6
+
+
+def _text(img, text, x, y, color):
+    """label text with its LEFT / TOP corner at screen position (x, y) (y up), rendering.py:18-23"""
+    H, W = img.shape[:2]
+    col0, row0 = int(round(x)), H - 1 - int(round(y))
+    for n, ch in enumerate(str(text)):
+        m = _GLYPH_MASKS.get(ch.upper(), _GLYPH_MASKS["?"])
+        c0 = col0 + n * GLYPH_ADVANCE
+        r_lo, r_hi = max(row0, 0), min(row0 + GLYPH_H, H)
+        c_lo, c_hi = max(c0, 0), min(c0 + GLYPH_W, W)
+        if r_lo >= r_hi or c_lo >= c_hi:
+            continue
+        sub = m[r_lo - row0:r_hi - row0, c_lo - c0:c_hi - c0]
+        block = img[r_lo:r_hi, c_lo:c_hi]
+        block[sub] = color
+        img[r_lo:r_hi, c_lo:c_hi] = block
+
+
 def rasterise(width, height, geoms, img=None):
     """RGB uint8 array [height, width, 3] of a list of scene primitives (row 0 = top of the window)."""
     if img is None:
@@ -161,6 +208,8 @@ def rasterise(width, height, geoms, img=None):
             t, r = g["translation"], g["radius"]
             ang = np.linspace(0, 2 * np.pi, 12, endpoint=False)
             _fill(img, np.stack([t[0] + r * np.cos(ang), t[1] + r * np.sin(ang)], 1), _u8(g["color"]))
+        elif kind == "Label":
+            _text(img, g["text"], g["x"], g["y"], _u8(g.get("color", LABEL)))
     return img
 
 

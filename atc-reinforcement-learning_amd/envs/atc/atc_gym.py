@@ -275,8 +275,8 @@ class AtcGym(Env):
 
     def render(self, mode='human'):
         """The pyglet window of the reference (atc_gym.py:367-552) is out of scope; `rgb_array` is served by
-        the headless numpy renderer (atc_hip/render.py: the reference's geometry — pinned on tests/golden/g10 — drawn without
-        label text) so recorders keep working, `human` is a no-op."""
+        the headless numpy renderer (atc_hip/render.py: the reference's geometry — pinned on tests/golden/g10 — with the label
+        text in a built-in bitmap font) so recorders keep working, `human` is a no-op."""
         if mode == 'rgb_array':
             from atc_hip import render
             return render.rgb_array(self._vec, env=0, history=self._airplane.position_history,

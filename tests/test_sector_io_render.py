@@ -104,3 +104,32 @@ def test_render_rasterises_the_scene():
                                                                              "history": [(29.0 + 0.1 * i, 40.0) for i in range(30)]}]), img.copy())
     plane = np.all(frame == render._u8(render.AIRPLANE), axis=2)
     assert 20 < plane.sum() < 400
+
+
+def test_render_draws_label_text():
+    """Label text (rendering.py:7-23: left / top anchored) in the built-in 5 x 7 font: callsign, altitude / speed and the two
+    reward lines appear at the anchors the scene names, in the label colour, and different texts give different pixels."""
+    comp = H.compiled("LOWW")
+    bg, sc = render.background(comp)
+    ac = [{"x": 30.0, "y": 40.0, "h": 9000.0, "v": 250.0, "name": "FLT07"}]
+    scene = render.frame_scene(comp, ac, 12.5, -0.05)
+    labels = [g for g in scene if g["kind"] == "Label"]
+    assert [g["text"] for g in labels] == ["FLT07", "90  25", "Total reward: 12.50", "Last reward: -0.05"]
+    frame = render.rasterise(sc.width, sc.height, scene, bg.copy())
+    ink = np.all(frame == render._u8(render.LABEL), axis=2)
+    assert not np.all(bg == render._u8(render.LABEL), axis=2).any()
+    for g in labels:                                       # all the ink of a label lies in its left / top anchored box
+        r0, c0 = sc.height - 1 - int(round(g["y"])), int(round(g["x"]))
+        box = ink[r0:r0 + render.GLYPH_H, c0:c0 + render.GLYPH_ADVANCE * len(g["text"])]
+        assert box.sum() >= 5 * len(g["text"].replace(" ", "")), g["text"]
+    boxes = np.zeros_like(ink)
+    for g in labels:
+        r0, c0 = sc.height - 1 - int(round(g["y"])), int(round(g["x"]))
+        boxes[r0:r0 + render.GLYPH_H, c0:c0 + render.GLYPH_ADVANCE * len(g["text"])] = True
+    assert not (ink & ~boxes).any()
+    other = render.rasterise(sc.width, sc.height, render.frame_scene(comp, ac, 13.5, -0.05), bg.copy())
+    assert (other != frame).any()
+    masks = [render._GLYPH_MASKS[c] for c in "0123456789"]
+    assert all((masks[i] != masks[j]).any() for i in range(10) for j in range(i))
+    clipped = render.rasterise(60, 30, [{"kind": "Label", "text": "CLIPPED AT THE EDGE", "x": 40, "y": 3}])   # no exception
+    assert clipped.shape == (30, 60, 3)
