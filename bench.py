@@ -203,6 +203,8 @@ def main():
     ap.add_argument("--grid-cell", type=float, default=0.5, help="cell size [nm] of the MVA lookup grid")
     ap.add_argument("--no-held-hint", action="store_true", help="do not tell atc_step that launches 2..%d of an action block "
                     "repeat the previous launch's actions (ATC_M_ACTIONS_HELD)" % HOLD)
+    ap.add_argument("--action-ring", type=int, default=64, help="number of pre-generated action tensors the loop cycles through "
+                    "(one per %d-step block)" % HOLD)
     ap.add_argument("--prewarm", type=int, default=-1, help="developer knob: untimed steps before the warm-up (default: "
                     "6000 / 12000, the steady episode mix); profiling passes use fewer")
     ap.add_argument("--rollout", type=int, default=0, help="fuse this many steps per launch (0 = one launch per step)")
@@ -259,7 +261,7 @@ def main():
     # action ring resident in HBM before timing (Philox, seed 0 + rank)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
-    n_ring = max(2, min(64, (K + W) // HOLD + 1))
+    n_ring = max(2, min(args.action_ring, (K + W) // HOLD + 1))
     ring = [torch.rand((B, N, 3), generator=g, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(n_ring)]
 
     launchers = None
