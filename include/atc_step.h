@@ -138,7 +138,7 @@ enum {
                                         corridor ends the episode and STAYS under control (no hand-over), so stepping on
                                         without reset keeps simulating it (learning/atc-gym-compute-performance.py:14-16) */
     ATC_M_ACTIONS_HELD = 1u << 6     /* atc_step only — a promise of the caller: `actions` holds, for every aircraft, the same
-                                        bits as in the previous atc_step of these envs (a held action block / frame skip,
+                                        bits as in the previous step of these envs — an atc_step or the last step of a multi-step launch (frame skip,
                                         learning/atc-gym-demo.py:18-19).  Results are identical to a launch without the bit;
                                         the kernel then skips the last_action record (12 of 110 bytes per aircraft-step):
                                         an aircraft under control in the previous step has last_action == its accepted
