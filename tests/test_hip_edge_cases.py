@@ -462,3 +462,27 @@ def test_check_held_catches_a_broken_promise():
     env.step(b)
     env.step(b.cpu().numpy(), held=True)  # arrays count by value too
     env.close()
+
+
+def test_held_hint_after_a_multi_step_launch():
+    """The promise also holds across launch forms: a single step that repeats the LAST action block of the preceding
+    atc_rollout_hold launch may carry ATC_M_ACTIONS_HELD."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+    scn = scenarios.LOWW(random_entrypoints=True)
+    B, N = 300, 16
+    a, b = (AtcVecEnv(B, N, scenario=scn, auto_reset=True, seed=9) for _ in range(2))
+    g = torch.Generator(device="cpu").manual_seed(77)
+    for rnd in range(6):
+        blocks = (torch.rand((3, B, N, 3), generator=g) * 2.1 - 1.05).cuda()
+        a.rollout(blocks, hold=4)
+        b.rollout(blocks, hold=4)
+        for k in range(3):
+            ra = a.step(blocks[2])
+            rb = b.step(blocks[2], held=True)
+            assert all(torch.equal(x, y) for x, y in zip(ra[:3], rb[:3])), (rnd, k)
+        for name in ("pos_hp", "v", "last_act", "env", "stats"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (name, rnd)
+    a.close()
+    b.close()
