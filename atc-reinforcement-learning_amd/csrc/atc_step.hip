@@ -93,6 +93,13 @@ constexpr int kBlock = ATC_BLOCK;
 #ifndef ATC_LOOP_SKIP_BOOK
 #define ATC_LOOP_SKIP_BOOK 1  // multi-step launches: no last-action bookkeeping on the steps that repeat an action block
 #endif
+#ifndef ATC_LOOP_REREAD_ARGS
+// which by-value arguments a multi-step launch re-reads from the kernarg segment inside its loop (see StepArgs) — bits:
+// 1 parameters, 2 derived constants, 4 output pointers, 8 state pointers (needed again after the loop).  Chosen per width by
+// measurement: everything for 64-aircraft envs, the state pointers alone below (all four: 36 B of scratch at N = 16, and
+// slower at N = 32).
+#define ATC_LOOP_REREAD_ARGS(W) ((W) == 64 ? 15 : 8)
+#endif
 #ifndef ATC_GRID_CAP
 #define ATC_GRID_CAP 8   // workgroups per CU before the reset / observe / query kernels grid-stride
 #endif
@@ -823,6 +830,34 @@ __device__ __forceinline__ void store_env_state(const atc_state_t& st, const Lan
     }
 }
 
+// The kernel's argument list as a struct: the kernarg segment is laid out by the same rules, so offsetof() names where an
+// argument lives.  Multi-step launches RE-READ their by-value arguments (output pointers, parameters, derived constants, the state
+// pointers needed again after the loop) from the kernarg segment inside the step instead of keeping ~60 SGPRs of them alive
+// across the loop: the allocator spills those to VGPR lanes and every use becomes a v_readlane — VALU work in a launch that is
+// bound by VALU issue — whereas a kernarg re-read is a scalar load.  The offset goes through an opaque zero, or the (invariant)
+// loads would be hoisted out of the loop again.
+struct StepArgs {
+    const float* blob;
+    int off_grid, B, N, T, hold;
+    atc_state_t st;
+    const float* actions;
+    atc_out_t out;
+    atc_params_t p;
+    StepDerived q;
+};
+template <typename T>
+__device__ __forceinline__ T kernarg_reread(size_t byte_off, int opaque_zero) {
+    T v;
+#if __HIP_DEVICE_COMPILE__   // (the host pass only parses this body; the builtin exists for the device target)
+    typedef __attribute__((address_space(4))) const char* karg_ptr;
+    karg_ptr base = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + byte_off + opaque_zero;
+    __builtin_memcpy(&v, base, sizeof(T));
+#else
+    __builtin_memset(&v, 0, sizeof(T));
+#endif
+    return v;
+}
+
 template <int W, bool FULL, bool ONE>  // ONE: single-step launch (T == 1)
 __global__ void __launch_bounds__(kBlock, (ONE ? ATC_MIN_WAVES : ((FULL || W < 8 || W >= 32) ? ATC_MIN_WAVES_LOOP - 1 : ATC_MIN_WAVES_LOOP)))
 k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int hold, atc_state_t st,
@@ -877,6 +912,20 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         LaneIds dl = d;
         const float* Kl = K;
         const float* gl = grid;
+        atc_params_t pl = p;
+        StepDerived ql = q;
+        atc_out_t outl = out;
+        int32_t* stats_l = st.stats;
+        constexpr int kReread = ONE ? 0 : ATC_LOOP_REREAD_ARGS(W);   // measured per width: profiles/r02_experiments.txt
+        if (!ONE) {   // (also makes the mode word's flag tests scalar compares inside the step, not
+            int zk;                           // 64-bit lane masks kept — and spilled — across the loop)
+            asm volatile("s_mov_b32 %0, 0" : "=s"(zk));
+            if (kReread & 1) pl = kernarg_reread<atc_params_t>(offsetof(StepArgs, p), zk);
+            else pl.mode += (uint32_t)zk;
+            if (kReread & 2) ql = kernarg_reread<StepDerived>(offsetof(StepArgs, q), zk);
+            if (kReread & 4) outl = kernarg_reread<atc_out_t>(offsetof(StepArgs, out), zk);
+            if (kReread & 8) stats_l = kernarg_reread<int32_t*>(offsetof(StepArgs, st) + offsetof(atc_state_t, stats), zk);
+        }
         if (!ONE && ATC_LOOP_OPAQUE) {
             uint32_t zv;
             int zs;
@@ -886,19 +935,19 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             Kl = K + zs;
             gl = grid ? grid + zs : nullptr;
         }
-        StepOut so = {out.obs + sBN * ATC_OBS_DIM, out.flags + sBN, out.reward + sB, out.done + sB,
-                      FULL && out.raw_obs ? out.raw_obs + sBN * ATC_OBS_DIM : nullptr,
-                      FULL && out.ac_reward ? out.ac_reward + sBN : nullptr,
-                      FULL && out.min_sep ? out.min_sep + sB : nullptr,
-                      FULL && out.term_obs ? out.term_obs + sBN * ATC_OBS_DIM : nullptr,
-                      FULL && out.packet ? out.packet + sB * (ATC_PKT_CHUNKS * 4) : nullptr
+        StepOut so = {outl.obs + sBN * ATC_OBS_DIM, outl.flags + sBN, outl.reward + sB, outl.done + sB,
+                      FULL && outl.raw_obs ? outl.raw_obs + sBN * ATC_OBS_DIM : nullptr,
+                      FULL && outl.ac_reward ? outl.ac_reward + sBN : nullptr,
+                      FULL && outl.min_sep ? outl.min_sep + sB : nullptr,
+                      FULL && outl.term_obs ? outl.term_obs + sBN * ATC_OBS_DIM : nullptr,
+                      FULL && outl.packet ? outl.packet + sB * (ATC_PKT_CHUNKS * 4) : nullptr
 #if ATC_TRACE
                       , trow
 #endif
         };
         if (!ONE && step == 0) act = *at<Float3>(act_t, dl.i * 12u);
         // (decoding a held block once per block instead of once per step was measured slower: 15.7 vs 15.1 us per step)
-        const Float3 tg = decode_targets(p, act);
+        const Float3 tg = decode_targets(pl, act);
         if (ONE && !la_live) {   // held block: the record equals the accepted targets (components that are refused are not compared)
             ls.la_v = tg.a;
             ls.la_h = tg.b;
@@ -907,7 +956,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         // multi-step launches know structurally which steps repeat an action block
         const bool repeated = ONE ? (same_actions && __ballot(la_live) == 0ull)
                                   : (ATC_LOOP_SKIP_BOOK && held > 0 && __ballot(es.t == 0) == 0ull);
-        const Mid m = step_part_a(Kl, gl, p, q, dl, tg.a, tg.b, tg.c, ls, es, repeated);
+        const Mid m = step_part_a(Kl, gl, pl, ql, dl, tg.a, tg.b, tg.c, ls, es, repeated);
         ATC_STAMP(1);
         Float3 nxt = act;
         const float* act_next = nullptr;   // the next block is fetched during the last step of the current one
@@ -916,13 +965,19 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             act_t += (size_t)BN * 3;
             if (step + 1 < n_steps) act_next = act_t;
         }
-        step_part_b<W, FULL, ONE>(Kl, gl, p, q, N, dl, m, ls, es, so, st.stats, pos, obs_stage, act_next, nxt);
+        step_part_b<W, FULL, ONE>(Kl, gl, pl, ql, N, dl, m, ls, es, so, stats_l, pos, obs_stage, act_next, nxt);
         act = nxt;
         ATC_STAMP(6);
     }
     // ---- write back persistent state -----------------------------------------------------------------------------------
-    store_lane_state(st, d, ls, la_live);
-    store_env_state<W>(st, d, es, hi0);
+    atc_state_t st_end = st;
+    if (!ONE && (ATC_LOOP_REREAD_ARGS(W) & 8)) {
+        int zk;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zk));
+        st_end = kernarg_reread<atc_state_t>(offsetof(StepArgs, st), zk);
+    }
+    store_lane_state(st_end, d, ls, la_live);
+    store_env_state<W>(st_end, d, es, hi0);
 #if ATC_TRACE
     if (lane == 0 && trace) trace[((size_t)(blockIdx.x * (kBlock / 64) + (tid >> 6)) * n_steps + (n_steps - 1)) * 8 + 7] = __builtin_amdgcn_s_memtime();
 #endif
