@@ -147,6 +147,7 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=()):
     gx0 = x0 - cell
     gy0 = y0 - cell
     nx = int(math.ceil((x1 - gx0) / cell)) + 2
+    assert nx < 1 << 20, "lookup grid too wide (the kernel indexes cells with a 24-bit multiply)"
     ny = int(math.ceil((y1 - gy0) / cell)) + 2
     inv = 1.0 / cell
     slack = guard + 1e-4 * max(1.0, abs(x1), abs(y1)) * 2.0 ** -10

@@ -182,7 +182,8 @@ __device__ __forceinline__ MvaCell mva_cell_load(const float* __restrict__ grid,
         c.in_grid = (fx >= 0.0f) & (fx < g.nx) & (fy >= 0.0f) & (fy < g.ny);
         // clamped index: the load is unconditional (no branch in front of it), the result is ignored when !in_grid
         const int ix = c.in_grid ? (int)fx : 0, iy = c.in_grid ? (int)fy : 0;
-        c.cell = *reinterpret_cast<const float2*>(grid + ATC_G_HDR + 2 * (iy * (int)g.nx + ix));
+        // (24-bit multiply-add: rows and columns are far below 2^23; the 32-bit multiply is a quarter-rate instruction)
+        c.cell = *reinterpret_cast<const float2*>(grid + ATC_G_HDR + 2 * (__mul24(iy, (int)g.nx) + ix));
     }
     return c;
 }

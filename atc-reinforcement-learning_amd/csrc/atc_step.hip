@@ -247,6 +247,18 @@ template <typename T>
 __device__ __forceinline__ const T* at(const void* base, uint32_t byte_off) {
     return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
+// Byte offsets of 12- and 40-byte records as shift-adds: the compiler multiplies (v_mul_lo_u32 is a quarter-rate instruction,
+// and lane indices do not fit the 24-bit multiplier); asm keeps the two full-rate instructions from being folded back.
+__device__ __forceinline__ uint32_t times12(uint32_t i) {
+    uint32_t t;
+    asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(t) : "v"(i));   // 3 i
+    return t << 2;
+}
+__device__ __forceinline__ uint32_t times40(uint32_t i) {
+    uint32_t t;
+    asm("v_lshl_add_u32 %0, %1, 2, %1" : "=v"(t) : "v"(i));   // 5 i
+    return t << 3;
+}
 template <typename T>
 __device__ __forceinline__ void stream_store(T* p, T v) {
 #if ATC_NT_STORE
@@ -528,7 +540,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     // Multi-step launches: the NEXT step's action is requested here — behind the MVA gathers (loads return in order: issued
     // earlier it would sit in front of them and its HBM latency would be paid at the MVA wait) and with the rest of the
     // step body (scan, corridor, observation, shaping, stores) still ahead to cover it.
-    if (act_next) a_next = *at<Float3>(act_next, i * 12u);
+    if (act_next) a_next = *at<Float3>(act_next, times12(i));
     float min_d2 = 1e30f;
     float margin = 1e30f;  // min over partners of max(d^2 - sep^2, |dh| - sep_ft): conflict iff negative
     if (W > 1 && !(ATC_ABLATE & 2)) {
@@ -680,7 +692,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
         if (FULL) {
 #pragma unroll
             for (int c = 0; c < ATC_OBS_DIM; ++c) zraw[c] = active ? ob.o[c] : 0.0f;  // zeros for handed-over aircraft
-            if (so.raw_obs && d.lane_valid) store_obs(at<float>(so.raw_obs, i * 40u), zraw);
+            if (so.raw_obs && d.lane_valid) store_obs(at<float>(so.raw_obs, times40(i)), zraw);
         }
         if (p.mode & ATC_M_NORMALIZE) {  // atc_gym.py:187-189: (s - min - max/2) / (max/2) as one fma
 #pragma unroll
@@ -760,7 +772,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if (d.lane_valid) {
-            if (FULL && so.term_obs) store_obs(at<float>(so.term_obs, i * 40u), o);
+            if (FULL && so.term_obs) store_obs(at<float>(so.term_obs, times40(i)), o);
             a = spawn(K, p, e, k, episode);
             ls.v_changed = true;
             const Obs ob = get_state(K, a.x, a.y, pos_to_real(K, 0, a.x), pos_to_real(K, 1, a.y), a.h, a.phi, a.v, 0.0f);
@@ -787,7 +799,8 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t wave_off = (d.slot0 + (uint32_t)(tid & ~63)) * 40u;  // first aircraft of this wavefront (N == W)
+        // first aircraft of this wavefront (N == W): wave-uniform, so the multiply runs on the scalar unit
+        const uint32_t wave_off = (d.slot0 + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63)) * 40u;
         const float4* src = reinterpret_cast<const float4*>(tb);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -805,7 +818,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
         }
         __builtin_amdgcn_wave_barrier();
     } else if (d.lane_valid) {
-        store_obs(at<float>(so.obs, i * 40u), o);
+        store_obs(at<float>(so.obs, times40(i)), o);
     }
 }
 
@@ -817,7 +830,7 @@ __device__ __forceinline__ void store_lane_state(const atc_state_t& st, const La
     if (__ballot(ls.v_changed) != 0ull && d.lane_valid) *at<float>(st.v, d.i * 4u) = ls.a.v;
     if (__ballot(ls.la_changed) != 0ull && d.lane_valid && la_live) {
         Float3 la = {ls.la_v, ls.la_h, ls.la_p};
-        *at<Float3>(st.last_act, d.i * 12u) = la;
+        *at<Float3>(st.last_act, times12(d.i)) = la;
     }
 }
 template <int W>
@@ -887,11 +900,11 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     // record is only read (and written) by envs that were reset since their last step (timesteps == 0), whose aircraft
     // may have been handed over when the action block started and still carry an older record.
     Float3 act = {0.0f, 0.0f, 0.0f};   // action of the current block (held for `hold` steps); one 12-byte load per lane
-    if (ONE) act = *at<Float3>(actions, d.i * 12u);   // requested before the env record is waited for below
+    if (ONE) act = *at<Float3>(actions, times12(d.i));   // requested before the env record is waited for below
     const bool same_actions = ONE && (p.mode & ATC_M_ACTIONS_HELD) != 0;
     const bool la_live = !same_actions || e0.x == 0;
     Float3 la0 = {0.0f, 0.0f, 0.0f};
-    if (la_live) la0 = *at<Float3>(st.last_act, d.i * 12u);
+    if (la_live) la0 = *at<Float3>(st.last_act, times12(d.i));
     LaneState ls = {{ps.x, ps.y, __int_as_float(ps.z), __int_as_float(ps.w), v0}, la0.a, la0.b, la0.c, false, false};
 
     // A single step is its own instantiation: with the step count a run-time value everything the loop carries (aircraft
@@ -945,7 +958,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
                       , trow
 #endif
         };
-        if (!ONE && step == 0) act = *at<Float3>(act_t, dl.i * 12u);
+        if (!ONE && step == 0) act = *at<Float3>(act_t, times12(dl.i));
         // (decoding a held block once per block instead of once per step was measured slower: 15.7 vs 15.1 us per step)
         const Float3 tg = decode_targets(pl, act);
         if (ONE && !la_live) {   // held block: the record equals the accepted targets (components that are refused are not compared)
