@@ -792,22 +792,26 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     if (ATC_ABLATE & 16) {
         if (d.lane_valid && o[0] == 12345.678f) so.obs[i] = o[1];
     } else if (d.wave_full) {
-        float* tb = obs_stage + (tid >> 6) * (64 * ATC_OBS_DIM);
-        float2* tb2 = reinterpret_cast<float2*>(tb) + lane * (ATC_OBS_DIM / 2);   // rows are 40 B: 8-byte aligned
+        // addresses from threadIdx itself, not from the lane ids a multi-step launch re-derives through an opaque zero: the
+        // compiler then knows the ranges (lane < 64: two of the three row tests fold away, 24-bit multiplies suffice) — with
+        // the opaque copies it emitted a quarter-rate 64-bit multiply-add per LDS read
+        const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+        float* tb = obs_stage + __umul24(wv, 64u * ATC_OBS_DIM);
+        float2* tb2 = reinterpret_cast<float2*>(tb) + __umul24(ln, ATC_OBS_DIM / 2);   // rows are 40 B: 8-byte aligned
 #pragma unroll
         for (int c = 0; c < ATC_OBS_DIM / 2; ++c) tb2[c] = make_float2(o[2 * c], o[2 * c + 1]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // first aircraft of this wavefront (N == W): wave-uniform, so the multiply runs on the scalar unit
-        const uint32_t wave_off = (d.slot0 + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63)) * 40u;
+        const uint32_t wave_off = (d.slot0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u))) * 40u;
         const float4* src = reinterpret_cast<const float4*>(tb);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int idx = j * 64 + lane;
-            if (idx < 64 * ATC_OBS_DIM / 4) {
+            const uint32_t idx = (uint32_t)j * 64u + ln;
+            if (idx < 64u * ATC_OBS_DIM / 4u) {
                 const float4 v = src[idx];
-                float* d4 = at<float>(so.obs, wave_off + (uint32_t)idx * 16u);
+                float* d4 = at<float>(so.obs, wave_off + idx * 16u);
 #if ATC_NT_STORE
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(d4));
