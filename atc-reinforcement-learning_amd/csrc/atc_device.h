@@ -183,7 +183,9 @@ __device__ __forceinline__ MvaCell mva_cell_load(const float* __restrict__ grid,
         // clamped index: the load is unconditional (no branch in front of it), the result is ignored when !in_grid
         const int ix = c.in_grid ? (int)fx : 0, iy = c.in_grid ? (int)fy : 0;
         // (24-bit multiply-add: rows and columns are far below 2^23; the 32-bit multiply is a quarter-rate instruction)
-        c.cell = *reinterpret_cast<const float2*>(grid + ATC_G_HDR + 2 * (__mul24(iy, (int)g.nx) + ix));
+        // uniform base + 32-bit byte offset: the scalar-base addressing form, no 64-bit address arithmetic per lane
+        c.cell = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(grid) +
+                                                  (uint32_t)(ATC_G_HDR * 4 + 8 * (__mul24(iy, (int)g.nx) + ix)));
     }
     return c;
 }
@@ -206,7 +208,8 @@ __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const fl
         // Records are fetched in batches of kBatch (both 16-byte halves of each, all loads issued before the first use):
         // one L2 round trip per batch instead of one per record.  Indices past the list are clamped (loads stay in
         // bounds) and their records ignored.
-        const float4* rec = reinterpret_cast<const float4*>(grid + (int)gh.off_pool) + 2 * (int)cell.y;
+        const char* pool = reinterpret_cast<const char*>(grid + (int)gh.off_pool);   // uniform
+        const uint32_t rec0 = 32u * (uint32_t)(int)cell.y;                          // this lane's first record, bytes
         constexpr int kBatch = ATC_MVA_BATCH;
         bool inside = false;
         for (int base = 0; base < n; base += kBatch) {
@@ -214,8 +217,8 @@ __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const fl
 #pragma unroll
             for (int u = 0; u < kBatch; ++u) {
                 const int e = min(base + u, n - 1);
-                g[u] = rec[2 * e];
-                m[u] = rec[2 * e + 1];
+                g[u] = *reinterpret_cast<const float4*>(pool + (rec0 + 32u * (uint32_t)e));
+                m[u] = *reinterpret_cast<const float4*>(pool + (rec0 + 32u * (uint32_t)e + 16u));
             }
 #pragma unroll
             for (int u = 0; u < kBatch; ++u) {
