@@ -51,7 +51,7 @@ class AtcStepCall(C.Structure):
 EXPORTS = ("atc_abi_version", "atc_last_error", "atc_host_mapped_ptr", "atc_scenario_create", "atc_scenario_destroy",
            "atc_query_mva",
            "atc_query_mva_index", "atc_query_corridor", "atc_query_shaping", "atc_reset", "atc_observe", "atc_step",
-           "atc_step_multi", "atc_rollout", "atc_rollout_hold")
+           "atc_step_multi", "atc_step_packet", "atc_rollout", "atc_rollout_hold")
 
 def load():
     """Loads libatcstep.so; raises (never falls back) when it has not been built."""
@@ -75,6 +75,7 @@ def load():
     lib.atc_query_shaping.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp]
     lib.atc_reset.argtypes = [vp, ci, ci, C.POINTER(AtcState), vp, vp, C.POINTER(AtcParams), ci, vp]
     lib.atc_observe.argtypes = [vp, ci, ci, C.POINTER(AtcState), vp, vp, C.POINTER(AtcParams), vp]
+    lib.atc_step_packet.argtypes = [vp, C.POINTER(AtcState), vp, C.POINTER(AtcOut), C.POINTER(AtcParams), C.c_uint32, vp, vp, ci, vp]
     lib.atc_step.argtypes = [vp, ci, ci, C.POINTER(AtcState), vp, C.POINTER(AtcOut), C.POINTER(AtcParams), vp]
     lib.atc_step_multi.argtypes = [ci, C.POINTER(AtcStepCall)]
     lib.atc_rollout.argtypes = [vp, ci, ci, ci, C.POINTER(AtcState), vp, C.POINTER(AtcOut), C.POINTER(AtcParams), vp]

@@ -25,6 +25,8 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared   (see build.py)
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <chrono>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -1296,6 +1298,30 @@ int atc_observe(const atc_scenario_t* s, int B, int N, const atc_state_t* st, co
 int atc_step(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const float* actions, const atc_out_t* out,
              const atc_params_t* p, void* stream) {
     return step_common(s, B, N, 1, 1, st, actions, out, p, stream);
+}
+
+int atc_step_packet(const atc_scenario_t* s, const atc_state_t* st, const float* actions, const atc_out_t* out,
+                    atc_params_t* p, uint32_t seq, const uint32_t* packet_host, uint32_t* payload, int timeout_us, void* stream) {
+    if (!p || !out || !out->packet || !packet_host || !payload) return fail_arg("atc_step_packet needs out->packet, packet_host, payload");
+    p->reserved0 = seq;
+    const int rc = step_common(s, 1, 1, 1, 1, st, actions, out, p, stream);
+    if (rc != ATC_OK) return rc;
+    const volatile uint32_t* pk = packet_host;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 1;; ++it) {
+        bool all = true;
+        for (int c = 0; c < ATC_PKT_CHUNKS; ++c) all = all && pk[4 * c + 3] == seq;
+        if (all) {
+            // a chunk is ONE 16-byte store: its payload is this step's as soon as its tag is
+            std::atomic_thread_fence(std::memory_order_acquire);
+            for (int c = 0; c < ATC_PKT_CHUNKS; ++c)
+                for (int w = 0; w < 3; ++w) payload[3 * c + w] = pk[4 * c + w];
+            return ATC_OK;
+        }
+        if ((it & 255u) == 0 &&
+            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_us)
+            return -3;
+    }
 }
 
 int atc_step_multi(int n, const atc_step_call_t* calls) {

@@ -110,6 +110,13 @@ class AtcGym(Env):
         self._pkt_i = self._vec.packet.numpy().reshape(L.PKT_CHUNKS, 4)
         self._pkt_tags = self._pkt_i[:, 3]
         self._pkt_f = self._pkt_i.view(np.float32)
+        # launch + poll in ONE foreign call (atc_step_packet): the 27 payload words land in _payload
+        self._payload_i = np.zeros(27, np.int32)     # (signed: the grid counts are)
+        self._payload_f = self._payload_i.view(np.float32)
+        self._step_packet = lambda stream, seq, _f=v._lib.atc_step_packet, _h=v.sector.handle, _s=C.byref(v._state), \
+            _a=C.c_void_p(_lib.mapped_ptr(self._host_act)), _o=C.byref(v._out), _p=C.byref(v.params), \
+            _k=C.c_void_p(self._vec.packet.data_ptr()), _w=C.c_void_p(self._payload_i.ctypes.data): \
+            _f(_h, _s, _a, _o, _p, seq, _k, _w, 20000, stream)   # 20 ms: a first launch on an idle device can take a while
         self._seq = 0
         self._outstanding = False
         self._pos_now = None                   # grid position after the last step (None: read it from the state record)
@@ -207,21 +214,17 @@ class AtcGym(Env):
         """One launch of the step kernel on host-mapped buffers, one stream synchronisation, results read in place."""
         stream = self._current_stream(self._backend.device)
         self._seq = seq = (self._seq + 1) & 0x7fffffff
-        self._backend.params.reserved0 = seq
-        rc = self._launch(stream.cuda_stream)
-        if rc:
-            self._check(rc)
         self._outstanding = True
-        tags = self._pkt_tags
-        for _ in range(20000):                 # ~10 us of kernel + host link; a few hundred polls at most
-            if (tags == seq).all():
-                break
-        else:                                  # never expected: fall back to the blocking wait
+        rc = self._step_packet(stream.cuda_stream, seq)   # ~10 us of kernel + host link, polled inside the library
+        if rc == -3:                           # never expected: fall back to the blocking wait
             stream.synchronize()
             self._outstanding = False
-            assert (tags == seq).all()
-        w = self._pkt_f[:, :3].reshape(27).copy()      # read AFTER the tags were seen current
-        iw = self._pkt_i[:, :3].reshape(27)
+            assert (self._pkt_tags == seq).all()
+            self._payload_i[:] = self._pkt_i[:, :3].reshape(27)
+        elif rc:
+            self._check(rc)
+        w = self._payload_f.copy()
+        iw = self._payload_i
         fd = int(iw[21])
         self._pos_now = (int(iw[24]), int(iw[25]))
         return (w[0:10], w[10:20], float(w[20]), bool(fd >> 16), fd & 0xffff, int(iw[22]), int(iw[23]))

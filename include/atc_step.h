@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ATC_ABI_VERSION 14
+#define ATC_ABI_VERSION 15
 
 /* ---------------------------------------------------------------------------------------------
  * Scenario blob: one flat array of 32-bit floats (device copy) compiled on the host from the sector
@@ -308,6 +308,16 @@ typedef struct atc_step_call {
     void* stream;
 } atc_step_call_t;
 int atc_step_multi(int n, const atc_step_call_t* calls);
+
+/* atc_step of ONE env x ONE aircraft (B = N = 1) whose outputs include out->packet in pinned mapped memory, followed by the
+ * wait for its result in the same foreign call: the step is launched with p->reserved0 = seq, then `packet_host` (the HOST
+ * address of the same packet buffer) is polled until all ATC_PKT_CHUNKS chunks carry the tag `seq`, and their 27 payload
+ * words are copied to payload[27] (see atc_out_t.packet for their meaning).  Returns 0, the launch's error, or -3 when the
+ * result has not arrived within `timeout_us` microseconds (the caller then synchronises the stream and reads the packet itself).
+ * `seq` must differ from the previous call's.  The kernel's trailing state stores may still be in flight on return: anything
+ * else that touches the env's buffers has to drain the stream first.  Replaces the wait in AtcGym.step (atc_gym.py:128-192). */
+int atc_step_packet(const atc_scenario_t* s, const atc_state_t* st, const float* actions, const atc_out_t* out,
+                    atc_params_t* p, uint32_t seq, const uint32_t* packet_host, uint32_t* payload, int timeout_us, void* stream);
 
 /* T consecutive steps in ONE launch with aircraft state held in registers.  actions: [T][B*N*3];
  * outputs are [T][...] versions of atc_out_t (each pointer strides by its per-step size).
