@@ -181,8 +181,10 @@ class AtcGym(Env):
 
     def step(self, action):
         """atc_gym.py:128-192 — one launch of the HIP step kernel + the reference's Python-side bookkeeping."""
-        a = np.asarray(action, dtype=np.float32).reshape(1, 1, 3)
-        self._act_np[:] = a.reshape(3)
+        try:
+            self._act_np[:] = action               # the common case: 3 values, converted to fp32 on assignment
+        except (ValueError, TypeError):
+            self._act_np[:] = np.asarray(action, dtype=np.float32).reshape(3)
         # model.py:123: Airplane.step first remembers where the aircraft IS (read by render() only), then moves it
         if self._pos_now is None:
             self._settle()
@@ -204,7 +206,7 @@ class AtcGym(Env):
         if flags & (L.F_INVALID_V | L.F_INVALID_H):  # atc_gym.py:314
             for bit, idx in ((L.F_INVALID_V, 0), (L.F_INVALID_H, 1)):
                 if flags & bit:
-                    print("Warning invalid action: %d for index: %d" % (self._denormalized_action(a[0, 0, idx], idx), idx))
+                    print("Warning invalid action: %d for index: %d" % (self._denormalized_action(self._act_np[idx], idx), idx))
         assert self.done == bool(dn)
         self.state = raw
         self._update_metrics(rew)
