@@ -102,6 +102,10 @@ class AtcGym(Env):
             _a=C.c_void_p(_lib.mapped_ptr(self._host_act)), _o=C.byref(v._out), _p=C.byref(v.params): \
             _f(_h, 1, 1, _s, _a, _o, _p, stream)
         self._current_stream = torch.cuda.current_stream
+        # the raw handle of the current stream without building a Stream object per step (private torch API, optional)
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        dev, dev_index = v.device, v.device.index
+        self._raw_stream = (lambda: raw(dev_index)) if raw is not None else (lambda: torch.cuda.current_stream(dev).cuda_stream)
         # Completion without a stream synchronisation: the kernel also writes the step result as 9 self-validating 16-byte
         # chunks (atc_out_t.packet), each ONE store tagged with this step's sequence number.  The host polls the tags in the
         # mapped buffer; a chunk whose tag is current holds this step's payload whatever order the chunks arrived in (this is
@@ -214,12 +218,11 @@ class AtcGym(Env):
 
     def _launch_and_fetch(self):
         """One launch of the step kernel on host-mapped buffers, one stream synchronisation, results read in place."""
-        stream = self._current_stream(self._backend.device)
         self._seq = seq = (self._seq + 1) & 0x7fffffff
         self._outstanding = True
-        rc = self._step_packet(stream.cuda_stream, seq)   # ~10 us of kernel + host link, polled inside the library
+        rc = self._step_packet(self._raw_stream(), seq)   # ~10 us of kernel + host link, polled inside the library
         if rc == -3:                           # never expected: fall back to the blocking wait
-            stream.synchronize()
+            self._current_stream(self._backend.device).synchronize()
             self._outstanding = False
             assert (self._pkt_tags == seq).all()
             self._payload_i[:] = self._pkt_i[:, :3].reshape(27)
