@@ -22,6 +22,7 @@ class AtcVecEnv:
         """host_mapped=True keeps state and outputs in pinned host memory mapped into the device (zero-copy): the kernels
         read / write it over the host link, every call ends with a stream synchronisation, and what is returned are CPU
         tensors.  Meant for tiny latency-bound batches (the single-env AtcGym); large batches belong in HBM.
+        host_mapped="io" maps only what crosses the host link every step (actions in, results out); the state stays in HBM.
         want_packet=True (host_mapped, N == 1) adds atc_out_t.packet: the step result as self-validating 16-byte chunks that a
         host can poll in mapped memory instead of synchronising the stream (see `poll_packet`).
         keep_active=True is the reference's single-aircraft rule (ATC_M_KEEP_ACTIVE): an aircraft that reaches the corridor
@@ -62,13 +63,16 @@ class AtcVecEnv:
             z = lambda shape, dt: torch.zeros(shape, dtype=dt).pin_memory()  # noqa: E731
         else:
             z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+        # host_mapped="io": only what crosses the host link every step (actions in, results out) lives in mapped host memory;
+        # the state stays in HBM, so the kernel's state loads and stores do not pay the link's round trip
+        zs = (lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)) if host_mapped == "io" else z  # noqa: E731
         f32, i32 = torch.float32, torch.int32
         # persistent state (atc_state_t): packed records, see include/atc_step.h
-        self.pos_hp = z((BN, 4), i32)         # x, y (position-grid counts), h, phi (float bit patterns)
-        self.v = z(BN, f32)                   # speed
-        self.last_act = z((BN, 3), f32)       # last accepted v / h / phi targets
-        self.env = z((B, L.ENV_WORDS), i32)   # per-step env record
-        self.stats = z((B, L.STAT_WORDS), i32)  # per-episode env record
+        self.pos_hp = zs((BN, 4), i32)         # x, y (position-grid counts), h, phi (float bit patterns)
+        self.v = zs(BN, f32)                   # speed
+        self.last_act = zs((BN, 3), f32)       # last accepted v / h / phi targets
+        self.env = zs((B, L.ENV_WORDS), i32)   # per-step env record
+        self.stats = zs((B, L.STAT_WORDS), i32)  # per-episode env record
         self._state = _lib.AtcState(*[self._ptr(getattr(self, n)) for n in _lib.STATE_FIELDS])
         self.pos_origin, self.pos_k = self.compiled.pos_origin, self.compiled.pos_k
         # named views into the records (live memory, usable for reads and in-place writes)

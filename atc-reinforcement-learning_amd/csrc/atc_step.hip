@@ -333,6 +333,17 @@ struct StepDerived {
     float sep2;           // sep_nm ^ 2
     double pos_inv, pos_x0, pos_y0;   // position grid (blob: ATC_C_POS_*) widened once for the fixed-point -> fp32 conversion
 };
+// atc_step_packet: the ONE env's action by value, a kernel argument of its own (no read over the host link on the device side)
+struct InlineAction {
+    float v, h, p;
+    int set;
+};
+static thread_local const float* t_inline_action = nullptr;   // set by atc_step_packet around its launch
+static InlineAction inline_action() {
+    InlineAction a = {0.0f, 0.0f, 0.0f, 0};
+    if (t_inline_action) a = InlineAction{t_inline_action[0], t_inline_action[1], t_inline_action[2], 1};
+    return a;
+}
 static StepDerived derive(const atc_params_t& p, const atc_scenario* s) {
     StepDerived q;
     q.pos_inv = (double)s->pos_inv;
@@ -863,6 +874,7 @@ struct StepArgs {
     atc_out_t out;
     atc_params_t p;
     StepDerived q;
+    InlineAction ia;
 };
 template <typename T>
 __device__ __forceinline__ T kernarg_reread(size_t byte_off, int opaque_zero) {
@@ -880,7 +892,7 @@ __device__ __forceinline__ T kernarg_reread(size_t byte_off, int opaque_zero) {
 template <int W, bool FULL, bool ONE>  // ONE: single-step launch (T == 1)
 __global__ void __launch_bounds__(kBlock, (ONE ? ATC_MIN_WAVES : ((FULL || W < 8 || W >= 32) ? ATC_MIN_WAVES_LOOP - 1 : ATC_MIN_WAVES_LOOP)))
 k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int hold, atc_state_t st,
-       const float* __restrict__ actions, atc_out_t out, atc_params_t p, StepDerived q) {
+       const float* __restrict__ actions, atc_out_t out, atc_params_t p, StepDerived q, InlineAction ia) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4* pos = reinterpret_cast<float4*>(smem);                    // [2 kBlock] pair-scan staging (W >= 32)
     float* obs_stage = smem + (W >= 32 ? 2 * kBlock * 4 : 0);  // [4 waves][64 x 10] obs transpose
@@ -906,7 +918,11 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     // record is only read (and written) by envs that were reset since their last step (timesteps == 0), whose aircraft
     // may have been handed over when the action block started and still carry an older record.
     Float3 act = {0.0f, 0.0f, 0.0f};   // action of the current block (held for `hold` steps); one 12-byte load per lane
-    if (ONE) act = *at<Float3>(actions, times12(d.i));   // requested before the env record is waited for below
+    if (ONE && W == 1 && FULL && ia.set) {   // the single env of atc_step_packet: the action came with the kernel arguments
+        act = Float3{ia.v, ia.h, ia.p};
+    } else if (ONE) {
+        act = *at<Float3>(actions, times12(d.i));   // requested before the env record is waited for below
+    }
     const bool same_actions = ONE && (p.mode & ATC_M_ACTIONS_HELD) != 0;
     const bool la_live = !same_actions || e0.x == 0;
     Float3 la0 = {0.0f, 0.0f, 0.0f};
@@ -1124,7 +1140,7 @@ static int launch_step2(const atc_scenario* s, int B, int N, int T, int hold, co
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long long slots = (long long)B * W;
     const int grid = (int)((slots + kBlock - 1) / kBlock);  // one workgroup per 256 slots, no grid-stride loop
-    hipLaunchKernelGGL((k_step<W, FULL, ONE>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->off_grid, B, N, T, hold, *st, actions, *out, *p, derive(*p, s));
+    hipLaunchKernelGGL((k_step<W, FULL, ONE>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->off_grid, B, N, T, hold, *st, actions, *out, *p, derive(*p, s), inline_action());
     HIP_TRY(hipGetLastError());
     return ATC_OK;
 }
@@ -1303,8 +1319,11 @@ int atc_step(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const
 int atc_step_packet(const atc_scenario_t* s, const atc_state_t* st, const float* actions, const atc_out_t* out,
                     atc_params_t* p, uint32_t seq, const uint32_t* packet_host, uint32_t* payload, int timeout_us, void* stream) {
     if (!p || !out || !out->packet || !packet_host || !payload) return fail_arg("atc_step_packet needs out->packet, packet_host, payload");
+    if (!actions) return fail_arg("null pointer");
     p->reserved0 = seq;
+    t_inline_action = actions;   // HOST pointer to the 3 action values: they travel in the kernel arguments
     const int rc = step_common(s, 1, 1, 1, 1, st, actions, out, p, stream);
+    t_inline_action = nullptr;
     if (rc != ATC_OK) return rc;
     const volatile uint32_t* pk = packet_host;
     const auto t0 = std::chrono::steady_clock::now();

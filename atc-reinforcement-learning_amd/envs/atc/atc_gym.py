@@ -85,8 +85,7 @@ class AtcGym(Env):
         self._host_act = torch.zeros(3, dtype=torch.float32).pin_memory()
         self._act_np = self._host_act.numpy()
         self._out_np = self._host_out.numpy()
-        self._env_np = self._vec.env.numpy()
-        self._pos_np = self._vec.pos_hp.numpy()
+        self._pos_rec = self._vec.pos_hp       # (device memory in "io" mode: read with a copy after a reset only)
         self._pos_inv = 2.0 ** -self._vec.pos_k
         self._pos_origin = tuple(self._vec.pos_origin)
         lay = self._out_layout
@@ -118,7 +117,7 @@ class AtcGym(Env):
         self._payload_i = np.zeros(27, np.int32)     # (signed: the grid counts are)
         self._payload_f = self._payload_i.view(np.float32)
         self._step_packet = lambda stream, seq, _f=v._lib.atc_step_packet, _h=v.sector.handle, _s=C.byref(v._state), \
-            _a=C.c_void_p(_lib.mapped_ptr(self._host_act)), _o=C.byref(v._out), _p=C.byref(v.params), \
+            _a=C.c_void_p(self._host_act.data_ptr()), _o=C.byref(v._out), _p=C.byref(v.params), \
             _k=C.c_void_p(self._vec.packet.data_ptr()), _w=C.c_void_p(self._payload_i.ctypes.data): \
             _f(_h, _s, _a, _o, _p, seq, _k, _w, 20000, stream)   # 20 ms: a first launch on an idle device can take a while
         self._seq = 0
@@ -163,7 +162,7 @@ class AtcGym(Env):
         # keep_active: the reference's aircraft is never handed over — after a win it keeps flying (and can win again) if
         # the caller steps on without reset (atc_gym.py:128-192 has no inactive state)
         return AtcVecEnv(1, 1, sim_parameters=sim_parameters, scenario=scenario, device=device, auto_reset=False,
-                         spawn="lattice", want_raw_obs=True, host_mapped=True, keep_active=True, want_packet=True)
+                         spawn="lattice", want_raw_obs=True, host_mapped="io", keep_active=True, want_packet=True)
 
     @property
     def last_action(self):
@@ -192,7 +191,8 @@ class AtcGym(Env):
         # model.py:123: Airplane.step first remembers where the aircraft IS (read by render() only), then moves it
         if self._pos_now is None:
             self._settle()
-            self._pos_now = (int(self._pos_np[0, 0]), int(self._pos_np[0, 1]))
+            px_py = self._pos_rec[0, :2].tolist()
+            self._pos_now = (int(px_py[0]), int(px_py[1]))
         px, py = self._pos_now
         self._airplane.position_history.append((self._pos_origin[0] + px * self._pos_inv,
                                                 self._pos_origin[1] + py * self._pos_inv))

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ATC_ABI_VERSION 15
+#define ATC_ABI_VERSION 16
 
 /* ---------------------------------------------------------------------------------------------
  * Scenario blob: one flat array of 32-bit floats (device copy) compiled on the host from the sector
@@ -310,7 +310,9 @@ typedef struct atc_step_call {
 int atc_step_multi(int n, const atc_step_call_t* calls);
 
 /* atc_step of ONE env x ONE aircraft (B = N = 1) whose outputs include out->packet in pinned mapped memory, followed by the
- * wait for its result in the same foreign call: the step is launched with p->reserved0 = seq, then `packet_host` (the HOST
+ * wait for its result in the same foreign call.  `actions` is a HOST pointer to the 3 action values here: they are read
+ * during the call and travel with the kernel arguments (no read over the host link on the device side).
+ * The step is launched with p->reserved0 = seq, then `packet_host` (the HOST
  * address of the same packet buffer) is polled until all ATC_PKT_CHUNKS chunks carry the tag `seq`, and their 27 payload
  * words are copied to payload[27] (see atc_out_t.packet for their meaning).  Returns 0, the launch's error, or -3 when the
  * result has not arrived within `timeout_us` microseconds (the caller then synchronises the stream and reads the packet itself).
