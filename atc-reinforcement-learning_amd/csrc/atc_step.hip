@@ -169,7 +169,7 @@ __device__ __forceinline__ uint64_t group_ballot(bool pred, int lane) {
     const uint64_t b = __ballot(pred);
     if (W == 64) return b;
     const int base = lane & ~(W - 1);
-    return (b >> base) & ((1ull << W) - 1ull);
+    return (b >> base) & ((1ull << (W & 63)) - 1ull);   // (W < 64 here; the mask keeps the W = 64 instantiation warning-free)
 }
 
 // Separation scan for N = 16: one env = one DPP row (16 lanes).  Partner state arrives by row rotation (v_*_dpp
