@@ -79,7 +79,7 @@ constexpr int kBlock = ATC_BLOCK;
 #define ATC_ABLATE 0  // developer-only timing ablations (bit mask, see uses); the shipped build always uses 0
 #endif
 #ifndef ATC_LOOP_OPAQUE
-#define ATC_LOOP_OPAQUE 1  // see the step loop of k_step
+#define ATC_LOOP_OPAQUE 0  // bits: 1 lane ids, 2 sector pointers — see the step loop of k_step (off since the kernarg re-reads)
 #endif
 #ifndef ATC_TRACE
 #define ATC_TRACE 0  // developer-only: per-wavefront s_memtime stamps at phase boundaries (pointer smuggled in params)
@@ -941,9 +941,11 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         if (lane == 0 && trow) trow[0] = step ? __builtin_amdgcn_s_memtime() : t_launch;
 #endif
         const size_t sBN = (size_t)step * BN, sB = (size_t)step * (uint32_t)B;  // uniform (scalar) per-step bases
-        // Multi-step launches: everything that is invariant across steps (lane ids and the address arithmetic on them, the
-        // sector base) is re-derived from an opaque zero inside the body, so that LICM cannot hoist it and keep it alive
-        // around the loop: under the 80-VGPR launch bound the loop form has no scratch with it and 88 B per lane without.
+        // Multi-step launches, history: before the by-value arguments were re-read from the kernarg segment (below), everything
+        // invariant across steps (lane ids, the address arithmetic on them, the sector base) had to be re-derived from an opaque
+        // zero inside the body, or LICM kept it alive around the loop and the 80-VGPR form spilled 88 B per lane.  With the
+        // re-reads the plain form is the faster one (12-20 B of scratch in some widths notwithstanding: 13.70 vs 13.80 us per
+        // step, 8 192 x 16 3.98 vs 4.05, profiles/r02_experiments.txt); the knob remains for A/B builds.
         LaneIds dl = d;
         const float* Kl = K;
         const float* gl = grid;
@@ -966,9 +968,8 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             int zs;
             asm volatile("v_mov_b32 %0, 0" : "=v"(zv));
             asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
-            dl.i += zv; dl.e += (int)zv; dl.k += (int)zv; dl.tid += (int)zv; dl.lane += (int)zv; dl.slot0 += (uint32_t)zs;
-            Kl = K + zs;
-            gl = grid ? grid + zs : nullptr;
+            if (ATC_LOOP_OPAQUE & 1) { dl.i += zv; dl.e += (int)zv; dl.k += (int)zv; dl.tid += (int)zv; dl.lane += (int)zv; dl.slot0 += (uint32_t)zs; }
+            if (ATC_LOOP_OPAQUE & 2) { Kl = K + zs; gl = grid ? grid + zs : nullptr; }
         }
         StepOut so = {outl.obs + sBN * ATC_OBS_DIM, outl.flags + sBN, outl.reward + sB, outl.done + sB,
                       FULL && outl.raw_obs ? outl.raw_obs + sBN * ATC_OBS_DIM : nullptr,
