@@ -98,9 +98,9 @@ constexpr int kBlock = ATC_BLOCK;
 #ifndef ATC_LOOP_REREAD_ARGS
 // which by-value arguments a multi-step launch re-reads from the kernarg segment inside its loop (see StepArgs) — bits:
 // 1 parameters, 2 derived constants, 4 output pointers, 8 state pointers (needed again after the loop).  Chosen per width by
-// measurement: everything for 64-aircraft envs, the state pointers alone below (all four: 36 B of scratch at N = 16, and
-// slower at N = 32).
-#define ATC_LOOP_REREAD_ARGS(W) ((W) == 64 ? 15 : 8)
+// measurement (profiles/r02_experiments.txt): the state pointers for the DPP widths, nothing for the LDS-scan widths (the
+// mode word goes through an opaque zero in either case).
+#define ATC_LOOP_REREAD_ARGS(W) ((W) >= 32 ? 0 : 8)
 #endif
 #ifndef ATC_GRID_CAP
 #define ATC_GRID_CAP 8   // workgroups per CU before the reset / observe / query kernels grid-stride
