@@ -20,7 +20,7 @@
 //   block barrier, no atomics in the fast variant, no MFMA (there is no dense contraction on this path).
 //   Workgroup = 256 threads = 256 consecutive slots; one workgroup per tile.  The single-step kernel has NO loop around
 //   the step body (neither grid-stride nor the step loop of multi-step launches): it is its own instantiation
-//   k_step<W, FULL, ONE = true> (N = 16: 63 VGPRs); multi-step launches keep the state in registers across a run-time step
+//   k_step<W, FULL, ONE = true> (N = 16: 56 VGPRs); multi-step launches keep the state in registers across a run-time step
 //   loop under an 80-VGPR launch bound (6 wavefronts per SIMD) and prefetch the next step's action.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared   (see build.py)
@@ -106,7 +106,7 @@ constexpr int kBlock = ATC_BLOCK;
 #define ATC_GRID_CAP 8   // workgroups per CU before the reset / observe / query kernels grid-stride
 #endif
 #ifndef ATC_MIN_WAVES
-#define ATC_MIN_WAVES 4  // waves per SIMD the single-step kernel is register-budgeted for (<= 128 VGPRs; it needs 69-75)
+#define ATC_MIN_WAVES 4  // waves per SIMD the single-step kernel is register-budgeted for (<= 128 VGPRs; it needs 55-72)
 #endif
 #ifndef ATC_MIN_WAVES_LOOP
 #define ATC_MIN_WAVES_LOOP 6  // multi-step launches: <= 80 VGPRs.  Without the bound the allocator keeps literal constants and
@@ -931,7 +931,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
 
     // A single step is its own instantiation: with the step count a run-time value everything the loop carries (aircraft
     // and env records, output bases, hoisted sector constants) stays live across the whole body — the straight-line form
-    // needs 63 VGPRs (N = 16), the loop form 80 under its launch bound (94 without it).
+    // needs 56 VGPRs (N = 16), the loop form 80 under its launch bound (94 without it).
     const int n_steps = ONE ? 1 : T;
     const float* act_t = actions;   // action block of the current step; a block is held for `hold` steps
     int held = 0;                   // steps the current block has been used for
