@@ -1,0 +1,51 @@
+"""CPU checks of bench.py's bookkeeping (no GPU): the algorithmic byte counts SURVEY §8(d) defines, the traffic table the
+roofline record is filled from, and the command line the driver uses."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_algorithmic_bytes_follow_survey_8d():
+    b = _bench()
+    # single step: 96 N + 13 (N = 1: 109, N = 16: 1 549, N = 64: 6 157)
+    assert b.algorithmic_bytes_per_env_step(1) == 109
+    assert b.algorithmic_bytes_per_env_step(16) == 1549
+    assert b.algorithmic_bytes_per_env_step(64) == 6157
+    # T fused steps: the 40-byte state term is paid once per T, a held action block once per `hold`
+    assert abs(b.algorithmic_bytes_per_env_step(16, 20, 20) - ((44 + 2 + 0.6) * 16 + 13)) < 1e-9
+    assert b.algorithmic_bytes_per_env_step(16, 1, 1) == b.algorithmic_bytes_per_env_step(16)
+
+
+def test_traffic_table_is_consistent():
+    """profiles/pmc_traffic.json: every entry's bytes follow from its two counters (FETCH_SIZE in 64-byte units on gfx950:
+    x 2 against the KB the tool prints, + WRITE_SIZE), its ratio from the algorithmic bytes, and the headline entry exists
+    for both launch modes."""
+    b = _bench()
+    j = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    seen = set()
+    for w in j["workloads"]:
+        hbm = (w["FETCH_SIZE_KB_raw"] * 2 + w["WRITE_SIZE_KB"]) * 1024
+        assert abs(hbm - w["hbm_bytes_per_launch"]) <= 1024, w
+        if w["rollout"] == 0:
+            alg = b.algorithmic_bytes_per_env_step(w["aircraft"]) * w["envs"]
+            assert alg == w["algorithmic_bytes_per_launch"], w
+        assert abs(w["hbm_bytes_per_launch"] / w["algorithmic_bytes_per_launch"] - w["ratio"]) < 2e-3, w
+        seen.add((w["envs"], w["aircraft"], w["rollout"], bool(w.get("held_hint", False))))
+    assert (65536, 16, 0, True) in seen and (65536, 16, 0, False) in seen and (65536, 16, 20, False) in seen
+
+
+def test_driver_command_line_parses():
+    """`python bench.py --gpus N --steps K --warmup W` (the driver's call) and the no-flag default."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert 'add_argument("%s"' % flag in src
+    assert 'default=ENVS_PER_GPU' in src and "ENVS_PER_GPU = 65536" in src.replace("65_536", "65536")
