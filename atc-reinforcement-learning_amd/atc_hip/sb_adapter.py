@@ -71,7 +71,8 @@ class AtcSBVecEnv:
             obs_h, raw_h = obs.numpy().copy(), info["original_state"].numpy().copy()
             term_h = info["terminal_observation"].numpy().copy()
             rew_h, done_h = rew.numpy().copy(), done.numpy() != 0
-            ep_r, ep_l = vec.ep_return.numpy().copy(), vec.ep_length.numpy().copy()
+            # (host_mapped="io" keeps the state and the episode records in HBM: those two come over with a copy)
+            ep_r, ep_l = vec.ep_return.cpu().numpy().copy(), vec.ep_length.cpu().numpy().copy()
         else:
             pack = torch.cat([obs, info["original_state"], info["terminal_observation"],
                               rew[:, None], done[:, None].to(torch.float32), vec.ep_return[:, None],

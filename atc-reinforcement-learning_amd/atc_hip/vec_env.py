@@ -98,7 +98,11 @@ class AtcVecEnv:
         if want_packet and not (self.host_mapped and N == 1):
             raise ValueError("want_packet needs host_mapped=True and num_aircraft=1")
         self.packet = z((B, L.PKT_CHUNKS, 4), i32) if want_packet else None
+        # twin of `params` with ATC_M_ACTIONS_HELD set: what step(held=True) and the held launchers pass.  A persistent object,
+        # refreshed by seed() / refresh_params(), so that pre-bound launchers see parameter changes like plain launches do
+        self._params_held = type(self.params).from_buffer_copy(self.params)
         self._bind_outputs()
+        self.refresh_params()
         self._lib = _lib.load()
         self.reset(first=True)
 
@@ -144,6 +148,7 @@ class AtcVecEnv:
         self._out_ref = C.byref(self._out)
         self._state_ref = C.byref(self._state)
         self._params_ref = C.byref(self.params)
+        self._params_held_ref = C.byref(self._params_held)
         self._n_act = self.B * self.N * L.ACT_DIM
         self._info_cache = self._info()
 
@@ -165,7 +170,14 @@ class AtcVecEnv:
     # ------------------------------------------------------------------------------------------------ VecEnv surface
     def seed(self, seed=None):
         self.params.seed = int(seed or 0) & (2 ** 64 - 1)
+        self.refresh_params()
         return [seed] * self.B
+
+    def refresh_params(self):
+        """Copies `params` into its held-action twin (the struct launches with ATC_M_ACTIONS_HELD pass).  seed() calls it; call
+        it after changing a field of `env.params` directly, or launchers made with held=True keep the old value."""
+        C.memmove(C.byref(self._params_held), C.byref(self.params), C.sizeof(self.params))
+        self._params_held.mode |= L.M_ACTIONS_HELD
 
     def reset(self, mask=None, first=False):
         """AtcGym.reset (atc_gym.py:337-365) for all envs (or those with mask != 0); returns RAW obs [B, N*10]."""
@@ -217,20 +229,15 @@ class AtcVecEnv:
                                                                               self._prev_actions.view(self.torch.int32))):
                 raise ValueError("step(held=True): the actions differ from the previous step's (or there was none)")
             self._prev_actions = cur
-        if held:
-            self.params.mode |= L.M_ACTIONS_HELD
-            try:
-                return self.step(actions)
-            finally:
-                self.params.mode &= ~L.M_ACTIONS_HELD
         torch = self.torch
+        pref = self._params_held_ref if held else self._params_ref
         # fast path: a float32 device tensor of the right size on this env's (current) device is handed over as it is —
         # small batches are host-bound otherwise (8 192 x 16: 6.4 us on the GPU against 10.4 us of Python per call)
         if (torch.is_tensor(actions) and actions.is_cuda and actions.dtype is torch.float32 and actions.is_contiguous()
                 and actions.numel() == self._n_act and actions.device == self.device
                 and torch.cuda.current_device() == self.device.index and not self.host_mapped):
             rc = self._lib.atc_step(self.sector.handle, self.B, self.N, self._state_ref, actions.data_ptr(), self._out_ref,
-                                    self._params_ref, torch.cuda.current_stream().cuda_stream)
+                                    pref, torch.cuda.current_stream().cuda_stream)
             if rc:
                 _lib.check(rc)
             self._keep = actions
@@ -238,7 +245,7 @@ class AtcVecEnv:
         a = self._as_actions(actions)
         with torch.cuda.device(self.device):
             _lib.check(self._lib.atc_step(self.sector.handle, self.B, self.N, C.byref(self._state), self._ptr(a),
-                                          C.byref(self._out), C.byref(self.params), self._stream()))
+                                          C.byref(self._out), pref, self._stream()))
         self._keep = a
         self._finish()
         return self.obs, self.reward, self.done, self._info_cache
@@ -249,15 +256,14 @@ class AtcVecEnv:
         microseconds instead of the argument handling of step().  Meant for pipelined actors that keep several
         independent sub-batches in flight on separate streams (tools/multi_stream.py, bench.py --streams): a sub-batch's
         launch ramp and tail then overlap the others' bodies.  Results are in self.obs / reward / done / flags once the
-        stream has reached the launch.  held=True binds a snapshot of the current parameters with ATC_M_ACTIONS_HELD set:
-        for the launches of a held action block after its first (see step())."""
+        stream has reached the launch.  held=True passes the env's held-action parameter twin (ATC_M_ACTIONS_HELD set; the live
+        object, so seed() / refresh_params() reach launchers that already exist): for the launches of a held action block after
+        its first (see step()).  The promise itself — same actions as the previous launch, no set_last_action() in between —
+        is the caller's and is not checked here (AtcVecEnv(check_held=True) checks it in step())."""
         torch = self.torch
         a = self._as_actions(actions)
         q = C.c_void_p((stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream)
-        params = self.params
-        if held:
-            params = type(self.params).from_buffer_copy(self.params)
-            params.mode |= L.M_ACTIONS_HELD
+        params = self._params_held if held else self.params
         args = (self.sector.handle, self.B, self.N, C.byref(self._state), C.c_void_p(self._ptr(a)), C.byref(self._out),
                 C.byref(params), q)
         fn, check = self._lib.atc_step, _lib.check
@@ -272,10 +278,7 @@ class AtcVecEnv:
         """The arguments of one atc_step of this env as an `atc_step_call_t` (+ the objects that must outlive it)."""
         a = self._as_actions(actions)
         q = (stream if stream is not None else self.torch.cuda.current_stream(self.device)).cuda_stream
-        params = self.params
-        if held:   # snapshot with ATC_M_ACTIONS_HELD, see make_launcher
-            params = type(self.params).from_buffer_copy(self.params)
-            params.mode |= L.M_ACTIONS_HELD
+        params = self._params_held if held else self.params   # the live objects, see make_launcher
         call = _lib.AtcStepCall(self.sector.handle, self.B, self.N, C.pointer(self._state), self._ptr(a),
                                 C.pointer(self._out), C.pointer(params), q)
         return call, (a, stream, self, params)

@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <chrono>
+#include <sched.h>
+#include <emmintrin.h>   // host side of atc_step_packet: 16-byte loads of the mapped result packet
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -1321,23 +1323,36 @@ int atc_step_packet(const atc_scenario_t* s, const atc_state_t* st, const float*
                     atc_params_t* p, uint32_t seq, const uint32_t* packet_host, uint32_t* payload, int timeout_us, void* stream) {
     if (!p || !out || !out->packet || !packet_host || !payload) return fail_arg("atc_step_packet needs out->packet, packet_host, payload");
     if (!actions) return fail_arg("null pointer");
+    if (reinterpret_cast<uintptr_t>(packet_host) & 15u) return fail_arg("packet_host must be 16-byte aligned");
     p->reserved0 = seq;
     t_inline_action = actions;   // HOST pointer to the 3 action values: they travel in the kernel arguments
     const int rc = step_common(s, 1, 1, 1, 1, st, actions, out, p, stream);
     t_inline_action = nullptr;
     if (rc != ATC_OK) return rc;
-    const volatile uint32_t* pk = packet_host;
+    // Every chunk is ONE 16-byte device store and is read here with ONE aligned 16-byte load (movdqa: a single access on every
+    // x86-64 with AVX — the tag and the payload words it validates come from the same access, so a reader can never pair a
+    // current tag with a stale payload word, whatever order the chunks or the words of other chunks become visible in).
     const auto t0 = std::chrono::steady_clock::now();
+    unsigned have = 0;   // bit c: chunk c taken
     for (unsigned it = 1;; ++it) {
-        bool all = true;
-        for (int c = 0; c < ATC_PKT_CHUNKS; ++c) all = all && pk[4 * c + 3] == seq;
-        if (all) {
-            // a chunk is ONE 16-byte store: its payload is this step's as soon as its tag is
-            std::atomic_thread_fence(std::memory_order_acquire);
-            for (int c = 0; c < ATC_PKT_CHUNKS; ++c)
-                for (int w = 0; w < 3; ++w) payload[3 * c + w] = pk[4 * c + w];
-            return ATC_OK;
+        for (int c = 0; c < ATC_PKT_CHUNKS; ++c) {
+            if (have >> c & 1u) continue;
+            const __m128i v = _mm_load_si128(reinterpret_cast<const __m128i*>(packet_host + 4 * c));
+            alignas(16) uint32_t w[4];
+            _mm_store_si128(reinterpret_cast<__m128i*>(w), v);
+            if (w[3] == seq) {
+                payload[3 * c] = w[0];
+                payload[3 * c + 1] = w[1];
+                payload[3 * c + 2] = w[2];
+                have |= 1u << c;
+            }
         }
+        if (have == (1u << ATC_PKT_CHUNKS) - 1u) return ATC_OK;
+        asm volatile("" ::: "memory");   // the buffer changes under us: reload on the next round
+        // The result arrives ~10 us after the launch: spin with the pipeline hint first, then give the core away between
+        // polls (eight SubprocVecEnv-style workers no longer pin eight cores while they wait).
+        if (it < 4096u) _mm_pause();
+        else sched_yield();
         if ((it & 255u) == 0 &&
             std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_us)
             return -3;

@@ -316,7 +316,8 @@ int atc_step_multi(int n, const atc_step_call_t* calls);
  * address of the same packet buffer) is polled until all ATC_PKT_CHUNKS chunks carry the tag `seq`, and their 27 payload
  * words are copied to payload[27] (see atc_out_t.packet for their meaning).  Returns 0, the launch's error, or -3 when the
  * result has not arrived within `timeout_us` microseconds (the caller then synchronises the stream and reads the packet itself).
- * `seq` must differ from the previous call's.  The kernel's trailing state stores may still be in flight on return: anything
+ * `seq` must differ from the previous call's; `packet_host` must be 16-byte aligned (each chunk is read with one 16-byte load, so
+ * a tag and the payload words it validates always come from the same access).  The kernel's trailing state stores may still be in flight on return: anything
  * else that touches the env's buffers has to drain the stream first.  Replaces the wait in AtcGym.step (atc_gym.py:128-192). */
 int atc_step_packet(const atc_scenario_t* s, const atc_state_t* st, const float* actions, const atc_out_t* out,
                     atc_params_t* p, uint32_t seq, const uint32_t* packet_host, uint32_t* payload, int timeout_us, void* stream);
