@@ -16,8 +16,18 @@ def world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init(backend=None):
-    """Initialises the default process group when WORLD_SIZE > 1 (nccl on GPU, gloo otherwise)."""
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def init(backend=None, force=False):
+    """Initialises the default process group when WORLD_SIZE > 1 (nccl on GPU, gloo otherwise).
+    force=True does so for a single process too — a world of one rank whose collectives still go through the backend (RCCL on a
+    GPU box): how `bench.py` and the GPU tests exercise the exact `init_process_group("nccl", device_id=...)` / device-tensor
+    collective calls of the multi-GPU path on a box with one GPU."""
     rank, ws, local = world()
     if backend is None:  # ATC_DIST_BACKEND=gloo lets the multi-rank control flow be exercised on a box with one GPU
         backend = os.environ.get("ATC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -30,15 +40,28 @@ def init(backend=None):
                 raise RuntimeError("LOCAL_RANK %d but only %d visible devices: one process per GPU" % (local, n_dev))
             local = 0
         torch.cuda.set_device(local)
-    if ws > 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+    if (ws > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (required by the host driver for RCCL)
-        if backend == "nccl":
-            dist.init_process_group(backend=backend, rank=rank, world_size=ws, device_id=torch.device("cuda", local))
+        kw = {}
+        if ws == 1 and "MASTER_PORT" not in os.environ:   # a world of one: nobody to meet, any free local port will do
+            kw["init_method"] = "tcp://127.0.0.1:%d" % _free_port()
         else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=ws, **kw)
     return rank, ws, local
+
+
+def shutdown():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def backend_name():
+    """Backend of the initialised default group ("nccl" = RCCL on ROCm, "gloo"), or None."""
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
 
 
 def shard_range(total_envs, rank, world_size):
@@ -53,28 +76,41 @@ def rank_seed(seed, rank):
     return (int(seed) + 0x9E3779B97F4A7C15 * (rank + 1)) & (2 ** 64 - 1) if rank else int(seed)
 
 
-_equal_shards_checked = set()
+_shard_rows = {}   # call signature (dtypes + trailing dims: the same on every rank) -> shard sizes verified equal on every rank
 
 
-def all_gather_stats(*tensors):
+def _collective(force):
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
+
+
+def all_gather_stats(*tensors, force=False):
     """All-gathers equally-shaped per-env tensors from every rank into [world, ...] tensors (one collective each).
-    Identity (with a leading axis of 1) when not distributed."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    Identity (with a leading axis of 1) when not distributed — unless force=True and a (one-rank) group exists: then the
+    backend's collective runs all the same.
+
+    all_gather_into_tensor needs equal shards (shard_range() gives them only when the world size divides the env count).
+    That is verified collectively by the FIRST call with a given signature (number of tensors, dtypes, trailing dimensions —
+    everything but the shard size itself), i.e. by a decision every rank takes alike whatever its own shard size: mismatching
+    ranks meet in the same MIN / MAX reductions and all of them raise.  Later calls with that signature must keep their
+    shard sizes (a local assertion)."""
+    if not _collective(force):
         return [t.unsqueeze(0) for t in tensors]
     ws = dist.get_world_size()
     host_staged = dist.get_backend() == "gloo"  # gloo gathers host tensors; RCCL gathers device tensors in place
+    key = tuple((str(t.dtype), tuple(t.shape[1:])) for t in tensors)
+    mine = [int(t.shape[0]) for t in tensors]
+    if key not in _shard_rows:
+        rows = torch.tensor(mine, dtype=torch.int64, device="cpu" if host_staged else tensors[0].device)
+        lo, hi = rows.clone(), rows.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise AssertionError("all_gather_stats needs equally sized shards on every rank (%s .. %s)" % (lo.tolist(), hi.tolist()))
+        _shard_rows[key] = mine
+    assert mine == _shard_rows[key], "shard sizes changed since the first all_gather_stats call of this kind"
     out = []
     for t in tensors:
         src = t.contiguous()
-        if src.shape[0] not in _equal_shards_checked:
-            # all_gather_into_tensor needs equal shards (shard_range() gives them only when ws divides the env count):
-            # checked once per shard size, not on every gather
-            _equal_shards_checked.add(src.shape[0])
-            n = torch.tensor([src.shape[0]], dtype=torch.int64, device="cpu" if host_staged else src.device)
-            lo, hi = n.clone(), n.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            assert int(lo) == int(hi), "all_gather_stats needs equally sized shards on every rank (%d..%d)" % (int(lo), int(hi))
         if host_staged and src.is_cuda:
             src = src.cpu()
         g = torch.empty((ws * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
@@ -88,16 +124,16 @@ def barrier():
         dist.barrier()
 
 
-def max_over_ranks(value, device):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def max_over_ranks(value, device, force=False):
+    if not _collective(force):
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def sum_over_ranks(value, device):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def sum_over_ranks(value, device, force=False):
+    if not _collective(force):
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)

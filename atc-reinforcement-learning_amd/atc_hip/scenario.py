@@ -144,13 +144,19 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=()):
     if guard is None:
         guard = 1e-3
     x0, y0, x1, y1 = bbox
-    gx0 = x0 - cell
-    gy0 = y0 - cell
+    for b in noise_bounds:   # the grid covers the noise-abatement areas too: beyond it no area has to be tested
+        x0, y0, x1, y1 = min(x0, b[0]), min(y0, b[1]), max(x1, b[2]), max(y1, b[3])
+    # Two cells of padding all round: the OUTERMOST ring of cells is then clean, outside the airspace and free of noise-area
+    # candidates (checked below) — the kernel clamps the cell index of a point beyond the grid into that ring instead of
+    # testing the range (csrc/atc_device.h:mva_cell_load), so the ring must give the answer of "beyond the grid".
+    gx0 = x0 - 2 * cell
+    gy0 = y0 - 2 * cell
     nx = int(math.ceil((x1 - gx0) / cell)) + 2
     assert nx < 1 << 20, "lookup grid too wide (the kernel indexes cells with a 24-bit multiply)"
     ny = int(math.ceil((y1 - gy0) / cell)) + 2
     inv = 1.0 / cell
     slack = guard + 1e-4 * max(1.0, abs(x1), abs(y1)) * 2.0 ** -10
+    assert slack < 0.5 * cell
     edges = [_ring_edges(r) for r in rings]
     near = np.zeros((ny, nx), dtype=bool)
     for ring in rings:
@@ -233,6 +239,8 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=()):
                     mask |= 1 << q
             c = cells[j, i, 0]
             cells[j, i, 0] = (c + 64.0 * mask) if c > 0 else (c - 64.0 * mask)
+    border = np.concatenate([cells[0, :, :].ravel(), cells[-1, :, :].ravel(), cells[:, 0, :].ravel(), cells[:, -1, :].ravel()])
+    assert not border.any(), "the outermost ring of lookup cells must be clean, outside the airspace, without noise candidates"
     n_rec = len(pool)
     hdr = np.zeros(L.G_HDR, dtype=np.float64)
     hdr[L.G_X0], hdr[L.G_Y0], hdr[L.G_INV], hdr[L.G_NX], hdr[L.G_NY] = gx0, gy0, inv, nx, ny

@@ -45,59 +45,64 @@ __device__ __forceinline__ void sincos_deg(float phi, float* sn, float* cs) {
     const float sp = fmaf(fmaf(fmaf(ATC_SIN_C3, r2, ATC_SIN_C2), r2, ATC_SIN_C1), r2, 1.0f);
     const float s = sp * r;
     const float c = fmaf(fmaf(fmaf(fmaf(ATC_COS_C4, r2, ATC_COS_C3), r2, ATC_COS_C2), r2, ATC_COS_C1), r2, 1.0f);
-    const int q = (int)k & 3;
-    const float s1 = (q & 1) ? c : s;
-    const float c1 = (q & 1) ? s : c;
-    *sn = (q & 2) ? -s1 : s1;
-    *cs = ((q + 1) & 2) ? -c1 : c1;
+    const uint32_t q = (uint32_t)(int)k;   // quadrant = q mod 4 (two's complement: also right for negative k)
+    const float s1 = (q & 1u) ? c : s;
+    const float c1 = (q & 1u) ? s : c;
+    // sin changes sign in quadrants 2, 3 (bit 1 of q), cos in quadrants 1, 2 (bit 1 of q + 1): the bit moved onto the sign bit
+    *sn = __uint_as_float(__float_as_uint(s1) ^ ((q << 30) & 0x80000000u));
+    *cs = __uint_as_float(__float_as_uint(c1) ^ (((q + 1u) << 30) & 0x80000000u));
 }
 
 // atan2 in DEGREES (np.degrees(np.arctan2(y, x)), atc_gym.py:289-292) — value-only: octant reduction to a = min/max in
-// [0,1], 8-term odd polynomial (1.5e-7 rad max error), reciprocal instead of a division.
+// [0,1], a * P(a^2) with a 7-term polynomial fitted in degrees for the error RELATIVE to max(1 deg, result) — raw (reset)
+// observations are compared with 1e-5 max(1, |value|): 7.8e-7 max in fp32 —, a reciprocal instead of a division, the sign of
+// y copied in with one bit-field insert.
 __device__ __forceinline__ float atan2_deg(float y, float x) {
     const float ax = fabsf(x), ay = fabsf(y);
-    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    const float a = (mx > 0.0f) ? mn * fast_rcp(mx) : 0.0f;
+    const float mx = fmaxf(fmaxf(ax, ay), 1e-30f), mn = fminf(ax, ay);   // (0, 0) -> a = 0 -> 0 like np.arctan2
+    const float a = mn * fast_rcp(mx);
     const float s = a * a;
-    float p = -0.004054565913975239f;
-    p = fmaf(p, s, 0.021862955763936043f);
-    p = fmaf(p, s, -0.0559123270213604f);
-    p = fmaf(p, s, 0.0964219719171524f);
-    p = fmaf(p, s, -0.1390862911939621f);
-    p = fmaf(p, s, 0.19946566224098206f);
-    p = fmaf(p, s, -0.33329859375953674f);
-    p = fmaf(p, s, 0.9999993443489075f);
-    float r = p * a;                                   // atan(min/max) in [0, pi/4]
-    r = (ay > ax) ? (0.5f * kPi - r) : r;              // first quadrant
-    r = (x < 0.0f) ? (kPi - r) : r;
-    r = (y < 0.0f) ? -r : r;
-    return r * kRadToDeg;
+    float p = 0.4501694142818451f;
+    p = fmaf(p, s, -2.119493007659912f);
+    p = fmaf(p, s, 4.8039751052856445f);
+    p = fmaf(p, s, -7.726700305938721f);
+    p = fmaf(p, s, 11.3909912109375f);
+    p = fmaf(p, s, -19.094654083251953f);
+    p = fmaf(p, s, 57.29574203491211f);
+    float r = p * a;                                   // atan(min/max) in [0, 45] degrees
+    r = (ay > ax) ? (90.0f - r) : r;                   // first quadrant
+    r = (x < 0.0f) ? (180.0f - r) : r;
+    return __uint_as_float((__float_as_uint(r) & 0x7fffffffu) | (__float_as_uint(y) & 0x80000000u));   // r >= 0: copysign
 }
 
 // Python float modulo by 360 (sign of the divisor), as used by relative_angle (model.py:340-342):  CPython computes
 // r = fmod(a, 360) exactly and, if r has the wrong sign, r += 360 (one rounding).
-// Here: q = floor(a * (1/360)) estimates the quotient (off by at most one either way), and r = fma(-360, q, a) is the
-// EXACT value a - 360 q rounded once (a and 360 q are both multiples of ulp(a) below 2^24 ulp(a)).
+// Here: q = floor(a * RN(1/360)) estimates the quotient, and r = fma(-360, q, a) is the EXACT value a - 360 q rounded
+// once (a and 360 q are both multiples of ulp(a) below 2^24 ulp(a)).
 //   * q exact        -> r is what CPython returns, including the a = -tiny case that rounds to 360.0
-//   * q one too big  -> r is exact and negative; r + 360 rounds once, like CPython's `r += b`
-//   * q one too small-> r in [360, 720) exactly, detected by a >= 360 (q + 1) (integers below 2^24: exact); r - 360 exact.
-// No IEEE division (bit-identical to the fmodf-based oracle on every input, checked in tests/test_hip_parity.py).
+//   * q one too big  -> r is exact and negative; r + 360 rounds once, like CPython's `r += b`.  Happens only just below a
+//                       multiple of 360 from a = 1799.9999 upwards (first of 50 184 floats below 2^25).
+//   * q too small    -> never: RN(1/360) > 1/360, so a RN(1/360) lies on the far side of the true quotient from zero, and
+//                       the rounding of the product is monotonic across the (representable) integer below it.
+// Both statements checked exhaustively for every float with 2^-12 <= |a| < 2^25 (tools/check_mod360.py).
+// No IEEE division (bit-identical to the fmodf-based oracle, tests/test_hip_parity.py).
 __device__ __forceinline__ float py_mod360(float a) {
     const float q = floorf(a * (1.0f / 360.0f));
-    float r = fmaf(-360.0f, q, a);
-    if (r < 0.0f) r += 360.0f;
-    else if (a >= (q + 1.0f) * 360.0f) r -= 360.0f;
-    return r;
+    const float r = fmaf(-360.0f, q, a);
+    return (r < 0.0f) ? r + 360.0f : r;
 }
 
 // model.py:340-342
 __device__ __forceinline__ float relative_angle(float a1, float a2) { return py_mod360(a2 - a1 + 180.0f) - 180.0f; }
-// The same for angles whose difference is known to lie in [-360, 720) (a bearing from atan2 against a runway heading):
-// there CPython's fmod is the identity or one subtraction and only the sign fix-up remains — same result, half the work.
-__device__ __forceinline__ float relative_angle_near(float a1, float a2) {
-    float r = a2 - a1 + 180.0f;
-    r = (r < 0.0f) ? r + 360.0f : ((r >= 360.0f) ? r - 360.0f : r);
-    return r - 180.0f;
+// relative_angle for a VALUE-ONLY argument that is itself an approximation (the bearing to the FAF out of atan2_deg in the
+// shaping terms): w - 360 floor((w + 180) / 360) with w = a2 - a1 — four operations for any range, no compares.  Agrees with
+// the exact form above to a few ulp(w) except within ~2e-5 deg of the wrap at +-180, where the reference's own result jumps
+// by 360 — a discontinuity that the fp32 bearing crosses at slightly different positions anyway.  Not used where the
+// arguments can sit ON the wrap exactly (integer headings against phi_to_runway) and not for anything that decides a flag.
+__device__ __forceinline__ float relative_angle_value(float a1, float a2) {
+    const float w = a2 - a1;
+    const float q = floorf(fmaf(w, 1.0f / 360.0f, 0.5f));
+    return fmaf(q, -360.0f, w);
 }
 // v / 3600 (model.py:124), correctly rounded without the IEEE division sequence: q0 = v * RN(1/3600), one fma gives the
 // exact remainder v - 3600 q0, a second folds it back.  Bit-identical to v / 3600.0f for every float with
@@ -150,42 +155,52 @@ __device__ __forceinline__ bool in_bounds(const float* rec, float x, float y) {
 // overlaps independent work (in the step kernel: the whole separation scan) instead of stalling the wavefront.
 struct MvaCell {
     float2 cell;   // (+-(code + 64 noise mask), first_record | height): > 0 dirty, code = n_records; <= 0 clean, code = polygon + 1
-    bool in_grid;  // false: beyond the padded bbox (also NaN) -> outside the airspace
 };
-// bit q set: the aircraft has to be tested against noise-abatement area q (all of them where there is no grid cell to ask)
+// bit q set: the aircraft has to be tested against noise-abatement area q (all of them where there is no grid to ask)
 __device__ __forceinline__ uint32_t noise_candidates(const float* __restrict__ grid, const MvaCell& c) {
-    if (!grid || !c.in_grid) return 0xffffu;
+    if (!grid) return 0xffffu;
     return (uint32_t)(int)fabsf(c.cell.x) >> 6;
 }
-// the grid header (origin, 1 / cell, columns, rows): read EARLY by the caller — as part of mva_cell_load it was a scalar-load
-// round trip (plus a second one behind a short-circuit test) between the new position and the cell gather
+// The grid header (origin, 1 / cell, columns, rows, record pool) — uniform.  The step kernel receives it with its arguments
+// (evaluated on the host: gfx950 has no scalar float conversion); the query kernel reads it from the blob.
 struct GridHdr {
-    float x0, y0, inv, nx, ny, off_pool;
+    float x0, y0, inv;
+    int nx, nx_last, ny_last;   // columns, columns - 1, rows - 1
+    int off_pool;               // words from the grid start to the record pool
 };
-__device__ __forceinline__ GridHdr grid_header(const float* __restrict__ grid) {
-    GridHdr g = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+__host__ __device__ inline GridHdr grid_header(const float* grid) {
+    GridHdr g = {0.0f, 0.0f, 0.0f, 1, 0, 0, 0};
     if (grid) {
-        const float4 a = *reinterpret_cast<const float4*>(grid);   // ATC_G_X0, ATC_G_Y0, ATC_G_INV, ATC_G_NX
-        const float2 b = *reinterpret_cast<const float2*>(grid + ATC_G_NY);   // ATC_G_NY, ATC_G_OFF_POOL
-        g.x0 = a.x; g.y0 = a.y; g.inv = a.z; g.nx = a.w;
-        g.ny = b.x; g.off_pool = b.y;
+        g.x0 = grid[ATC_G_X0]; g.y0 = grid[ATC_G_Y0]; g.inv = grid[ATC_G_INV];
+        g.nx = (int)grid[ATC_G_NX]; g.nx_last = g.nx - 1; g.ny_last = (int)grid[ATC_G_NY] - 1;
+        g.off_pool = (int)grid[ATC_G_OFF_POOL];
     }
     return g;
 }
+// float -> int32 as the hardware defines it for EVERY input (v_cvt_i32_f32: truncation, saturation at both ends, NaN -> 0).
+// A C cast is undefined outside the int range, so the instruction is named explicitly where that range matters.
+__device__ __forceinline__ int cvt_i32_sat(float f) {
+    int i;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(i) : "v"(f));
+    return i;
+}
+// Cell of a point.  The grid's outermost ring of cells is CLEAN and OUTSIDE the airspace with no noise-area candidate
+// (atc_hip/scenario.py:build_grid pads for it, atc_scenario_create checks it), so a point beyond the grid — or NaN — simply
+// takes the border cell its clamped index names: (int) of a float saturates, NaN converts to 0, and one unsigned minimum per
+// axis clamps both ends (a negative index is a huge unsigned).  No range compare, no select; the answer of such a point
+// is "outside the airspace" (model.py:289) as it must be.
 __device__ __forceinline__ MvaCell mva_cell_load(const float* __restrict__ grid, const GridHdr& g, float x, float y) {
     MvaCell c;
     c.cell = make_float2(0.0f, 0.0f);
-    c.in_grid = false;
     if (grid) {
         const float fx = (x - g.x0) * g.inv;
         const float fy = (y - g.y0) * g.inv;
-        c.in_grid = (fx >= 0.0f) & (fx < g.nx) & (fy >= 0.0f) & (fy < g.ny);
-        // clamped index: the load is unconditional (no branch in front of it), the result is ignored when !in_grid
-        const int ix = c.in_grid ? (int)fx : 0, iy = c.in_grid ? (int)fy : 0;
+        const uint32_t ix = min((uint32_t)cvt_i32_sat(fx), (uint32_t)g.nx_last);
+        const uint32_t iy = min((uint32_t)cvt_i32_sat(fy), (uint32_t)g.ny_last);
         // (24-bit multiply-add: rows and columns are far below 2^23; the 32-bit multiply is a quarter-rate instruction)
         // uniform base + 32-bit byte offset: the scalar-base addressing form, no 64-bit address arithmetic per lane
         c.cell = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(grid) +
-                                                  (uint32_t)(ATC_G_HDR * 4 + 8 * (__mul24(iy, (int)g.nx) + ix)));
+                                                  (uint32_t)(ATC_G_HDR * 4 + 8 * __umul24(iy, (uint32_t)g.nx) + 8 * ix));
     }
     return c;
 }
@@ -193,7 +208,6 @@ __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const fl
                                            const MvaCell& c, float x, float y, float* height) {
     *height = 0.0f;
     if (grid) {
-        if (!c.in_grid) return -1;
         const float2 cell = c.cell;
         const int code = (int)fabsf(cell.x) & 63;
         if (!(cell.x > 0.0f)) {  // clean cell: polygon + 1 (0 = outside the airspace), height
@@ -208,7 +222,7 @@ __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const fl
         // Records are fetched in batches of kBatch (both 16-byte halves of each, all loads issued before the first use):
         // one L2 round trip per batch instead of one per record.  Indices past the list are clamped (loads stay in
         // bounds) and their records ignored.
-        const char* pool = reinterpret_cast<const char*>(grid + (int)gh.off_pool);   // uniform
+        const char* pool = reinterpret_cast<const char*>(grid + gh.off_pool);   // uniform
         const uint32_t rec0 = 32u * (uint32_t)(int)cell.y;                          // this lane's first record, bytes
         constexpr int kBatch = ATC_MVA_BATCH;
         bool inside = false;
@@ -291,12 +305,14 @@ __device__ __forceinline__ bool inside_corridor_angle(const float* __restrict__ 
     return false;
 }
 
-// model.py:188-210 Corridor.inside_corridor
-__device__ __forceinline__ bool inside_corridor(const float* __restrict__ K, float x, float y, float h, float phi) {
-    // exact early-out: a point the crossing test accepts lies within the ring's bounds (precomputed on the host)
-    // (one 16-byte scalar load and bitwise ands: four short-circuit tests were four dependent scalar-load round trips)
+__device__ __forceinline__ float4 tri_bbox(const float* __restrict__ K) {
     static_assert(ATC_C_TRI_BBOX % 4 == 0, "bounds must be 16-byte aligned");
-    const float4 bb = *reinterpret_cast<const float4*>(K + ATC_C_TRI_BBOX);
+    return *reinterpret_cast<const float4*>(K + ATC_C_TRI_BBOX);
+}
+// model.py:188-210 Corridor.inside_corridor
+__device__ __forceinline__ bool inside_corridor(const float* __restrict__ K, const float4& bb, float x, float y, float h, float phi) {
+    // exact early-out: a point the crossing test accepts lies within the ring's bounds bb = ATC_C_TRI_BBOX (precomputed on
+    // the host; the step kernel has them among its arguments, so the test waits for no load)
     if (!((x >= bb.x) & (x <= bb.z) & (y >= bb.y) & (y <= bb.w))) return false;
     if (!ray_tracing(x, y, K + ATC_C_TRI_H, 4)) return false;
     const float fx = K[ATC_C_FAF_X], fy = K[ATC_C_FAF_Y], nx = K[ATC_C_NRM_X], ny = K[ATC_C_NRM_Y];
@@ -309,35 +325,76 @@ __device__ __forceinline__ bool inside_corridor(const float* __restrict__ K, flo
     return inside_corridor_angle(K, x, y, phi);
 }
 
-// atc_gym.py:17-19  (1 - tanh(4 d/dmax - 2)) / 2  ==  1 / (1 + exp(2 (4 d/dmax - 2)))   [exact identity]
-__device__ __forceinline__ float sigmoid_distance(float d, float inv_d_max) {
-    const float z2 = fmaf(8.0f * inv_d_max, d, -4.0f);  // 2 * (4 d/dmax - 2)
-    return fast_rcp(1.0f + fast_exp(z2));
+// Uniform constants of the observation / shaping stage.  The step kernel receives them precomputed on the host with its
+// arguments (kernel arguments live in SGPRs; evaluated in the kernel, uniform float arithmetic occupies the vector unit
+// in every lane: gfx950 has no scalar float ALU); reset / observe / query kernels derive them from the blob.
+struct alignas(8) ObsConst {
+    int faf_x, faf_y;   // the FAF on the position grid (ATC_C_FAF_FIX)
+    float pos_inv;      // nm per grid count (ATC_C_POS_INV)
+    float to_rwy;       // phi_to_runway (ATC_C_PHI_TO_RWY)
+    float on_gp_c;      // faf_mva - 200: on_gp_altitude = 318.4 d_faf + faf_mva - 200 (atc_gym.py:279-287)
+    float sig_a;        // 8 log2(e) / world_diag, see sigmoid2
+};
+__host__ __device__ inline ObsConst obs_const(const float* K) {
+    ObsConst c;
+    c.faf_x = (int)K[ATC_C_FAF_FIX] * 65536 + (int)K[ATC_C_FAF_FIX + 1];
+    c.faf_y = (int)K[ATC_C_FAF_FIX + 2] * 65536 + (int)K[ATC_C_FAF_FIX + 3];
+    c.pos_inv = K[ATC_C_POS_INV];
+    c.to_rwy = K[ATC_C_PHI_TO_RWY];
+    c.on_gp_c = K[ATC_C_FAF_MVA] - 200.0f;
+    c.sig_a = (8.0f * 1.44269504088896341f) / K[ATC_C_WORLD_DIAG];
+    return c;
+}
+constexpr float kSigB = -4.0f * 1.44269504088896341f;
+constexpr float kSigGs = (8.0f * 1.44269504088896341f) / 36000.0f;   // glideslope: d_max = 36000 (atc_gym.py:236)
+
+// atc_gym.py:17-19  (1 - tanh(4 d/dmax - 2)) / 2  ==  1 / (1 + exp(2 (4 d/dmax - 2)))  ==  1 / (1 + 2^(a d + kSigB)) with
+// a = 8 log2(e) / dmax   [exact identities; value-only]
+__device__ __forceinline__ float sigmoid2(float d, float a) {
+    return fast_rcp(1.0f + __builtin_amdgcn_exp2f(fmaf(d, a, kSigB)));
 }
 
 struct Shaping {
     float pos, ang, gs;
 };
-// atc_gym.py:199-260: _reward_approach_position, _reward_approach_angle, _reward_glideslope
-__device__ __forceinline__ Shaping shaping_rewards(const float* __restrict__ K, float d_faf, float phi_rel_faf, float plane_to_runway,
-                                                   float h, float on_gp) {
+struct ShapingCore {
+    float pos;   // _reward_approach_position
+    float m;     // (-(q ** 2) + 1) ** 32: _reward_approach_angle = m * pos * 1.2
+    float sg;    // sigmoid of the glideslope error: _reward_glideslope = sg * pos * 0.8
+};
+// atc_gym.py:199-260: _reward_approach_position, _reward_approach_angle, _reward_glideslope (value-only arithmetic)
+__device__ __forceinline__ ShapingCore shaping_core(const ObsConst& c, float d_faf, float phi_rel_faf, float plane_to_runway,
+                                                     float h, float on_gp) {
     // plane_to_runway = relative_angle(phi_to_runway, phi_plane): the caller already has it as obs[9]
-    const float to_rwy = K[ATC_C_PHI_TO_RWY];
-    Shaping r;
-    const float rel_faf = relative_angle_near(to_rwy, phi_rel_faf);  // phi_rel_faf = atan2 in [-180, 180], to_rwy in [0, 360)
+    ShapingCore r;
+    const float rel_faf = relative_angle_value(c.to_rwy, phi_rel_faf);
     const float u = fabsf(rel_faf) * (1.0f / 180.0f);
-    r.pos = sigmoid_distance(d_faf, fast_rcp(K[ATC_C_WORLD_DIAG])) * (u * fast_sqrt(u)) * 0.8f;  // u ** 1.5
-    const float side = (rel_faf > 0.0f) ? 1.0f : ((rel_faf < 0.0f) ? -1.0f : 0.0f);  // np.sign
-    const float q = (side * plane_to_runway - 22.5f) * (1.0f / 202.0f);
-    float m = -(q * q) + 1.0f;  // (-(q ** 2.0) + 1.0) ** 32.0 by five squarings (even power: sign-safe)
+    r.pos = sigmoid2(d_faf, c.sig_a) * (u * fast_sqrt(u)) * 0.8f;   // u ** 1.5
+    // np.sign(rel_faf) * plane_to_runway as a sign-bit xor.  (np.sign(0) = 0 is not reproduced: there u = 0, so pos = 0 and
+    // the angle term m * pos * 1.2 is 0 whatever the sign factor — m is finite.)
+    const float sp = __uint_as_float(__float_as_uint(plane_to_runway) ^ (__float_as_uint(rel_faf) & 0x80000000u));
+    const float q = fmaf(sp, 1.0f / 202.0f, -22.5f / 202.0f);
+    float m = fmaf(-q, q, 1.0f);   // (-(q ** 2.0) + 1.0) ** 32.0 by five squarings (even power: sign-safe)
     m = m * m;
     m = m * m;
     m = m * m;
     m = m * m;
-    m = m * m;
-    r.ang = m * r.pos * 1.2f;
-    r.gs = sigmoid_distance(fabsf(h - on_gp), 1.0f / 36000.0f) * r.pos * 0.8f;
+    r.m = m * m;
+    r.sg = sigmoid2(fabsf(h - on_gp), kSigGs);
     return r;
+}
+__device__ __forceinline__ Shaping shaping_rewards(const ObsConst& c, float d_faf, float phi_rel_faf, float plane_to_runway,
+                                                   float h, float on_gp) {
+    const ShapingCore k = shaping_core(c, d_faf, phi_rel_faf, plane_to_runway, h, on_gp);
+    Shaping r;
+    r.pos = k.pos;
+    r.ang = k.m * k.pos * 1.2f;
+    r.gs = k.sg * k.pos * 0.8f;
+    return r;
+}
+// pos + ang + gs as pos * (1 + 1.2 m + 0.8 sg): what the step adds to the reward (atc_gym.py:179-185)
+__device__ __forceinline__ float shaping_total(const ShapingCore& k) {
+    return k.pos * fmaf(k.sg, 0.8f, fmaf(k.m, 1.2f, 1.0f));
 }
 
 // counter-based RNG for entry draws: integer-only, identical to the oracle's (oracle/atc_oracle_impl.h: mix64/draw)
@@ -355,13 +412,24 @@ __device__ __forceinline__ uint64_t draw(uint64_t seed, uint32_t env, uint32_t e
 // ---- aircraft positions: 32-bit fixed point on the sector's position grid (include/atc_step.h "Aircraft positions") ----
 __device__ __forceinline__ int sat_add(int a, int b) { return __builtin_elementwise_add_sat(a, b); }
 __device__ __forceinline__ int sat_sub(int a, int b) { return __builtin_elementwise_sub_sat(a, b); }
-// the fp32 position every formula of the reference sees: (float)(origin + fix * 2^-k), ONE rounding
+// the fp32 position every formula of the reference sees: (float)(origin + fix * 2^-k), ONE rounding (the sum is exact in
+// float64: a 32-bit integer scaled by a power of two plus a small integer)
 __device__ __forceinline__ float pos_to_real(const float* __restrict__ K, int axis, int p) {
     return (float)fma((double)p, (double)K[ATC_C_POS_INV], (double)K[ATC_C_POS_X0 + axis]);
+}
+// the same from the exponent k and the origin as kernel arguments: conversion, exponent adjustment, addition, conversion —
+// each takes its uniform operand from a scalar register (the fma form needs two: one goes through vector registers first)
+__device__ __forceinline__ float pos_to_real(int neg_k, double origin, int p) {
+    return (float)(__builtin_ldexp((double)p, neg_k) + origin);
 }
 // model.py:122-129: x += d with d computed in fp32; the grid advances by rint(d 2^k) counts, saturating
 __device__ __forceinline__ int pos_advance(const float* __restrict__ K, int p, float d) {
     float c = d * K[ATC_C_POS_SCALE];
+    c = fminf(fmaxf(c, -1073741824.0f), 1073741824.0f);
+    return sat_add(p, (int)rintf(c));
+}
+// the same with the displacement already in grid counts (the caller scaled the distance, an exact power-of-two scaling)
+__device__ __forceinline__ int pos_advance_counts(int p, float c) {
     c = fminf(fmaxf(c, -1073741824.0f), 1073741824.0f);
     return sat_add(p, (int)rintf(c));
 }
@@ -372,10 +440,7 @@ __device__ __forceinline__ int pos_spawn(const float* __restrict__ K, int axis, 
     return (int)rintf(c);
 }
 // faf - position (atc_gym.py:289-297): exact integer difference on the grid -> fp32 relative precision near the FAF
-__device__ __forceinline__ float pos_to_faf(const float* __restrict__ K, int axis, int p) {
-    const int faf = (int)K[ATC_C_FAF_FIX + 2 * axis] * 65536 + (int)K[ATC_C_FAF_FIX + 2 * axis + 1];
-    return (float)sat_sub(faf, p) * K[ATC_C_POS_INV];
-}
+__device__ __forceinline__ float pos_to_faf(int faf, float pos_inv, int p) { return (float)sat_sub(faf, p) * pos_inv; }
 
 struct Aircraft {
     int x, y;         // position grid counts
@@ -413,14 +478,14 @@ struct Obs {
     float d_faf, phi_rel_faf, on_gp;
 };
 // atc_gym.py:262-297 _get_state.  (px, py) = grid position, (x, y) = its fp32 value
-__device__ __forceinline__ Obs get_state(const float* __restrict__ K, int px, int py, float x, float y, float h, float phi,
-                                         float v, float mva) {
+__device__ __forceinline__ Obs get_state(const ObsConst& c, int px, int py, float x, float y, float h, float phi, float v,
+                                         float mva) {
     Obs r;
-    const float to_faf_x = pos_to_faf(K, 0, px);
-    const float to_faf_y = pos_to_faf(K, 1, py);
+    const float to_faf_x = pos_to_faf(c.faf_x, c.pos_inv, px);
+    const float to_faf_y = pos_to_faf(c.faf_y, c.pos_inv, py);
     r.d_faf = fast_sqrt(fmaf(to_faf_x, to_faf_x, to_faf_y * to_faf_y));   // np.hypot (value-only)
     r.phi_rel_faf = atan2_deg(to_faf_y, to_faf_x);                        // np.degrees(np.arctan2) (value-only)
-    r.on_gp = 318.4f * r.d_faf + K[ATC_C_FAF_MVA] - 200.0f;
+    r.on_gp = fmaf(318.4f, r.d_faf, c.on_gp_c);
     r.o[0] = x;
     r.o[1] = y;
     r.o[2] = h;
@@ -430,7 +495,7 @@ __device__ __forceinline__ Obs get_state(const float* __restrict__ K, int px, in
     r.o[6] = r.on_gp;
     r.o[7] = r.d_faf;
     r.o[8] = r.phi_rel_faf;
-    r.o[9] = relative_angle(K[ATC_C_PHI_TO_RWY], phi);
+    r.o[9] = relative_angle(c.to_rwy, phi);   // exact form: headings and phi_to_runway are often integers, i.e. ON the wrap
     return r;
 }
 

@@ -43,7 +43,8 @@ struct atc_scenario {
     int off_grid;    // 0 = no grid
     int device;
     int n_cu;
-    float pos_inv, pos_x0, pos_y0;   // host copies of ATC_C_POS_INV / ATC_C_POS_X0 / ATC_C_POS_Y0
+    float consts[ATC_C_END];   // host copy of the blob's header + constants block (derive() evaluates uniform terms from it)
+    float ghdr[ATC_G_HDR];     // host copy of the lookup grid's header (zeros without a grid)
 };
 
 static thread_local char g_err[512] = "";
@@ -102,7 +103,11 @@ constexpr int kBlock = ATC_BLOCK;
 // 1 parameters, 2 derived constants, 4 output pointers, 8 state pointers (needed again after the loop).  Chosen per width by
 // measurement (profiles/r02_experiments.txt): the state pointers for the DPP widths, nothing for the LDS-scan widths (the
 // mode word goes through an opaque zero in either case).
+#ifdef ATC_REREAD_MASK   // developer A/B builds: one mask for every width
+#define ATC_LOOP_REREAD_ARGS(W) (ATC_REREAD_MASK)
+#else
 #define ATC_LOOP_REREAD_ARGS(W) ((W) >= 32 ? 0 : 8)
+#endif
 #endif
 #ifndef ATC_GRID_CAP
 #define ATC_GRID_CAP 8   // workgroups per CU before the reset / observe / query kernels grid-stride
@@ -205,6 +210,36 @@ struct PairScan16 {
 template <bool WANT_MIN>
 struct PairScan16<9, WANT_MIN> {
     static __device__ __forceinline__ void run(float, float, float, float, float, float&, float&) {}
+};
+// The same scan for launches that do not report the minimum separation (the fast variant): almost every pair of a sector is
+// far apart horizontally, so each rotation first asks ONLY that — two rotated subtracts, a multiply, an fma and one compare
+// into a lane mask — and the altitude test and the hand-back to the partner run only in wavefronts where some lane has a
+// partner inside the horizontal minimum at this rotation (a wave-uniform branch on the compare's mask; about a third of
+// the rotations of the headline workload).  Conflict = (d^2 < sep^2) & (|dh| < sep_ft), the oracle's expression.
+template <int D>
+__device__ __forceinline__ int row_ror_i(int v) {
+    // (every lane of a row rotation has a source: `old` is never used — passing v itself spares the zero the compiler would
+    // otherwise materialise for it)
+    return __builtin_amdgcn_update_dpp(v, v, 0x120 + D, 0xf, 0xf, false);
+}
+template <int D>
+struct NearScan16 {
+    static __device__ __forceinline__ void run(float xs, float y, float h, float sep2, float sep_ft, int& conf) {
+        const float dx = xs - row_ror<D>(xs), dy = y - row_ror<D>(y);
+        const float d2 = fmaf(dx, dx, dy * dy);
+        const bool near = d2 < sep2;
+        if (__builtin_amdgcn_ballot_w64(near) != 0ull) {
+            const float dh = h - row_ror<D>(h);
+            const int c = (near && fabsf(dh) < sep_ft) ? 1 : 0;
+            conf |= c;
+            if (D < 8) conf |= row_ror_i<16 - D>(c);   // the partner's copy of the same pair (D = 8 is its own inverse)
+        }
+        NearScan16<D + 1>::run(xs, y, h, sep2, sep_ft, conf);
+    }
+};
+template <>
+struct NearScan16<9> {
+    static __device__ __forceinline__ void run(float, float, float, float, float, int&) {}
 };
 
 // Separation scan for N <= 8 (W = 2, 4, 8): the partners of lane k are the lanes k ^ m, m = 1..W-1, of its aligned group,
@@ -321,19 +356,44 @@ struct Mid {            // what the first half of a step hands to the second
     int acts;
     float x32, y32;
     MvaCell cell;       // MVA lookup cell, gather issued in the first half, resolved after the separation scan
-    GridHdr gh;         // uniform: the lookup grid's header, read at the top of the step
     bool repeated;      // uniform: no action bookkeeping in this step (acts == 0 in every lane)
 };
 // Uniform products of the step parameters, evaluated ONCE on the host in fp32 (the same IEEE operations the kernel
 // would do) and passed as kernel arguments: gfx950 has no scalar float ALU, so computed in the kernel they would occupy
 // vector registers — and a multi-step launch would keep them there across its whole step loop.
-struct StepDerived {
+// Grouped by the stage that consumes them: a multi-step launch re-reads each group from the kernarg segment right where its
+// stage starts (QGET below) instead of keeping ~70 uniform values alive across the step loop.
+struct alignas(16) QRates {   // first half of the step
     float dv_hi, dv_lo;   // kAMax * dt, kAMin * dt           (model.py:47-48,75-78)
     float dh_hi, dh_lo;   // kHDotMax * dt, kHDotMin * dt     (model.py:45-46,97-100)
     float dp_hi, dp_lo;   // kPhiDotMax * dt, kPhiDotMin * dt (model.py:49-50,113-120)
     float r_base;         // -0.05 * dt                       (atc_gym.py:137)
+    float dts;            // dt * 2^k: the step's distance comes out in position-grid counts (an exact power-of-two scaling)
+    // _denormalized_action (atc_gym.py:318-335) as target = RN(RN(a * m) + c) [+ c2 for the speed] — see decode_targets
+    float dec_mv, dec_cv, dec_cv2, dec_mh, dec_ch, dec_mp, dec_cp;
+    int pos_neg_k;        // position grid: nm = origin + fix * 2^-k (blob: ATC_C_POS_*)
+};
+struct alignas(16) QGrid {    // position conversion + MVA cell lookup
+    double pos_x0, pos_y0;
+    GridHdr gh;           // lookup grid header (7 words)
+    int pad;
+};
+struct alignas(16) QScan {    // second half: separation scan, override chain
     float sep2;           // sep_nm ^ 2
-    double pos_inv, pos_x0, pos_y0;   // position grid (blob: ATC_C_POS_*) widened once for the fixed-point -> fp32 conversion
+    float sep_ft, conflict_reward;
+    int timestep_limit;
+    float4 tri_bbox;      // bounds of the corridor's horizontal triangle (ATC_C_TRI_BBOX)
+};
+struct alignas(16) QNorm {
+    float a[ATC_OBS_DIM], b[ATC_OBS_DIM];   // ATC_C_NORM_A / ATC_C_NORM_B
+};
+struct StepDerived {
+    QRates r;
+    QGrid g;
+    QScan s;
+    ObsConst oc;          // observation / shaping constants
+    int pad[2];
+    QNorm n;
 };
 // atc_step_packet: the ONE env's action by value, a kernel argument of its own (no read over the host link on the device side)
 struct InlineAction {
@@ -347,19 +407,80 @@ static InlineAction inline_action() {
     return a;
 }
 static StepDerived derive(const atc_params_t& p, const atc_scenario* s) {
+    const float* K = s->consts;
     StepDerived q;
-    q.pos_inv = (double)s->pos_inv;
-    q.pos_x0 = (double)s->pos_x0;
-    q.pos_y0 = (double)s->pos_y0;
-    q.dv_hi = kAMax * p.dt;
-    q.dv_lo = kAMin * p.dt;
-    q.dh_hi = kHDotMax * p.dt;
-    q.dh_lo = kHDotMin * p.dt;
-    q.dp_hi = kPhiDotMax * p.dt;
-    q.dp_lo = kPhiDotMin * p.dt;
-    q.r_base = -0.05f * p.dt;
-    q.sep2 = p.sep_nm * p.sep_nm;
+    memset(&q, 0, sizeof q);
+    {
+        int e = 0;
+        (void)frexpf(K[ATC_C_POS_SCALE], &e);   // 2^k = 0.5 * 2^(k + 1)
+        q.r.pos_neg_k = -(e - 1);
+    }
+    q.g.pos_x0 = (double)K[ATC_C_POS_X0];
+    q.g.pos_y0 = (double)K[ATC_C_POS_Y0];
+    q.r.dv_hi = kAMax * p.dt;
+    q.r.dv_lo = kAMin * p.dt;
+    q.r.dh_hi = kHDotMax * p.dt;
+    q.r.dh_lo = kHDotMin * p.dt;
+    q.r.dp_hi = kPhiDotMax * p.dt;
+    q.r.dp_lo = kPhiDotMin * p.dt;
+    q.r.r_base = -0.05f * p.dt;
+    q.r.dts = p.dt * K[ATC_C_POS_SCALE];
+    // atc_gym.py:64-78,318-335: offset (v_min, 0, 0); factor (10, 100, 1) discrete | (v_max - v_min, h_max, 360) continuous.
+    //   discrete   : a * fac + off
+    //   continuous : a * fac / 2 + fac / 2 + off.  Halving is exact, so RN(a * fac) / 2 == RN(a * (fac / 2)) (no result here
+    //                is subnormal-sensitive: a sum with fac / 2 + off >= 100 follows) and fac / 2 is exact: the same bits as
+    //                the reference's operation order with one multiplication and one or two additions.
+    const bool discrete = (p.mode & ATC_M_DISCRETE) != 0;
+    q.r.dec_mv = discrete ? 10.0f : (kVMax - kVMin) / 2.0f;
+    q.r.dec_cv = discrete ? kVMin : (kVMax - kVMin) / 2.0f;
+    q.r.dec_cv2 = discrete ? -0.0f : kVMin;   // (x + -0 == x for every x)
+    q.r.dec_mh = discrete ? 100.0f : kHMax / 2.0f;
+    q.r.dec_ch = discrete ? 0.0f : kHMax / 2.0f;
+    q.r.dec_mp = discrete ? 1.0f : 360.0f / 2.0f;
+    q.r.dec_cp = discrete ? 0.0f : 360.0f / 2.0f;
+    q.g.gh = grid_header(s->off_grid ? s->ghdr : nullptr);
+    q.s.sep2 = p.sep_nm * p.sep_nm;
+    q.s.sep_ft = p.sep_ft;
+    q.s.conflict_reward = p.conflict_reward;
+    q.s.timestep_limit = p.timestep_limit;
+    q.s.tri_bbox = make_float4(K[ATC_C_TRI_BBOX], K[ATC_C_TRI_BBOX + 1], K[ATC_C_TRI_BBOX + 2], K[ATC_C_TRI_BBOX + 3]);
+    q.oc = obs_const(K);
+    for (int c = 0; c < ATC_OBS_DIM; ++c) {
+        q.n.a[c] = K[ATC_C_NORM_A + c];
+        q.n.b[c] = K[ATC_C_NORM_B + c];
+    }
     return q;
+}
+
+// The kernel's argument list as a struct: the kernarg segment is laid out by the same rules, so offsetof() names where an
+// argument lives.  Multi-step launches RE-READ their by-value arguments (output pointers, parameters, derived constants, the state
+// pointers needed again after the loop) from the kernarg segment inside the step instead of keeping ~60 SGPRs of them alive
+// across the loop: the allocator spills those to VGPR lanes and every use becomes a v_readlane — VALU work in a launch that is
+// bound by VALU issue — whereas a kernarg re-read is a scalar load.  The offset goes through an opaque zero, or the (invariant)
+// loads would be hoisted out of the loop again.
+struct StepArgs {
+    const float* blob;
+    int off_grid, B, N, T, hold;
+    atc_state_t st;
+    const float* actions;
+    atc_out_t out;
+    atc_params_t p;
+    StepDerived q;
+    InlineAction ia;
+};
+template <typename T>
+__device__ __forceinline__ T kernarg_reread(size_t byte_off, int opaque_zero) {
+#if __HIP_DEVICE_COMPILE__   // (the host pass only parses this body; the builtin exists for the device target)
+    // A TYPED load through the constant address space: the alignment of T is then known to the compiler, which it needs
+    // for scalar loads (a byte-wise copy from an address with an opaque term became per-lane vector loads).
+    typedef __attribute__((address_space(4))) const char* karg_ptr;
+    typedef __attribute__((address_space(4))) const T* typed_ptr;
+    return *(typed_ptr)((karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + byte_off + (size_t)opaque_zero * alignof(T));
+#else
+    T v;
+    __builtin_memset(&v, 0, sizeof(T));
+    return v;
+#endif
 }
 
 struct StepOut {        // per-step output bases (uniform pointers)
@@ -401,30 +522,23 @@ __device__ __forceinline__ LaneIds make_ids(uint32_t slot0, int B, int N) {
 // action, outside the action space) yields lo here and hi there — unspecified input either way.
 __device__ __forceinline__ float clamp_rate(float d, float lo, float hi) { return __builtin_amdgcn_fmed3f(d, lo, hi); }
 
-// _denormalized_action (atc_gym.py:318-335): action -> (v, h, phi) targets.  offset (v_min, 0, 0); factor (10, 100, 1)
-// discrete | (v_max - v_min, h_max, 360) continuous (atc_gym.py:64-78), same operation order.
-__device__ __forceinline__ Float3 decode_targets(const atc_params_t& p, const Float3& act) {
-    constexpr float v_min = kVMin, v_max = kVMax, h_max = kHMax;
-    const bool discrete = (p.mode & ATC_M_DISCRETE) != 0;
-    const float a_v = act.a, a_h = act.b, a_p = act.c;
-    const float fac_v = discrete ? 10.0f : v_max - v_min;
-    const float fac_h = discrete ? 100.0f : h_max;
-    const float fac_p = discrete ? 1.0f : 360.0f;
+// _denormalized_action (atc_gym.py:318-335): action -> (v, h, phi) targets with the host-evaluated (multiplier, offset)
+// pairs of derive() — bit-identical to the reference's operation order (see there), 7 operations instead of 18.
+// The discrete forms keep their `+ 0` (it turns a -0 product into +0, like the reference's `+ offset`).
+__device__ __forceinline__ Float3 decode_targets(const QRates& q, const Float3& act) {
     Float3 t;
-    t.a = discrete ? a_v * fac_v + v_min : a_v * fac_v / 2.0f + fac_v / 2.0f + v_min;
-    t.b = discrete ? a_h * fac_h + 0.0f : a_h * fac_h / 2.0f + fac_h / 2.0f + 0.0f;
-    t.c = discrete ? a_p * fac_p + 0.0f : a_p * fac_p / 2.0f + fac_p / 2.0f + 0.0f;
+    t.a = (act.a * q.dec_mv + q.dec_cv) + q.dec_cv2;
+    t.b = act.b * q.dec_mh + q.dec_ch;
+    t.c = act.c * q.dec_mp + q.dec_cp;
     return t;
 }
 
 // ---- first half of AtcGym.step: timestep, rate limits towards the targets, kinematics, MVA floor ---------------------
-__device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const float* __restrict__ grid,
-                                           const atc_params_t& p, const StepDerived& q, const LaneIds& d, float tv,
-                                           float th, float tp, LaneState& ls, EnvState& es, bool repeated) {
+__device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const QRates& q, const QGrid& qg,
+                                           const LaneIds& d, float tv, float th, float tp, LaneState& ls, EnvState& es,
+                                           bool repeated) {
     Mid m;
     Aircraft& a = ls.a;
-    const GridHdr gh = grid_header(grid);   // requested here, needed after the kinematics
-    const float dt = p.dt;
     // `repeated` (wave-uniform): this step repeats the previous step's actions and no env of the wavefront was reset in
     // between — last_action == the accepted targets, so nothing can be counted or changed (see ATC_M_ACTIONS_HELD)
     const bool book = !repeated;
@@ -481,17 +595,18 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ K, const fl
     }
     // ---- Airplane.step (model.py:122-129): rot_matrix(phi) . [0, (v/3600) dt] ----------------------------------------
     {
-        const float dist = active ? div3600(a.v) * dt : 0.0f;
+        // the displacement in grid counts: (sin * (v/3600 * dt)) * 2^k == sin * (v/3600 * (dt * 2^k)) — scaling by a power of
+        // two is exact, so the host folds it into the time step (QRates.dts)
+        const float dist = active ? div3600(a.v) * q.dts : 0.0f;
         float sn, cs;
         if (ATC_ABLATE & 32) { sn = 0.6f; cs = 0.8f; } else sincos_deg(a.phi, &sn, &cs);
-        a.x = pos_advance(K, a.x, sn * dist);
-        a.y = pos_advance(K, a.y, cs * dist);
+        a.x = pos_advance_counts(a.x, sn * dist);
+        a.y = pos_advance_counts(a.y, cs * dist);
     }
-    m.x32 = (float)fma((double)a.x, q.pos_inv, q.pos_x0);   // atc::pos_to_real with the widened constants
-    m.y32 = (float)fma((double)a.y, q.pos_inv, q.pos_y0);
+    m.x32 = pos_to_real(q.pos_neg_k, qg.pos_x0, a.x);
+    m.y32 = pos_to_real(q.pos_neg_k, qg.pos_y0, a.y);
     // MVA floor, first half: only ISSUE the lookup-cell gather here; nothing until the override chain needs its result
-    m.cell = mva_cell_load(grid, gh, m.x32, m.y32);
-    m.gh = gh;
+    m.cell = mva_cell_load(grid, qg.gh, m.x32, m.y32);
     m.active = active;
     m.r = r;
     m.fl = fl;
@@ -522,12 +637,18 @@ __device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, con
 }
 
 // ---- second half: separation scan, win/timeout, observation, shaping, reductions, outputs, auto-reset --------------
+// A by-value kernel argument group where it is needed: the single-step kernel names the argument (the compiler places its
+// kernarg load), a multi-step launch re-reads it from the kernarg segment through this step's opaque zero — a scalar load
+// inside the step instead of registers held (and spilled to vector-register lanes) across the whole step loop.
+#define QGET(member) (ONE ? q.member : kernarg_reread<decltype(q.member)>(offsetof(StepArgs, q) + offsetof(StepDerived, member), zk))
+
 template <int W, bool FULL, bool ONE>
 __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const float* __restrict__ grid,
-                                            const atc_params_t& p, const StepDerived& q, int N, const LaneIds& d,
+                                            const atc_params_t& p, const StepDerived& q, int zk, int N, const LaneIds& d,
                                             const Mid& m, LaneState& ls,
                                             EnvState& es, const StepOut& so, int32_t* stp, float4* pos, float* obs_stage,
                                             const float* act_next, Float3& a_next) {
+    const QScan qs = QGET(s);
     Aircraft& a = ls.a;
     const bool active = m.active;
     const float x32 = m.x32, y32 = m.y32;
@@ -548,7 +669,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     int pi = 0;
     if (!kResolveAfterScan) {
         float hgt = 0.0f;
-        pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, m.gh, m.cell, x32, y32, &hgt);
+        pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt);
         mva = pi >= 0 ? hgt : 0.0f;
         fl |= noise_areas(K, grid, m.cell, x32, y32, a.h);
     }
@@ -560,11 +681,15 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     float margin = 1e30f;  // min over partners of max(d^2 - sep^2, |dh| - sep_ft): conflict iff negative
     if (W > 1 && !(ATC_ABLATE & 2)) {
         const float xs = active ? x32 : 1e18f;
-        const float sep2 = q.sep2;
-        if (W == 16) {
-            PairScan16<1, FULL>::run(xs, y32, a.h, sep2, p.sep_ft, min_d2, margin);
+        const float sep2 = qs.sep2;
+        if (W == 16 && !FULL) {
+            int conf = 0;
+            NearScan16<1>::run(xs, y32, a.h, sep2, qs.sep_ft, conf);
+            margin = conf ? -1.0f : margin;
+        } else if (W == 16) {
+            PairScan16<1, FULL>::run(xs, y32, a.h, sep2, qs.sep_ft, min_d2, margin);
         } else if (W <= 8) {
-            pair_scan_xor<W, FULL>(xs, y32, a.h, sep2, p.sep_ft, min_d2, margin);
+            pair_scan_xor<W, FULL>(xs, y32, a.h, sep2, qs.sep_ft, min_d2, margin);
         } else {
             // W = 32 / 64: partners come from LDS and every unordered pair is evaluated ONCE — lane k visits the partners
             // k + 1 .. k + W/2 (mod W) of its group (the pair at distance W/2 is visited from both ends, harmless).  The result
@@ -599,7 +724,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
             // acc = rot1(acc | mask_d) — so every distance costs one rotation by ONE (constant shifts) instead of one by d.
             uint64_t first = 0, acc = 0;
             const v2f xs2 = {xs, xs}, ys2 = {y32, y32}, hs2 = {a.h, a.h};
-            const float sep_ft = p.sep_ft;
+            const float sep_ft = qs.sep_ft;
 #pragma unroll 1   // (fully unrolled, the 2 H compare masks stay live together: 140-220 spilled SGPRs)
             for (int d0 = H - U + 1; d0 >= 1; d0 -= U) {
                 v2f qx[U / 2], qy[U / 2], qh[U / 2];
@@ -651,7 +776,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     {
         if (kResolveAfterScan) {
             float hgt = 0.0f;
-            pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, m.gh, m.cell, x32, y32, &hgt);
+            pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt);
             mva = pi >= 0 ? hgt : 0.0f;                // atc_gym.py:161: mva = 0 outside
             fl |= noise_areas(K, grid, m.cell, x32, y32, a.h);
         }
@@ -661,19 +786,19 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     }
     {   // conflict override comes after the MVA overrides in the chain
         const bool conflict = margin < 0.0f;
-        r = conflict ? p.conflict_reward : r;
+        r = conflict ? qs.conflict_reward : r;
         fl |= conflict ? (uint32_t)ATC_F_CONFLICT : 0u;
     }
 
     // ---- win / timeout overrides (atc_gym.py:163-173) -------------------------------------------------------------------
-    if (!(ATC_ABLATE & 4) && inside_corridor(K, x32, y32, a.h, a.phi)) {
-        int bonus = (p.timestep_limit - es.t) * 5;
+    if (!(ATC_ABLATE & 4) && inside_corridor(K, qs.tri_bbox, x32, y32, a.h, a.phi)) {
+        int bonus = (qs.timestep_limit - es.t) * 5;
         bonus = bonus < 0 ? 0 : bonus;
         r = (float)(10000 + bonus);
         fl |= ATC_F_WON;
     }
     {
-        const bool timeout = es.t > p.timestep_limit;
+        const bool timeout = es.t > qs.timestep_limit;
         r = timeout ? -200.0f : r;
         fl |= timeout ? (uint32_t)ATC_F_TIMEOUT : 0u;
     }
@@ -683,18 +808,17 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     float zraw[ATC_OBS_DIM];   // FULL only: raw observation (zeros for handed-over aircraft)
     {
         Obs ob;
+        const ObsConst oc = QGET(oc);
         if (ATC_ABLATE & 8) {
 #pragma unroll
             for (int c = 0; c < ATC_OBS_DIM; ++c) ob.o[c] = x32;
             ob.d_faf = ob.phi_rel_faf = ob.on_gp = y32;
         } else {
-            ob = get_state(K, a.x, a.y, x32, y32, a.h, a.phi, a.v, mva);
+            ob = get_state(oc, a.x, a.y, x32, y32, a.h, a.phi, a.v, mva);
         }
         if ((p.mode & ATC_M_REWARD_SHAPING) && !(ATC_ABLATE & 8)) {
-            const Shaping sh = shaping_rewards(K, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp);
-            r += sh.pos;
-            r += sh.ang;
-            r += sh.gs;
+            // r += pos; r += ang; r += gs (atc_gym.py:179-185) as one fma of the factored sum (value-only, within 1e-5)
+            r += shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
         }
         // extension (README.md:62): noise-abatement areas — which ones the aircraft is in was decided next to the MVA lookup
         // (bits 16.. of fl); the penalties are subtracted here, after the shaping terms, in area order.
@@ -710,8 +834,9 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
             if (so.raw_obs && d.lane_valid) store_obs(at<float>(so.raw_obs, times40(i)), zraw);
         }
         if (p.mode & ATC_M_NORMALIZE) {  // atc_gym.py:187-189: (s - min - max/2) / (max/2) as one fma
+            const QNorm qn = QGET(n);
 #pragma unroll
-            for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = fmaf(ob.o[c], K[ATC_C_NORM_A + c], K[ATC_C_NORM_B + c]);
+            for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = fmaf(ob.o[c], qn.a[c], qn.b[c]);
         } else {
 #pragma unroll
             for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = ob.o[c];
@@ -790,7 +915,9 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
             if (FULL && so.term_obs) store_obs(at<float>(so.term_obs, times40(i)), o);
             a = spawn(K, p, e, k, episode);
             ls.v_changed = true;
-            const Obs ob = get_state(K, a.x, a.y, pos_to_real(K, 0, a.x), pos_to_real(K, 1, a.y), a.h, a.phi, a.v, 0.0f);
+            const QGrid qg = QGET(g);
+            const int neg_k = QGET(r.pos_neg_k);
+            const Obs ob = get_state(QGET(oc), a.x, a.y, pos_to_real(neg_k, qg.pos_x0, a.x), pos_to_real(neg_k, qg.pos_y0, a.y), a.h, a.phi, a.v, 0.0f);
 #pragma unroll
             for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = ob.o[c];
         }
@@ -862,35 +989,6 @@ __device__ __forceinline__ void store_env_state(const atc_state_t& st, const Lan
     }
 }
 
-// The kernel's argument list as a struct: the kernarg segment is laid out by the same rules, so offsetof() names where an
-// argument lives.  Multi-step launches RE-READ their by-value arguments (output pointers, parameters, derived constants, the state
-// pointers needed again after the loop) from the kernarg segment inside the step instead of keeping ~60 SGPRs of them alive
-// across the loop: the allocator spills those to VGPR lanes and every use becomes a v_readlane — VALU work in a launch that is
-// bound by VALU issue — whereas a kernarg re-read is a scalar load.  The offset goes through an opaque zero, or the (invariant)
-// loads would be hoisted out of the loop again.
-struct StepArgs {
-    const float* blob;
-    int off_grid, B, N, T, hold;
-    atc_state_t st;
-    const float* actions;
-    atc_out_t out;
-    atc_params_t p;
-    StepDerived q;
-    InlineAction ia;
-};
-template <typename T>
-__device__ __forceinline__ T kernarg_reread(size_t byte_off, int opaque_zero) {
-    T v;
-#if __HIP_DEVICE_COMPILE__   // (the host pass only parses this body; the builtin exists for the device target)
-    typedef __attribute__((address_space(4))) const char* karg_ptr;
-    karg_ptr base = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + byte_off + opaque_zero;
-    __builtin_memcpy(&v, base, sizeof(T));
-#else
-    __builtin_memset(&v, 0, sizeof(T));
-#endif
-    return v;
-}
-
 template <int W, bool FULL, bool ONE>  // ONE: single-step launch (T == 1)
 __global__ void __launch_bounds__(kBlock, (ONE ? ATC_MIN_WAVES : ((FULL || W < 8 || W >= 32) ? ATC_MIN_WAVES_LOOP - 1 : ATC_MIN_WAVES_LOOP)))
 k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int hold, atc_state_t st,
@@ -952,16 +1050,14 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         const float* Kl = K;
         const float* gl = grid;
         atc_params_t pl = p;
-        StepDerived ql = q;
         atc_out_t outl = out;
         int32_t* stats_l = st.stats;
         constexpr int kReread = ONE ? 0 : ATC_LOOP_REREAD_ARGS(W);   // measured per width: profiles/r02_experiments.txt
+        int zk = 0;   // this step's opaque zero: kernarg re-reads that depend on it cannot be hoisted out of the step loop
         if (!ONE) {   // (also makes the mode word's flag tests scalar compares inside the step, not
-            int zk;                           // 64-bit lane masks kept — and spilled — across the loop)
-            asm volatile("s_mov_b32 %0, 0" : "=s"(zk));
+            asm volatile("s_mov_b32 %0, 0" : "=s"(zk));   // 64-bit lane masks kept — and spilled — across the loop)
             if (kReread & 1) pl = kernarg_reread<atc_params_t>(offsetof(StepArgs, p), zk);
             else pl.mode += (uint32_t)zk;
-            if (kReread & 2) ql = kernarg_reread<StepDerived>(offsetof(StepArgs, q), zk);
             if (kReread & 4) outl = kernarg_reread<atc_out_t>(offsetof(StepArgs, out), zk);
             if (kReread & 8) stats_l = kernarg_reread<int32_t*>(offsetof(StepArgs, st) + offsetof(atc_state_t, stats), zk);
         }
@@ -985,7 +1081,8 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         };
         if (!ONE && step == 0) act = *at<Float3>(act_t, times12(dl.i));
         // (decoding a held block once per block instead of once per step was measured slower: 15.7 vs 15.1 us per step)
-        const Float3 tg = decode_targets(pl, act);
+        const QRates qr = QGET(r);
+        const Float3 tg = decode_targets(qr, act);
         if (ONE && !la_live) {   // held block: the record equals the accepted targets (components that are refused are not compared)
             ls.la_v = tg.a;
             ls.la_h = tg.b;
@@ -994,7 +1091,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         // multi-step launches know structurally which steps repeat an action block
         const bool repeated = ONE ? (same_actions && __ballot(la_live) == 0ull)
                                   : (ATC_LOOP_SKIP_BOOK && held > 0 && __ballot(es.t == 0) == 0ull);
-        const Mid m = step_part_a(Kl, gl, pl, ql, dl, tg.a, tg.b, tg.c, ls, es, repeated);
+        const Mid m = step_part_a(gl, qr, QGET(g), dl, tg.a, tg.b, tg.c, ls, es, repeated);
         ATC_STAMP(1);
         Float3 nxt = act;
         const float* act_next = nullptr;   // the next block is fetched during the last step of the current one
@@ -1003,7 +1100,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             act_t += (size_t)BN * 3;
             if (step + 1 < n_steps) act_next = act_t;
         }
-        step_part_b<W, FULL, ONE>(Kl, gl, pl, ql, N, dl, m, ls, es, so, stats_l, pos, obs_stage, act_next, nxt);
+        step_part_b<W, FULL, ONE>(Kl, gl, pl, q, zk, N, dl, m, ls, es, so, stats_l, pos, obs_stage, act_next, nxt);
         act = nxt;
         ATC_STAMP(6);
     }
@@ -1038,7 +1135,7 @@ k_reset(const float* __restrict__ blob, int B, int N, atc_state_t st, const uint
         // atc_gym.py:86: last_action = [0,0,0] once, in __init__ — never on reset (quirk Q7)
         if (first) st.last_act[3 * (size_t)i] = st.last_act[3 * (size_t)i + 1] = st.last_act[3 * (size_t)i + 2] = 0.0f;
         if (obs) {  // mva = 0, atc_gym.py:351
-            const Obs ob = get_state(blob, a.x, a.y, pos_to_real(blob, 0, a.x), pos_to_real(blob, 1, a.y), a.h, a.phi, a.v, 0.0f);
+            const Obs ob = get_state(obs_const(blob), a.x, a.y, pos_to_real(blob, 0, a.x), pos_to_real(blob, 1, a.y), a.h, a.phi, a.v, 0.0f);
             store_obs(obs + (size_t)i * ATC_OBS_DIM, ob.o);
         }
     }
@@ -1052,7 +1149,7 @@ k_observe(const float* __restrict__ blob, int B, int N, atc_state_t st, const ui
         const int e = (int)(i / (uint32_t)N);
         if (mask && !mask[e]) continue;
         const int4 ps = reinterpret_cast<const int4*>(st.pos_hp)[i];
-        const Obs ob = get_state(blob, ps.x, ps.y, pos_to_real(blob, 0, ps.x), pos_to_real(blob, 1, ps.y),
+        const Obs ob = get_state(obs_const(blob), ps.x, ps.y, pos_to_real(blob, 0, ps.x), pos_to_real(blob, 1, ps.y),
                                  __int_as_float(ps.z), __int_as_float(ps.w), st.v[i], 0.0f);
         store_obs(obs + (size_t)i * ATC_OBS_DIM, ob.o);
     }
@@ -1102,14 +1199,14 @@ k_query_corridor(const float* __restrict__ blob, int n, const float* __restrict_
                  uint8_t* __restrict__ out) {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
         out[i] = angle_only ? inside_corridor_angle(blob, x[i], y[i], phi[i])
-                            : inside_corridor(blob, x[i], y[i], h[i], phi[i]);
+                            : inside_corridor(blob, tri_bbox(blob), x[i], y[i], h[i], phi[i]);
 }
 __global__ void __launch_bounds__(kBlock)
 k_query_shaping(const float* __restrict__ blob, int n, const float* __restrict__ d_faf,
                 const float* __restrict__ phi_rel_faf, const float* __restrict__ phi_plane, const float* __restrict__ h,
                 const float* __restrict__ on_gp, float* __restrict__ out3) {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const Shaping s = shaping_rewards(blob, d_faf[i], phi_rel_faf[i], relative_angle(blob[ATC_C_PHI_TO_RWY], phi_plane[i]),
+        const Shaping s = shaping_rewards(obs_const(blob), d_faf[i], phi_rel_faf[i], relative_angle(blob[ATC_C_PHI_TO_RWY], phi_plane[i]),
                                           h[i], on_gp[i]);
         out3[3 * i + 0] = s.pos;
         out3[3 * i + 1] = s.ang;
@@ -1206,6 +1303,20 @@ int atc_scenario_create(const float* blob_host, size_t n_words, int device, atc_
         return fail_arg("not a scenario blob of this ABI version");
     if ((int)blob_host[ATC_H_N_MVA] > 32) return fail_arg("at most 32 MVA polygons");
     if ((int)blob_host[ATC_H_N_NOISE] > 16) return fail_arg("at most 16 noise-abatement areas");
+    if (const int og = (int)blob_host[ATC_H_OFF_GRID]) {   // the kernel clamps cell indices into the grid's outermost ring
+        if ((size_t)og + ATC_G_HDR > n_words) return fail_arg("lookup grid offset beyond the blob");
+        const float* g = blob_host + og;
+        const long nx = (long)g[ATC_G_NX], ny = (long)g[ATC_G_NY];
+        if (nx < 3 || ny < 3 || nx >= (1 << 20) || ny >= (1 << 20) || (size_t)og + ATC_G_HDR + 2 * (size_t)nx * ny > n_words)
+            return fail_arg("lookup grid dimensions");
+        const float* c = g + ATC_G_HDR;
+        for (long i = 0; i < nx; ++i)
+            if (c[2 * i] != 0.0f || c[2 * i + 1] != 0.0f || c[2 * ((ny - 1) * nx + i)] != 0.0f || c[2 * ((ny - 1) * nx + i) + 1] != 0.0f)
+                return fail_arg("the outermost ring of lookup cells must be clean and outside the airspace");
+        for (long j = 0; j < ny; ++j)
+            if (c[2 * j * nx] != 0.0f || c[2 * j * nx + 1] != 0.0f || c[2 * (j * nx + nx - 1)] != 0.0f || c[2 * (j * nx + nx - 1) + 1] != 0.0f)
+                return fail_arg("the outermost ring of lookup cells must be clean and outside the airspace");
+    }
     {   // compiled-in aircraft constants (csrc/atc_device.h) must match the blob
         const float want[] = {kVMin, kVMax, kHMin, kHMax, kAMin, kAMax, kHDotMin, kHDotMax, kPhiDotMin, kPhiDotMax, kVInit};
         for (int c = 0; c < 11; ++c)
@@ -1218,9 +1329,9 @@ int atc_scenario_create(const float* blob_host, size_t n_words, int device, atc_
     atc_scenario* s = new atc_scenario();
     s->n_words = (int)n_words;
     s->off_grid = (int)blob_host[ATC_H_OFF_GRID];
-    s->pos_inv = blob_host[ATC_C_POS_INV];
-    s->pos_x0 = blob_host[ATC_C_POS_X0];
-    s->pos_y0 = blob_host[ATC_C_POS_Y0];
+    memcpy(s->consts, blob_host, sizeof s->consts);
+    memset(s->ghdr, 0, sizeof s->ghdr);
+    if (s->off_grid) memcpy(s->ghdr, blob_host + s->off_grid, sizeof s->ghdr);
     s->device = device;
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, device);

@@ -138,36 +138,194 @@ def parity_gate(scn, N, grid_cell, sep_nm, device, held_hint=False):
         raise RuntimeError("parity gate (a): obs %.2e / reward %.2e beyond 1e-5" % (worst_o, worst_r))
     out["reference_fixture"] = {"fixture": "tests/golden/g2_scripted.npz", "episodes": len(eps), "steps": n_steps,
                                 "integer_outputs_exact": True, "max_obs_err": worst_o, "max_rel_reward_err": worst_r}
-    # (b) this workload vs the fp32 oracle
-    B, T = 256, 40
-    comp = scenarios.compile_scenario(scn, grid_cell=grid_cell)
+    out["fp32_oracle"] = oracle_gate(scn, N, grid_cell, sep_nm, device, held_hint)
+    return out
+
+
+def oracle_gate(scn, N, grid_cell, sep_nm, device, held_hint=False, B=256, T=40):
+    """Single launches of a workload (its first B envs, T steps, the launch mode of the timed loop: held steps carry the hint)
+    against the fp32 oracle; raises on any difference beyond the parity bar."""
+    import numpy as np
+    import torch
+    from atc_hip.vec_env import AtcVecEnv
     env = AtcVecEnv(B, N, scenario=scn, device=device, auto_reset=True, seed=0, grid_cell=grid_cell, sep_nm=sep_nm)
-    orc = O.OracleEnv(comp, B, N, O.make_params(auto_reset=True, seed=0, random_entry=bool(env.params.mode & 16),
-                                                sep_nm=sep_nm), np.float32)
+    orc = _oracle_for(env, scn, N, grid_cell, sep_nm)
     g = torch.Generator(device="cpu").manual_seed(99)
-    worst_o = worst_r = 0.0
+    worst = [0.0, 0.0]
     for t in range(T):
         if t % HOLD == 0:
             a = (torch.rand((B, N, 3), generator=g) * 2 - 1).numpy()
-        obs, rew, done, info = env.step(a, held=held_hint and t % HOLD != 0)   # the launch mode of the timed loop
+        obs, rew, done, info = env.step(a, held=held_hint and t % HOLD != 0)
         orc.step(a)
-        if not (np.array_equal(info["flags"].cpu().numpy().astype(np.uint16), orc.flags)
-                and np.array_equal(done.cpu().numpy(), orc.done)
-                and np.array_equal(env.actions_taken.cpu().numpy(), orc.actions_taken)):
-            raise RuntimeError("parity gate (b): flags / done / actions_taken differ from the fp32 oracle at step %d" % t)
-        o = obs.cpu().numpy().reshape(B, N, 10)
-        worst_o = max(worst_o, float((np.abs(o - orc.obs) / np.maximum(1.0, np.abs(orc.obs))).max()))
-        worst_r = max(worst_r, float((np.abs(rew.cpu().numpy() - orc.reward) / np.maximum(1.0, np.abs(orc.reward))).max()))
-    env_last_act = env.last_act.cpu().numpy().reshape(B * N, 3)
+        _compare("single steps", t, obs, rew, done, info["flags"], orc, B, N, worst)
+    rec = _finish_gate("single steps", env, orc, worst, {"envs": B, "aircraft": N, "steps": T, "held_hint": bool(held_hint),
+                                                          "actions_taken_exact": True, "last_action_exact": True})
     env.close()
-    if worst_o > 1e-5 or worst_r > 1e-5:
-        raise RuntimeError("parity gate (b): obs %.2e / reward %.2e beyond 1e-5" % (worst_o, worst_r))
-    if not np.array_equal(env_last_act, orc.last_act.T.reshape(B * N, 3)):
-        raise RuntimeError("parity gate (b): last_action records differ from the fp32 oracle")
-    out["fp32_oracle"] = {"envs": B, "aircraft": N, "steps": T, "flags_done_exact": True, "actions_taken_exact": True,
-                          "last_action_exact": True, "held_hint": bool(held_hint), "max_rel_obs_err": worst_o,
-                          "max_rel_reward_err": worst_r}
+    return rec
+
+
+def _oracle_for(env, scn, N, grid_cell, sep_nm, seed=0):
+    """The fp32 CPU oracle configured like `env` (checker only)."""
+    import numpy as np
+    from envs.atc import scenarios
+    from oracle import oracle as O
+    comp = scenarios.compile_scenario(scn, grid_cell=grid_cell)
+    return O.OracleEnv(comp, env.B, N, O.make_params(auto_reset=True, seed=seed, random_entry=bool(env.params.mode & 16),
+                                                     sep_nm=sep_nm), np.float32)
+
+
+def _compare(tag, t, obs, rew, done, flags, orc, B, N, worst):
+    import numpy as np
+    if not (np.array_equal(flags.cpu().numpy().astype(np.uint16).reshape(B, N), orc.flags)
+            and np.array_equal(done.cpu().numpy(), orc.done)):
+        raise RuntimeError("parity gate (%s): flags / done differ from the fp32 oracle at step %d" % (tag, t))
+    o = obs.cpu().numpy().reshape(B, N, 10)
+    worst[0] = max(worst[0], float((np.abs(o - orc.obs) / np.maximum(1.0, np.abs(orc.obs))).max()))
+    worst[1] = max(worst[1], float((np.abs(rew.cpu().numpy() - orc.reward) / np.maximum(1.0, np.abs(orc.reward))).max()))
+
+
+def _finish_gate(tag, env, orc, worst, extra):
+    import numpy as np
+    if worst[0] > 1e-5 or worst[1] > 1e-5:
+        raise RuntimeError("parity gate (%s): obs %.2e / reward %.2e beyond 1e-5" % (tag, worst[0], worst[1]))
+    if not (np.array_equal(env.actions_taken.cpu().numpy(), orc.actions_taken)
+            and np.array_equal(env.last_act.cpu().numpy().reshape(-1, 3), orc.last_act.T.reshape(-1, 3))
+            and np.array_equal(env.pos_hp[:, 0].cpu().numpy(), orc.px) and np.array_equal(env.pos_hp[:, 1].cpu().numpy(), orc.py)):
+        raise RuntimeError("parity gate (%s): actions_taken / last_action / positions differ from the fp32 oracle" % tag)
+    out = {"flags_done_exact": True, "state_and_counters_exact": True, "max_rel_obs_err": worst[0], "max_rel_reward_err": worst[1]}
+    out.update(extra)
     return out
+
+
+def rollout_gate(scn, N, grid_cell, sep_nm, device, T=HOLD, hold=HOLD, launches=2, B=256):
+    """The multi-step entry (atc_rollout_hold, `launches` launches of T steps, one action block per `hold` steps) on the first
+    B envs of the workload against the fp32 oracle stepped once per step: raises unless flags / done are exact, obs / rewards
+    within 1e-5 and the state, actions_taken and last-action records identical afterwards."""
+    import torch
+    from atc_hip.vec_env import AtcVecEnv
+    env = AtcVecEnv(B, N, scenario=scn, device=device, auto_reset=True, seed=0, grid_cell=grid_cell, sep_nm=sep_nm)
+    orc = _oracle_for(env, scn, N, grid_cell, sep_nm)
+    g = torch.Generator(device="cpu").manual_seed(77)
+    worst = [0.0, 0.0]
+    for j in range(launches):
+        blocks = torch.rand((T // hold, B, N, 3), generator=g) * 2 - 1
+        out = env.rollout(blocks, hold=hold)
+        for t in range(T):
+            orc.step(blocks[t // hold].numpy())
+            _compare("rollout", j * T + t, out["obs"][t], out["reward"][t], out["done"][t], out["flags"][t], orc, B, N, worst)
+    rec = _finish_gate("rollout", env, orc, worst, {"entry": "atc_rollout_hold", "envs": B, "aircraft": N, "T": T, "hold": hold,
+                                                     "launches": launches})
+    env.close()
+    return rec
+
+
+def multi_stream_gate(scn, N, grid_cell, sep_nm, device, held_hint, steps=2 * HOLD, B_half=128):
+    """Two independent sub-batches stepped through atc_step_multi on two HIP streams (the launch form of the `two_streams`
+    record), each against its own fp32 oracle."""
+    import torch
+    from atc_hip.vec_env import AtcVecEnv, make_multi_launcher
+    dev = torch.device("cuda", device)
+    halves = [AtcVecEnv(B_half, N, scenario=scn, device=device, auto_reset=True, seed=7919 * (s + 1), grid_cell=grid_cell,
+                        sep_nm=sep_nm) for s in range(2)]
+    orcs = [_oracle_for(e, scn, N, grid_cell, sep_nm, seed=7919 * (s + 1)) for s, e in enumerate(halves)]
+    qs = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    g = torch.Generator(device="cpu").manual_seed(78)
+    worst = [0.0, 0.0]
+    for t in range(steps):
+        if t % HOLD == 0:
+            a = torch.rand((2, B_half, N, 3), generator=g) * 2 - 1
+            a_dev = a.to(dev)
+            torch.cuda.synchronize(dev)
+            first = make_multi_launcher(halves, [a_dev[0], a_dev[1]], qs)
+            rest = make_multi_launcher(halves, [a_dev[0], a_dev[1]], qs, held=True) if held_hint else first
+        (rest if t % HOLD else first)()
+        for q in qs:
+            q.synchronize()
+        for s, (e, o) in enumerate(zip(halves, orcs)):
+            o.step(a[s].numpy())
+            _compare("two streams", t, e.obs, e.reward, e.done, e.flags, o, B_half, N, worst)
+    recs = [_finish_gate("two streams", e, o, worst, {}) for e, o in zip(halves, orcs)]
+    for e in halves:
+        e.close()
+    rec = recs[0]
+    rec.update({"entry": "atc_step_multi", "sub_batches": 2, "envs_per_sub_batch": B_half, "aircraft": N, "steps": steps,
+                "held_hint": bool(held_hint)})
+    return rec
+
+
+def traffic_entry(B, N, rollout, held_hint, streams=1):
+    """HBM bytes per launch of this workload from the committed PMC passes (profiles/pmc_traffic.json: separate rocprofv3 --pmc
+    runs, FETCH_SIZE / WRITE_SIZE with the gfx950 corrections) — counters cannot be read from inside the process.  Entries are
+    keyed by the ABI version of the library they were measured on: a kernel change cannot silently keep an old figure."""
+    from atc_hip import layout as L
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tpath) or streams != 1:
+        return None, None
+    try:
+        for tj in json.load(open(tpath))["workloads"]:
+            if (tj.get("abi") == L.ABI_VERSION and tj["envs"] == B and tj["aircraft"] == N and tj["rollout"] == (rollout or 0)
+                    and bool(tj.get("held_hint", False)) == bool(held_hint)):
+                return tj["hbm_bytes_per_launch"], tj["source"]
+    except Exception:
+        pass
+    return None, None
+
+
+def side_config(name, B, N, scn, grid_cell, sep_nm, device, held_hint, n_single=2000, n_fused=100):
+    """One of BASELINE.json's other single-GPU configurations as a side record of the default line: the launch mode of the
+    headline loop (one atc_step per step, a new action tensor every HOLD steps, the held-action hint in between) and the same
+    envs with HOLD steps fused per launch — each parity-gated on its own first 256 envs before it is timed."""
+    import torch
+    from atc_hip.vec_env import AtcVecEnv
+    dev = torch.device("cuda", device)
+    gate = {"single_steps": oracle_gate(scn, N, grid_cell, sep_nm, device, held_hint),
+            "fused": rollout_gate(scn, N, grid_cell, sep_nm, device)}
+    env = AtcVecEnv(B, N, scenario=scn, device=device, auto_reset=True, seed=11, grid_cell=grid_cell, sep_nm=sep_nm)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    ring = [torch.rand((B, N, 3), generator=g, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(8)]
+    first = [env.make_launcher(a) for a in ring]
+    rest = [env.make_launcher(a, held=True) for a in ring] if held_hint else first
+
+    def run(n, t0=0):
+        for t in range(t0, t0 + n):
+            (rest if t % HOLD else first)[(t // HOLD) % len(ring)]()
+    run(3000)
+    torch.cuda.synchronize(dev)
+    blocks = []
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run(n_single)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        blocks.append(e0.elapsed_time(e1) * 1e3 / n_single)
+    us = sorted(blocks)[1]
+    ro = {"obs": torch.empty((HOLD, B, N * 10), dtype=torch.float32, device=dev),
+          "reward": torch.empty((HOLD, B), dtype=torch.float32, device=dev),
+          "done": torch.empty((HOLD, B), dtype=torch.uint8, device=dev),
+          "flags": torch.empty((HOLD, B, N), dtype=torch.int16, device=dev)}
+    for j in range(30):
+        env.rollout(ring[j % len(ring)][None], out=ro, hold=HOLD)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for j in range(n_fused):
+        env.rollout(ring[j % len(ring)][None], out=ro, hold=HOLD)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    usf = e0.elapsed_time(e1) * 1e3 / (n_fused * HOLD)
+    env.close()
+    b1, bf = algorithmic_bytes_per_env_step(N), algorithmic_bytes_per_env_step(N, HOLD, HOLD)
+    tr1, src1 = traffic_entry(B, N, 0, held_hint)
+    trf, srcf = traffic_entry(B, N, HOLD, False)
+    return {"config": name, "envs": B, "aircraft": N, "sector": type(scn).__name__, "parity_gate": gate,
+            "single_steps": {"steps": n_single, "us_per_step": us, "env_steps_per_s": B / (us * 1e-6),
+                             "algorithmic_bytes_per_env_step": b1, "hbm_frac": b1 * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": tr1, "traffic_source": src1, "timed_blocks_us_per_step": blocks},
+            "fused_rollout": {"entry": "atc_rollout_hold", "T": HOLD, "hold": HOLD, "launches": n_fused, "us_per_step": usf,
+                              "env_steps_per_s": B / (usf * 1e-6), "algorithmic_bytes_per_env_step": bf,
+                              "hbm_frac": bf * B / (usf * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": trf, "traffic_source": srcf}}
 
 
 def single_env_protocol(n_steps=100000):
@@ -213,6 +371,10 @@ def main():
                     "separate HIP streams (no join between steps): launch ramp / tail of one overlaps the others")
     ap.add_argument("--lib", default=None, help="developer knob: path of a libatcstep.so build variant to A/B (default: the "
                     "in-tree build)")
+    ap.add_argument("--no-baseline-configs", action="store_true", help="skip the side records of BASELINE.json's other single-GPU "
+                    "configurations (65 536 x 1, 8 192 x 16, 4 096 x 64 + noise areas)")
+    ap.add_argument("--no-collective", action="store_true", help="N = 1 only: do not create the one-rank RCCL group that "
+                    "exercises the multi-GPU path's collective calls on this GPU (untimed)")
     ap.add_argument("--graph", action="store_true", help="replay the %d-step action-hold block as one captured HIP graph "
                     "(removes per-launch host overhead; matters for the small launch-bound configs)" % HOLD)
     args = ap.parse_args()
@@ -243,6 +405,16 @@ def main():
 
     rank, ws, local = D.init()
     assert ws == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (ws, args.gpus)
+    collective = {"world_size": ws, "backend": D.backend_name()}
+    if ws == 1 and not args.no_collective:
+        # One GPU: create a world of ONE rank on the real backend (RCCL) all the same, so that the exact calls of the multi-GPU
+        # path — init_process_group("nccl", device_id=...), all_gather_into_tensor / all_reduce on device tensors — run on
+        # this box; the collective is issued once, untimed, below.  A failure is recorded, never fatal at N = 1.
+        try:
+            D.init(force=True)
+            collective["backend"] = D.backend_name()
+        except Exception as exc:
+            collective["error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
     assert torch.cuda.is_available(), "bench.py needs the GPU (no CPU fallback)"
     if local >= torch.cuda.device_count():  # only when ATC_DIST_BACKEND=gloo lets several ranks share the one visible GPU
         assert torch.cuda.device_count() == 1, "LOCAL_RANK %d >= %d visible devices" % (local, torch.cuda.device_count())
@@ -349,8 +521,15 @@ def main():
     run(PREWARM - PREWARM % max(1, args.rollout, HOLD if args.graph else 1), 0)
     run(W, 0)
     torch.cuda.synchronize(dev)
-    D.all_gather_stats(*stats())  # untimed: creates the RCCL communicator / channels (N > 1)
+    warm = D.all_gather_stats(*stats(), force=True)  # untimed: creates the RCCL communicator / channels
     torch.cuda.synchronize(dev)
+    if ws == 1 and collective.get("backend") and "error" not in collective:
+        try:   # the one-rank group's collectives really ran: device tensors in, the same values out
+            collective.update({"forced_single_rank": True, "gathered_shape": list(warm[0].shape), "device_tensors": bool(warm[0].is_cuda),
+                               "matches_local": bool(torch.equal(warm[0][0], stats()[0])),
+                               "all_reduce_max": D.max_over_ranks(1.5, dev, force=True), "all_reduce_sum": D.sum_over_ranks(2.5, dev, force=True)})
+        except Exception as exc:
+            collective["error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
     # HIP events on the stream(s) the kernels are launched on (torch's current stream, or one per sub-batch)
     qs = streams if S > 1 else [torch.cuda.current_stream(dev)]
     blocks = []   # (wall seconds, HIP-event milliseconds) of each timed block of K steps, max over ranks
@@ -383,19 +562,7 @@ def main():
     bytes_launch = algorithmic_bytes_per_env_step(N, T, min(T, HOLD) if args.rollout else 1) * (B // S) * T
     # S > 1: launch_ms is the wall duration of ONE sub-batch launch while S - 1 others are in flight
     achieved = S * bytes_launch / (launch_ms * 1e-3) / 1e9
-    # HBM traffic per launch from the PMC passes of THIS workload (tools/pmc_profile.sh: separate rocprofv3 --pmc runs,
-    # FETCH_SIZE / WRITE_SIZE with the gfx950 corrections) — PMC counters cannot be read from inside the process, so the
-    # figure comes from the committed summary of those passes and is null for any other workload.
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            for tj in json.load(open(tpath))["workloads"]:
-                if (tj["envs"] == B and tj["aircraft"] == N and tj["rollout"] == (args.rollout or 0) and S == 1
-                        and bool(tj.get("held_hint", False)) == (held_launchers is not None)):
-                    traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
-        except Exception:
-            traffic = None
+    traffic, traffic_src = traffic_entry(B, N, args.rollout, held_launchers is not None, S)
 
     if rank == 0:
         line = {
@@ -418,6 +585,7 @@ def main():
                                              "promise that the block is repeated; results identical, last_action record skipped)"
                                              % (HOLD, HOLD)) if held_launchers is not None else None,
                        "prewarm_steps": PREWARM, "parity_gate": gate, "gathered_returns_shape": list(returns.shape),
+                       "collective": collective, "collective_backend": collective.get("backend"),
                        "rank_seeds": [int(v) for v in rank_seeds.reshape(-1).tolist()]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -431,6 +599,7 @@ def main():
             # the same envs with 20 steps fused per launch (atc_rollout_hold, the action held like in the timed loop): a
             # side record, not `value` — the headline stays one launch per step, what env.step() costs
             Tf = HOLD
+            fused_gate = None if args.no_parity_gate else rollout_gate(scn, N, args.grid_cell, args.sep_nm, local)   # raises if wrong
             ro = {"obs": torch.empty((Tf, B, N * 10), dtype=torch.float32, device=dev),
                   "reward": torch.empty((Tf, B), dtype=torch.float32, device=dev),
                   "done": torch.empty((Tf, B), dtype=torch.uint8, device=dev),
@@ -450,7 +619,8 @@ def main():
             line["config"]["fused_rollout"] = {"entry": "atc_rollout_hold", "T": Tf, "hold": Tf, "launches": n_l,
                                                "us_per_step": us, "env_steps_per_s": B / (us * 1e-6),
                                                "algorithmic_bytes_per_env_step": fb,
-                                               "hbm_frac": fb * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                                               "hbm_frac": fb * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                               "traffic": traffic_entry(B, N, Tf, False)[0], "parity_gate": fused_gate}
             del ro
             if held_launchers is not None:
                 # the same loop without the held-action promise (every launch reads the last-action record): a side record
@@ -473,6 +643,8 @@ def main():
                 # per step, no join between steps, so one sub-batch's launch floor overlaps the other's body): a side record too —
                 # `value` / `roofline` stay the single in-order launch whose rocprofv3 kernel duration can be compared
                 from atc_hip.vec_env import make_multi_launcher
+                ms_gate = None if args.no_parity_gate else multi_stream_gate(scn, N, args.grid_cell, args.sep_nm, local,
+                                                                             not args.no_held_hint)   # raises if wrong
                 halves = [AtcVecEnv(B // 2, N, scenario=scn, device=local, auto_reset=True, seed=7919 * (s + 1),
                                     grid_cell=args.grid_cell, sep_nm=args.sep_nm) for s in range(2)]
                 qs2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
@@ -496,9 +668,22 @@ def main():
                 us2 = (time.perf_counter() - t0) / n2 * 1e6
                 line["config"]["two_streams"] = {"entry": "atc_step_multi", "sub_batches": 2, "envs_per_sub_batch": B // 2, "steps": n2,
                                                  "us_per_step": us2, "env_steps_per_s": B / (us2 * 1e-6),
-                                                 "hbm_frac": algorithmic_bytes_per_env_step(N) * B / (us2 * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                                                 "hbm_frac": algorithmic_bytes_per_env_step(N) * B / (us2 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                 "parity_gate": ms_gate}
                 for e in halves:
                     e.close()
+        if (ws == 1 and not args.no_baseline_configs and not args.no_parity_gate and N == AIRCRAFT and B == ENVS_PER_GPU
+                and not args.rollout and S == 1 and graph is None):
+            # BASELINE.json's other single-GPU configurations, each gated on its own first 256 envs (side records: `value`
+            # stays the headline configuration)
+            hh = not args.no_held_hint
+            line["config"]["baseline_configs"] = [
+                side_config("C2: 65 536 envs x 1 aircraft (kinematics + MVA only)", 65536, 1, scenarios.LOWW(), args.grid_cell,
+                            args.sep_nm, local, hh),
+                side_config("C3: 8 192 envs x 16 aircraft", 8192, 16, scenarios.LOWW(random_entrypoints=True), args.grid_cell,
+                            args.sep_nm, local, hh),
+                side_config("C4: 4 096 envs x 64 aircraft, multi-polygon MVA + noise-abatement areas", 4096, 64,
+                            scenarios.LOWWDense(), args.grid_cell, args.sep_nm, local, hh)]
         if ws == 1 and not args.no_single_env:
             line["config"]["single_env"] = single_env_protocol()
         if ws == 1 and not args.no_cpu_baseline:
@@ -506,9 +691,7 @@ def main():
         print(json.dumps(line))
     for e in subs:
         e.close()
-    if ws > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    D.shutdown()
 
 
 if __name__ == "__main__":

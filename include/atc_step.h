@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ATC_ABI_VERSION 16
+#define ATC_ABI_VERSION 17
 
 /* ---------------------------------------------------------------------------------------------
  * Scenario blob: one flat array of 32-bit floats (device copy) compiled on the host from the sector
@@ -35,7 +35,7 @@ extern "C" {
  * envs/atc/atc_gym.py:45-58,88-110).  Integer fields are stored as exactly representable floats.
  * The float64 master (used by the f64 oracle) has the identical word layout.
  * ------------------------------------------------------------------------------------------- */
-#define ATC_BLOB_VERSION 1011.0f
+#define ATC_BLOB_VERSION 1012.0f
 enum {
     ATC_H_VERSION = 0,   /* ATC_BLOB_VERSION */
     ATC_H_NWORDS = 1,    /* total words */
@@ -99,6 +99,8 @@ enum { ATC_E_X = 0, ATC_E_Y = 1, ATC_E_PHI = 2, ATC_E_NLEV = 3, ATC_E_LEV0 = 4, 
  *                    c > 0  : dirty cell, code = n_records (< 64), v = first record: walk that many edge records
  *                    c <= 0 : clean cell, code = polygon + 1 and v = MVA height — every point has this answer;
  *                             code = 0: outside the airspace
+ *                    The OUTERMOST ring of cells is (0, 0) — clean, outside, no noise candidate: a point beyond the grid is
+ *                    answered by the border cell its clamped index names (atc_scenario_create refuses other grids).
  *   pool           : 8-word records, two 16-byte halves G | M (flags and folding rules: atc_hip/scenario.py:build_grid):
  *                    edge       G = p1x, p1y, p2x, p2y          M = min(p1y,p2y), max(p1y,p2y), polygon height, code
  *                    terminator G = polygon bounds x0,y0,x1,y1  M = 0, 0, polygon height, code

@@ -54,3 +54,62 @@ def test_shard_range_remainders():
     assert spans == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert D.shard_range(524288, 7, 8) == (458752, 524288)
     assert [t.shape[0] for t in D.all_gather_stats(torch.zeros(5))] == [1]
+
+
+def _worker_unequal(rank, ws, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "atc-reinforcement-learning_amd"))
+    from atc_hip import dist as D
+    D.init(backend="gloo")
+    try:
+        D.all_gather_stats(torch.zeros(8 + rank))   # rank 1 owns one env more: every rank must notice, none may hang
+        q.put((rank, "no error"))
+    except AssertionError as exc:
+        q.put((rank, str(exc)))
+    D.shutdown()
+
+
+@pytest.mark.timeout(120)
+def test_unequal_shards_raise_on_every_rank():
+    """the equal-shard guard has to be a decision all ranks take alike — here rank 0 and rank 1 hold different
+    shard sizes and both must raise (before: one could enter all_reduce while the other entered all_gather)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_unequal, args=(r, 2, 29631, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=90) for _ in range(2))
+    for p in procs:
+        p.join(30)
+    assert all("equally sized shards" in res[r] for r in (0, 1)), res
+
+
+def _worker_single(q):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        os.environ.pop(k, None)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "atc-reinforcement-learning_amd"))
+    from atc_hip import dist as D
+    assert D.backend_name() is None
+    plain = D.all_gather_stats(torch.arange(6.0))[0]          # no group: identity
+    D.init(backend="gloo", force=True)                          # a world of one rank, real backend
+    skipped = D.all_gather_stats(torch.arange(6.0))[0]         # group exists but world size 1: still the identity ...
+    forced = D.all_gather_stats(torch.arange(6.0), force=True)[0]   # ... unless the collective is asked for
+    q.put((D.backend_name(), plain.tolist(), skipped.tolist(), forced.tolist(), D.max_over_ranks(3.0, torch.device("cpu"), force=True),
+           D.sum_over_ranks(4.0, torch.device("cpu"), force=True)))
+    D.shutdown()
+
+
+@pytest.mark.timeout(120)
+def test_forced_collective_in_a_world_of_one():
+    """The code path bench.py and tests/test_rccl_single_rank.py take on a one-GPU box, here on gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_single, args=(q,))
+    p.start()
+    name, plain, skipped, forced, mx, sm = q.get(timeout=90)
+    p.join(30)
+    want = [[0.0, 1.0, 2.0, 3.0, 4.0, 5.0]]
+    assert name == "gloo" and plain == want and skipped == want and forced == want and mx == 3.0 and sm == 4.0

@@ -1,6 +1,6 @@
 """Randomised differential test of the HIP step path against the fp32 oracle: random batch shapes, aircraft counts,
 sectors, lookup-grid cells, modes (dt, discrete, shaping, normalisation, spawn, timeout limit, separation minimum),
-kernel variant (fast / full) and launch form (single steps / fused rollout).  ATC_FUZZ_CASES sets the number of cases
+kernel variant (fast / full) and launch form (single steps / fused rollout / fused rollout with held action blocks).  ATC_FUZZ_CASES sets the number of cases
 (default: a short pass), ATC_FUZZ_SEED the first seed; every case is reproducible from its seed
 (tests/fuzz_debug.py <seed> replays one and prints the first deviation with its context).
 
@@ -39,8 +39,13 @@ def _case(seed):
               shaping=bool(rng.integers(4) > 0), normalize=bool(rng.integers(4) > 0),
               sep_nm=float(rng.choice([3.0, 3.0, 0.0, 5.0])), keep_active=bool(rng.integers(5) == 0))
     kw["held_hint"] = bool(rng.integers(2))   # drawn last: the cases of earlier sweeps keep their configurations
+    # atc_rollout_hold with hold > 1 (drawn after everything else for the same reason): a quarter of the cases
+    rh = int(rng.choice([1, 1, 1, 1, 1, 1, 4, 20]))
+    if rh > 1:
+        rollout = rh * int(rng.choice([1, 2, 5]))
+        kw.update(use_rollout=rollout, rollout_hold=rh, hold=rh * int(rng.choice([1, 2])))
     if rollout:
-        kw["steps"] = (kw["steps"] // rollout) * rollout
+        kw["steps"] = max(rollout, (kw["steps"] // rollout) * rollout)
     return scn, comp, kw
 
 

@@ -370,10 +370,13 @@ def test_atcgym_keeps_flying_after_a_win():
 # ------------------------------------------------------------------------------------------------ batched vs fp32 oracle
 def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, spawn="lattice", hold=20, grid_cell=0.5,
                    use_rollout=0, timestep_limit=6000, full=True, shaping=True, normalize=True, sep_nm=3.0,
-                   keep_active=False, held_hint=False):
+                   keep_active=False, held_hint=False, rollout_hold=1):
     """full=False drives the fast kernel variant (obs / reward / done / flags only), full=True the one with every optional
     output; everything the variant produces is compared with the fp32 oracle.  held_hint: single steps that repeat the
-    previous step's action array are launched with ATC_M_ACTIONS_HELD (must change nothing)."""
+    previous step's action array are launched with ATC_M_ACTIONS_HELD (must change nothing).
+    rollout_hold > 1 (with use_rollout): the multi-step launches go through atc_rollout_hold — one action block per
+    `rollout_hold` steps (frame skip, learning/atc-gym-demo.py:18-19), whose repeated steps skip the last-action bookkeeping
+    inside the kernel; the oracle is stepped once per step with the block's actions."""
     torch = _torch()
     from atc_hip.vec_env import AtcVecEnv
     from envs.atc import model
@@ -395,6 +398,8 @@ def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, sp
     act = None
     if use_rollout:
         assert steps % use_rollout == 0
+    if rollout_hold > 1:
+        assert use_rollout and use_rollout % rollout_hold == 0 and hold % rollout_hold == 0
     t = 0
     while t < steps:
         chunk = use_rollout or 1
@@ -407,7 +412,11 @@ def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, sp
                 else:
                     act = rng.uniform(-1.05, 1.05, (B, N, 3)).astype(np.float32)
             acts.append(act)
-        if use_rollout:
+        if use_rollout and rollout_hold > 1:
+            assert all(acts[c] is acts[c - c % rollout_hold] for c in range(chunk))   # blocks are constant by construction
+            out = env.rollout(torch.as_tensor(np.stack(acts[::rollout_hold])), hold=rollout_hold)
+            res = [(out["obs"][c], out["reward"][c], out["done"][c], out["flags"][c]) for c in range(chunk)]
+        elif use_rollout:
             out = env.rollout(torch.as_tensor(np.stack(acts)))
             res = [(out["obs"][c], out["reward"][c], out["done"][c], out["flags"][c]) for c in range(chunk)]
         else:
@@ -515,6 +524,20 @@ def test_rollout_equals_single_steps_vs_oracle():
     scn = scenarios.LOWW(random_entrypoints=True)
     _run_vs_oracle(scn, scenarios.compile_scenario(scn, grid_cell=0.5), B=256, N=16, steps=120, seed=8, use_rollout=24)
     _run_vs_oracle(scenarios.LOWW(), H.compiled("LOWW", 0.5), B=1000, N=1, steps=250, seed=2, use_rollout=50)
+
+
+@pytest.mark.parametrize("N,B,T,rh,hold,full", [(16, 256, 20, 20, 20, False), (16, 256, 40, 20, 20, True), (16, 300, 20, 4, 20, False),
+                                               (1, 1000, 40, 20, 40, False), (64, 64, 20, 20, 20, False), (5, 200, 24, 4, 8, True)])
+def test_rollout_hold_matches_oracle(N, B, T, rh, hold, full):
+    """atc_rollout_hold with hold > 1 — the entry behind bench.py's fused-rollout record and the protocol of
+    learning/atc-gym-demo.py:18-19 — directly against the fp32 oracle (round-2 review: it was only compared with single
+    steps of the same library): every step's flags / done exact, obs / rewards within 1e-5, and after the run the whole
+    state incl. actions_taken and the last-action records bit-identical."""
+    from envs.atc import scenarios
+    scn = scenarios.LOWWDense() if N > 16 else scenarios.LOWW(random_entrypoints=True)
+    n_done, seen = _run_vs_oracle(scn, scenarios.compile_scenario(scn, grid_cell=0.5), B=B, N=N, steps=12 * T, seed=100 + N + T,
+                                  use_rollout=T, rollout_hold=rh, hold=hold, full=full, spawn="lattice")
+    assert n_done > 0
 
 
 def test_flying_on_beyond_the_position_grid():
