@@ -3,7 +3,7 @@
 tests/test_abi.py parses the header and checks that every constant here matches it.
 """
 ABI_VERSION = 17
-BLOB_VERSION = 1012.0
+BLOB_VERSION = 1013.0
 
 H_VERSION, H_NWORDS, H_N_MVA, H_N_NOISE, H_N_ENTRY, H_OFF_POLY, H_OFF_VERT, H_OFF_ENTRY, H_OFF_GRID, H_N_VERTW = range(10)
 H_OFF_SLOT = 10

@@ -114,7 +114,7 @@ GRID_F_BASE = 8.0        # the polygon has an ODD number of edges that every poi
 _BIG = 3.0e38
 
 
-def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=()):
+def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=(), corridor_bounds=None):
     """Uniform lookup grid for Airspace.find_mva (model.py:282-289) with IDENTICAL results to the ordered polygon scan.
 
     * CLEAN cell: every point of the cell has the same answer; stored directly.
@@ -138,13 +138,18 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=()):
     Noise-abatement areas (extension): every cell also carries the bit mask of the noise polygons whose bounds meet the
     (inflated) cell — the step kernel tests an aircraft only against those (usually none) instead of every noise polygon.
 
+    Corridor candidate: bit 22 of |c| marks the cells that meet the bounds of the corridor's horizontal triangle (the exact
+    early-out of Runway.inside_corridor, model.py:198) — the step kernel asks the cell it has already fetched instead of
+    comparing four bounds per aircraft.
+
     Layout (words): header[8] = x0, y0, inv_cell, nx, ny, offset of the edge pool (from grid start), n_records, 0;
-    cells[ny*nx][2] = (c, first_record | MVA height) with |c| = code + 64 * noise mask: c > 0 dirty cell, code = n_records
+    cells[ny*nx][2] = (c, first_record | MVA height) with |c| = code + 64 * noise mask + 2^22 * corridor candidate: c > 0 dirty cell, code = n_records
     (< 64); c <= 0 clean cell, code = polygon + 1 (0 = outside the airspace); pool of 8-word records."""
     if guard is None:
         guard = 1e-3
     x0, y0, x1, y1 = bbox
-    for b in noise_bounds:   # the grid covers the noise-abatement areas too: beyond it no area has to be tested
+    # the grid covers the noise-abatement areas and the corridor triangle too: beyond it neither has to be tested
+    for b in list(noise_bounds) + ([corridor_bounds] if corridor_bounds is not None else []):
         x0, y0, x1, y1 = min(x0, b[0]), min(y0, b[1]), max(x1, b[2]), max(y1, b[3])
     # Two cells of padding all round: the OUTERMOST ring of cells is then clean, outside the airspace and free of noise-area
     # candidates (checked below) — the kernel clamps the cell index of a point beyond the grid into that ring instead of
@@ -237,6 +242,10 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=()):
             for q, b in enumerate(noise_bounds):
                 if not (b[2] < cx0s or b[0] > cx1s or b[3] < cy0s or b[1] > cy1s):
                     mask |= 1 << q
+            if corridor_bounds is not None:
+                b = corridor_bounds
+                if not (b[2] < cx0s or b[0] > cx1s or b[3] < cy0s or b[1] > cy1s):
+                    mask |= 1 << 16   # bit 22 of |c|
             c = cells[j, i, 0]
             cells[j, i, 0] = (c + 64.0 * mask) if c > 0 else (c - 64.0 * mask)
     border = np.concatenate([cells[0, :, :].ravel(), cells[-1, :, :].ravel(), cells[:, 0, :].ravel(), cells[:, -1, :].ravel()])
@@ -331,8 +340,10 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
     grid = None
     off_grid = 0
     if grid_cell is not None and mva_rings:
+        th = cg["tri_h"]
         grid = build_grid(mva_rings, bounds[:len(mva_rings)], mva_heights, bbox, float(grid_cell), grid_guard,
-                          noise_bounds=bounds[len(mva_rings):])
+                          noise_bounds=bounds[len(mva_rings):],
+                          corridor_bounds=(th[:, 0].min(), th[:, 1].min(), th[:, 0].max(), th[:, 1].max()))
         off_grid = (end + 3) & ~3  # 16-byte aligned: cells are read as 8-byte pairs, edge records as 16-byte vectors
         end = off_grid + len(grid)
 

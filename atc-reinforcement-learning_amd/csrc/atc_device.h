@@ -159,8 +159,11 @@ struct MvaCell {
 // bit q set: the aircraft has to be tested against noise-abatement area q (all of them where there is no grid to ask)
 __device__ __forceinline__ uint32_t noise_candidates(const float* __restrict__ grid, const MvaCell& c) {
     if (!grid) return 0xffffu;
-    return (uint32_t)(int)fabsf(c.cell.x) >> 6;
+    return ((uint32_t)(int)fabsf(c.cell.x) >> 6) & 0xffffu;
 }
+// the bounds of the corridor's horizontal triangle meet the aircraft's cell (bit 22 of the cell code): only then can
+// Runway.inside_corridor (model.py:198) accept the point
+__device__ __forceinline__ bool corridor_candidate(const MvaCell& c) { return (uint32_t)(int)fabsf(c.cell.x) >= (1u << 22); }
 // The grid header (origin, 1 / cell, columns, rows, record pool) — uniform.  The step kernel receives it with its arguments
 // (evaluated on the host: gfx950 has no scalar float conversion); the query kernel reads it from the blob.
 struct GridHdr {

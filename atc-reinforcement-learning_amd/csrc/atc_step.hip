@@ -357,6 +357,7 @@ struct Mid {            // what the first half of a step hands to the second
     float x32, y32;
     MvaCell cell;       // MVA lookup cell, gather issued in the first half, resolved after the separation scan
     bool repeated;      // uniform: no action bookkeeping in this step (acts == 0 in every lane)
+    bool plain;         // uniform: every lane flies an aircraft under control towards valid targets (fl == 0, no refusal)
 };
 // Uniform products of the step parameters, evaluated ONCE on the host in fp32 (the same IEEE operations the kernel
 // would do) and passed as kernel arguments: gfx950 has no scalar float ALU, so computed in the kernel they would occupy
@@ -548,12 +549,33 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     float r = q.r_base;  // -0.05 * dt, atc_gym.py:137
     int acts = 0;
     // ---- _action_with_reward x3 (atc_gym.py:139-141,299-335) -> Airplane.action_* (model.py:60-120) ------------------
-    // branch-free form of: invalid target -> ValueError -> -1 reward, nothing applied, last_action kept
-    // (atc_gym.py:303-315); valid -> rate-limited move, actions_taken++ unless |target - last| < discriminator
-    {
-        constexpr float v_min = kVMin, v_max = kVMax, h_min = kHMin, h_max = kHMax;
+    // invalid target -> ValueError -> -1 reward, nothing applied, last_action kept (atc_gym.py:303-315); valid -> rate-limited
+    // move, actions_taken++ unless |target - last| < discriminator.
+    constexpr float v_min = kVMin, v_max = kVMax, h_min = kHMin, h_max = kHMax;
+    const bool valid_v = !(tv < v_min || tv > v_max);
+    const bool valid_h = !(th < h_min || th > h_max);
+    // `plain` (wave-uniform): every lane of the wavefront flies an aircraft under control towards valid targets — the normal
+    // case by far (a refused target or a handed-over aircraft in 64 is the exception).  Then nothing is conditional: no
+    // select per state component, no refusal penalties, no flag bits.  Otherwise the branch-free general form below.  Both
+    // evaluate the same expressions on the lanes they share.
+    const bool plain = __ballot(!(active && valid_v && valid_h)) == 0ull;
+    if (plain) {
+        const float v_new = a.v + clamp_rate(tv - a.v, q.dv_lo, q.dv_hi);
+        ls.v_changed = ls.v_changed || v_new != a.v;
+        a.v = v_new;
+        a.h = a.h + clamp_rate(th - a.h, q.dh_lo, q.dh_hi);
+        a.phi = a.phi + clamp_rate(tp - a.phi, q.dp_lo, q.dp_hi);
+        if (book) {
+            acts = (!(fabsf(tv - ls.la_v) < kDiscrV) ? 1 : 0) + (!(fabsf(th - ls.la_h) < kDiscrH) ? 1 : 0) +
+                   (!(fabsf(tp - ls.la_p) < kDiscrPhi) ? 1 : 0);
+            ls.la_changed = ls.la_changed || tv != ls.la_v || th != ls.la_h || tp != ls.la_p;
+            ls.la_v = tv;
+            ls.la_h = th;
+            ls.la_p = tp;
+        }
+    } else {
         {
-            const bool valid = !(tv < v_min || tv > v_max);
+            const bool valid = valid_v;
             const bool ok = valid && active;
             float dd = tv - a.v;
             dd = clamp_rate(dd, q.dv_lo, q.dv_hi);
@@ -569,7 +591,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
             fl |= valid ? 0u : (uint32_t)ATC_F_INVALID_V;
         }
         {
-            const bool valid = !(th < h_min || th > h_max);
+            const bool valid = valid_h;
             const bool ok = valid && active;
             float dd = th - a.h;
             dd = clamp_rate(dd, q.dh_lo, q.dh_hi);
@@ -597,7 +619,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     {
         // the displacement in grid counts: (sin * (v/3600 * dt)) * 2^k == sin * (v/3600 * (dt * 2^k)) — scaling by a power of
         // two is exact, so the host folds it into the time step (QRates.dts)
-        const float dist = active ? div3600(a.v) * q.dts : 0.0f;
+        const float dist = (plain || active) ? div3600(a.v) * q.dts : 0.0f;
         float sn, cs;
         if (ATC_ABLATE & 32) { sn = 0.6f; cs = 0.8f; } else sincos_deg(a.phi, &sn, &cs);
         a.x = pos_advance_counts(a.x, sn * dist);
@@ -612,6 +634,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     m.fl = fl;
     m.acts = acts;
     m.repeated = repeated;
+    m.plain = plain;
     return m;
 }
 
@@ -664,13 +687,18 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     // Where the MVA cell (gather issued in the first half) is resolved: after the separation scan for the LDS-staged
     // widths, so that the L2 round trip overlaps the scan; before it for the DPP widths (W <= 16), where keeping the cell
     // in flight across the unrolled scan only costs registers.
-    constexpr bool kResolveAfterScan = (W >= 32);
+#ifndef ATC_RESOLVE_LATE
+#define ATC_RESOLVE_LATE 1   // resolve the MVA cell after the separation scan from W = 16 up (0: only for the LDS-scan widths):
+                             // 18.5 vs 18.9 us single steps, 11.2 vs 11.4 fused at 65 536 x 16 (profiles/r03_experiments.txt)
+#endif
+    constexpr bool kResolveAfterScan = ATC_RESOLVE_LATE ? (W >= 16) : (W >= 32);   // (W = 2 .. 8: the unrolled xor scan with the cell
+                                                                                   // in flight costs 4 - 22 registers)
     float mva = 0.0f;
     int pi = 0;
     if (!kResolveAfterScan) {
         float hgt = 0.0f;
         pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt);
-        mva = pi >= 0 ? hgt : 0.0f;
+        mva = hgt;   // (0 when outside: mva_resolve leaves the height at 0, atc_gym.py:161)
         fl |= noise_areas(K, grid, m.cell, x32, y32, a.h);
     }
     // Multi-step launches: the NEXT step's action is requested here — behind the MVA gathers (loads return in order: issued
@@ -680,7 +708,8 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     float min_d2 = 1e30f;
     float margin = 1e30f;  // min over partners of max(d^2 - sep^2, |dh| - sep_ft): conflict iff negative
     if (W > 1 && !(ATC_ABLATE & 2)) {
-        const float xs = active ? x32 : 1e18f;
+        float xs = x32;
+        if (!m.plain) xs = active ? x32 : 1e18f;
         const float sep2 = qs.sep2;
         if (W == 16 && !FULL) {
             int conf = 0;
@@ -772,57 +801,84 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
         }
     }
     ATC_STAMP_B(2);
+#ifndef ATC_OBS_FIRST_W1
+#define ATC_OBS_FIRST_W1 0   // (W = 1: 7.97 vs 8.07 us single steps, 5.05 vs 4.94 fused: no clear gain)
+#endif
+#ifndef ATC_OBS_FIRST
+#define ATC_OBS_FIRST 0   // 1: observation and shaping terms BEFORE the lookup cell is resolved (they do not depend on the MVA,
+#endif                    // only obs[5] = h - mva does).  Measured: no gain at any size (profiles/r03_experiments.txt)
+    Obs ob;
+    float shaping = 0.0f;
+    const ObsConst oc = QGET(oc);
+    // (W = 1 has no scan to cover the gather: there the observation goes first)
+    constexpr bool kObsFirst = ATC_OBS_FIRST || (ATC_OBS_FIRST_W1 && W == 1);
+    if (kObsFirst && !(ATC_ABLATE & 8)) {
+        ob = get_state(oc, a.x, a.y, x32, y32, a.h, a.phi, a.v, 0.0f);
+        if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
+    }
     // ---- MVA floor (atc_gym.py:146-161), second half ---------------------------------------------------------------------
-    {
-        if (kResolveAfterScan) {
-            float hgt = 0.0f;
-            pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt);
-            mva = pi >= 0 ? hgt : 0.0f;                // atc_gym.py:161: mva = 0 outside
-            fl |= noise_areas(K, grid, m.cell, x32, y32, a.h);
+    if (kResolveAfterScan) {
+        float hgt = 0.0f;
+        pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt);
+        mva = hgt;                                 // atc_gym.py:161: mva = 0 outside (mva_resolve leaves the height at 0)
+        fl |= noise_areas(K, grid, m.cell, x32, y32, a.h);
+    }
+    // ---- the override chain (atc_gym.py:146-173) -----------------------------------------------------------------------
+    // `quiet` (wave-uniform): nothing of it applies to any lane of this wavefront — every aircraft under control with accepted
+    // targets (plain), inside the airspace at or above its MVA, no separation lost, no time-out, outside the bounds of the
+    // corridor's horizontal triangle (the exact early-out of Runway.inside_corridor; asked of the lookup cell, which carries a
+    // candidate bit), in no noise-abatement area.  That is
+    // what almost every step of almost every wavefront looks like, and then reward and flag word are what the first half left
+    // (base reward, no flag): the chain's selects run only in the other wavefronts — the same expressions, lane for lane.
+    const bool conflict = margin < 0.0f;
+    const bool timeout = es.t > qs.timestep_limit;
+    const bool quiet = !(ATC_ABLATE & 512) && m.plain &&
+                       __ballot((pi < 0) | (a.h < mva) | conflict | timeout | ((fl >> 16) != 0u) |
+                                (grid ? corridor_candidate(m.cell)
+                                      : ((x32 >= qs.tri_bbox.x) & (x32 <= qs.tri_bbox.z) & (y32 >= qs.tri_bbox.y) & (y32 <= qs.tri_bbox.w)))) == 0ull;
+    if (!quiet) {
+        {
+            const bool below = pi >= 0 && a.h < mva;
+            r = pi < 0 ? -50.0f : (below ? -200.0f : r);
+            fl |= pi < 0 ? (uint32_t)ATC_F_OUTSIDE : (below ? (uint32_t)ATC_F_BELOW_MVA : 0u);
         }
-        const bool below = pi >= 0 && a.h < mva;
-        r = pi < 0 ? -50.0f : (below ? -200.0f : r);
-        fl |= pi < 0 ? (uint32_t)ATC_F_OUTSIDE : (below ? (uint32_t)ATC_F_BELOW_MVA : 0u);
-    }
-    {   // conflict override comes after the MVA overrides in the chain
-        const bool conflict = margin < 0.0f;
-        r = conflict ? qs.conflict_reward : r;
-        fl |= conflict ? (uint32_t)ATC_F_CONFLICT : 0u;
-    }
-
-    // ---- win / timeout overrides (atc_gym.py:163-173) -------------------------------------------------------------------
-    if (!(ATC_ABLATE & 4) && inside_corridor(K, qs.tri_bbox, x32, y32, a.h, a.phi)) {
-        int bonus = (qs.timestep_limit - es.t) * 5;
-        bonus = bonus < 0 ? 0 : bonus;
-        r = (float)(10000 + bonus);
-        fl |= ATC_F_WON;
-    }
-    {
-        const bool timeout = es.t > qs.timestep_limit;
-        r = timeout ? -200.0f : r;
-        fl |= timeout ? (uint32_t)ATC_F_TIMEOUT : 0u;
+        {   // conflict override comes after the MVA overrides in the chain
+            r = conflict ? qs.conflict_reward : r;
+            fl |= conflict ? (uint32_t)ATC_F_CONFLICT : 0u;
+        }
+        // ---- win / timeout overrides (atc_gym.py:163-173) ---------------------------------------------------------------
+        if (!(ATC_ABLATE & 4) && inside_corridor(K, qs.tri_bbox, x32, y32, a.h, a.phi)) {
+            int bonus = (qs.timestep_limit - es.t) * 5;
+            bonus = bonus < 0 ? 0 : bonus;
+            r = (float)(10000 + bonus);
+            fl |= ATC_F_WON;
+        }
+        {
+            r = timeout ? -200.0f : r;
+            fl |= timeout ? (uint32_t)ATC_F_TIMEOUT : 0u;
+        }
     }
     ATC_STAMP_B(3);
     // ---- observation, shaping, noise areas, normalisation (atc_gym.py:175-189) ------------------------------------------
     float o[ATC_OBS_DIM];
     float zraw[ATC_OBS_DIM];   // FULL only: raw observation (zeros for handed-over aircraft)
     {
-        Obs ob;
-        const ObsConst oc = QGET(oc);
         if (ATC_ABLATE & 8) {
 #pragma unroll
             for (int c = 0; c < ATC_OBS_DIM; ++c) ob.o[c] = x32;
             ob.d_faf = ob.phi_rel_faf = ob.on_gp = y32;
+        } else if (kObsFirst) {
+            ob.o[5] = a.h - mva;
         } else {
             ob = get_state(oc, a.x, a.y, x32, y32, a.h, a.phi, a.v, mva);
+            if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
         }
-        if ((p.mode & ATC_M_REWARD_SHAPING) && !(ATC_ABLATE & 8)) {
-            // r += pos; r += ang; r += gs (atc_gym.py:179-185) as one fma of the factored sum (value-only, within 1e-5)
-            r += shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
-        }
+        // r += pos; r += ang; r += gs (atc_gym.py:179-185, after the override chain) as one addition of the factored sum
+        // (value-only, within 1e-5)
+        if ((p.mode & ATC_M_REWARD_SHAPING) && !(ATC_ABLATE & 8)) r += shaping;
         // extension (README.md:62): noise-abatement areas — which ones the aircraft is in was decided next to the MVA lookup
         // (bits 16.. of fl); the penalties are subtracted here, after the shaping terms, in area order.
-        if (__ballot((fl >> 16) != 0u) != 0ull) {
+        if (!quiet && __ballot((fl >> 16) != 0u) != 0ull) {
             const int n_noise = (int)K[ATC_H_N_NOISE];
             for (int q = 0; q < n_noise; ++q)
                 if ((fl >> (16 + q)) & 1u) r -= (K + (int)K[ATC_H_OFF_POLY] + ((int)K[ATC_H_N_MVA] + q) * ATC_P_WORDS)[ATC_P_PENALTY];
@@ -844,7 +900,7 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     }
     // lanes without an aircraft under control: nothing happened.  Almost every wavefront has none, so the selects sit
     // behind a wave-uniform test.
-    if (__ballot(!active) != 0ull) {
+    if (!m.plain && __ballot(!active) != 0ull) {
 #pragma unroll
         for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = active ? o[c] : 0.0f;
         r = active ? r : 0.0f;
@@ -857,15 +913,18 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     // ---- per-env reductions over the W lanes of the group ----------------------------------------------------------------
     const float env_r = group_sum<W>(r);
     const int env_acts = m.repeated ? 0 : group_sum_i<W>(acts);
-    const uint64_t won = group_ballot<W>((fl & ATC_F_WON) != 0, lane);
-    const uint64_t term = group_ballot<W>(
-        (fl & (ATC_F_BELOW_MVA | ATC_F_OUTSIDE | ATC_F_CONFLICT | ATC_F_TIMEOUT)) != 0, lane);
-    // extension: an aircraft that reaches the corridor is handed over; the episode is won when all are.
-    // ATC_M_KEEP_ACTIVE: the reference's rule (atc_gym.py:163-169) — any win ends the episode, nobody is handed over.
-    const bool keep_active = (p.mode & ATC_M_KEEP_ACTIVE) != 0;
-    if (!keep_active) es.amask &= ~won;
-    const bool env_won = keep_active ? won != 0 : es.amask == 0;
-    const bool done = d.env_valid && (term != 0 || env_won);
+    bool done = false, env_won = false;
+    if (!quiet) {
+        const uint64_t won = group_ballot<W>((fl & ATC_F_WON) != 0, lane);
+        const uint64_t term = group_ballot<W>(
+            (fl & (ATC_F_BELOW_MVA | ATC_F_OUTSIDE | ATC_F_CONFLICT | ATC_F_TIMEOUT)) != 0, lane);
+        // extension: an aircraft that reaches the corridor is handed over; the episode is won when all are.
+        // ATC_M_KEEP_ACTIVE: the reference's rule (atc_gym.py:163-169) — any win ends the episode, nobody is handed over.
+        const bool keep_active = (p.mode & ATC_M_KEEP_ACTIVE) != 0;
+        if (!keep_active) es.amask &= ~won;
+        env_won = keep_active ? won != 0 : es.amask == 0;
+        done = d.env_valid && (term != 0 || env_won);
+    }
     es.total_reward += env_r;  // atc_gym.py:194-197
     es.n_actions += env_acts;
 
@@ -913,7 +972,9 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if (d.lane_valid) {
             if (FULL && so.term_obs) store_obs(at<float>(so.term_obs, times40(i)), o);
-            a = spawn(K, p, e, k, episode);
+            // (slot through this step's opaque zero: the spawn-record address is then formed here, on the rare path, instead of
+            // being carried — and spilled — across the step loop as a 64-bit per-lane pointer)
+            a = spawn(K, p, e, k + zk, episode);
             ls.v_changed = true;
             const QGrid qg = QGET(g);
             const int neg_k = QGET(r.pos_neg_k);
@@ -990,7 +1051,7 @@ __device__ __forceinline__ void store_env_state(const atc_state_t& st, const Lan
 }
 
 template <int W, bool FULL, bool ONE>  // ONE: single-step launch (T == 1)
-__global__ void __launch_bounds__(kBlock, (ONE ? ATC_MIN_WAVES : ((FULL || W < 8 || W >= 32) ? ATC_MIN_WAVES_LOOP - 1 : ATC_MIN_WAVES_LOOP)))
+__global__ void __launch_bounds__(kBlock, (ONE ? ATC_MIN_WAVES : ((FULL || W <= 8 || W >= 32) ? ATC_MIN_WAVES_LOOP - 1 : ATC_MIN_WAVES_LOOP)))
 k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int hold, atc_state_t st,
        const float* __restrict__ actions, atc_out_t out, atc_params_t p, StepDerived q, InlineAction ia) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1106,7 +1167,10 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     }
     // ---- write back persistent state -----------------------------------------------------------------------------------
     atc_state_t st_end = st;
-    if (!ONE && (ATC_LOOP_REREAD_ARGS(W) & 8)) {
+#ifndef ATC_ONE_REREAD_STATE
+#define ATC_ONE_REREAD_STATE 1   // single-step launches also fetch the state pointers again for the final stores (instead of
+#endif                           // carrying ten scalar registers through the body: they were spilled to vector-register lanes)
+    if ((ONE && ATC_ONE_REREAD_STATE) || (!ONE && (ATC_LOOP_REREAD_ARGS(W) & 8))) {
         int zk;
         asm volatile("s_mov_b32 %0, 0" : "=s"(zk));
         st_end = kernarg_reread<atc_state_t>(offsetof(StepArgs, st), zk);
@@ -1234,7 +1298,11 @@ static size_t lds_bytes(const atc_scenario*, bool pair_scan, bool step_kernel = 
 template <int W, bool FULL, bool ONE>
 static int launch_step2(const atc_scenario* s, int B, int N, int T, int hold, const atc_state_t* st, const float* actions,
                         const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
+#ifdef ATC_LDS_PAD_LOOP   // developer A/B builds: cap the multi-step launch's workgroups per CU through its LDS allocation
+    const size_t lds = ONE ? lds_bytes(s, W >= 32, true) : (size_t)ATC_LDS_PAD_LOOP;
+#else
     const size_t lds = lds_bytes(s, W >= 32, true);
+#endif
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<W, FULL, ONE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -385,6 +385,12 @@ def main():
         cmd += sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner through C stdio
+    # when a communicator is created): from here on file descriptor 1 is stderr, and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     # a fresh checkout has no native pieces yet: local rank 0 compiles them, the other ranks wait for the files
     import __graft_entry__ as entry
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:
@@ -688,7 +694,7 @@ def main():
             line["config"]["single_env"] = single_env_protocol()
         if ws == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N)
-        print(json.dumps(line))
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     for e in subs:
         e.close()
     D.shutdown()

@@ -35,7 +35,7 @@ extern "C" {
  * envs/atc/atc_gym.py:45-58,88-110).  Integer fields are stored as exactly representable floats.
  * The float64 master (used by the f64 oracle) has the identical word layout.
  * ------------------------------------------------------------------------------------------- */
-#define ATC_BLOB_VERSION 1012.0f
+#define ATC_BLOB_VERSION 1013.0f
 enum {
     ATC_H_VERSION = 0,   /* ATC_BLOB_VERSION */
     ATC_H_NWORDS = 1,    /* total words */
@@ -96,6 +96,7 @@ enum { ATC_E_X = 0, ATC_E_Y = 1, ATC_E_PHI = 2, ATC_E_NLEV = 3, ATC_E_LEV0 = 4, 
  * ordered polygon scan by construction — see atc_hip/scenario.py:build_grid).  16-byte aligned in the blob.
  *   header 8 words : x0, y0, 1/cell, nx, ny, offset of the edge pool (from grid start), number of edge records, 0
  *   cells  ny*nx*2 : (c, v) with |c| = code + 64 * noise mask (bit q: the bounds of noise-abatement area q meet the cell)
+ *                    + 2^22 if the bounds of the corridor's horizontal triangle (ATC_C_TRI_BBOX) meet the cell
  *                    c > 0  : dirty cell, code = n_records (< 64), v = first record: walk that many edge records
  *                    c <= 0 : clean cell, code = polygon + 1 and v = MVA height — every point has this answer;
  *                             code = 0: outside the airspace

@@ -69,9 +69,11 @@ def _walk_grid(b, g, tabs, tabs_h, x, y):
     """Host emulation (float64) of the device's grid walk (csrc/atc_device.h: find_mva)."""
     x0, y0, inv, nx, ny = b[g + L.G_X0], b[g + L.G_Y0], b[g + L.G_INV], int(b[g + L.G_NX]), int(b[g + L.G_NY])
     fx, fy = (x - x0) * inv, (y - y0) * inv
+    # the device clamps the cell index into the grid's outermost ring (clean, outside) instead of testing the range
+    ix, iy = min(max(int(fx), 0), nx - 1), min(max(int(fy), 0), ny - 1)
     if not (0 <= fx < nx and 0 <= fy < ny):
-        return -1
-    c = g + L.G_HDR + 2 * (int(fy) * nx + int(fx))
+        assert b[g + L.G_HDR + 2 * (iy * nx + ix)] == 0 and b[g + L.G_HDR + 2 * (iy * nx + ix) + 1] == 0
+    c = g + L.G_HDR + 2 * (iy * nx + ix)
     code, v = int(abs(b[c])) & 63, int(b[c + 1])
     if not b[c] > 0:
         if code > 0:
@@ -131,5 +133,18 @@ def test_grid_matches_ordered_scan_on_host(scen, cell):
     cells = b[g + L.G_HDR: g + L.G_HDR + 2 * int(b[g + L.G_NX]) * int(b[g + L.G_NY])].reshape(-1, 2)
     n_dirty = int((cells[:, 0] > 0).sum())
     assert 0 < n_dirty < 0.45 * len(cells)
-    assert cells[:, 0].max() < 64
-    print(scen, cell, 'dirty cells', n_dirty, 'of', len(cells), 'records per dirty cell %.2f' % (cells[cells[:, 0] > 0, 0].mean()), 'max', cells[:, 0].max())
+    codes = np.abs(cells[:, 0]).astype(np.int64)
+    assert (codes & 63)[cells[:, 0] > 0].max() < 64 and ((codes >> 6) & 0xffff).max() == 0   # no noise areas in these sectors
+    # corridor candidates (bit 22): every point within the bounds of the corridor's horizontal triangle lies in a marked cell,
+    # and the marked cells are few
+    nx, ny = int(b[g + L.G_NX]), int(b[g + L.G_NY])
+    tb = b[L.C_TRI_BBOX:L.C_TRI_BBOX + 4]
+    cand = (codes >> 22).reshape(ny, nx)
+    for x in np.linspace(tb[0], tb[2], 41):
+        for y in np.linspace(tb[1], tb[3], 41):
+            assert cand[int((y - b[g + L.G_Y0]) * b[g + L.G_INV]), int((x - b[g + L.G_X0]) * b[g + L.G_INV])] == 1
+    assert 0 < cand.sum() <= ((tb[2] - tb[0]) / cell + 3) * ((tb[3] - tb[1]) / cell + 3)
+    border = np.concatenate([cells.reshape(ny, nx, 2)[0].ravel(), cells.reshape(ny, nx, 2)[-1].ravel(),
+                             cells.reshape(ny, nx, 2)[:, 0].ravel(), cells.reshape(ny, nx, 2)[:, -1].ravel()])
+    assert not border.any()   # the outermost ring: clean, outside, no candidates of any kind
+    print(scen, cell, 'dirty cells', n_dirty, 'of', len(cells), 'records per dirty cell %.2f' % ((codes & 63)[cells[:, 0] > 0].mean()))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: per-wavefront phase timing of k_step with the ATC_TRACE build (s_memtime stamps).
-  hipcc ... -DATC_TRACE=1 -o build_variants/libatcstep_trace.so ; python tools/trace_phases.py [envs]"""
+  hipcc ... -DATC_TRACE=1 -o build_variants/libatcstep_trace.so ; python tools/trace_phases.py [envs] [aircraft]"""
 import ctypes as C
 import os
 import struct
@@ -15,13 +15,14 @@ _binding.use_library(os.path.join(ROOT, "build_variants", "libatcstep_trace.so")
 from atc_hip.vec_env import AtcVecEnv
 from envs.atc import scenarios
 
-B, N = (int(sys.argv[1]) if len(sys.argv) > 1 else 65536), 16
-env = AtcVecEnv(B, N, scenario=scenarios.LOWW(random_entrypoints=True), auto_reset=True)
+B, N = (int(sys.argv[1]) if len(sys.argv) > 1 else 65536), (int(sys.argv[2]) if len(sys.argv) > 2 else 16)
+W = 1 << max(0, (N - 1).bit_length())
+env = AtcVecEnv(B, N, scenario=scenarios.LOWWDense() if N > 16 else scenarios.LOWW(random_entrypoints=N > 1), auto_reset=True)
 acts = [(torch.rand((B, N, 3), device="cuda") * 2 - 1) for _ in range(4)]
 HELD = os.environ.get("ATC_TRACE_HELD", "1") != "0"   # launches 2..20 of an action block carry ATC_M_ACTIONS_HELD
 for t in range(300):
     env.step(acts[(t // 20) % 4], held=HELD and t % 20 != 0)
-n_waves = B * 16 // 64
+n_waves = (B * W + 255) // 256 * 4
 trace = torch.zeros((n_waves, 8), dtype=torch.int64, device="cuda")
 ptr = trace.data_ptr()
 env.params.reserved0 = ptr & 0xffffffff
@@ -46,9 +47,8 @@ torch.cuda.synchronize()
 kernel_us = ev0.elapsed_time(ev1) / 200 * 1e3
 wave = np.arange(len(raw))
 xcd = (wave // 4) % 8
-span = np.median([raw[xcd == x, 7].max() - raw[xcd == x, 0].min() for x in range(8)])
-tick_us = kernel_us / span
-print("kernel %.2f us (HIP events), span %.0f ticks on one XCD -> %.3f ns per tick" % (kernel_us, span, tick_us * 1e3))
+tick_us = 0.01   # s_memtime: the 100 MHz reference clock
+print("kernel %.2f us per launch (HIP events, launch to launch); s_memtime tick = 10 ns" % kernel_us)
 d = np.diff(raw.astype(np.float64), axis=1) * tick_us
 print("phase durations per wavefront [us]: mean / median / p90 / share of lifetime")
 life = (raw[:, 7] - raw[:, 0]) * tick_us
@@ -56,6 +56,8 @@ for k, nme in enumerate(names):
     print("%-44s %6.2f %6.2f %6.2f   %4.1f %%" % (nme, d[:, k].mean(), np.median(d[:, k]), np.percentile(d[:, k], 90),
                                                   100 * d[:, k].sum() / life.sum()))
 print("wave lifetime [us]: mean %.2f median %.2f p90 %.2f" % (life.mean(), np.median(life), np.percentile(life, 90)))
+if B * W < 65536 * 16:
+    sys.exit(0)
 x = 0
 r = raw[xcd == x].astype(np.float64)
 t0 = r[:, 0].min()
