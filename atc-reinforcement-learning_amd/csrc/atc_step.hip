@@ -537,14 +537,17 @@ __device__ __forceinline__ Float3 decode_targets(const QRates& q, const Float3& 
 // ---- first half of AtcGym.step: timestep, rate limits towards the targets, kinematics, MVA floor ---------------------
 __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const QRates& q, const QGrid& qg,
                                            const LaneIds& d, float tv, float th, float tp, LaneState& ls, EnvState& es,
-                                           bool repeated) {
+                                           bool repeated, bool all_active, bool track_v) {
     Mid m;
     Aircraft& a = ls.a;
     // `repeated` (wave-uniform): this step repeats the previous step's actions and no env of the wavefront was reset in
     // between — last_action == the accepted targets, so nothing can be counted or changed (see ATC_M_ACTIONS_HELD)
     const bool book = !repeated;
     es.t += 1;  // atc_gym.py:135
-    const bool active = d.lane_valid && ((d.k < 32 ? ((uint32_t)es.amask >> d.k) : ((uint32_t)(es.amask >> 32) >> (d.k - 32))) & 1u);
+    // all_active (wave-uniform, multi-step launches): the caller knows that every lane's aircraft is under control — the masks
+    // only change in steps that end an episode or hand an aircraft over — and the per-lane bit test is skipped
+    const bool active = all_active ||
+                        (d.lane_valid && ((d.k < 32 ? ((uint32_t)es.amask >> d.k) : ((uint32_t)(es.amask >> 32) >> (d.k - 32))) & 1u));
     uint32_t fl = 0;
     float r = q.r_base;  // -0.05 * dt, atc_gym.py:137
     int acts = 0;
@@ -558,10 +561,10 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     // case by far (a refused target or a handed-over aircraft in 64 is the exception).  Then nothing is conditional: no
     // select per state component, no refusal penalties, no flag bits.  Otherwise the branch-free general form below.  Both
     // evaluate the same expressions on the lanes they share.
-    const bool plain = __ballot(!(active && valid_v && valid_h)) == 0ull;
+    const bool plain = (all_active ? __ballot(!(valid_v && valid_h)) : __ballot(!(active && valid_v && valid_h))) == 0ull;
     if (plain) {
         const float v_new = a.v + clamp_rate(tv - a.v, q.dv_lo, q.dv_hi);
-        ls.v_changed = ls.v_changed || v_new != a.v;
+        if (track_v) ls.v_changed = ls.v_changed || v_new != a.v;
         a.v = v_new;
         a.h = a.h + clamp_rate(th - a.h, q.dh_lo, q.dh_hi);
         a.phi = a.phi + clamp_rate(tp - a.phi, q.dp_lo, q.dp_hi);
@@ -666,7 +669,7 @@ __device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, con
 #define QGET(member) (ONE ? q.member : kernarg_reread<decltype(q.member)>(offsetof(StepArgs, q) + offsetof(StepDerived, member), zk))
 
 template <int W, bool FULL, bool ONE>
-__device__ __forceinline__ void step_part_b(const float* __restrict__ K, const float* __restrict__ grid,
+__device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const float* __restrict__ grid,
                                             const atc_params_t& p, const StepDerived& q, int zk, int N, const LaneIds& d,
                                             const Mid& m, LaneState& ls,
                                             EnvState& es, const StepOut& so, int32_t* stp, float4* pos, float* obs_stage,
@@ -1027,14 +1030,17 @@ __device__ __forceinline__ void step_part_b(const float* __restrict__ K, const f
     } else if (d.lane_valid) {
         store_obs(at<float>(so.obs, times40(i)), o);
     }
+    return quiet;
 }
 
-__device__ __forceinline__ void store_lane_state(const atc_state_t& st, const LaneIds& d, const LaneState& ls, bool la_live) {
+__device__ __forceinline__ void store_lane_state(const atc_state_t& st, const LaneIds& d, const LaneState& ls, bool la_live,
+                                                 bool v_always) {
     if (d.lane_valid)
         *at<int4>(st.pos_hp, d.i * 16u) = make_int4(ls.a.x, ls.a.y, __float_as_int(ls.a.h), __float_as_int(ls.a.phi));
     // speed and last-action targets are typically constant for many steps (actions are held, the speed reaches its target):
     // written back only by wavefronts in which one of them changed
-    if (__ballot(ls.v_changed) != 0ull && d.lane_valid) *at<float>(st.v, d.i * 4u) = ls.a.v;
+    // (multi-step launches do not track speed changes per step: one unconditional 4-byte store per aircraft and launch)
+    if ((v_always || __ballot(ls.v_changed) != 0ull) && d.lane_valid) *at<float>(st.v, d.i * 4u) = ls.a.v;
     if (__ballot(ls.la_changed) != 0ull && d.lane_valid && la_live) {
         Float3 la = {ls.la_v, ls.la_h, ls.la_p};
         *at<Float3>(st.last_act, times12(d.i)) = la;
@@ -1096,6 +1102,8 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     const int n_steps = ONE ? 1 : T;
     const float* act_t = actions;   // action block of the current step; a block is held for `hold` steps
     int held = 0;                   // steps the current block has been used for
+    Float3 tg = {0.0f, 0.0f, 0.0f};   // decoded targets of the current step / block
+    bool all_active = false, mask_dirty = true;
     for (int step = 0; step < n_steps; ++step) {
 #if ATC_TRACE
         unsigned long long* trow = trace ? trace + ((size_t)(blockIdx.x * (kBlock / 64) + (tid >> 6)) * n_steps + step) * 8 : nullptr;
@@ -1140,10 +1148,15 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
                       , trow
 #endif
         };
-        if (!ONE && step == 0) act = *at<Float3>(act_t, times12(dl.i));
-        // (decoding a held block once per block instead of once per step was measured slower: 15.7 vs 15.1 us per step)
+#ifndef ATC_LOOP_DECODE_ONCE
+#define ATC_LOOP_DECODE_ONCE 0   // 1: carry the DECODED targets of a held block across its steps (7 operations fewer per step, but
+#endif                           // a second re-read site of the rate group: 331.9 vs 331.2 VALU, 11.50 vs 11.46 us — no gain)
+#ifndef ATC_LOOP_ALLACT
+#define ATC_LOOP_ALLACT 1        // carry "every lane's aircraft is under control" across the steps (re-established after steps that
+#endif                           // can change a mask): 325.5 vs 331.2 VALU per wavefront-step, 11.37 vs 11.46 us at 65 536 x 16
         const QRates qr = QGET(r);
-        const Float3 tg = decode_targets(qr, act);
+        if (!ONE && step == 0) act = *at<Float3>(act_t, times12(dl.i));
+        if (ONE || !ATC_LOOP_DECODE_ONCE || step == 0) tg = decode_targets(qr, act);
         if (ONE && !la_live) {   // held block: the record equals the accepted targets (components that are refused are not compared)
             ls.la_v = tg.a;
             ls.la_h = tg.b;
@@ -1152,7 +1165,12 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         // multi-step launches know structurally which steps repeat an action block
         const bool repeated = ONE ? (same_actions && __ballot(la_live) == 0ull)
                                   : (ATC_LOOP_SKIP_BOOK && held > 0 && __ballot(es.t == 0) == 0ull);
-        const Mid m = step_part_a(gl, qr, QGET(g), dl, tg.a, tg.b, tg.c, ls, es, repeated);
+        // ... and whether every lane's aircraft is under control: re-established after the steps in which a mask can change
+        if (!ONE && ATC_LOOP_ALLACT && mask_dirty) {
+            all_active = __ballot(!(dl.lane_valid && ((dl.k < 32 ? ((uint32_t)es.amask >> dl.k) : ((uint32_t)(es.amask >> 32) >> (dl.k - 32))) & 1u))) == 0ull;
+            mask_dirty = false;
+        }
+        const Mid m = step_part_a(gl, qr, QGET(g), dl, tg.a, tg.b, tg.c, ls, es, repeated, !ONE && all_active, ONE);
         ATC_STAMP(1);
         Float3 nxt = act;
         const float* act_next = nullptr;   // the next block is fetched during the last step of the current one
@@ -1161,8 +1179,13 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             act_t += (size_t)BN * 3;
             if (step + 1 < n_steps) act_next = act_t;
         }
-        step_part_b<W, FULL, ONE>(Kl, gl, pl, q, zk, N, dl, m, ls, es, so, stats_l, pos, obs_stage, act_next, nxt);
-        act = nxt;
+        const bool quiet = step_part_b<W, FULL, ONE>(Kl, gl, pl, q, zk, N, dl, m, ls, es, so, stats_l, pos, obs_stage, act_next, nxt);
+        if (!quiet) mask_dirty = true;
+        if (ATC_LOOP_DECODE_ONCE) {
+            if (act_next) tg = decode_targets(QGET(r), nxt);
+        } else {
+            act = nxt;
+        }
         ATC_STAMP(6);
     }
     // ---- write back persistent state -----------------------------------------------------------------------------------
@@ -1175,7 +1198,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         asm volatile("s_mov_b32 %0, 0" : "=s"(zk));
         st_end = kernarg_reread<atc_state_t>(offsetof(StepArgs, st), zk);
     }
-    store_lane_state(st_end, d, ls, la_live);
+    store_lane_state(st_end, d, ls, la_live, !ONE);
     store_env_state<W>(st_end, d, es, hi0);
 #if ATC_TRACE
     if (lane == 0 && trace) trace[((size_t)(blockIdx.x * (kBlock / 64) + (tid >> 6)) * n_steps + (n_steps - 1)) * 8 + 7] = __builtin_amdgcn_s_memtime();
