@@ -16,7 +16,7 @@ from . import lib as _lib
 
 class AtcVecEnv:
     def __init__(self, num_envs, num_aircraft=1, sim_parameters=None, scenario=None, device=0, auto_reset=True,
-                 spawn="auto", seed=0, grid_cell=0.5, want_raw_obs=False, want_ac_reward=False, want_min_sep=False,
+                 spawn="auto", seed=0, grid_cell=0.25, want_raw_obs=False, want_ac_reward=False, want_min_sep=False,
                  want_term_obs=False, timestep_limit=6000, sep_nm=3.0, sep_ft=1000.0, conflict_reward=-200.0,
                  host_mapped=False, keep_active=False, want_packet=False, check_held=False):
         """host_mapped=True keeps state and outputs in pinned host memory mapped into the device (zero-copy): the kernels

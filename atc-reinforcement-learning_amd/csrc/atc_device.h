@@ -207,6 +207,7 @@ __device__ __forceinline__ MvaCell mva_cell_load(const float* __restrict__ grid,
     }
     return c;
 }
+template <int kBatch = ATC_MVA_BATCH>
 __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const float* __restrict__ grid, const GridHdr& gh,
                                            const MvaCell& c, float x, float y, float* height) {
     *height = 0.0f;
@@ -227,7 +228,6 @@ __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const fl
         // bounds) and their records ignored.
         const char* pool = reinterpret_cast<const char*>(grid + gh.off_pool);   // uniform
         const uint32_t rec0 = 32u * (uint32_t)(int)cell.y;                          // this lane's first record, bytes
-        constexpr int kBatch = ATC_MVA_BATCH;
         bool inside = false;
         for (int base = 0; base < n; base += kBatch) {
             float4 g[kBatch], m[kBatch];

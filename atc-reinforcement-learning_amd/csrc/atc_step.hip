@@ -171,9 +171,11 @@ __device__ __forceinline__ float group_min(float v) {
     if (W > 32) v = fminf(v, xchg<32>(v));
     return v;
 }
+// (__builtin_amdgcn_ballot_w64 takes the predicate as the lane mask it already is; HIP's __ballot(int) first materialises
+// it per lane and compares again: two vector instructions per use)
 template <int W>
 __device__ __forceinline__ uint64_t group_ballot(bool pred, int lane) {
-    const uint64_t b = __ballot(pred);
+    const uint64_t b = __builtin_amdgcn_ballot_w64(pred);
     if (W == 64) return b;
     const int base = lane & ~(W - 1);
     return (b >> base) & ((1ull << (W & 63)) - 1ull);   // (W < 64 here; the mask keeps the W = 64 instantiation warning-free)
@@ -561,13 +563,16 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     // case by far (a refused target or a handed-over aircraft in 64 is the exception).  Then nothing is conditional: no
     // select per state component, no refusal penalties, no flag bits.  Otherwise the branch-free general form below.  Both
     // evaluate the same expressions on the lanes they share.
-    const bool plain = (all_active ? __ballot(!(valid_v && valid_h)) : __ballot(!(active && valid_v && valid_h))) == 0ull;
+    const bool plain = (all_active ? __builtin_amdgcn_ballot_w64(!(valid_v && valid_h)) : __builtin_amdgcn_ballot_w64(!(active && valid_v && valid_h))) == 0ull;
+    // (speed and heading limits are symmetric — kAMin == -kAMax, kPhiDotMin == -kPhiDotMax, checked at compile time below —
+    // so the plain path clamps with ONE scalar operand and its negation; two scalars cost a register move per clamp)
+    static_assert(kAMin == -kAMax && kPhiDotMin == -kPhiDotMax, "symmetric rate limits assumed by the plain path");
     if (plain) {
-        const float v_new = a.v + clamp_rate(tv - a.v, q.dv_lo, q.dv_hi);
+        const float v_new = a.v + clamp_rate(tv - a.v, -q.dv_hi, q.dv_hi);
         if (track_v) ls.v_changed = ls.v_changed || v_new != a.v;
         a.v = v_new;
         a.h = a.h + clamp_rate(th - a.h, q.dh_lo, q.dh_hi);
-        a.phi = a.phi + clamp_rate(tp - a.phi, q.dp_lo, q.dp_hi);
+        a.phi = a.phi + clamp_rate(tp - a.phi, -q.dp_hi, q.dp_hi);
         if (book) {
             acts = (!(fabsf(tv - ls.la_v) < kDiscrV) ? 1 : 0) + (!(fabsf(th - ls.la_h) < kDiscrH) ? 1 : 0) +
                    (!(fabsf(tp - ls.la_p) < kDiscrPhi) ? 1 : 0);
@@ -650,7 +655,7 @@ __device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, con
     uint32_t bits = 0;
     if (n_noise > 0) {
         const uint32_t cand = noise_candidates(grid, c);
-        if (__ballot(cand != 0u) != 0ull) {
+        if (__builtin_amdgcn_ballot_w64(cand != 0u) != 0ull) {
             for (int q = 0; q < n_noise; ++q) {
                 const float* rec = K + (int)K[ATC_H_OFF_POLY] + ((int)K[ATC_H_N_MVA] + q) * ATC_P_WORDS;
                 if (((cand >> q) & 1u) && in_bounds(rec, x, y) && h < rec[ATC_P_HEIGHT] &&
@@ -694,13 +699,17 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
 #define ATC_RESOLVE_LATE 1   // resolve the MVA cell after the separation scan from W = 16 up (0: only for the LDS-scan widths):
                              // 18.5 vs 18.9 us single steps, 11.2 vs 11.4 fused at 65 536 x 16 (profiles/r03_experiments.txt)
 #endif
+    // edge records fetched per L2 round trip in dirty lookup cells: W = 1 is one wavefront per SIMD at any batch size the
+    // sector sees (latency-bound, registers to spare): four per trip (65 536 x 1: 7.4 vs 7.7 us single steps, 4.26 vs 4.44 fused);
+    // wider envs two (four cost the fused 65 536 x 16 launch 0.5 us per step)
+    constexpr int kWalkBatch = (W == 1) ? 4 : ATC_MVA_BATCH;
     constexpr bool kResolveAfterScan = ATC_RESOLVE_LATE ? (W >= 16) : (W >= 32);   // (W = 2 .. 8: the unrolled xor scan with the cell
                                                                                    // in flight costs 4 - 22 registers)
     float mva = 0.0f;
     int pi = 0;
     if (!kResolveAfterScan) {
         float hgt = 0.0f;
-        pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt);
+        pi = (ATC_ABLATE & 1) ? 0 : mva_resolve<kWalkBatch>(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt);
         mva = hgt;   // (0 when outside: mva_resolve leaves the height at 0, atc_gym.py:161)
         fl |= noise_areas(K, grid, m.cell, x32, y32, a.h);
     }
@@ -822,7 +831,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     // ---- MVA floor (atc_gym.py:146-161), second half ---------------------------------------------------------------------
     if (kResolveAfterScan) {
         float hgt = 0.0f;
-        pi = (ATC_ABLATE & 1) ? 0 : mva_resolve(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt);
+        pi = (ATC_ABLATE & 1) ? 0 : mva_resolve<kWalkBatch>(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt);
         mva = hgt;                                 // atc_gym.py:161: mva = 0 outside (mva_resolve leaves the height at 0)
         fl |= noise_areas(K, grid, m.cell, x32, y32, a.h);
     }
@@ -836,7 +845,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     const bool conflict = margin < 0.0f;
     const bool timeout = es.t > qs.timestep_limit;
     const bool quiet = !(ATC_ABLATE & 512) && m.plain &&
-                       __ballot((pi < 0) | (a.h < mva) | conflict | timeout | ((fl >> 16) != 0u) |
+                       __builtin_amdgcn_ballot_w64((pi < 0) | (a.h < mva) | conflict | timeout | ((fl >> 16) != 0u) |
                                 (grid ? corridor_candidate(m.cell)
                                       : ((x32 >= qs.tri_bbox.x) & (x32 <= qs.tri_bbox.z) & (y32 >= qs.tri_bbox.y) & (y32 <= qs.tri_bbox.w)))) == 0ull;
     if (!quiet) {
@@ -881,7 +890,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         if ((p.mode & ATC_M_REWARD_SHAPING) && !(ATC_ABLATE & 8)) r += shaping;
         // extension (README.md:62): noise-abatement areas — which ones the aircraft is in was decided next to the MVA lookup
         // (bits 16.. of fl); the penalties are subtracted here, after the shaping terms, in area order.
-        if (!quiet && __ballot((fl >> 16) != 0u) != 0ull) {
+        if (!quiet && __builtin_amdgcn_ballot_w64((fl >> 16) != 0u) != 0ull) {
             const int n_noise = (int)K[ATC_H_N_NOISE];
             for (int q = 0; q < n_noise; ++q)
                 if ((fl >> (16 + q)) & 1u) r -= (K + (int)K[ATC_H_OFF_POLY] + ((int)K[ATC_H_N_MVA] + q) * ATC_P_WORDS)[ATC_P_PENALTY];
@@ -903,7 +912,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     }
     // lanes without an aircraft under control: nothing happened.  Almost every wavefront has none, so the selects sit
     // behind a wave-uniform test.
-    if (!m.plain && __ballot(!active) != 0ull) {
+    if (!m.plain && __builtin_amdgcn_ballot_w64(!active) != 0ull) {
 #pragma unroll
         for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = active ? o[c] : 0.0f;
         r = active ? r : 0.0f;
@@ -1040,8 +1049,8 @@ __device__ __forceinline__ void store_lane_state(const atc_state_t& st, const La
     // speed and last-action targets are typically constant for many steps (actions are held, the speed reaches its target):
     // written back only by wavefronts in which one of them changed
     // (multi-step launches do not track speed changes per step: one unconditional 4-byte store per aircraft and launch)
-    if ((v_always || __ballot(ls.v_changed) != 0ull) && d.lane_valid) *at<float>(st.v, d.i * 4u) = ls.a.v;
-    if (__ballot(ls.la_changed) != 0ull && d.lane_valid && la_live) {
+    if ((v_always || __builtin_amdgcn_ballot_w64(ls.v_changed) != 0ull) && d.lane_valid) *at<float>(st.v, d.i * 4u) = ls.a.v;
+    if (__builtin_amdgcn_ballot_w64(ls.la_changed) != 0ull && d.lane_valid && la_live) {
         Float3 la = {ls.la_v, ls.la_h, ls.la_p};
         *at<Float3>(st.last_act, times12(d.i)) = la;
     }
@@ -1163,11 +1172,11 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             ls.la_p = tg.c;
         }
         // multi-step launches know structurally which steps repeat an action block
-        const bool repeated = ONE ? (same_actions && __ballot(la_live) == 0ull)
-                                  : (ATC_LOOP_SKIP_BOOK && held > 0 && __ballot(es.t == 0) == 0ull);
+        const bool repeated = ONE ? (same_actions && __builtin_amdgcn_ballot_w64(la_live) == 0ull)
+                                  : (ATC_LOOP_SKIP_BOOK && held > 0 && __builtin_amdgcn_ballot_w64(es.t == 0) == 0ull);
         // ... and whether every lane's aircraft is under control: re-established after the steps in which a mask can change
         if (!ONE && ATC_LOOP_ALLACT && mask_dirty) {
-            all_active = __ballot(!(dl.lane_valid && ((dl.k < 32 ? ((uint32_t)es.amask >> dl.k) : ((uint32_t)(es.amask >> 32) >> (dl.k - 32))) & 1u))) == 0ull;
+            all_active = __builtin_amdgcn_ballot_w64(!(dl.lane_valid && ((dl.k < 32 ? ((uint32_t)es.amask >> dl.k) : ((uint32_t)(es.amask >> 32) >> (dl.k - 32))) & 1u))) == 0ull;
             mask_dirty = false;
         }
         const Mid m = step_part_a(gl, qr, QGET(g), dl, tg.a, tg.b, tg.c, ls, es, repeated, !ONE && all_active, ONE);

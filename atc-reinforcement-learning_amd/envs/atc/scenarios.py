@@ -109,14 +109,21 @@ class LOWWDense(Scenario):
         _assemble(self, _LOWW_MVA, _LOWW_RUNWAY, entries, self.NOISE if noise else ())
 
 
+_compiled = {}   # (sector description, grid cell) -> CompiledSector: compiling is pure, and the lookup grid takes seconds
+
+
 def compile_scenario(scn, grid_cell=None):
-    """Scenario object (this module's or a duck-typed one) -> atc_hip.scenario.CompiledSector."""
+    """Scenario object (this module's or a duck-typed one) -> atc_hip.scenario.CompiledSector (cached per process by the
+    sector's content: the result is read-only data)."""
     from atc_hip import scenario as _scn
     rw = scn.runway
-    return _scn.compile_sector(
-        [(m.area_as_list, m.height) for m in scn.mvas],
-        (rw.x, rw.y, rw.h, rw.phi_from_runway),
-        [(e.x, e.y, e.phi, list(e.levels)) for e in scn.entrypoints],
-        noise=[(a.area_as_list, a.ceiling, a.penalty) for a in getattr(scn, "noise_areas", [])],
-        grid_cell=grid_cell,
-    )
+    mvas = [(m.area_as_list, m.height) for m in scn.mvas]
+    runway = (rw.x, rw.y, rw.h, rw.phi_from_runway)
+    entries = [(e.x, e.y, e.phi, list(e.levels)) for e in scn.entrypoints]
+    noise = [(a.area_as_list, a.ceiling, a.penalty) for a in getattr(scn, "noise_areas", [])]
+    key = repr(([([tuple(map(float, p)) for p in ring], float(h)) for ring, h in mvas], tuple(map(float, runway)),
+                [(float(x), float(y), float(phi), [float(v) for v in lev]) for x, y, phi, lev in entries],
+                [([tuple(map(float, p)) for p in ring], float(c), float(pen)) for ring, c, pen in noise], grid_cell))
+    if key not in _compiled:
+        _compiled[key] = _scn.compile_sector(mvas, runway, entries, noise=noise, grid_cell=grid_cell)
+    return _compiled[key]

@@ -358,7 +358,7 @@ def main():
     ap.add_argument("--no-parity-gate", action="store_true", help="developer knob: skip the pre-timing correctness gate")
     ap.add_argument("--no-single-env", action="store_true", help="skip the single-env compute-performance.py protocol")
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; value = the median block")
-    ap.add_argument("--grid-cell", type=float, default=0.5, help="cell size [nm] of the MVA lookup grid")
+    ap.add_argument("--grid-cell", type=float, default=0.25, help="cell size [nm] of the MVA lookup grid")
     ap.add_argument("--no-held-hint", action="store_true", help="do not tell atc_step that launches 2..%d of an action block "
                     "repeat the previous launch's actions (ATC_M_ACTIONS_HELD)" % HOLD)
     ap.add_argument("--action-ring", type=int, default=64, help="number of pre-generated action tensors the loop cycles through "
@@ -536,6 +536,9 @@ def main():
                                "all_reduce_max": D.max_over_ranks(1.5, dev, force=True), "all_reduce_sum": D.sum_over_ranks(2.5, dev, force=True)})
         except Exception as exc:
             collective["error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
+    if ws == 1:
+        D.shutdown()   # the one-rank group has served its purpose: no communicator (proxy thread, streams) during the timed region
+        torch.cuda.synchronize(dev)
     # HIP events on the stream(s) the kernels are launched on (torch's current stream, or one per sub-batch)
     qs = streams if S > 1 else [torch.cuda.current_stream(dev)]
     blocks = []   # (wall seconds, HIP-event milliseconds) of each timed block of K steps, max over ranks

@@ -125,8 +125,10 @@ def replay_wide(fx, make_backend, obs_tol, state_tol, rew_tol, max_envs=4096):
 
     Stated exception to the 1e-5 bar (fp32 backends only; the float64 oracle never needs it): the bearing to the FAF
     (obs[8], atc_gym.py:289-292) and the shaping terms built on it are ILL-CONDITIONED next to the FAF — a position error e
-    moves the bearing by e / d_faf radians.  Any fp32 displacement path is ~1e-6 nm off the float64 reference after a
-    few hundred steps, i.e. beyond 1e-5 once d_faf < ~0.1 nm.  Inside FAF_RADIUS the tolerance of the reward and of obs[8]
+    moves the bearing by e / d_faf radians.  Any implementation with fp32 aircraft STATE is ~1e-6 nm off the float64
+    reference after a few hundred steps (tools/faf_conditioning.py, profiles/r03_faf_conditioning.txt: 9e-7 median / 4.7e-6 max
+    after 700 steps even with float64 kinematics on the fp32 speed / heading — the fp32 rounding of the decoded targets is what
+    accumulates), i.e. beyond 1e-5 once d_faf < ~0.1 nm.  Inside FAF_RADIUS the tolerance of the reward and of obs[8]
     is scaled by FAF_RADIUS / d_faf; everywhere else it is the plain bar.  Returns (steps, steps inside the radius)."""
     total, near = 0, 0
     for (scen, dt, shaping, normalize, discrete), eps in fx.groups().items():

@@ -47,8 +47,9 @@ torch.cuda.synchronize()
 kernel_us = ev0.elapsed_time(ev1) / 200 * 1e3
 wave = np.arange(len(raw))
 xcd = (wave // 4) % 8
-tick_us = 0.01   # s_memtime: the 100 MHz reference clock
-print("kernel %.2f us per launch (HIP events, launch to launch); s_memtime tick = 10 ns" % kernel_us)
+GHZ = float(os.environ.get("ATC_TRACE_GHZ", "2.1"))   # s_memtime counts shader-clock cycles (~2.05-2.1 GHz under this load)
+tick_us = 1e-3 / GHZ
+print("kernel %.2f us per launch (HIP events, launch to launch); stamps in cycles, converted at %.2f GHz" % (kernel_us, GHZ))
 d = np.diff(raw.astype(np.float64), axis=1) * tick_us
 print("phase durations per wavefront [us]: mean / median / p90 / share of lifetime")
 life = (raw[:, 7] - raw[:, 0]) * tick_us
