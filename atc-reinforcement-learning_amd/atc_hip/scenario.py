@@ -114,6 +114,55 @@ GRID_F_BASE = 8.0        # the polygon has an ODD number of edges that every poi
 _BIG = 3.0e38
 
 
+def _box_records(cx0s, cx1s, cy0s, cy1s, edges, bounds, heights):
+    """Edge-list of one (slack-inflated) box, polygon by polygon in priority order — see build_grid.  [] = no point of the box
+    is inside any polygon; a single record with -_BIG bounds = every point is inside that polygon."""
+    recs = []
+    for pi, (e, b) in enumerate(zip(edges, bounds)):
+        if b[2] < cx0s or b[0] > cx1s or b[3] < cy0s or b[1] > cy1s:
+            continue  # the (inclusive) bounds test of model.py:286 rejects every point of the cell
+        ymin = np.minimum(e[:, 1], e[:, 3])
+        ymax = np.maximum(e[:, 1], e[:, 3])
+        xmin = np.minimum(e[:, 0], e[:, 2])
+        xmax = np.maximum(e[:, 0], e[:, 2])
+        rel = (cy1s > ymin) & (cy0s <= ymax) & (cx0s <= xmax) & (ymax > ymin)   # (a horizontal edge is never counted)
+        # Where does the box lie relative to the edge's LINE over the part of the edge's y-range it can reach?  (Round 3; the
+        # edge's bounding box was used before: every cell inside the bounding box of a long diagonal edge was dirty.)  The
+        # x-intersection of model.py:331 is linear in y: its extremes over the clipped y-interval are at the interval's ends.
+        with np.errstate(divide="ignore", invalid="ignore"):
+            slope = np.where(ymax > ymin, (e[:, 2] - e[:, 0]) / (e[:, 3] - e[:, 1]), 0.0)
+        ya = np.clip(cy0s, ymin, ymax)
+        yb = np.clip(cy1s, ymin, ymax)
+        xa = e[:, 0] + (ya - e[:, 1]) * slope
+        xb = e[:, 0] + (yb - e[:, 1]) * slope
+        margin = 1e-3   # >> the fp32 error of the kernel's x-intersection (~1e-5 nm) + the rounding of the position
+        right = cx1s < np.minimum(xa, xb) - margin      # whole box left of the line: x <= xints holds whatever the rounding
+        rel &= ~(cx0s > np.maximum(xa, xb) + margin)    # whole box right of the line: x <= xints fails for every point
+        const = rel & right & (cy0s > ymin) & (cy1s <= ymax)
+        base = GRID_F_BASE if int(const.sum()) & 1 else 0.0
+        idx = np.nonzero(rel & ~const)[0]
+        inside_bounds = b[0] <= cx0s and cx1s <= b[2] and b[1] <= cy0s and cy1s <= b[3]
+        if len(idx) == 0:
+            if not base:
+                continue              # no point of the cell is inside this polygon
+            if inside_bounds:         # every point of the cell is inside it: nothing below it can be reached
+                recs.append([-_BIG, -_BIG, _BIG, _BIG, 0.0, 0.0, heights[pi], 16.0 * pi + GRID_F_TERM + base])
+                break
+            recs.append([b[0], b[1], b[2], b[3], 0.0, 0.0, heights[pi], 16.0 * pi + GRID_F_TERM + base])
+            continue
+        certain = right[idx]
+        order = np.argsort(certain, kind="stable")  # intersection-test edges first: lanes diverge less
+        for pos, k in enumerate(order):
+            ek = e[idx[k]]
+            fl = GRID_F_CERTAIN if certain[k] else 0.0
+            if inside_bounds and pos == len(order) - 1:
+                fl += GRID_F_LAST + base
+            recs.append([ek[0], ek[1], ek[2], ek[3], min(ek[1], ek[3]), max(ek[1], ek[3]), heights[pi], 16.0 * pi + fl])
+        if not inside_bounds:
+            recs.append([b[0], b[1], b[2], b[3], 0.0, 0.0, heights[pi], 16.0 * pi + GRID_F_TERM + base])
+    return recs
+
+
 def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=(), corridor_bounds=None):
     """Uniform lookup grid for Airspace.find_mva (model.py:282-289) with IDENTICAL results to the ordered polygon scan.
 
@@ -191,38 +240,7 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=(), 
                 continue
             cx0s = gx0 + i * cell - slack
             cx1s = gx0 + (i + 1) * cell + slack
-            recs = []
-            for pi, (e, b) in enumerate(zip(edges, bounds)):
-                if b[2] < cx0s or b[0] > cx1s or b[3] < cy0s or b[1] > cy1s:
-                    continue  # the (inclusive) bounds test of model.py:286 rejects every point of the cell
-                ymin = np.minimum(e[:, 1], e[:, 3])
-                ymax = np.maximum(e[:, 1], e[:, 3])
-                xmin = np.minimum(e[:, 0], e[:, 2])
-                xmax = np.maximum(e[:, 0], e[:, 2])
-                rel = (cy1s > ymin) & (cy0s <= ymax) & (cx0s <= xmax)
-                right = cx1s < xmin - 1e-3
-                const = rel & right & (cy0s > ymin) & (cy1s <= ymax)
-                base = GRID_F_BASE if int(const.sum()) & 1 else 0.0
-                idx = np.nonzero(rel & ~const)[0]
-                inside_bounds = b[0] <= cx0s and cx1s <= b[2] and b[1] <= cy0s and cy1s <= b[3]
-                if len(idx) == 0:
-                    if not base:
-                        continue              # no point of the cell is inside this polygon
-                    if inside_bounds:         # every point of the cell is inside it: nothing below it can be reached
-                        recs.append([-_BIG, -_BIG, _BIG, _BIG, 0.0, 0.0, heights[pi], 16.0 * pi + GRID_F_TERM + base])
-                        break
-                    recs.append([b[0], b[1], b[2], b[3], 0.0, 0.0, heights[pi], 16.0 * pi + GRID_F_TERM + base])
-                    continue
-                certain = right[idx]
-                order = np.argsort(certain, kind="stable")  # intersection-test edges first: lanes diverge less
-                for pos, k in enumerate(order):
-                    ek = e[idx[k]]
-                    fl = GRID_F_CERTAIN if certain[k] else 0.0
-                    if inside_bounds and pos == len(order) - 1:
-                        fl += GRID_F_LAST + base
-                    recs.append([ek[0], ek[1], ek[2], ek[3], min(ek[1], ek[3]), max(ek[1], ek[3]), heights[pi], 16.0 * pi + fl])
-                if not inside_bounds:
-                    recs.append([b[0], b[1], b[2], b[3], 0.0, 0.0, heights[pi], 16.0 * pi + GRID_F_TERM + base])
+            recs = _box_records(cx0s, cx1s, cy0s, cy1s, edges, bounds, heights)
             if len(recs) == 1 and recs[0][0] == -_BIG:   # a single unconditional answer: the cell is clean after all
                 cells[j, i, 0] = -(recs[0][7] // 16 + 1.0)
                 cells[j, i, 1] = recs[0][6]

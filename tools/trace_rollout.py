@@ -17,7 +17,7 @@ from envs.atc import scenarios
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-env = AtcVecEnv(B, N, scenario=scenarios.LOWW(random_entrypoints=True), auto_reset=True)
+env = AtcVecEnv(B, N, scenario=scenarios.LOWWDense() if N > 16 else scenarios.LOWW(random_entrypoints=N > 1), auto_reset=True)
 acts = [(torch.rand((1, B, N, 3), device="cuda") * 2 - 1) for _ in range(4)]
 out = None
 for t in range(30):
