@@ -85,6 +85,31 @@ def _first_polygon(x, y, rings, bounds):
     return -1
 
 
+def _first_polygon_many(X, Y, rings, bounds):
+    """_first_polygon for arrays of points (the same float64 operations, vectorised over the points): the clean cells of a fine
+    lookup grid are hundreds of thousands of centre points."""
+    X = np.asarray(X, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64)
+    res = np.full(X.shape, -1, dtype=np.int64)
+    for i, (ring, b) in enumerate(zip(rings, bounds)):
+        todo = np.nonzero((res < 0) & (b[0] <= X) & (X <= b[2]) & (b[1] <= Y) & (Y <= b[3]))[0]
+        if len(todo) == 0:
+            continue
+        x, y = X[todo], Y[todo]
+        inside = np.zeros(len(todo), dtype=bool)
+        n = len(ring)
+        p1x, p1y = ring[0]
+        for k in range(n + 1):
+            p2x, p2y = ring[k % n]
+            if p1y != p2y:   # (an edge with p1y == p2y fails y > min or y <= max for every y)
+                cond = (y > min(p1y, p2y)) & (y <= max(p1y, p2y)) & (x <= max(p1x, p2x))
+                xints = (y - p1y) * (p2x - p1x) / (p2y - p1y) + p1x
+                inside ^= cond & ((p1x == p2x) | (x <= xints))
+            p1x, p1y = p2x, p2y
+        res[todo[inside]] = i
+    return res
+
+
 def _seg_near_box(p, q, bx0, by0, bx1, by1):
     """True if segment p-q may touch the (already inflated) box — conservative: segment bbox overlap + separating axis
     along the segment normal."""
@@ -228,16 +253,16 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=(), 
                         near[j, i] = True
     cells = np.zeros((ny, nx, 2), dtype=np.float64)
     pool = []
+    # clean cells (no edge near): the answer of the centre point, all of them at once
+    jj, ii = np.nonzero(~near)
+    pis = _first_polygon_many(gx0 + (ii + 0.5) * cell, gy0 + (jj + 0.5) * cell, rings, bounds)
+    hit = pis >= 0
+    cells[jj[hit], ii[hit], 0] = -(pis[hit] + 1.0)
+    cells[jj[hit], ii[hit], 1] = np.asarray(heights, dtype=np.float64)[pis[hit]]
     for j in range(ny):
         cy0s = gy0 + j * cell - slack
         cy1s = gy0 + (j + 1) * cell + slack
-        for i in range(nx):
-            if not near[j, i]:
-                pi = _first_polygon(gx0 + (i + 0.5) * cell, gy0 + (j + 0.5) * cell, rings, bounds)
-                if pi >= 0:
-                    cells[j, i, 0] = -(pi + 1.0)
-                    cells[j, i, 1] = heights[pi]
-                continue
+        for i in np.nonzero(near[j])[0]:
             cx0s = gx0 + i * cell - slack
             cx1s = gx0 + (i + 1) * cell + slack
             recs = _box_records(cx0s, cx1s, cy0s, cy1s, edges, bounds, heights)

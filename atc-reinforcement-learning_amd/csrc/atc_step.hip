@@ -45,6 +45,7 @@ struct atc_scenario {
     int n_cu;
     float consts[ATC_C_END];   // host copy of the blob's header + constants block (derive() evaluates uniform terms from it)
     float ghdr[ATC_G_HDR];     // host copy of the lookup grid's header (zeros without a grid)
+    uint64_t uid;              // unique per created handle (never reused: keys the per-thread cache of derive())
 };
 
 static thread_local char g_err[512] = "";
@@ -94,6 +95,9 @@ constexpr int kBlock = ATC_BLOCK;
 #else
 #define ATC_STAMP(n) do {} while (0)
 #define ATC_STAMP_B(n) do {} while (0)
+#endif
+#ifndef ATC_OBS_FIRST_W1
+#define ATC_OBS_FIRST_W1 0   // single-step launches of one-aircraft envs: observation before the MVA resolve (A/B below)
 #endif
 #ifndef ATC_LOOP_SKIP_BOOK
 #define ATC_LOOP_SKIP_BOOK 1  // multi-step launches: no last-action bookkeeping on the steps that repeat an action block
@@ -409,7 +413,27 @@ static InlineAction inline_action() {
     if (t_inline_action) a = InlineAction{t_inline_action[0], t_inline_action[1], t_inline_action[2], 1};
     return a;
 }
-static StepDerived derive(const atc_params_t& p, const atc_scenario* s) {
+static StepDerived derive_uncached(const atc_params_t& p, const atc_scenario* s);
+// The uniform terms depend on the sector and on a few parameters only; a caller steps the same env thousands of times with the
+// same ones, so each thread remembers its last evaluation (the single-env path launches one tiny kernel per step: the
+// evaluation would be a measurable part of its host time).  Thread-local: the library stays free of shared mutable state.
+static const StepDerived& derive(const atc_params_t& p, const atc_scenario* s) {
+    struct Key {
+        uint64_t uid;
+        float dt, sep_nm, sep_ft, conflict_reward;
+        int32_t timestep_limit;
+        uint32_t discrete;
+    };
+    static thread_local Key last = {0ull, 0.0f, 0.0f, 0.0f, 0.0f, 0, 0u};
+    static thread_local StepDerived q;
+    const Key k = {s->uid, p.dt, p.sep_nm, p.sep_ft, p.conflict_reward, p.timestep_limit, p.mode & (uint32_t)ATC_M_DISCRETE};
+    if (memcmp(&k, &last, sizeof k) != 0) {
+        q = derive_uncached(p, s);
+        last = k;
+    }
+    return q;
+}
+static StepDerived derive_uncached(const atc_params_t& p, const atc_scenario* s) {
     const float* K = s->consts;
     StepDerived q;
     memset(&q, 0, sizeof q);
@@ -703,7 +727,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     // sector sees (latency-bound, registers to spare): four per trip (65 536 x 1: 7.4 vs 7.7 us single steps, 4.26 vs 4.44 fused);
     // wider envs two (four cost the fused 65 536 x 16 launch 0.5 us per step)
     constexpr int kWalkBatch = (W == 1) ? 4 : ATC_MVA_BATCH;
-    constexpr bool kResolveAfterScan = ATC_RESOLVE_LATE ? (W >= 16) : (W >= 32);   // (W = 2 .. 8: the unrolled xor scan with the cell
+    constexpr bool kResolveAfterScan = ATC_RESOLVE_LATE ? (W >= 16 || (ATC_OBS_FIRST_W1 && W == 1 && ONE)) : (W >= 32);   // (W = 2 .. 8: the unrolled xor scan with the cell
                                                                                    // in flight costs 4 - 22 registers)
     float mva = 0.0f;
     int pi = 0;
@@ -813,9 +837,6 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         }
     }
     ATC_STAMP_B(2);
-#ifndef ATC_OBS_FIRST_W1
-#define ATC_OBS_FIRST_W1 0   // (W = 1: 7.97 vs 8.07 us single steps, 5.05 vs 4.94 fused: no clear gain)
-#endif
 #ifndef ATC_OBS_FIRST
 #define ATC_OBS_FIRST 0   // 1: observation and shaping terms BEFORE the lookup cell is resolved (they do not depend on the MVA,
 #endif                    // only obs[5] = h - mva does).  Measured: no gain at any size (profiles/r03_experiments.txt)
@@ -823,7 +844,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     float shaping = 0.0f;
     const ObsConst oc = QGET(oc);
     // (W = 1 has no scan to cover the gather: there the observation goes first)
-    constexpr bool kObsFirst = ATC_OBS_FIRST || (ATC_OBS_FIRST_W1 && W == 1);
+    constexpr bool kObsFirst = ATC_OBS_FIRST || (ATC_OBS_FIRST_W1 && W == 1 && ONE);
     if (kObsFirst && !(ATC_ABLATE & 8)) {
         ob = get_state(oc, a.x, a.y, x32, y32, a.h, a.phi, a.v, 0.0f);
         if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
@@ -1426,7 +1447,9 @@ int atc_scenario_create(const float* blob_host, size_t n_words, int device, atc_
             return fail_arg("action discriminator differs from the compiled-in constants");
     }
     HIP_TRY(hipSetDevice(device));
+    static std::atomic<uint64_t> next_uid{1};
     atc_scenario* s = new atc_scenario();
+    s->uid = next_uid.fetch_add(1);
     s->n_words = (int)n_words;
     s->off_grid = (int)blob_host[ATC_H_OFF_GRID];
     memcpy(s->consts, blob_host, sizeof s->consts);

@@ -271,13 +271,14 @@ def traffic_entry(B, N, rollout, held_hint, streams=1):
     return None, None
 
 
-def side_config(name, B, N, scn, grid_cell, sep_nm, device, held_hint, n_single=2000, n_fused=100):
+def side_config(name, B, N, scn, sep_nm, device, held_hint, n_single=2000, n_fused=100):
     """One of BASELINE.json's other single-GPU configurations as a side record of the default line: the launch mode of the
     headline loop (one atc_step per step, a new action tensor every HOLD steps, the held-action hint in between) and the same
     envs with HOLD steps fused per launch — each parity-gated on its own first 256 envs before it is timed."""
     import torch
-    from atc_hip.vec_env import AtcVecEnv
+    from atc_hip.vec_env import AtcVecEnv, auto_grid_cell
     dev = torch.device("cuda", device)
+    grid_cell = auto_grid_cell(B, N)   # the library's default for this batch; the gates run on the same grid
     gate = {"single_steps": oracle_gate(scn, N, grid_cell, sep_nm, device, held_hint),
             "fused": rollout_gate(scn, N, grid_cell, sep_nm, device)}
     env = AtcVecEnv(B, N, scenario=scn, device=device, auto_reset=True, seed=11, grid_cell=grid_cell, sep_nm=sep_nm)
@@ -319,7 +320,7 @@ def side_config(name, B, N, scn, grid_cell, sep_nm, device, held_hint, n_single=
     b1, bf = algorithmic_bytes_per_env_step(N), algorithmic_bytes_per_env_step(N, HOLD, HOLD)
     tr1, src1 = traffic_entry(B, N, 0, held_hint)
     trf, srcf = traffic_entry(B, N, HOLD, False)
-    return {"config": name, "envs": B, "aircraft": N, "sector": type(scn).__name__, "parity_gate": gate,
+    return {"config": name, "envs": B, "aircraft": N, "sector": type(scn).__name__, "grid_cell_nm": grid_cell, "parity_gate": gate,
             "single_steps": {"steps": n_single, "us_per_step": us, "env_steps_per_s": B / (us * 1e-6),
                              "algorithmic_bytes_per_env_step": b1, "hbm_frac": b1 * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                              "traffic": tr1, "traffic_source": src1, "timed_blocks_us_per_step": blocks},
@@ -358,7 +359,8 @@ def main():
     ap.add_argument("--no-parity-gate", action="store_true", help="developer knob: skip the pre-timing correctness gate")
     ap.add_argument("--no-single-env", action="store_true", help="skip the single-env compute-performance.py protocol")
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; value = the median block")
-    ap.add_argument("--grid-cell", type=float, default=0.25, help="cell size [nm] of the MVA lookup grid")
+    ap.add_argument("--grid-cell", default="auto", help="cell size [nm] of the MVA lookup grid (default: by batch size, "
+                    "atc_hip.vec_env.auto_grid_cell)")
     ap.add_argument("--no-held-hint", action="store_true", help="do not tell atc_step that launches 2..%d of an action block "
                     "repeat the previous launch's actions (ATC_M_ACTIONS_HELD)" % HOLD)
     ap.add_argument("--action-ring", type=int, default=64, help="number of pre-generated action tensors the loop cycles through "
@@ -428,6 +430,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     B, N, K, W = args.envs, args.aircraft, args.steps, args.warmup
+    from atc_hip.vec_env import auto_grid_cell
+    args.grid_cell = auto_grid_cell(B // max(1, args.streams), N) if args.grid_cell == "auto" else float(args.grid_cell)
 
     scn = scenarios.LOWWDense() if N > 16 else scenarios.LOWW(random_entrypoints=N > 1)
     S = args.streams
@@ -687,12 +691,12 @@ def main():
             # stays the headline configuration)
             hh = not args.no_held_hint
             line["config"]["baseline_configs"] = [
-                side_config("C2: 65 536 envs x 1 aircraft (kinematics + MVA only)", 65536, 1, scenarios.LOWW(), args.grid_cell,
+                side_config("C2: 65 536 envs x 1 aircraft (kinematics + MVA only)", 65536, 1, scenarios.LOWW(),
                             args.sep_nm, local, hh),
-                side_config("C3: 8 192 envs x 16 aircraft", 8192, 16, scenarios.LOWW(random_entrypoints=True), args.grid_cell,
+                side_config("C3: 8 192 envs x 16 aircraft", 8192, 16, scenarios.LOWW(random_entrypoints=True),
                             args.sep_nm, local, hh),
                 side_config("C4: 4 096 envs x 64 aircraft, multi-polygon MVA + noise-abatement areas", 4096, 64,
-                            scenarios.LOWWDense(), args.grid_cell, args.sep_nm, local, hh)]
+                            scenarios.LOWWDense(), args.sep_nm, local, hh)]
         if ws == 1 and not args.no_single_env:
             line["config"]["single_env"] = single_env_protocol()
         if ws == 1 and not args.no_cpu_baseline:
