@@ -96,8 +96,12 @@ constexpr int kBlock = ATC_BLOCK;
 #define ATC_STAMP(n) do {} while (0)
 #define ATC_STAMP_B(n) do {} while (0)
 #endif
+#ifndef ATC_OBS_DIRECT
+#define ATC_OBS_DIRECT 0   // developer A/B: bit 0 single-step, bit 1 multi-step launches store the observation rows per lane (no LDS transpose)
+#endif
 #ifndef ATC_OBS_FIRST_W1
-#define ATC_OBS_FIRST_W1 0   // single-step launches of one-aircraft envs: observation before the MVA resolve (A/B below)
+#define ATC_OBS_FIRST_W1 1   // single-step launches of one-aircraft envs: observation and shaping BEFORE the MVA resolve (no scan to
+                             // cover the cell gather there): 65 536 x 1 6.65-6.87 vs 6.99-7.04 us (profiles/r03_experiments.txt)
 #endif
 #ifndef ATC_LOOP_SKIP_BOOK
 #define ATC_LOOP_SKIP_BOOK 1  // multi-step launches: no last-action bookkeeping on the steps that repeat an action block
@@ -1027,7 +1031,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     //      contiguous bytes as 16-byte stores.
     if (ATC_ABLATE & 16) {
         if (d.lane_valid && o[0] == 12345.678f) so.obs[i] = o[1];
-    } else if (d.wave_full) {
+    } else if (d.wave_full && !(ATC_OBS_DIRECT & (ONE ? 1 : 2))) {
         // addresses from threadIdx itself, not from the lane ids a multi-step launch re-derives through an opaque zero: the
         // compiler then knows the ranges (lane < 64: two of the three row tests fold away, 24-bit multiplies suffice) — with
         // the opaque copies it emitted a quarter-rate 64-bit multiply-add per LDS read

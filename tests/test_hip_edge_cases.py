@@ -488,3 +488,49 @@ def test_held_hint_after_a_multi_step_launch():
             assert torch.equal(getattr(a, name), getattr(b, name)), (name, rnd)
     a.close()
     b.close()
+
+
+def test_envs_with_different_parameters_interleaved_on_one_thread():
+    """The library caches the host-evaluated step constants per thread, keyed by sector handle and the parameters they
+    depend on: envs that differ in time step / action space / separation minima / time-step limit — over the SAME sector,
+    stepped alternately from one thread, single steps and fused launches — must each keep getting their own constants."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import model, scenarios
+    from oracle import oracle as O
+    scn = scenarios.LOWW(random_entrypoints=True)
+    comp = scenarios.compile_scenario(scn, grid_cell=0.25)
+    B, N = 96, 16
+    cfgs = [dict(dt=1.0, discrete=False, sep_nm=3.0, limit=6000), dict(dt=2.0, discrete=True, sep_nm=5.0, limit=6000),
+            dict(dt=5.0, discrete=False, sep_nm=3.0, limit=30)]
+    envs, orcs = [], []
+    for c in cfgs:
+        sp = model.SimParameters(c["dt"], discrete_action_space=c["discrete"])
+        envs.append(AtcVecEnv(B, N, sim_parameters=sp, scenario=scn, auto_reset=True, spawn="lattice", seed=3, grid_cell=0.25,
+                              sep_nm=c["sep_nm"], timestep_limit=c["limit"]))
+        orcs.append(O.OracleEnv(comp, B, N, O.make_params(dt=c["dt"], discrete=c["discrete"], auto_reset=True, seed=3,
+                                                           sep_nm=c["sep_nm"], timestep_limit=c["limit"]), np.float32))
+    rng = np.random.default_rng(77)
+
+    def draw(c):
+        if c["discrete"]:
+            return np.floor(rng.uniform(0, 1, (B, N, 3)) * np.array([20, 380, 360])).astype(np.float32)
+        return rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    for rnd in range(12):
+        for c, env, orc in zip(cfgs, envs, orcs):   # one call per env, round robin: every call meets another env's cache entry
+            a = draw(c)
+            if rnd % 3 == 2:
+                out = env.rollout(torch.as_tensor(a[None]), hold=4)
+                res = [(out["flags"][t], out["done"][t], out["reward"][t]) for t in range(4)]
+            else:
+                _, rew, done, info = env.step(a)
+                res = [(info["flags"], done, rew)]
+            for fl, done, rew in res:
+                orc.step(a)
+                assert np.array_equal(fl.cpu().numpy().astype(np.uint32), orc.flags), (c, rnd)
+                assert np.array_equal(done.cpu().numpy(), orc.done), (c, rnd)
+                assert np.all(np.abs(rew.cpu().numpy() - orc.reward) <= 1e-5 * np.maximum(1.0, np.abs(orc.reward)) + 6e-8 * N * np.abs(orc.ac_reward).sum(1)), (c, rnd)
+    for env, orc in zip(envs, orcs):
+        assert np.array_equal(env.pos_hp[:, 0].cpu().numpy(), orc.px) and np.array_equal(env.h.cpu().numpy(), orc.h)
+        assert np.array_equal(env.timesteps.cpu().numpy(), orc.timesteps)
+        env.close()

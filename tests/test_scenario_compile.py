@@ -148,3 +148,17 @@ def test_grid_matches_ordered_scan_on_host(scen, cell):
                              cells.reshape(ny, nx, 2)[:, 0].ravel(), cells.reshape(ny, nx, 2)[:, -1].ravel()])
     assert not border.any()   # the outermost ring: clean, outside, no candidates of any kind
     print(scen, cell, 'dirty cells', n_dirty, 'of', len(cells), 'records per dirty cell %.2f' % ((codes & 63)[cells[:, 0] > 0].mean()))
+
+
+def test_grid_cell_by_batch_size_and_compile_cache():
+    """auto_grid_cell: fine cells for batches up to 262 144 aircraft slots, 0.25 nm beyond; compile_scenario returns the cached
+    object for an equal sector description and a new one when anything differs."""
+    from atc_hip.vec_env import auto_grid_cell
+    from envs.atc import scenarios
+    assert auto_grid_cell(1, 1) == 0.125 and auto_grid_cell(65536, 1) == 0.125 and auto_grid_cell(8192, 16) == 0.125
+    assert auto_grid_cell(4096, 64) == 0.125 and auto_grid_cell(4096, 33) == 0.125   # 33 aircraft occupy 64 slots
+    assert auto_grid_cell(65536, 16) == 0.25 and auto_grid_cell(4097, 64) == 0.25
+    a = scenarios.compile_scenario(scenarios.LOWW(), grid_cell=0.5)
+    assert scenarios.compile_scenario(scenarios.LOWW(), grid_cell=0.5) is a
+    assert scenarios.compile_scenario(scenarios.LOWW(), grid_cell=1.0) is not a
+    assert scenarios.compile_scenario(scenarios.LOWW(random_entrypoints=True), grid_cell=0.5) is not a
