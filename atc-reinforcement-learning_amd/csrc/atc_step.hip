@@ -96,6 +96,10 @@ constexpr int kBlock = ATC_BLOCK;
 #define ATC_STAMP(n) do {} while (0)
 #define ATC_STAMP_B(n) do {} while (0)
 #endif
+#ifndef ATC_NEAR_FIRST_LDS
+#define ATC_NEAR_FIRST_LDS 0   // N > 16 fast variant: horizontal test first, altitude plane only for close pairs: 459 vs 503 VALU
+                               // per wavefront at 32 768 x 64 but no faster (39.9 vs 40.2 us; 4 096 x 64 8.36 vs 8.24): off
+#endif
 #ifndef ATC_OBS_DIRECT
 #define ATC_OBS_DIRECT 0   // developer A/B: bit 0 single-step, bit 1 multi-step launches store the observation rows per lane (no LDS transpose)
 #endif
@@ -802,19 +806,35 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
                     const float* q0 = own + d0 + 2 * u;
                     qx[u] = v2f{q0[0], q0[1]};
                     qy[u] = v2f{q0[P], q0[P + 1]};
-                    qh[u] = v2f{q0[2 * P], q0[2 * P + 1]};
+                    // the fast variant asks the horizontal question first (round 3, like the N = 16 scan): the altitude plane is
+                    // only read for partner pairs some lane of the wavefront is horizontally close to
+                    if (FULL || !ATC_NEAR_FIRST_LDS) qh[u] = v2f{q0[2 * P], q0[2 * P + 1]};
                 }
 #pragma unroll
                 for (int u = U / 2 - 1; u >= 0; --u) {
-                    const v2f dx = xs2 - qx[u], dy = ys2 - qy[u], dh = hs2 - qh[u];
+                    const v2f dx = xs2 - qx[u], dy = ys2 - qy[u];
                     const v2f d2 = __builtin_elementwise_fma(dx, dx, dy * dy);
-#pragma unroll
-                    for (int w = 1; w >= 0; --w) {
+                    uint64_t mk[2];
+                    if (FULL || !ATC_NEAR_FIRST_LDS) {
+                        const v2f dh = hs2 - qh[u];
                         // (two ballots anded as scalars: the compare masks themselves — a ballot of the anded predicate is
                         // materialised per lane and compared again)
-                        const uint64_t mk = __builtin_amdgcn_ballot_w64(d2[w] < sep2) & __builtin_amdgcn_ballot_w64(fabsf(dh[w]) < sep_ft);
-                        first |= mk;
-                        const uint64_t t = acc | mk;
+                        mk[0] = __builtin_amdgcn_ballot_w64(d2[0] < sep2) & __builtin_amdgcn_ballot_w64(fabsf(dh[0]) < sep_ft);
+                        mk[1] = __builtin_amdgcn_ballot_w64(d2[1] < sep2) & __builtin_amdgcn_ballot_w64(fabsf(dh[1]) < sep_ft);
+                    } else {
+                        mk[0] = __builtin_amdgcn_ballot_w64(d2[0] < sep2);
+                        mk[1] = __builtin_amdgcn_ballot_w64(d2[1] < sep2);
+                        if ((mk[0] | mk[1]) != 0ull) {   // wave-uniform
+                            const float* q0 = own + d0 + 2 * u;
+                            const v2f dh = hs2 - v2f{q0[2 * P], q0[2 * P + 1]};
+                            mk[0] &= __builtin_amdgcn_ballot_w64(fabsf(dh[0]) < sep_ft);
+                            mk[1] &= __builtin_amdgcn_ballot_w64(fabsf(dh[1]) < sep_ft);
+                        }
+                    }
+#pragma unroll
+                    for (int w = 1; w >= 0; --w) {
+                        first |= mk[w];
+                        const uint64_t t = acc | mk[w];
                         if (W == 64) {
                             acc = (t << 1) | (t >> 63);
                         } else {  // two groups of 32 lanes: rotate inside each half
