@@ -1,0 +1,123 @@
+// Developer micro-benchmark (gfx950): issue cost of the VALU instruction classes the step kernel uses, per SIMD.
+// Every wavefront runs ITER iterations of 16 independent copies of one instruction (16 destination registers, so the
+// dependent-issue latency of a single wavefront does not bound the rate once several wavefronts share a SIMD).
+// Reported: SIMD cycles per wave-instruction = elapsed * clock / (ITER * 16 * wavefronts per SIMD), clock from s_memtime.
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/valu_rates.hip -o /tmp/valu_rates && /tmp/valu_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define ITER 2048
+#define R16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+
+#define KERNEL(NAME, DECL, BODY, SINK)                                                       \
+    __global__ void __launch_bounds__(256) NAME(float* out, unsigned long long* cyc, float seed) { \
+        DECL;                                                                                \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();                          \
+        for (int it = 0; it < ITER; ++it) { BODY; }                                          \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();                          \
+        SINK;                                                                                \
+        if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;                           \
+    }
+
+#define DECL_F float r[16]; for (int i = 0; i < 16; ++i) r[i] = seed + threadIdx.x * 1e-3f + i; float s = seed * 0.5f
+#define SINK_F float acc = 0; for (int i = 0; i < 16; ++i) acc += r[i]; if (acc == 12345.0f) out[threadIdx.x] = acc
+
+#define OP_FMA(i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(r[i]) : "v"(s));
+KERNEL(k_fma, DECL_F, R16(OP_FMA), SINK_F)
+#define OP_MUL(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r[i]) : "v"(s));
+KERNEL(k_mul, DECL_F, R16(OP_MUL), SINK_F)
+#define OP_RCP(i) asm volatile("v_rcp_f32 %0, %0" : "+v"(r[i]));
+KERNEL(k_rcp, DECL_F, R16(OP_RCP), SINK_F)
+#define OP_EXP(i) asm volatile("v_exp_f32 %0, %0" : "+v"(r[i]));
+KERNEL(k_exp, DECL_F, R16(OP_EXP), SINK_F)
+#define OP_SQRT(i) asm volatile("v_sqrt_f32 %0, %0" : "+v"(r[i]));
+KERNEL(k_sqrt, DECL_F, R16(OP_SQRT), SINK_F)
+#define OP_DPP(i) asm volatile("v_subrev_f32_dpp %0, %0, %1 row_ror:3 row_mask:0xf bank_mask:0xf" : "+v"(r[i]) : "v"(s));
+KERNEL(k_dpp, DECL_F, R16(OP_DPP), SINK_F)
+#define OP_CMP(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(r[i]), "v"(s) : "vcc");
+KERNEL(k_cmp, DECL_F, R16(OP_CMP), SINK_F)
+#define OP_CNDMASK(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(s) : "vcc");
+KERNEL(k_cndmask, DECL_F, R16(OP_CNDMASK), SINK_F)
+#define OP_MED3(i) asm volatile("v_med3_f32 %0, %0, %1, %1" : "+v"(r[i]) : "v"(s));
+KERNEL(k_med3, DECL_F, R16(OP_MED3), SINK_F)
+#define OP_MULLO(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(r[i]) : "v"(s));
+KERNEL(k_mul_lo_u32, DECL_F, R16(OP_MULLO), SINK_F)
+#define OP_MUL24(i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(r[i]) : "v"(s));
+KERNEL(k_mul_u24, DECL_F, R16(OP_MUL24), SINK_F)
+#define OP_CVTI(i) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(r[i]));
+KERNEL(k_cvt_i32_f32, DECL_F, R16(OP_CVTI), SINK_F)
+#define OP_RNDNE(i) asm volatile("v_rndne_f32 %0, %0" : "+v"(r[i]));
+KERNEL(k_rndne, DECL_F, R16(OP_RNDNE), SINK_F)
+#define OP_READLANE(i) asm volatile("v_readlane_b32 s20, %0, 3" : : "v"(r[i]) : "s20");
+KERNEL(k_readlane, DECL_F, R16(OP_READLANE), SINK_F)
+#define OP_MOV(i) asm volatile("v_mov_b32 %0, %1" : "+v"(r[i]) : "v"(s));
+KERNEL(k_mov, DECL_F, R16(OP_MOV), SINK_F)
+#define OP_SALU(i) asm volatile("s_add_u32 s20, s20, 1" : : : "s20", "scc");
+KERNEL(k_salu, DECL_F, R16(OP_SALU), SINK_F)
+// one SALU between every two VALU: do the two units overlap within ONE wavefront?
+#define OP_MIX(i) asm volatile("v_fma_f32 %0, %0, %1, %0\n s_add_u32 s20, s20, 1" : "+v"(r[i]) : "v"(s) : "s20", "scc");
+KERNEL(k_fma_salu_mix, DECL_F, R16(OP_MIX), SINK_F)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define DECL_P v2f r[16]; for (int i = 0; i < 16; ++i) r[i] = v2f{seed + threadIdx.x * 1e-3f + i, seed + i}; v2f s = {seed * 0.5f, seed}
+#define SINK_P float acc = 0; for (int i = 0; i < 16; ++i) acc += r[i][0] + r[i][1]; if (acc == 12345.0f) out[threadIdx.x] = acc
+#define OP_PKFMA(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(r[i]) : "v"(s));
+KERNEL(k_pk_fma, DECL_P, R16(OP_PKFMA), SINK_P)
+#define OP_PKMUL(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(r[i]) : "v"(s));
+KERNEL(k_pk_mul, DECL_P, R16(OP_PKMUL), SINK_P)
+#define OP_PKADD(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(r[i]) : "v"(s));
+KERNEL(k_pk_add, DECL_P, R16(OP_PKADD), SINK_P)
+
+#define DECL_D double r[16]; for (int i = 0; i < 16; ++i) r[i] = seed + threadIdx.x * 1e-3 + i; double s = seed * 0.5; int k = (int)seed
+#define SINK_D double acc = 0; for (int i = 0; i < 16; ++i) acc += r[i]; if (acc == 12345.0) out[threadIdx.x] = (float)acc
+#define OP_ADD64(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(r[i]) : "v"(s));
+KERNEL(k_add_f64, DECL_D, R16(OP_ADD64), SINK_D)
+#define OP_FMA64(i) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(r[i]) : "v"(s));
+KERNEL(k_fma_f64, DECL_D, R16(OP_FMA64), SINK_D)
+#define OP_LDEXP64(i) asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(r[i]) : "v"(k));
+KERNEL(k_ldexp_f64, DECL_D, R16(OP_LDEXP64), SINK_D)
+#define DECL_C float r[16]; double q[16]; for (int i = 0; i < 16; ++i) { r[i] = seed + threadIdx.x + i; q[i] = i; } float s = seed
+#define SINK_C double acc = 0; for (int i = 0; i < 16; ++i) acc += q[i] + r[i]; if (acc == 12345.0) out[threadIdx.x] = (float)acc
+#define OP_CVT64(i) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(q[i]) : "v"(r[i]));
+KERNEL(k_cvt_f64_i32, DECL_C, R16(OP_CVT64), SINK_C)
+#define OP_CVT32(i) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(r[i]) : "v"(q[i]));
+KERNEL(k_cvt_f32_f64, DECL_C, R16(OP_CVT32), SINK_C)
+
+template <typename F>
+static void run(const char* name, F kernel, int waves_per_simd, float* out, unsigned long long* cyc, int n_cu) {
+    // 256 threads = 4 wavefronts = one per SIMD of a CU; `waves_per_simd` workgroups per CU
+    const int blocks = n_cu * waves_per_simd;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.5f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.5f);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long c = 0;
+    hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    // per-SIMD cycles per wave-instruction from the wavefront's own clock (includes the loop's SALU)
+    printf("%-16s waves/SIMD %d: %7.2f cycles per wave-instruction per SIMD (wave 0: %llu cycles, %.1f us, %.2f GHz)\n", name,
+           waves_per_simd, (double)c / ((double)ITER * 16 * waves_per_simd), c, ms * 1e3, c / (ms * 1e6));
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int n_cu = prop.multiProcessorCount;
+    float* out; unsigned long long* cyc;
+    hipMalloc(&out, 4096); hipMalloc(&cyc, 64);
+    printf("%s, %d CUs\n", prop.name, n_cu);
+    for (int w : {1, 2, 4, 8}) {
+#define RUN(k) run(#k, k, w, out, cyc, n_cu)
+        RUN(k_fma); RUN(k_mul); RUN(k_mov); RUN(k_pk_fma); RUN(k_pk_mul); RUN(k_pk_add); RUN(k_rcp); RUN(k_exp); RUN(k_sqrt);
+        RUN(k_dpp); RUN(k_cmp); RUN(k_cndmask); RUN(k_med3); RUN(k_mul_lo_u32); RUN(k_mul_u24); RUN(k_cvt_i32_f32); RUN(k_rndne);
+        RUN(k_readlane); RUN(k_add_f64); RUN(k_fma_f64); RUN(k_ldexp_f64); RUN(k_cvt_f64_i32); RUN(k_cvt_f32_f64);
+        RUN(k_salu); RUN(k_fma_salu_mix);
+        printf("\n");
+    }
+    return 0;
+}
