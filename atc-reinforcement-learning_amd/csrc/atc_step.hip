@@ -398,6 +398,8 @@ struct alignas(16) QScan {    // second half: separation scan, override chain
     float sep_ft, conflict_reward;
     int timestep_limit;
     float4 tri_bbox;      // bounds of the corridor's horizontal triangle (ATC_C_TRI_BBOX)
+    int n_noise;          // number of noise-abatement areas (blob header word; read from the blob inside the step it was a
+    int pad[3];           // dependent scalar load with nothing to hide its latency behind, in every step of every wavefront)
 };
 struct alignas(16) QNorm {
     float a[ATC_OBS_DIM], b[ATC_OBS_DIM];   // ATC_C_NORM_A / ATC_C_NORM_B
@@ -430,11 +432,11 @@ static const StepDerived& derive(const atc_params_t& p, const atc_scenario* s) {
         uint64_t uid;
         float dt, sep_nm, sep_ft, conflict_reward;
         int32_t timestep_limit;
-        uint32_t discrete;
+        uint32_t mode_bits;   // the mode flags the derived values depend on
     };
     static thread_local Key last = {0ull, 0.0f, 0.0f, 0.0f, 0.0f, 0, 0u};
     static thread_local StepDerived q;
-    const Key k = {s->uid, p.dt, p.sep_nm, p.sep_ft, p.conflict_reward, p.timestep_limit, p.mode & (uint32_t)ATC_M_DISCRETE};
+    const Key k = {s->uid, p.dt, p.sep_nm, p.sep_ft, p.conflict_reward, p.timestep_limit, p.mode & (uint32_t)(ATC_M_DISCRETE | ATC_M_NORMALIZE)};
     if (memcmp(&k, &last, sizeof k) != 0) {
         q = derive_uncached(p, s);
         last = k;
@@ -479,10 +481,14 @@ static StepDerived derive_uncached(const atc_params_t& p, const atc_scenario* s)
     q.s.conflict_reward = p.conflict_reward;
     q.s.timestep_limit = p.timestep_limit;
     q.s.tri_bbox = make_float4(K[ATC_C_TRI_BBOX], K[ATC_C_TRI_BBOX + 1], K[ATC_C_TRI_BBOX + 2], K[ATC_C_TRI_BBOX + 3]);
+    q.s.n_noise = (int)K[ATC_H_N_NOISE];
     q.oc = obs_const(K);
+    // atc_gym.py:187-189.  Without ATC_M_NORMALIZE the same fma runs with (1, -0): x * 1 + -0 == x for every x, signed
+    // zeros included — the step has no branch on the flag and the constants can be requested ahead of the observation.
+    const bool normalize = (p.mode & ATC_M_NORMALIZE) != 0;
     for (int c = 0; c < ATC_OBS_DIM; ++c) {
-        q.n.a[c] = K[ATC_C_NORM_A + c];
-        q.n.b[c] = K[ATC_C_NORM_B + c];
+        q.n.a[c] = normalize ? K[ATC_C_NORM_A + c] : 1.0f;
+        q.n.b[c] = normalize ? K[ATC_C_NORM_B + c] : -0.0f;
     }
     return q;
 }
@@ -595,7 +601,11 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     // case by far (a refused target or a handed-over aircraft in 64 is the exception).  Then nothing is conditional: no
     // select per state component, no refusal penalties, no flag bits.  Otherwise the branch-free general form below.  Both
     // evaluate the same expressions on the lanes they share.
-    const bool plain = (all_active ? __builtin_amdgcn_ballot_w64(!(valid_v && valid_h)) : __builtin_amdgcn_ballot_w64(!(active && valid_v && valid_h))) == 0ull;
+    // (one lane mask per COMPARE, combined on the scalar unit: the ballot of a compound predicate is materialised per lane and
+    // compared again — two vector operations per site)
+    const uint64_t refused = __builtin_amdgcn_ballot_w64(tv < v_min) | __builtin_amdgcn_ballot_w64(tv > v_max) |
+                             __builtin_amdgcn_ballot_w64(th < h_min) | __builtin_amdgcn_ballot_w64(th > h_max);
+    const bool plain = (all_active ? refused : (refused | __builtin_amdgcn_ballot_w64(!active))) == 0ull;
     // (speed and heading limits are symmetric — kAMin == -kAMax, kPhiDotMin == -kPhiDotMax, checked at compile time below —
     // so the plain path clamps with ONE scalar operand and its negation; two scalars cost a register move per clamp)
     static_assert(kAMin == -kAMax && kPhiDotMin == -kPhiDotMax, "symmetric rate limits assumed by the plain path");
@@ -681,9 +691,9 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
 // Extension (README.md:62): noise-abatement areas the aircraft is inside of and below the ceiling of — ATC_F_NOISE plus one
 // bit per area in bits 16.. (consumed by the reward stage).  Evaluated while the lookup-grid cell is at hand: the cell names
 // the areas whose bounds meet it, and almost every wavefront has no candidate at all.
-__device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, const float* __restrict__ grid, const MvaCell& c,
-                                               float x, float y, float h) {
-    const int n_noise = (ATC_ABLATE & 256) ? 0 : (int)K[ATC_H_N_NOISE];
+__device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, const float* __restrict__ grid, int n_areas,
+                                               const MvaCell& c, float x, float y, float h) {
+    const int n_noise = (ATC_ABLATE & 256) ? 0 : n_areas;
     uint32_t bits = 0;
     if (n_noise > 0) {
         const uint32_t cand = noise_candidates(grid, c);
@@ -707,11 +717,10 @@ __device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, con
 
 template <int W, bool FULL, bool ONE>
 __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const float* __restrict__ grid,
-                                            const atc_params_t& p, const StepDerived& q, int zk, int N, const LaneIds& d,
-                                            const Mid& m, LaneState& ls,
+                                            const atc_params_t& p, const StepDerived& q, const QScan& qs, int zk, int N,
+                                            const LaneIds& d, const Mid& m, LaneState& ls,
                                             EnvState& es, const StepOut& so, int32_t* stp, float4* pos, float* obs_stage,
-                                            const float* act_next, Float3& a_next) {
-    const QScan qs = QGET(s);
+                                            const float* act_next, Float3& a_next, QRates& qr_next) {
     Aircraft& a = ls.a;
     const bool active = m.active;
     const float x32 = m.x32, y32 = m.y32;
@@ -743,7 +752,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         float hgt = 0.0f;
         pi = (ATC_ABLATE & 1) ? 0 : mva_resolve<kWalkBatch>(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt);
         mva = hgt;   // (0 when outside: mva_resolve leaves the height at 0, atc_gym.py:161)
-        fl |= noise_areas(K, grid, m.cell, x32, y32, a.h);
+        fl |= noise_areas(K, grid, qs.n_noise, m.cell, x32, y32, a.h);
     }
     // Multi-step launches: the NEXT step's action is requested here — behind the MVA gathers (loads return in order: issued
     // earlier it would sit in front of them and its HBM latency would be paid at the MVA wait) and with the rest of the
@@ -755,7 +764,10 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         float xs = x32;
         if (!m.plain) xs = active ? x32 : 1e18f;
         const float sep2 = qs.sep2;
-        if (W == 16 && !FULL) {
+#ifndef ATC_SCAN16_MARGIN
+#define ATC_SCAN16_MARGIN 0   // developer A/B: the fast variant scans with the branch-free margin form as well
+#endif
+        if (W == 16 && !FULL && !ATC_SCAN16_MARGIN) {
             int conf = 0;
             NearScan16<1>::run(xs, y32, a.h, sep2, qs.sep_ft, conf);
             margin = conf ? -1.0f : margin;
@@ -878,7 +890,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         float hgt = 0.0f;
         pi = (ATC_ABLATE & 1) ? 0 : mva_resolve<kWalkBatch>(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt);
         mva = hgt;                                 // atc_gym.py:161: mva = 0 outside (mva_resolve leaves the height at 0)
-        fl |= noise_areas(K, grid, m.cell, x32, y32, a.h);
+        fl |= noise_areas(K, grid, qs.n_noise, m.cell, x32, y32, a.h);
     }
     // ---- the override chain (atc_gym.py:146-173) -----------------------------------------------------------------------
     // `quiet` (wave-uniform): nothing of it applies to any lane of this wavefront — every aircraft under control with accepted
@@ -889,10 +901,13 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     // (base reward, no flag): the chain's selects run only in the other wavefronts — the same expressions, lane for lane.
     const bool conflict = margin < 0.0f;
     const bool timeout = es.t > qs.timestep_limit;
+    // (one lane mask per compare, combined on the scalar unit — see `plain`)
+    const uint64_t in_tri = grid ? __builtin_amdgcn_ballot_w64(corridor_candidate(m.cell))
+                                 : (__builtin_amdgcn_ballot_w64(x32 >= qs.tri_bbox.x) & __builtin_amdgcn_ballot_w64(x32 <= qs.tri_bbox.z) &
+                                    __builtin_amdgcn_ballot_w64(y32 >= qs.tri_bbox.y) & __builtin_amdgcn_ballot_w64(y32 <= qs.tri_bbox.w));
     const bool quiet = !(ATC_ABLATE & 512) && m.plain &&
-                       __builtin_amdgcn_ballot_w64((pi < 0) | (a.h < mva) | conflict | timeout | ((fl >> 16) != 0u) |
-                                (grid ? corridor_candidate(m.cell)
-                                      : ((x32 >= qs.tri_bbox.x) & (x32 <= qs.tri_bbox.z) & (y32 >= qs.tri_bbox.y) & (y32 <= qs.tri_bbox.w)))) == 0ull;
+                       (__builtin_amdgcn_ballot_w64(pi < 0) | __builtin_amdgcn_ballot_w64(a.h < mva) | __builtin_amdgcn_ballot_w64(margin < 0.0f) |
+                        __builtin_amdgcn_ballot_w64(es.t > qs.timestep_limit) | __builtin_amdgcn_ballot_w64(fl > 0xffffu) | in_tri) == 0ull;
     if (!quiet) {
         {
             const bool below = pi >= 0 && a.h < mva;
@@ -917,6 +932,9 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     }
     ATC_STAMP_B(3);
     // ---- observation, shaping, noise areas, normalisation (atc_gym.py:175-189) ------------------------------------------
+    // (multi-step launches: the normalisation constants are requested here, a hundred vector operations ahead of their use —
+    // requested where they are used, the scalar load's whole latency was a stall)
+    const QNorm qn = QGET(n);
     float o[ATC_OBS_DIM];
     float zraw[ATC_OBS_DIM];   // FULL only: raw observation (zeros for handed-over aircraft)
     {
@@ -936,7 +954,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         // extension (README.md:62): noise-abatement areas — which ones the aircraft is in was decided next to the MVA lookup
         // (bits 16.. of fl); the penalties are subtracted here, after the shaping terms, in area order.
         if (!quiet && __builtin_amdgcn_ballot_w64((fl >> 16) != 0u) != 0ull) {
-            const int n_noise = (int)K[ATC_H_N_NOISE];
+            const int n_noise = qs.n_noise;
             for (int q = 0; q < n_noise; ++q)
                 if ((fl >> (16 + q)) & 1u) r -= (K + (int)K[ATC_H_OFF_POLY] + ((int)K[ATC_H_N_MVA] + q) * ATC_P_WORDS)[ATC_P_PENALTY];
             fl &= 0xffffu;
@@ -946,14 +964,9 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             for (int c = 0; c < ATC_OBS_DIM; ++c) zraw[c] = active ? ob.o[c] : 0.0f;  // zeros for handed-over aircraft
             if (so.raw_obs && d.lane_valid) store_obs(at<float>(so.raw_obs, times40(i)), zraw);
         }
-        if (p.mode & ATC_M_NORMALIZE) {  // atc_gym.py:187-189: (s - min - max/2) / (max/2) as one fma
-            const QNorm qn = QGET(n);
+        // atc_gym.py:187-189: (s - min - max/2) / (max/2) as one fma; the identity (1, -0) without ATC_M_NORMALIZE (derive())
 #pragma unroll
-            for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = fmaf(ob.o[c], qn.a[c], qn.b[c]);
-        } else {
-#pragma unroll
-            for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = ob.o[c];
-        }
+        for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = fmaf(ob.o[c], qn.a[c], qn.b[c]);
     }
     // lanes without an aircraft under control: nothing happened.  Almost every wavefront has none, so the selects sit
     // behind a wave-uniform test.
@@ -985,14 +998,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     es.total_reward += env_r;  // atc_gym.py:194-197
     es.n_actions += env_acts;
 
-    if (d.lane_valid) {
-        stream_store(at<uint16_t>(so.flags, i * 2u), (uint16_t)fl);
-        if (FULL && so.ac_reward) *at<float>(so.ac_reward, i * 4u) = r;
-    }
-    if (d.env_valid && k == 0) {
-        *at<float>(so.reward, (uint32_t)e * 4u) = env_r;
-        *at<uint8_t>(so.done, (uint32_t)e) = done ? 1 : 0;
-    }
+    // (flag word, reward and done are stored at the END of the step, behind the observation: see there)
     if (FULL && ONE && W == 1 && so.packet && d.lane_valid) {
         // The step result of a single-aircraft env as 9 self-validating 16-byte chunks (include/atc_step.h, atc_out_t.packet):
         // each chunk is ONE store carrying the caller's sequence tag, so a host polling mapped memory never mixes steps.
@@ -1018,13 +1024,16 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         // an earlier step of this wavefront may have written it (lane k == 0 writes, all lanes of the env read): wavefront-
         // scope fences order those accesses (they compile to nothing — a wavefront's memory operations are issued in order).
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        int4* sr = at<int4>(stp, (uint32_t)e * (ATC_STAT_WORDS * 4u));
+        // (multi-step launches fetch the record's base here, on the rare path: carried from the top of the step it sat in
+        // vector-register lanes)
+        int32_t* stats = ONE ? stp : kernarg_reread<int32_t*>(offsetof(StepArgs, st) + offsetof(atc_state_t, stats), zk);
+        int4* sr = at<int4>(stats, (uint32_t)e * (ATC_STAT_WORDS * 4u));
         const int4 s0 = sr[0];  // episodes, ep_length, ep_return, win_bits
         const int episode = s0.x;
         if (d.env_valid && k == 0) {
             const uint32_t win_bits = (((uint32_t)s0.w << 1) | (env_won ? 1u : 0u)) & 0x3ffu;
             sr[0] = make_int4(episode + 1, es.t, __float_as_int(es.total_reward), (int)win_bits);
-            *at<int>(stp, (uint32_t)e * (ATC_STAT_WORDS * 4u) + ATC_STAT_EP_ACTIONS * 4u) = es.n_actions;
+            *at<int>(stats, (uint32_t)e * (ATC_STAT_WORDS * 4u) + ATC_STAT_EP_ACTIONS * 4u) = es.n_actions;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if (d.lane_valid) {
@@ -1046,6 +1055,13 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     }
 
     ATC_STAMP_B(5);
+    // Multi-step launches: the NEXT step's rate group is requested here, with the observation store still ahead — requested at
+    // the top of the step that uses it, its latency was a stall before the first instruction of the kinematics.
+    if (!ONE) {
+        int zn;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zn));
+        qr_next = kernarg_reread<QRates>(offsetof(StepArgs, q) + offsetof(StepDerived, r), zn);
+    }
     // ---- observation store: [aircraft][10] rows are 40 B apart, so per-lane stores would scatter 8-byte pieces over 20
     //      cache lines per instruction; a full wavefront instead transposes its 64 x 10 block through LDS and writes 2 560
     //      contiguous bytes as 16-byte stores.
@@ -1083,6 +1099,18 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         __builtin_amdgcn_wave_barrier();
     } else if (d.lane_valid) {
         store_obs(at<float>(so.obs, times40(i)), o);
+    }
+    // ---- flag word, reward, done: last.  The compiler guards the observation's staging registers with a wait for ALL vector
+    //      memory operations (one counter for loads and stores; the auto-reset path's loads merge in above) — issued before the
+    //      observation, these three small stores were waited for there, a store round trip in every step.  Here the next such
+    //      wait is the lookup-cell gather of the following step, a kinematics stage and a separation scan later.
+    if (d.lane_valid) {
+        stream_store(at<uint16_t>(so.flags, i * 2u), (uint16_t)fl);
+        if (FULL && so.ac_reward) *at<float>(so.ac_reward, i * 4u) = r;
+    }
+    if (d.env_valid && k == 0) {
+        *at<float>(so.reward, (uint32_t)e * 4u) = env_r;
+        *at<uint8_t>(so.done, (uint32_t)e) = done ? 1 : 0;
     }
     return quiet;
 }
@@ -1155,9 +1183,16 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     // needs 56 VGPRs (N = 16), the loop form 80 under its launch bound (94 without it).
     const int n_steps = ONE ? 1 : T;
     const float* act_t = actions;   // action block of the current step; a block is held for `hold` steps
-    int held = 0;                   // steps the current block has been used for
+    int left = hold;                // steps the current block is still used for
+    bool block_start = true;        // this step is the first of its block
     Float3 tg = {0.0f, 0.0f, 0.0f};   // decoded targets of the current step / block
     bool all_active = false, mask_dirty = true;
+    QRates qr_next = q.r;   // the rate group of the coming step (multi-step launches fetch it one step ahead, see step_part_b)
+    if (!ONE) {
+        int zn;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zn));
+        qr_next = kernarg_reread<QRates>(offsetof(StepArgs, q) + offsetof(StepDerived, r), zn);
+    }
     for (int step = 0; step < n_steps; ++step) {
 #if ATC_TRACE
         unsigned long long* trow = trace ? trace + ((size_t)(blockIdx.x * (kBlock / 64) + (tid >> 6)) * n_steps + step) * 8 : nullptr;
@@ -1182,7 +1217,6 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             if (kReread & 1) pl = kernarg_reread<atc_params_t>(offsetof(StepArgs, p), zk);
             else pl.mode += (uint32_t)zk;
             if (kReread & 4) outl = kernarg_reread<atc_out_t>(offsetof(StepArgs, out), zk);
-            if (kReread & 8) stats_l = kernarg_reread<int32_t*>(offsetof(StepArgs, st) + offsetof(atc_state_t, stats), zk);
         }
         if (!ONE && ATC_LOOP_OPAQUE) {
             uint32_t zv;
@@ -1208,7 +1242,8 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
 #ifndef ATC_LOOP_ALLACT
 #define ATC_LOOP_ALLACT 1        // carry "every lane's aircraft is under control" across the steps (re-established after steps that
 #endif                           // can change a mask): 325.5 vs 331.2 VALU per wavefront-step, 11.37 vs 11.46 us at 65 536 x 16
-        const QRates qr = QGET(r);
+        const QRates qr = qr_next;
+        const QScan qs = QGET(s);   // (requested here, consumed after the kinematics)
         if (!ONE && step == 0) act = *at<Float3>(act_t, times12(dl.i));
         if (ONE || !ATC_LOOP_DECODE_ONCE || step == 0) tg = decode_targets(qr, act);
         if (ONE && !la_live) {   // held block: the record equals the accepted targets (components that are refused are not compared)
@@ -1218,7 +1253,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         }
         // multi-step launches know structurally which steps repeat an action block
         const bool repeated = ONE ? (same_actions && __builtin_amdgcn_ballot_w64(la_live) == 0ull)
-                                  : (ATC_LOOP_SKIP_BOOK && held > 0 && __builtin_amdgcn_ballot_w64(es.t == 0) == 0ull);
+                                  : (ATC_LOOP_SKIP_BOOK && !block_start && __builtin_amdgcn_ballot_w64(es.t == 0) == 0ull);
         // ... and whether every lane's aircraft is under control: re-established after the steps in which a mask can change
         if (!ONE && ATC_LOOP_ALLACT && mask_dirty) {
             all_active = __builtin_amdgcn_ballot_w64(!(dl.lane_valid && ((dl.k < 32 ? ((uint32_t)es.amask >> dl.k) : ((uint32_t)(es.amask >> 32) >> (dl.k - 32))) & 1u))) == 0ull;
@@ -1228,12 +1263,14 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         ATC_STAMP(1);
         Float3 nxt = act;
         const float* act_next = nullptr;   // the next block is fetched during the last step of the current one
-        if (!ONE && ++held == hold) {
-            held = 0;
+        block_start = false;
+        if (!ONE && --left == 0) {   // (the block length is fetched again here, at block ends, not kept — or re-fetched — every step)
+            left = kernarg_reread<int>(offsetof(StepArgs, hold), zk);
+            block_start = true;
             act_t += (size_t)BN * 3;
             if (step + 1 < n_steps) act_next = act_t;
         }
-        const bool quiet = step_part_b<W, FULL, ONE>(Kl, gl, pl, q, zk, N, dl, m, ls, es, so, stats_l, pos, obs_stage, act_next, nxt);
+        const bool quiet = step_part_b<W, FULL, ONE>(Kl, gl, pl, q, qs, zk, N, dl, m, ls, es, so, stats_l, pos, obs_stage, act_next, nxt, qr_next);
         if (!quiet) mask_dirty = true;
         if (ATC_LOOP_DECODE_ONCE) {
             if (act_next) tg = decode_targets(QGET(r), nxt);

@@ -36,7 +36,7 @@ KERNEL(k_sqrt, DECL_F, R16(OP_SQRT), SINK_F)
 KERNEL(k_dpp, DECL_F, R16(OP_DPP), SINK_F)
 #define OP_CMP(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(r[i]), "v"(s) : "vcc");
 KERNEL(k_cmp, DECL_F, R16(OP_CMP), SINK_F)
-#define OP_CNDMASK(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(s) : "vcc");
+#define OP_CNDMASK(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(r[i]) : "v"(s) : "s20", "s21");
 KERNEL(k_cndmask, DECL_F, R16(OP_CNDMASK), SINK_F)
 #define OP_MED3(i) asm volatile("v_med3_f32 %0, %0, %1, %1" : "+v"(r[i]) : "v"(s));
 KERNEL(k_med3, DECL_F, R16(OP_MED3), SINK_F)
@@ -57,6 +57,44 @@ KERNEL(k_salu, DECL_F, R16(OP_SALU), SINK_F)
 // one SALU between every two VALU: do the two units overlap within ONE wavefront?
 #define OP_MIX(i) asm volatile("v_fma_f32 %0, %0, %1, %0\n s_add_u32 s20, s20, 1" : "+v"(r[i]) : "v"(s) : "s20", "scc");
 KERNEL(k_fma_salu_mix, DECL_F, R16(OP_MIX), SINK_F)
+
+// dependent chains: the same instruction on 1 / 2 / 4 registers (a wavefront alone on its SIMD: what ILP is worth)
+#define OP_FMA1(i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(r[0]) : "v"(s));
+KERNEL(k_fma_chain1, DECL_F, R16(OP_FMA1), SINK_F)
+#define OP_FMA2(i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(r[(i) & 1]) : "v"(s));
+KERNEL(k_fma_chain2, DECL_F, R16(OP_FMA2), SINK_F)
+#define OP_FMA4(i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(r[(i) & 3]) : "v"(s));
+KERNEL(k_fma_chain4, DECL_F, R16(OP_FMA4), SINK_F)
+#define OP_RCP1(i) asm volatile("v_rcp_f32 %0, %0" : "+v"(r[0]));
+KERNEL(k_rcp_chain1, DECL_F, R16(OP_RCP1), SINK_F)
+// a compare into a scalar register pair consumed by the next instruction's select (the override chain's shape)
+#define OP_CMPSEL(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(s) : "vcc");
+KERNEL(k_cmp_select_pair, DECL_F, R16(OP_CMPSEL), SINK_F)
+// a compare, a scalar test of its mask and a branch never taken (the wave-uniform fast-path tests' shape)
+#define OP_CMPBR(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n s_cmp_eq_u64 vcc, 0\n s_cbranch_scc1 1f\n s_nop 0\n1:" : : "v"(r[i]), "v"(s) : "vcc", "scc");
+KERNEL(k_cmp_test_branch, DECL_F, R16(OP_CMPBR), SINK_F)
+// the pieces of such a test: scalar compare + branch taken / not taken; branch on vcc directly; exec-mask region
+#define OP_SBR_T(i) asm volatile("s_cmp_eq_u32 s20, s20\n s_cbranch_scc1 1f\n s_nop 0\n1:" : : : "s20", "scc");
+KERNEL(k_scmp_branch_taken, DECL_F, R16(OP_SBR_T), SINK_F)
+#define OP_SBR_N(i) asm volatile("s_cmp_lg_u32 s20, s20\n s_cbranch_scc1 1f\n s_nop 0\n1:" : : : "s20", "scc");
+KERNEL(k_scmp_branch_not, DECL_F, R16(OP_SBR_N), SINK_F)
+#define OP_VCCBR_T(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n s_cbranch_vccz 1f\n s_nop 0\n1:" : : "v"(r[i]), "v"(s) : "vcc");
+KERNEL(k_vcmp_vccz_taken, DECL_F, R16(OP_VCCBR_T), SINK_F)
+#define OP_VCCBR_N(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n s_cbranch_vccnz 1f\n s_nop 0\n1:" : : "v"(r[i]), "v"(s) : "vcc");
+KERNEL(k_vcmp_vccnz_not, DECL_F, R16(OP_VCCBR_N), SINK_F)
+#define OP_VCMP_SCMP(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n s_cmp_eq_u64 vcc, 0" : : "v"(r[i]), "v"(s) : "vcc", "scc");
+KERNEL(k_vcmp_scmp, DECL_F, R16(OP_VCMP_SCMP), SINK_F)
+#define OP_EXECZ(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n s_and_saveexec_b64 s[20:21], vcc\n s_cbranch_execz 1f\n s_nop 0\n1:\n s_mov_b64 exec, s[20:21]" : : "v"(r[i]), "v"(s) : "vcc", "s20", "s21");
+KERNEL(k_saveexec_execz_taken, DECL_F, R16(OP_EXECZ), SINK_F)
+// the same region without the branch: the skipped instruction runs with an empty exec mask
+#define OP_EXEC_NOBR(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n s_and_saveexec_b64 s[20:21], vcc\n v_mov_b32 %0, %0\n s_mov_b64 exec, s[20:21]" : "+v"(r[i]) : "v"(s) : "vcc", "s20", "s21");
+KERNEL(k_saveexec_nobranch, DECL_F, R16(OP_EXEC_NOBR), SINK_F)
+// VALU result consumed by a scalar instruction (v_readfirstlane -> s_add)
+#define OP_RFL_SALU(i) asm volatile("v_readfirstlane_b32 s20, %0\n s_add_u32 s21, s20, 1" : : "v"(r[i]) : "s20", "s21", "scc");
+KERNEL(k_readfirstlane_salu, DECL_F, R16(OP_RFL_SALU), SINK_F)
+// scalar loads with an immediate wait (kernarg re-reads)
+#define OP_SLOAD(i) asm volatile("s_load_dword s20, %0, 0x0\n s_waitcnt lgkmcnt(0)" : : "s"(out) : "s20", "memory");
+KERNEL(k_sload_wait, DECL_F, R16(OP_SLOAD), SINK_F)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 #define DECL_P v2f r[16]; for (int i = 0; i < 16; ++i) r[i] = v2f{seed + threadIdx.x * 1e-3f + i, seed + i}; v2f s = {seed * 0.5f, seed}
@@ -100,8 +138,10 @@ static void run(const char* name, F kernel, int waves_per_simd, float* out, unsi
     unsigned long long c = 0;
     hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
     // per-SIMD cycles per wave-instruction from the wavefront's own clock (includes the loop's SALU)
-    printf("%-16s waves/SIMD %d: %7.2f cycles per wave-instruction per SIMD (wave 0: %llu cycles, %.1f us, %.2f GHz)\n", name,
-           waves_per_simd, (double)c / ((double)ITER * 16 * waves_per_simd), c, ms * 1e3, c / (ms * 1e6));
+    // wave 0 is the oldest wavefront of its SIMD (issue arbitration favours it): its own clock gives the cost of an instruction
+    // to ONE wavefront; the elapsed time gives the SIMD's throughput with `waves_per_simd` wavefronts sharing it
+    printf("%-18s waves/SIMD %d: %6.2f cycles per instruction in wave 0 | %7.2f ns per wave-instruction per SIMD (%.1f us)\n", name,
+           waves_per_simd, (double)c / ((double)ITER * 16), ms * 1e6 / ((double)ITER * 16 * waves_per_simd), ms * 1e3);
 }
 
 int main() {
@@ -117,6 +157,9 @@ int main() {
         RUN(k_dpp); RUN(k_cmp); RUN(k_cndmask); RUN(k_med3); RUN(k_mul_lo_u32); RUN(k_mul_u24); RUN(k_cvt_i32_f32); RUN(k_rndne);
         RUN(k_readlane); RUN(k_add_f64); RUN(k_fma_f64); RUN(k_ldexp_f64); RUN(k_cvt_f64_i32); RUN(k_cvt_f32_f64);
         RUN(k_salu); RUN(k_fma_salu_mix);
+        RUN(k_fma_chain1); RUN(k_fma_chain2); RUN(k_fma_chain4); RUN(k_rcp_chain1); RUN(k_cmp_select_pair); RUN(k_cmp_test_branch); RUN(k_sload_wait);
+        RUN(k_scmp_branch_taken); RUN(k_scmp_branch_not); RUN(k_vcmp_vccz_taken); RUN(k_vcmp_vccnz_not); RUN(k_vcmp_scmp);
+        RUN(k_saveexec_execz_taken); RUN(k_saveexec_nobranch); RUN(k_readfirstlane_salu);
         printf("\n");
     }
     return 0;
