@@ -71,6 +71,19 @@ static int fail_hip(hipError_t e, const char* what) {
 
 #ifndef ATC_BLOCK
 #define ATC_BLOCK 256
+// Wave-uniform conditions that almost never hold (or almost always): the hint moves the rare block out of the step's straight
+// line, so that the common path FALLS THROUGH its branches instead of jumping over code (a taken branch refills the
+// instruction buffer: ~20 cycles to a wavefront alone on its SIMD, tools/ubench/valu_rates.hip).
+#ifndef ATC_BRANCH_HINTS
+#define ATC_BRANCH_HINTS 1
+#endif
+#if ATC_BRANCH_HINTS
+#define ATC_RARE(x) __builtin_expect(!!(x), 0)
+#define ATC_USUAL(x) __builtin_expect(!!(x), 1)
+#else
+#define ATC_RARE(x) (x)
+#define ATC_USUAL(x) (x)
+#endif
 #endif
 #ifndef ATC_NT_LOAD
 #define ATC_NT_LOAD 0   // non-temporal action loads: measured SLOWER (36.0 vs 31.9 us)
@@ -242,7 +255,7 @@ struct NearScan16 {
         const float dx = xs - row_ror<D>(xs), dy = y - row_ror<D>(y);
         const float d2 = fmaf(dx, dx, dy * dy);
         const bool near = d2 < sep2;
-        if (__builtin_amdgcn_ballot_w64(near) != 0ull) {
+        if (ATC_RARE(__builtin_amdgcn_ballot_w64(near) != 0ull)) {   // (a third of the rotations of the headline workload)
             const float dh = h - row_ror<D>(h);
             const int c = (near && fabsf(dh) < sep_ft) ? 1 : 0;
             conf |= c;
@@ -609,7 +622,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     // (speed and heading limits are symmetric — kAMin == -kAMax, kPhiDotMin == -kPhiDotMax, checked at compile time below —
     // so the plain path clamps with ONE scalar operand and its negation; two scalars cost a register move per clamp)
     static_assert(kAMin == -kAMax && kPhiDotMin == -kPhiDotMax, "symmetric rate limits assumed by the plain path");
-    if (plain) {
+    if (ATC_USUAL(plain)) {
         const float v_new = a.v + clamp_rate(tv - a.v, -q.dv_hi, q.dv_hi);
         if (track_v) ls.v_changed = ls.v_changed || v_new != a.v;
         a.v = v_new;
@@ -695,7 +708,7 @@ __device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, con
                                                const MvaCell& c, float x, float y, float h) {
     const int n_noise = (ATC_ABLATE & 256) ? 0 : n_areas;
     uint32_t bits = 0;
-    if (n_noise > 0) {
+    if (ATC_RARE(n_noise > 0)) {
         const uint32_t cand = noise_candidates(grid, c);
         if (__builtin_amdgcn_ballot_w64(cand != 0u) != 0ull) {
             for (int q = 0; q < n_noise; ++q) {
@@ -757,7 +770,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     // Multi-step launches: the NEXT step's action is requested here — behind the MVA gathers (loads return in order: issued
     // earlier it would sit in front of them and its HBM latency would be paid at the MVA wait) and with the rest of the
     // step body (scan, corridor, observation, shaping, stores) still ahead to cover it.
-    if (act_next) a_next = *at<Float3>(act_next, times12(i));
+    if (ATC_RARE(act_next != nullptr)) a_next = *at<Float3>(act_next, times12(i));
     float min_d2 = 1e30f;
     float margin = 1e30f;  // min over partners of max(d^2 - sep^2, |dh| - sep_ft): conflict iff negative
     if (W > 1 && !(ATC_ABLATE & 2)) {
@@ -908,7 +921,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     const bool quiet = !(ATC_ABLATE & 512) && m.plain &&
                        (__builtin_amdgcn_ballot_w64(pi < 0) | __builtin_amdgcn_ballot_w64(a.h < mva) | __builtin_amdgcn_ballot_w64(margin < 0.0f) |
                         __builtin_amdgcn_ballot_w64(es.t > qs.timestep_limit) | __builtin_amdgcn_ballot_w64(fl > 0xffffu) | in_tri) == 0ull;
-    if (!quiet) {
+    if (ATC_RARE(!quiet)) {
         {
             const bool below = pi >= 0 && a.h < mva;
             r = pi < 0 ? -50.0f : (below ? -200.0f : r);
@@ -953,7 +966,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         if ((p.mode & ATC_M_REWARD_SHAPING) && !(ATC_ABLATE & 8)) r += shaping;
         // extension (README.md:62): noise-abatement areas — which ones the aircraft is in was decided next to the MVA lookup
         // (bits 16.. of fl); the penalties are subtracted here, after the shaping terms, in area order.
-        if (!quiet && __builtin_amdgcn_ballot_w64((fl >> 16) != 0u) != 0ull) {
+        if (ATC_RARE(!quiet && __builtin_amdgcn_ballot_w64((fl >> 16) != 0u) != 0ull)) {
             const int n_noise = qs.n_noise;
             for (int q = 0; q < n_noise; ++q)
                 if ((fl >> (16 + q)) & 1u) r -= (K + (int)K[ATC_H_OFF_POLY] + ((int)K[ATC_H_N_MVA] + q) * ATC_P_WORDS)[ATC_P_PENALTY];
@@ -970,7 +983,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     }
     // lanes without an aircraft under control: nothing happened.  Almost every wavefront has none, so the selects sit
     // behind a wave-uniform test.
-    if (!m.plain && __builtin_amdgcn_ballot_w64(!active) != 0ull) {
+    if (ATC_RARE(!m.plain && __builtin_amdgcn_ballot_w64(!active) != 0ull)) {
 #pragma unroll
         for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = active ? o[c] : 0.0f;
         r = active ? r : 0.0f;
@@ -984,7 +997,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     const float env_r = group_sum<W>(r);
     const int env_acts = m.repeated ? 0 : group_sum_i<W>(acts);
     bool done = false, env_won = false;
-    if (!quiet) {
+    if (ATC_RARE(!quiet)) {
         const uint64_t won = group_ballot<W>((fl & ATC_F_WON) != 0, lane);
         const uint64_t term = group_ballot<W>(
             (fl & (ATC_F_BELOW_MVA | ATC_F_OUTSIDE | ATC_F_CONFLICT | ATC_F_TIMEOUT)) != 0, lane);
@@ -1017,7 +1030,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         if (d.env_valid && k == 0) *at<float>(so.min_sep, (uint32_t)e * 4u) = (m2 >= 1e30f) ? 1e30f : sqrtf(m2);
     }
 
-    if (done && (p.mode & ATC_M_AUTO_RESET)) {
+    if (ATC_RARE(done && (p.mode & ATC_M_AUTO_RESET))) {
         // VecEnv semantics: the env restarts inside the step; the returned obs is the RAW reset state
         // (atc_gym.py:351,365: reset() returns the un-normalised state computed with mva = 0).
         // The per-episode record is read, updated and written here and nowhere else on the step path.  In a multi-step launch
@@ -1067,7 +1080,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     //      contiguous bytes as 16-byte stores.
     if (ATC_ABLATE & 16) {
         if (d.lane_valid && o[0] == 12345.678f) so.obs[i] = o[1];
-    } else if (d.wave_full && !(ATC_OBS_DIRECT & (ONE ? 1 : 2))) {
+    } else if (ATC_USUAL(d.wave_full && !(ATC_OBS_DIRECT & (ONE ? 1 : 2)))) {
         // addresses from threadIdx itself, not from the lane ids a multi-step launch re-derives through an opaque zero: the
         // compiler then knows the ranges (lane < 64: two of the three row tests fold away, 24-bit multiplies suffice) — with
         // the opaque copies it emitted a quarter-rate 64-bit multiply-add per LDS read
@@ -1244,7 +1257,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
 #endif                           // can change a mask): 325.5 vs 331.2 VALU per wavefront-step, 11.37 vs 11.46 us at 65 536 x 16
         const QRates qr = qr_next;
         const QScan qs = QGET(s);   // (requested here, consumed after the kinematics)
-        if (!ONE && step == 0) act = *at<Float3>(act_t, times12(dl.i));
+        if (!ONE && ATC_RARE(step == 0)) act = *at<Float3>(act_t, times12(dl.i));
         if (ONE || !ATC_LOOP_DECODE_ONCE || step == 0) tg = decode_targets(qr, act);
         if (ONE && !la_live) {   // held block: the record equals the accepted targets (components that are refused are not compared)
             ls.la_v = tg.a;
@@ -1255,7 +1268,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         const bool repeated = ONE ? (same_actions && __builtin_amdgcn_ballot_w64(la_live) == 0ull)
                                   : (ATC_LOOP_SKIP_BOOK && !block_start && __builtin_amdgcn_ballot_w64(es.t == 0) == 0ull);
         // ... and whether every lane's aircraft is under control: re-established after the steps in which a mask can change
-        if (!ONE && ATC_LOOP_ALLACT && mask_dirty) {
+        if (!ONE && ATC_LOOP_ALLACT && ATC_RARE(mask_dirty)) {
             all_active = __builtin_amdgcn_ballot_w64(!(dl.lane_valid && ((dl.k < 32 ? ((uint32_t)es.amask >> dl.k) : ((uint32_t)(es.amask >> 32) >> (dl.k - 32))) & 1u))) == 0ull;
             mask_dirty = false;
         }
@@ -1264,14 +1277,14 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         Float3 nxt = act;
         const float* act_next = nullptr;   // the next block is fetched during the last step of the current one
         block_start = false;
-        if (!ONE && --left == 0) {   // (the block length is fetched again here, at block ends, not kept — or re-fetched — every step)
+        if (!ONE && ATC_RARE(--left == 0)) {   // (the block length is fetched again here, at block ends, not kept — or re-fetched — every step)
             left = kernarg_reread<int>(offsetof(StepArgs, hold), zk);
             block_start = true;
             act_t += (size_t)BN * 3;
             if (step + 1 < n_steps) act_next = act_t;
         }
         const bool quiet = step_part_b<W, FULL, ONE>(Kl, gl, pl, q, qs, zk, N, dl, m, ls, es, so, stats_l, pos, obs_stage, act_next, nxt, qr_next);
-        if (!quiet) mask_dirty = true;
+        if (ATC_RARE(!quiet)) mask_dirty = true;
         if (ATC_LOOP_DECODE_ONCE) {
             if (act_next) tg = decode_targets(QGET(r), nxt);
         } else {

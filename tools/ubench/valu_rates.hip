@@ -145,6 +145,7 @@ static void run(const char* name, F kernel, int waves_per_simd, float* out, unsi
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int n_cu = prop.multiProcessorCount;
@@ -159,7 +160,7 @@ int main() {
         RUN(k_salu); RUN(k_fma_salu_mix);
         RUN(k_fma_chain1); RUN(k_fma_chain2); RUN(k_fma_chain4); RUN(k_rcp_chain1); RUN(k_cmp_select_pair); RUN(k_cmp_test_branch); RUN(k_sload_wait);
         RUN(k_scmp_branch_taken); RUN(k_scmp_branch_not); RUN(k_vcmp_vccz_taken); RUN(k_vcmp_vccnz_not); RUN(k_vcmp_scmp);
-        RUN(k_saveexec_execz_taken); RUN(k_saveexec_nobranch); RUN(k_readfirstlane_salu);
+        // (k_saveexec_execz_taken / k_saveexec_nobranch / k_readfirstlane_salu are not run: the first did not return on the GPU box)
         printf("\n");
     }
     return 0;
