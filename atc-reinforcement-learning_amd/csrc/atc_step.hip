@@ -778,8 +778,8 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         if (!m.plain) xs = active ? x32 : 1e18f;
         const float sep2 = qs.sep2;
 #ifndef ATC_SCAN16_MARGIN
-#define ATC_SCAN16_MARGIN 0   // developer A/B: the fast variant scans with the branch-free margin form as well
-#endif
+#define ATC_SCAN16_MARGIN 0   // developer A/B: the fast variant scans with the branch-free margin form as well (80 VALU, no
+#endif                        // wave-uniform tests): 12.1 vs 10.1 us per fused step at 65 536 x 16, 2.9 vs 2.6 at 8 192 x 16 — rejected
         if (W == 16 && !FULL && !ATC_SCAN16_MARGIN) {
             int conf = 0;
             NearScan16<1>::run(xs, y32, a.h, sep2, qs.sep_ft, conf);
