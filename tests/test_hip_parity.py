@@ -334,7 +334,7 @@ def test_wide_fixture_batched():
     kernel: every integer output of every step exact, rewards and sampled observations within 1e-5 (stated near-FAF
     exception: helpers.replay_wide)."""
     fx = H.WideFixture()
-    n, near = H.replay_wide(fx, _HipLockstep, obs_tol=1e-5, state_tol=2e-5, rew_tol=1e-5)
+    n, near = H.replay_wide(fx, _HipLockstep, obs_tol=1e-5, state_tol=1e-5, rew_tol=1e-5)
     assert n == len(fx.flags) > 500000 and near < 2e-3 * n
 
 
@@ -361,7 +361,7 @@ def test_atcgym_keeps_flying_after_a_win():
             obs, rew, done, info = env.step(fx.action[row])
             assert done == bool(fx.done[row]) and env.actions_taken == int(fx.actions_taken[row]), (t, done)
             gw = float(fx.reward[row])
-            assert abs(rew - gw) <= 2e-5 * max(1.0, abs(gw)), (t, rew, gw)   # 1e-5 + the fixture's float32 storage
+            assert abs(rew - gw) <= (1e-5 + 1e-7) * max(1.0, abs(gw)), (t, rew, gw)   # 1e-5 + the fixture's float32 storage (6e-8)
             wins += int(done and rew > 9000)
         assert wins >= 2          # it won, kept flying inside the corridor and won again
     env.close()

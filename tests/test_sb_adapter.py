@@ -40,7 +40,7 @@ def test_adapter_equals_loop_of_single_envs():
                 finished += 1
                 assert np.allclose(infos[b]["terminal_observation"], so, atol=1e-5)
                 assert infos[b]["episode"]["l"] == ep_lens[b]
-                assert abs(infos[b]["episode"]["r"] - ep_returns[b]) <= 2e-5 * max(1.0, abs(ep_returns[b]))
+                assert abs(infos[b]["episode"]["r"] - ep_returns[b]) <= 1e-5 * max(1.0, abs(ep_returns[b]))
                 so = e.reset()                  # what a SubprocVecEnv worker does
                 ep_returns[b], ep_lens[b] = 0.0, 0
             else:
@@ -92,7 +92,7 @@ def test_adapter_against_reference_episodes_with_wins():
             row = rows[b]
             gw = fx.reward[row]
             assert bool(done[b]) == bool(fx.done[row]), (b, t)
-            assert abs(rew[b] - gw) <= 2e-5 * max(1.0, abs(gw)), (b, t, rew[b], gw)      # 1e-5 + float32 storage of the fixture
+            assert abs(rew[b] - gw) <= (1e-5 + 1e-7) * max(1.0, abs(gw)), (b, t, rew[b], gw)      # 1e-5 + float32 storage of the fixture (6e-8)
             si = fx.samp_index[row]
             if done[b]:
                 ep = eps[b]
