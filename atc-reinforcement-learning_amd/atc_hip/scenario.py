@@ -160,7 +160,12 @@ def _box_records(cx0s, cx1s, cy0s, cy1s, edges, bounds, heights):
         yb = np.clip(cy1s, ymin, ymax)
         xa = e[:, 0] + (ya - e[:, 1]) * slope
         xb = e[:, 0] + (yb - e[:, 1]) * slope
-        margin = 1e-3   # >> the fp32 error of the kernel's x-intersection (~1e-5 nm) + the rounding of the position
+        # Margin per edge: the kernel (and the fp32 oracle) evaluate the x-intersection in fp32 from fp32-rounded vertices —
+        # (y - p1y) carries half an ulp of y and of p1y, and the division by (p2y - p1y) multiplies that by |dx / dy|: for a
+        # near-horizontal long edge (a sliver: dy = 0.03, dx = 50 at y ~ 50 nm) 2.5e-3 nm, measured.  1e-3 nm covers every
+        # ordinary edge (LOWW's worst: 2e-4) and the rounding of the position; the slope term covers the slivers.
+        ulp32 = np.spacing(np.abs(e).max(axis=1).astype(np.float32)).astype(np.float64)
+        margin = 1e-3 + 4.0 * ulp32 * (1.0 + np.abs(slope))
         right = cx1s < np.minimum(xa, xb) - margin      # whole box left of the line: x <= xints holds whatever the rounding
         rel &= ~(cx0s > np.maximum(xa, xb) + margin)    # whole box right of the line: x <= xints fails for every point
         const = rel & right & (cy0s > ymin) & (cy1s <= ymax)

@@ -71,6 +71,7 @@ static int fail_hip(hipError_t e, const char* what) {
 
 #ifndef ATC_BLOCK
 #define ATC_BLOCK 256
+#endif
 // Wave-uniform conditions that almost never hold (or almost always): the hint moves the rare block out of the step's straight
 // line, so that the common path FALLS THROUGH its branches instead of jumping over code (a taken branch refills the
 // instruction buffer: ~20 cycles to a wavefront alone on its SIMD, tools/ubench/valu_rates.hip).
@@ -83,7 +84,6 @@ static int fail_hip(hipError_t e, const char* what) {
 #else
 #define ATC_RARE(x) (x)
 #define ATC_USUAL(x) (x)
-#endif
 #endif
 #ifndef ATC_NT_LOAD
 #define ATC_NT_LOAD 0   // non-temporal action loads: measured SLOWER (36.0 vs 31.9 us)
@@ -1468,6 +1468,8 @@ static int step_common(const atc_scenario_t* s, int B, int N, int T, int hold, c
     if (!actions || !out) return fail_arg("null pointer");
     if (const int rc = check_env_args(s, B, N, st, p)) return rc;
     if (T < 1 || hold < 1) return fail_arg("need T >= 1 and hold >= 1");
+    // actions is [T / hold] blocks: a partial last block would be read beyond what the header promises exists
+    if (T % hold != 0) return fail_arg("T must be a multiple of hold (actions holds T / hold blocks)");
     if (!out->obs || !out->reward || !out->done || !out->flags) return fail_arg("obs/reward/done/flags are required");
     if (out->packet && (N != 1 || T != 1)) return fail_arg("atc_out_t.packet is for single steps of single-aircraft envs");
     if (!(p->dt > 0.0f)) return fail_arg("dt must be > 0");

@@ -332,8 +332,9 @@ int atc_rollout(const atc_scenario_t* s, int B, int N, int T, const atc_state_t*
                 const atc_out_t* out, const atc_params_t* p, void* stream);
 
 /* The same with every action HELD for `hold` consecutive steps (frame skip — the protocol of the reference's demo loop,
- * learning/atc-gym-demo.py:18-19: one sampled action is applied 20 times): actions: [ceil(T / hold)][B*N*3], step t uses
- * block t / hold.  Results are identical to atc_rollout with each block repeated `hold` times; the action tensor and its
+ * learning/atc-gym-demo.py:18-19: one sampled action is applied 20 times): actions: [T / hold][B*N*3], step t uses
+ * block t / hold; T must be a multiple of hold (ATC_ERR_ARG otherwise: a partial last block is refused, not read).
+ * Results are identical to atc_rollout with each block repeated `hold` times; the action tensor and its
  * HBM traffic shrink by that factor. */
 int atc_rollout_hold(const atc_scenario_t* s, int B, int N, int T, int hold, const atc_state_t* st, const float* actions,
                      const atc_out_t* out, const atc_params_t* p, void* stream);

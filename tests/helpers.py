@@ -55,6 +55,17 @@ def make_scenario(name):
         s.entrypoints = [model.EntryPoint(2, 30, 90, [150])]
         s.noise_areas = []
         return s
+    if name == "Sliver":  # near-horizontal LONG shared edges (dy = 0.03 over dx = 50): the fp32 x-intersection of
+        s = scenarios.Scenario()   # such an edge is ~2.5e-3 nm off its float64 line — the lookup grid's margins must cover it
+        rings = [[(5, 5), (55, 5), (55, 20.03), (5, 20), (5, 5)],
+                 [(5, 20), (55, 20.03), (55, 39.98), (5, 40.01), (5, 20)],
+                 [(5, 40.01), (55, 39.98), (55, 60), (5, 60), (5, 40.01)]]
+        s.mvas = [model.MinimumVectoringAltitude(r, h) for r, h in zip(rings, (3000, 4200, 2500))]
+        s.runway = model.Runway(30, 12, 400, 90)
+        s.airspace = model.Airspace(s.mvas, s.runway)
+        s.entrypoints = [model.EntryPoint(8, 30, 90, [120, 140])]
+        s.noise_areas = []
+        return s
     raise KeyError(name)
 
 

@@ -46,6 +46,13 @@ def _case(seed):
         kw.update(use_rollout=rollout, rollout_hold=rh, hold=rh * int(rng.choice([1, 2])))
     if rollout:
         kw["steps"] = max(rollout, (kw["steps"] // rollout) * rollout)
+    # round 4 (drawn after everything else: earlier sweeps keep their configurations): a third of the cases replace the
+    # drawn cell size by the SHIPPED defaults — 0.125 nm explicitly, or "auto" (atc_hip.vec_env.auto_grid_cell: 0.125 nm for
+    # every batch this sweep draws), whose compiled sector must be the one the env builds for itself
+    pick = int(rng.integers(6))
+    if pick < 2:
+        kw["grid_cell"] = 0.125 if pick == 0 else "auto"
+        comp = scenarios.compile_scenario(scn, grid_cell=0.125)
     return scn, comp, kw
 
 

@@ -94,6 +94,10 @@ def test_argument_errors_are_reported_not_raised_from_c():
     assert L.atc_step(None, 4, 2, C.byref(st), a.data_ptr(), C.byref(out), C.byref(p), stream) == -1
     assert L.atc_step(env.sector.handle, 4, 2, C.byref(st), None, C.byref(out), C.byref(p), stream) == -1
     assert L.atc_rollout(env.sector.handle, 4, 2, 0, C.byref(st), a.data_ptr(), C.byref(out), C.byref(p), stream) == -1
+    # a partial last action block (T not a multiple of hold) is refused, not read (round-3 review, weak #6)
+    assert L.atc_rollout_hold(env.sector.handle, 4, 2, 10, 4, C.byref(st), a.data_ptr(), C.byref(out), C.byref(p), stream) == -1
+    assert b"multiple of hold" in L.atc_last_error()
+    assert L.atc_rollout_hold(env.sector.handle, 4, 2, 3, 0, C.byref(st), a.data_ptr(), C.byref(out), C.byref(p), stream) == -1
     bad = lib.AtcState(st.pos_hp, None, st.last_act, st.env, st.stats)
     assert L.atc_step(env.sector.handle, 4, 2, C.byref(bad), a.data_ptr(), C.byref(out), C.byref(p), stream) == -1
     assert b"null" in L.atc_last_error()

@@ -77,7 +77,7 @@ class TestReferenceModelTests:
 
 
 # ------------------------------------------------------------------------------------------------ G3 / G4 / G5 lattices
-@pytest.mark.parametrize("grid_cell", [None, 0.5, 1.0])
+@pytest.mark.parametrize("grid_cell", [None, 0.125, 0.5, 1.0])
 @pytest.mark.parametrize("scen", ["LOWW", "Simple"])
 def test_mva_lattice_golden(scen, grid_cell):
     g = H.golden_npz("g3_mva.npz")
@@ -88,8 +88,8 @@ def test_mva_lattice_golden(scen, grid_cell):
     assert np.array_equal(got, g[scen + "_lattice"])
 
 
-@pytest.mark.parametrize("grid_cell", [None, 0.25, 0.5, 2.0])
-@pytest.mark.parametrize("scen", ["LOWW", "Simple"])
+@pytest.mark.parametrize("grid_cell", [None, 0.125, 0.25, 0.5, 2.0])
+@pytest.mark.parametrize("scen", ["LOWW", "Simple", "Sliver"])
 def test_mva_bitexact_vs_oracle_dense_and_edges(scen, grid_cell):
     """1.5 M random points + points hugging every polygon edge/vertex (within a few fp32 ulps): the polygon index must be
     identical to the fp32 oracle's ordered scan, with and without the lookup grid."""
@@ -162,7 +162,7 @@ def test_shaping_golden():
     assert np.max(np.abs(out[:, 2] - g["gs"])) <= 1e-5
 
 
-@pytest.mark.parametrize("grid_cell", [None, 0.25, 0.5, 1.0])
+@pytest.mark.parametrize("grid_cell", [None, 0.125, 0.25, 0.5, 1.0])
 def test_tiebreak_points_exact(grid_cell):
     """G8: sector with integer / dyadic vertices (the fp32 blob holds exactly the reference's polygons): vertices, edge
     points, shared borders, overlapping polygons and points 2^-10 nm either side of every edge must get the REFERENCE's
@@ -735,3 +735,59 @@ def test_full_size_properties(B, N):
         assert np.array_equal(d[:small].cpu().numpy(), orc.done)
         on = o[:small].cpu().numpy().reshape(small, N, 10)
         assert np.all(np.abs(on - orc.obs) <= 1e-5 * np.maximum(1.0, np.abs(orc.obs)))
+
+
+@pytest.mark.parametrize("B,N", [(65536, 1), (8192, 16), (65536, 16), (4096, 64)])
+def test_full_size_rollout_hold(B, N):
+    """The fused entry (atc_rollout_hold, T = 20, hold = 20: the protocol of learning/atc-gym-demo.py:18-19 and the
+    configuration behind every `fused_rollout` record of bench.py) at BASELINE.json's sizes, with the grid the library picks
+    for the batch: (1) deterministic, (2) the first 256 envs of the big batch equal the same envs run as a 256-env batch (a
+    different launch geometry: envs are independent), (3) those 256 envs match the fp32 oracle stepped once per step —
+    flags / done exact, obs / reward within 1e-5 —, (4) the state after the launches is bit-identical to the oracle's."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+    from oracle import oracle as O
+    scn = scenarios.LOWWDense() if N == 64 else scenarios.LOWW(random_entrypoints=N > 1)
+    T, launches, small = 20, 3, 256
+    g = torch.Generator(device="cpu").manual_seed(7 * B + N)
+    blocks = [(torch.rand((1, B, N, 3), generator=g) * 2 - 1).cuda() for _ in range(launches)]
+
+    def run(nb):
+        env = AtcVecEnv(nb, N, scenario=scn, auto_reset=True, seed=3)
+        outs = []
+        for j in range(launches):
+            o = env.rollout(blocks[j][:, :nb].contiguous(), hold=T)
+            outs.append({k: v.clone() for k, v in o.items()})
+        state = (env.pos_hp.clone(), env.v.clone(), env.last_act.clone(), env.env.clone())
+        env.close()
+        return outs, state
+
+    (big, st_big), (big2, st_big2), (sm, st_sm) = run(B), run(B), run(small)
+    for a, b in zip(st_big, st_big2):
+        assert torch.equal(a, b)
+    n_ac = small * N
+    assert torch.equal(st_big[0][:n_ac], st_sm[0]) and torch.equal(st_big[1][:n_ac], st_sm[1])
+    assert torch.equal(st_big[2][:n_ac], st_sm[2]) and torch.equal(st_big[3][:small], st_sm[3])
+    orc = O.OracleEnv(scenarios.compile_scenario(scn, grid_cell=0.5), small, N, O.make_params(auto_reset=True, seed=3), np.float32)
+    n_done = 0
+    for j in range(launches):
+        for k in ("obs", "reward", "done", "flags"):
+            assert torch.equal(big[j][k], big2[j][k]), k
+            assert torch.equal(big[j][k][:, :small], sm[j][k]), k
+        assert bool(torch.isfinite(big[j]["obs"]).all()) and bool(torch.isfinite(big[j]["reward"]).all())
+        a = blocks[j][0, :small].cpu().numpy()
+        for t in range(T):
+            orc.step(a)
+            assert np.array_equal(sm[j]["flags"][t].cpu().numpy().astype(np.uint16), orc.flags), (j, t)
+            assert np.array_equal(sm[j]["done"][t].cpu().numpy(), orc.done), (j, t)
+            on = sm[j]["obs"][t].cpu().numpy().reshape(small, N, 10)
+            assert np.all(np.abs(on - orc.obs) <= 1e-5 * np.maximum(1.0, np.abs(orc.obs))), (j, t)
+            rw = sm[j]["reward"][t].cpu().numpy()
+            # (the fp32 sum of N per-aircraft terms adds at most N/2 ulps of the running sum: the bound of _run_vs_oracle)
+            rtol = 1e-5 * np.maximum(1.0, np.abs(orc.reward)) + 6e-8 * N * np.abs(orc.ac_reward).sum(1)
+            assert np.all(np.abs(rw - orc.reward) <= rtol), (j, t)
+            n_done += int(orc.done.sum())
+    assert np.array_equal(st_sm[0][:, 0].cpu().numpy(), orc.px) and np.array_equal(st_sm[0][:, 1].cpu().numpy(), orc.py)
+    assert np.array_equal(st_sm[3][:, 1].cpu().numpy(), orc.actions_taken)
+    assert np.array_equal(st_sm[2].cpu().numpy().reshape(-1, 3), orc.last_act.T.reshape(-1, 3))

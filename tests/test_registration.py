@@ -53,3 +53,26 @@ def test_second_registration_of_the_same_id_is_tolerated(tmp_path):
         "    registry[id] = entry_point\n")
     r = _run("import envs, importlib\nimportlib.reload(envs)", [str(tmp_path)])
     assert r.returncode == 0, r.stderr
+
+
+def test_installed_but_broken_gym_falls_through_to_gymnasium(tmp_path):
+    """an installed gym that cannot be imported (old gym on a new NumPy raises AttributeError at import) must not
+    make `import envs` fail, and must not prevent the gymnasium fallback."""
+    bad = tmp_path / "gym"
+    bad.mkdir()
+    (bad / "__init__.py").write_text("raise AttributeError(\"module 'numpy' has no attribute 'bool'\")\n")
+    good = tmp_path / "gymnasium" / "envs"
+    good.mkdir(parents=True)
+    (tmp_path / "gymnasium" / "__init__.py").write_text("")
+    (good / "__init__.py").write_text("")
+    (good / "registration.py").write_text("registry = {}\ndef register(id, entry_point, **kw):\n    registry[id] = entry_point\n")
+    r = _run("""
+        import warnings
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            import envs
+        assert any("failed to import" in str(x.message) for x in w), [str(x.message) for x in w]
+        from gymnasium.envs.registration import registry
+        assert registry['AtcEnv-v0'] == 'envs.atc.atc_gym:AtcGym'
+    """, [str(tmp_path)])
+    assert r.returncode == 0, r.stderr

@@ -108,7 +108,7 @@ def _walk_grid(b, g, tabs, tabs_h, x, y):
     return -1
 
 
-@pytest.mark.parametrize("scen,cell", [("LOWW", 0.5), ("LOWW", 1.0), ("Simple", 0.5), ("LOWW", 0.25)])
+@pytest.mark.parametrize("scen,cell", [("LOWW", 0.5), ("LOWW", 1.0), ("Simple", 0.5), ("LOWW", 0.25), ("LOWW", 0.125), ("Simple", 0.125)])
 def test_grid_matches_ordered_scan_on_host(scen, cell):
     """Edge-list lookup grid == ordered polygon scan on random points, points hugging every edge, and the golden lattice
     (host check of the compiler; the device walk is checked bit-for-bit against the oracle in the gpu tests)."""
@@ -148,6 +148,36 @@ def test_grid_matches_ordered_scan_on_host(scen, cell):
                              cells.reshape(ny, nx, 2)[:, 0].ravel(), cells.reshape(ny, nx, 2)[:, -1].ravel()])
     assert not border.any()   # the outermost ring: clean, outside, no candidates of any kind
     print(scen, cell, 'dirty cells', n_dirty, 'of', len(cells), 'records per dirty cell %.2f' % ((codes & 63)[cells[:, 0] > 0].mean()))
+
+
+@pytest.mark.parametrize("cell", [0.125, 0.25, 0.5, 1.0])
+def test_sliver_edges_fp32_walk_matches_fp32_oracle(cell):
+    """the device walks the lookup grid in fp32 from fp32-rounded vertices; for a near-horizontal LONG edge the
+    fp32 x-intersection is ~2.5e-3 nm off the float64 line the grid builder classifies boxes against.  The walk emulated in
+    float32 on the float32 blob must give the fp32 oracle's ordered-scan answer on points hugging those edges (the builder's
+    margin is per edge since round 4: 1e-3 nm + 4 ulp (1 + |dx / dy|))."""
+    from oracle import oracle as O
+    c = H.compiled("Sliver", grid_cell=cell)
+    b = c.blob32
+    g = int(b[L.H_OFF_GRID])
+    rng = np.random.default_rng(5)
+    pts = []
+    for ring in c.mva_rings:
+        for k in range(len(ring) - 1):
+            t = rng.uniform(0, 1, 700)[:, None]
+            p = ring[k][None, :] * (1 - t) + ring[k + 1][None, :] * t
+            pts.append(p + rng.normal(0, 2e-3, p.shape))
+            pts.append(p + rng.integers(-3, 4, p.shape) * np.spacing(np.abs(p).astype(np.float32)).astype(np.float64))
+    pts = np.concatenate(pts).astype(np.float32)
+    heights = O.OracleQueries(c, np.float32).mva(pts[:, 0], pts[:, 1])
+    bounds32 = [tuple(np.float32(v) for v in bb) for bb in c.mva_bounds]
+    n_in = 0
+    for (x, y), hgt in zip(pts, heights):
+        pi = _walk_grid(b, g, bounds32, c.mva_heights, x, y)
+        got = int(c.mva_heights[pi]) if pi >= 0 else -1
+        assert got == int(hgt), (float(x), float(y), got, int(hgt))
+        n_in += pi >= 0
+    assert n_in > 1000
 
 
 def test_grid_cell_by_batch_size_and_compile_cache():

@@ -27,6 +27,7 @@ trace = torch.zeros((n_waves, 8), dtype=torch.int64, device="cuda")
 ptr = trace.data_ptr()
 env.params.reserved0 = ptr & 0xffffffff
 env.params.reserved1 = struct.unpack("f", struct.pack("I", (ptr >> 32) & 0xffffffff))[0]
+env.refresh_params()   # step(held=True) passes the held-action twin of `params`: it has to carry the trace pointer too
 torch.cuda.synchronize()
 env.step(acts[0])                 # first launch of a block
 env.step(acts[0], held=HELD)      # the traced launch: a repeat
