@@ -26,6 +26,14 @@ ENVS_PER_GPU = 65536
 AIRCRAFT = 16
 HOLD = 20            # action re-sampling interval [steps]
 HBM_PEAK_GBS = 8000  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+INFINITY_CACHE_BYTES = 256 << 20  # MI355X_MICROARCH.md: 256 MiB memory-side cache (MALL) in front of HBM
+
+
+def working_set_bytes(B, N, T=1):
+    """Bytes one launch touches: aircraft records (pos_hp 16 + v 4 + last_act 12), env records (16 + 32 per env), ONE action
+    tensor (12 per aircraft; the other ring tensors are cold) and the outputs of its T steps (obs 40 + flags 2 per aircraft,
+    reward 4 + done 1 per env)."""
+    return B * N * (32 + 12 + 42 * T) + B * (48 + 5 * T)
 
 
 def algorithmic_bytes_per_env_step(n, fused_steps=1, hold=1):
@@ -35,11 +43,12 @@ def algorithmic_bytes_per_env_step(n, fused_steps=1, hold=1):
     return (44 + 40.0 / fused_steps + 12.0 / hold) * n + 13
 
 
-def _time_oracle(n_aircraft, B, threads, seconds_target):
+def _time_oracle(n_aircraft, B, threads, seconds_target, scn=None):
     import numpy as np
     from envs.atc import scenarios
     from oracle import oracle as O
-    scn = scenarios.LOWW(random_entrypoints=True)
+    if scn is None:
+        scn = scenarios.LOWWDense() if n_aircraft > 16 else scenarios.LOWW(random_entrypoints=n_aircraft > 1)
     comp = scenarios.compile_scenario(scn)
     O.set_threads(threads)
     env = O.OracleEnv(comp, B, n_aircraft, O.make_params(auto_reset=True, seed=0), np.float32)
@@ -57,6 +66,36 @@ def _time_oracle(n_aircraft, B, threads, seconds_target):
     dt = time.perf_counter() - t0
     O.set_threads(1)
     return B * steps / dt, steps, dt
+
+
+def cpu_side_baseline(n_aircraft, scn, seconds_target=3.0):
+    """The same sampler as `cpu_baseline` for one of BASELINE.json's other configurations: ONE core, ~3 s."""
+    Bs = max(64, 32768 // max(1, n_aircraft))
+    v, steps, dt = _time_oracle(n_aircraft, Bs, 1, seconds_target, scn)
+    return {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d envs x %d aircraft x %d steps (%.1f s) of the same workload through oracle/ (fp32 C port of the "
+                      "reference step, 1 thread)" % (Bs, n_aircraft, steps, dt)}
+
+
+def single_env_cpu_oracle(n_steps=100000):
+    """The reference's own protocol (learning/atc-gym-compute-performance.py:10-19: ONE env x ONE aircraft, 100 000 x step(one
+    fixed sampled action), no reset on done, FPS = N / wall time) through the CPU oracle stepped 1 x 1 from Python — the
+    compiled-CPU counterpart of `single_env` (the GPU-backed drop-in AtcGym), on 1 core of this host."""
+    import numpy as np
+    from envs.atc import scenarios
+    from oracle import oracle as O
+    comp = scenarios.compile_scenario(scenarios.LOWW())
+    out = {}
+    for name, dt_ in (("f64", np.float64), ("f32", np.float32)):
+        env = O.OracleEnv(comp, 1, 1, O.make_params(auto_reset=False, keep_active=True), dt_)
+        action = np.random.default_rng(0).uniform(-1, 1, (1, 1, 3)).astype(dt_)
+        for _ in range(200):
+            env.step(action)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            env.step(action)
+        out[name] = n_steps / (time.perf_counter() - t0)
+    return out
 
 
 def host_cores():
@@ -271,7 +310,7 @@ def traffic_entry(B, N, rollout, held_hint, streams=1):
     return None, None
 
 
-def side_config(name, B, N, scn, sep_nm, device, held_hint, n_single=2000, n_fused=100):
+def side_config(name, B, N, scn, sep_nm, device, held_hint, n_single=2000, n_fused=100, cpu=True):
     """One of BASELINE.json's other single-GPU configurations as a side record of the default line: the launch mode of the
     headline loop (one atc_step per step, a new action tensor every HOLD steps, the held-action hint in between) and the same
     envs with HOLD steps fused per launch — each parity-gated on its own first 256 envs before it is timed."""
@@ -321,6 +360,8 @@ def side_config(name, B, N, scn, sep_nm, device, held_hint, n_single=2000, n_fus
     tr1, src1 = traffic_entry(B, N, 0, held_hint)
     trf, srcf = traffic_entry(B, N, HOLD, False)
     return {"config": name, "envs": B, "aircraft": N, "sector": type(scn).__name__, "grid_cell_nm": grid_cell, "parity_gate": gate,
+            "working_set_bytes": working_set_bytes(B, N), "fits_infinity_cache": working_set_bytes(B, N) <= INFINITY_CACHE_BYTES,
+            "cpu_baseline": cpu_side_baseline(N, scn) if cpu else None,
             "single_steps": {"steps": n_single, "us_per_step": us, "env_steps_per_s": B / (us * 1e-6),
                              "algorithmic_bytes_per_env_step": b1, "hbm_frac": b1 * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                              "traffic": tr1, "traffic_source": src1, "timed_blocks_us_per_step": blocks},
@@ -346,6 +387,71 @@ def single_env_protocol(n_steps=100000):
     env.close()
     return {"protocol": "learning/atc-gym-compute-performance.py:10-19 (1 env x 1 aircraft, one fixed action, no reset)",
             "steps": n_steps, "steps_per_s": n_steps / dt, "us_per_step": dt / n_steps * 1e6}
+
+
+def measure_collective(D, stats, dev, force, block=None, reps=100):
+    """Cost of the episode-statistics exchange on the initialised group (microseconds, mean of `reps`; wall clock around a
+    stream synchronisation and HIP events on the current stream):
+      blocking_two_all_gathers_plus_barrier — round 3's report: all_gather_stats(ep_return, ep_length) (two collectives) and
+        a barrier, what every timed block of round 3 contained;
+      packed_blocking — snapshot + ONE packed all-gather, waited for at once;
+      barrier — the backend's barrier alone;
+      block_with / block_without — a %d-step block of the timed loop with the asynchronous packed exchange issued before its
+        launches and waited for after them, against the same block without any exchange: the difference is what the
+        exchange adds to a timed block when it overlaps the step kernels."""
+    import torch
+    out = {"reps": reps, "world_size": torch.distributed.get_world_size()}
+
+    def timed(fn):
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return {"wall": (time.perf_counter() - t0) / reps * 1e6, "hip_events": e0.elapsed_time(e1) * 1e3 / reps}
+
+    def old():
+        D.all_gather_stats(*stats(), force=force)
+        torch.cuda.synchronize(dev)
+        D.barrier(force=force)
+    xch = D.StatsExchange(force=force)
+
+    def packed():
+        xch.snapshot(*stats())
+        xch.issue()
+        xch.wait()
+        torch.cuda.synchronize(dev)
+    for f in (old, packed):
+        f()
+    out["blocking_two_all_gathers_plus_barrier"] = timed(old)
+    out["packed_blocking"] = timed(packed)
+    out["barrier"] = timed(lambda: D.barrier(force=force))
+    if block is not None:
+        def with_x():
+            xch.snapshot(*stats())
+            xch.issue()
+            block()
+            xch.wait()
+            torch.cuda.synchronize(dev)
+
+        def without():
+            block()
+            torch.cuda.synchronize(dev)
+        with_x()
+        without()
+        reps_b = 30
+        for name, f in (("block_without", without), ("block_with", with_x), ("block_without_2", without), ("block_with_2", with_x)):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(reps_b):
+                f()
+            out[name] = (time.perf_counter() - t0) / reps_b * 1e6
+        out["block_steps"] = HOLD
+        out["exchange_adds_us_per_block"] = min(out["block_with"], out["block_with_2"]) - min(out["block_without"], out["block_without_2"])
+    return out
 
 
 def main():
@@ -531,41 +637,65 @@ def main():
     run(PREWARM - PREWARM % max(1, args.rollout, HOLD if args.graph else 1), 0)
     run(W, 0)
     torch.cuda.synchronize(dev)
+    forced = ws == 1 and bool(collective.get("backend")) and "error" not in collective
     warm = D.all_gather_stats(*stats(), force=True)  # untimed: creates the RCCL communicator / channels
     torch.cuda.synchronize(dev)
-    if ws == 1 and collective.get("backend") and "error" not in collective:
+    if forced:
         try:   # the one-rank group's collectives really ran: device tensors in, the same values out
             collective.update({"forced_single_rank": True, "gathered_shape": list(warm[0].shape), "device_tensors": bool(warm[0].is_cuda),
                                "matches_local": bool(torch.equal(warm[0][0], stats()[0])),
                                "all_reduce_max": D.max_over_ranks(1.5, dev, force=True), "all_reduce_sum": D.sum_over_ranks(2.5, dev, force=True)})
         except Exception as exc:
             collective["error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
+    if (ws > 1 or forced) and "error" not in collective:
+        # What the exchange costs on THIS group (untimed; the real backend: RCCL on a GPU box, one rank here or eight on the
+        # driver's node), so that the line says what a blocking report would have added to a timed block and what the
+        # asynchronous one does add (round-3 review, next #1).
+        try:
+            collective["us"] = measure_collective(D, stats, dev, force=forced,
+                                                  block=(lambda: run(HOLD, 0)) if (launchers is not None or args.rollout in (0, HOLD)) and not args.graph else None)
+        except Exception as exc:
+            collective["us_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
+        last_block[0] = None
     if ws == 1:
         D.shutdown()   # the one-rank group has served its purpose: no communicator (proxy thread, streams) during the timed region
         torch.cuda.synchronize(dev)
     # HIP events on the stream(s) the kernels are launched on (torch's current stream, or one per sub-batch)
     qs = streams if S > 1 else [torch.cuda.current_stream(dev)]
-    blocks = []   # (wall seconds, HIP-event milliseconds) of each timed block of K steps, max over ranks
+    # The path's only exchange: ONE packed all-gather of the per-env episode statistics per rollout, asynchronous
+    # (atc_hip.dist.StatsExchange).  Timed block r issues the collective for the statistics of rollout r - 1 (block 0: the
+    # warm-up's) on the backend's stream BEFORE its own launches, queues its K step launches, then waits for the collective:
+    # every timed block contains exactly one exchange, overlapped with its step kernels, and nothing of it sits between the
+    # last step and the end of the window but its completion.
+    xch = D.StatsExchange()
+    xch.snapshot(*stats())
+    blocks = []   # per timed block, max over ranks: (step-window seconds, HIP-event ms, seconds incl. the closing barrier)
     for rep in range(max(1, args.repeats)):
         D.barrier()
         torch.cuda.synchronize(dev)
         ev0 = [torch.cuda.Event(enable_timing=True) for _ in qs]
         ev1 = [torch.cuda.Event(enable_timing=True) for _ in qs]
         t0 = time.perf_counter()
+        xch.issue()
         for e, q in zip(ev0, qs):
             e.record(q)
         run(K, W + rep * K)
         for e, q in zip(ev1, qs):
             e.record(q)
-        torch.cuda.synchronize(dev)  # (sub-batch streams are joined here, before the statistics are gathered)
-        returns, lengths = D.all_gather_stats(*stats())  # the path's only exchange (RCCL, N > 1)
-        torch.cuda.synchronize(dev)
+        gathered = xch.wait()            # rollout r - 1's statistics of every rank (the current stream waits, not the host)
+        torch.cuda.synchronize(dev)      # every local step AND the overlapped exchange have completed (sub-batch streams joined)
+        t1 = time.perf_counter()         # <- the step window closes here, on every rank by its own clock; MAX over ranks below
+        xch.snapshot(*stats())           # this rollout's statistics: reported during the next block
         D.barrier()
-        wall = time.perf_counter() - t0
-        blocks.append((D.max_over_ranks(wall, dev), D.max_over_ranks(max(a.elapsed_time(b) for a, b in zip(ev0, ev1)), dev)))
+        t2 = time.perf_counter()
+        blocks.append((D.max_over_ranks(t1 - t0, dev), D.max_over_ranks(max(a.elapsed_time(b) for a, b in zip(ev0, ev1)), dev),
+                       D.max_over_ranks(t2 - t0, dev)))
+    xch.issue()                          # the last rollout's report (untimed)
+    returns, lengths = xch.wait()
+    torch.cuda.synchronize(dev)
     rank_seeds = D.all_gather_stats(torch.tensor([D.rank_seed(0, rank) & 0x7fffffffffffffff], dtype=torch.int64, device=dev))[0]
     order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
-    elapsed, kernel_ms_total = blocks[order[len(order) // 2]]   # the median block
+    elapsed, kernel_ms_total, elapsed_with_barrier = blocks[order[len(order) // 2]]   # the median block
     T = args.rollout or 1
     n_launches = K // T
     launch_ms = kernel_ms_total / n_launches   # average launch duration (HIP events) of the median block
@@ -592,8 +722,17 @@ def main():
                                                 "(atc_step_multi), no join between steps" % (S, B // S, S) if S > 1 else "one atc_step launch per step")), "parallelism": "env-sharded x%d, no step-path collective, "
                        "1 all-gather of episode returns per rollout" % ws,
                        "episodes_finished": int(episodes), "positions": "32-bit fixed point (2^-25 nm grid)",
-                       "timed_blocks_ms_per_step": [b[0] / K * 1e3 for b in blocks], "timing": "median of %d timed blocks "
-                       "of %d steps, each bracketed by barrier + synchronize" % (len(blocks), K),
+                       "timed_blocks_ms_per_step": [b[0] / K * 1e3 for b in blocks],
+                       "timing": "median of %d timed blocks of %d steps; a block = barrier + synchronize | t0 | issue the async "
+                                 "packed all-gather of the previous rollout's episode statistics, queue the %d step launches, wait "
+                                 "for the all-gather, synchronize | t1 | barrier; window = t1 - t0, MAX over ranks (every rank "
+                                 "starts at the opening barrier, so the max is the time until the slowest rank's steps and the "
+                                 "exchange are done; the closing barrier's own latency is not charged to the steps: "
+                                 "`ms_per_step_incl_closing_barrier` carries it)" % (len(blocks), K, n_launches),
+                       "ms_per_step_incl_closing_barrier": elapsed_with_barrier / K * 1e3,
+                       "exchange": {"collectives_per_report": 1, "issued": xch.collectives, "reports": len(blocks) + 1,
+                                    "async": True, "payload": "ep_return + ep_length packed as one [envs, 2] 32-bit tensor, "
+                                    "%d bytes per rank" % (8 * B)},
                        "actions_held_hint": ("launches 2..%d of every %d-step action block carry ATC_M_ACTIONS_HELD (the caller's "
                                              "promise that the block is repeated; results identical, last_action record skipped)"
                                              % (HOLD, HOLD)) if held_launchers is not None else None,
@@ -605,6 +744,12 @@ def main():
                          "kernel": "k_step<%d, false, %s>" % (1 << max(0, (N - 1).bit_length()), "false" if args.rollout else "true"),
                          "avg_launch_ms": launch_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "concurrent_launches": S,
+                         "working_set_bytes": working_set_bytes(B, N, T), "fits_infinity_cache": working_set_bytes(B, N, T) <= INFINITY_CACHE_BYTES,
+                         "frac_of": "algorithmic bytes per launch / launch duration / 8 TB/s (HBM3E spec).  The step's working set "
+                                    "(state + one action tensor + outputs) is re-touched every launch: where it fits the 256 MiB "
+                                    "Infinity Cache (`fits_infinity_cache`) part of those bytes is served by the MALL, not DRAM — "
+                                    "the rate is a rate of algorithmic bytes, not proven DRAM traffic; `config.beyond_l3` is the same "
+                                    "kernel on a working set 4x larger than the cache",
                          "note": "HIP events on the launch stream around the %d timed launches (includes inter-launch "
                                  "gaps)" % n_launches},
         }
@@ -685,6 +830,37 @@ def main():
                                                  "parity_gate": ms_gate}
                 for e in halves:
                     e.close()
+        if (ws == 1 and not args.no_baseline_configs and N == AIRCRAFT and B == ENVS_PER_GPU and not args.rollout and S == 1
+                and graph is None):
+            # The headline kernel on a working set beyond the 256 MiB Infinity Cache (4 x the envs: 366 MB per launch): what
+            # the same code does when the bytes provably come from and go to DRAM (round-3 review, next #7).  Same kernel
+            # instantiation and the same 0.25 nm grid as the gated headline; a side record, never `value`.
+            Bl = 4 * ENVS_PER_GPU
+            big = AtcVecEnv(Bl, N, scenario=scn, device=local, auto_reset=True, seed=5, grid_cell=args.grid_cell, sep_nm=args.sep_nm)
+            gb = torch.Generator(device=dev)
+            gb.manual_seed(99)
+            ring_b = [torch.rand((Bl, N, 3), generator=gb, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(3)]
+            fb = [big.make_launcher(a) for a in ring_b]
+            rb = [big.make_launcher(a, held=True) for a in ring_b] if not args.no_held_hint else fb
+
+            def run_big(n):
+                for t in range(n):
+                    (rb if t % HOLD else fb)[(t // HOLD) % 3]()
+            run_big(1500)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run_big(600)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            usb = e0.elapsed_time(e1) * 1e3 / 600
+            line["config"]["beyond_l3"] = {"envs": Bl, "aircraft": N, "grid_cell_nm": args.grid_cell, "steps": 600, "us_per_step": usb,
+                                           "env_steps_per_s": Bl / (usb * 1e-6), "working_set_bytes": working_set_bytes(Bl, N),
+                                           "fits_infinity_cache": working_set_bytes(Bl, N) <= INFINITY_CACHE_BYTES,
+                                           "hbm_frac": algorithmic_bytes_per_env_step(N) * Bl / (usb * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                           "traffic": traffic_entry(Bl, N, 0, not args.no_held_hint)[0]}
+            big.close()
+            del big, ring_b, fb, rb
         if (ws == 1 and not args.no_baseline_configs and not args.no_parity_gate and N == AIRCRAFT and B == ENVS_PER_GPU
                 and not args.rollout and S == 1 and graph is None):
             # BASELINE.json's other single-GPU configurations, each gated on its own first 256 envs (side records: `value`
@@ -692,13 +868,23 @@ def main():
             hh = not args.no_held_hint
             line["config"]["baseline_configs"] = [
                 side_config("C2: 65 536 envs x 1 aircraft (kinematics + MVA only)", 65536, 1, scenarios.LOWW(),
-                            args.sep_nm, local, hh),
+                            args.sep_nm, local, hh, cpu=not args.no_cpu_baseline),
                 side_config("C3: 8 192 envs x 16 aircraft", 8192, 16, scenarios.LOWW(random_entrypoints=True),
-                            args.sep_nm, local, hh),
+                            args.sep_nm, local, hh, cpu=not args.no_cpu_baseline),
                 side_config("C4: 4 096 envs x 64 aircraft, multi-polygon MVA + noise-abatement areas", 4096, 64,
-                            scenarios.LOWWDense(), args.sep_nm, local, hh)]
+                            scenarios.LOWWDense(), args.sep_nm, local, hh, cpu=not args.no_cpu_baseline)]
         if ws == 1 and not args.no_single_env:
-            line["config"]["single_env"] = single_env_protocol()
+            se = single_env_protocol()
+            if not args.no_cpu_baseline:
+                # the compiled-CPU counterpart on 1 host core, same protocol: a one-env step is a launch-latency path on a
+                # GPU — the number that says by how much a CPU step beats it belongs beside it
+                co = single_env_cpu_oracle()
+                se["cpu_oracle_steps_per_s"] = co["f32"]
+                se["cpu_oracle_f64_steps_per_s"] = co["f64"]
+                se["cpu_oracle_note"] = ("oracle/ (C restatement of the reference step) stepped 1 env x 1 aircraft from Python, "
+                                         "1 core; the GPU-backed drop-in is %.2fx of it: one env cannot amortise a kernel launch"
+                                         % (se["steps_per_s"] / co["f32"]))
+            line["config"]["single_env"] = se
         if ws == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N)
         os.write(json_fd, (json.dumps(line) + "\n").encode())

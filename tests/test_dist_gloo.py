@@ -113,3 +113,71 @@ def test_forced_collective_in_a_world_of_one():
     p.join(30)
     want = [[0.0, 1.0, 2.0, 3.0, 4.0, 5.0]]
     assert name == "gloo" and plain == want and skipped == want and forced == want and mx == 3.0 and sm == 4.0
+
+
+def _worker_exchange(rank, ws, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "atc-reinforcement-learning_amd"))
+    import torch.distributed as dist
+    from atc_hip import dist as D
+    D.init(backend="gloo")
+    calls = {"all_gather": 0, "all_reduce": 0}
+    real_ag, real_ar = dist.all_gather_into_tensor, dist.all_reduce
+
+    def count_ag(*a, **k):
+        calls["all_gather"] += 1
+        return real_ag(*a, **k)
+
+    def count_ar(*a, **k):
+        calls["all_reduce"] += 1
+        return real_ar(*a, **k)
+    dist.all_gather_into_tensor, dist.all_reduce = count_ag, count_ar
+    n = 16
+    # the per-episode env record of atc_state_t: ep_length and ep_return are neighbouring 32-bit words of an 8-word record
+    stats = torch.zeros((n, 8), dtype=torch.int32)
+    ep_len = stats[:, 1]
+    ep_ret = stats[:, 2:3].view(torch.float32).squeeze(1)
+    xch = D.StatsExchange()
+    log = []
+    for block in range(4):       # four "rollouts": statistics of rollout b are reported while rollout b + 1 is queued
+        ep_len += 1 + rank       # ... the rollout's steps change the live statistics ...
+        ep_ret += 0.5 * (block + 1) + 100.0 * rank
+        if block:
+            xch.issue()                       # rollout b - 1's snapshot, asynchronously
+            n_after_issue = calls["all_gather"]
+            ep_len += 1000                    # the next rollout is already overwriting the live record
+            ret, length = xch.wait()
+            ep_len -= 1000
+            log.append((block - 1, ret.tolist(), length.tolist(), n_after_issue))
+        xch.snapshot(ep_ret, ep_len)
+    xch.issue()
+    ret, length = xch.wait()
+    log.append((3, ret.tolist(), length.tolist(), calls["all_gather"]))
+    q.put((rank, log, dict(calls), xch.collectives))
+    dist.all_gather_into_tensor, dist.all_reduce = real_ag, real_ar
+    D.shutdown()
+
+
+@pytest.mark.timeout(120)
+def test_stats_exchange_one_async_collective_per_report():
+    """Round-3 review, next #1: the episode statistics travel as ONE packed collective per report, issued asynchronously, and
+    what a report returns is the SNAPSHOT of the finished rollout — not whatever the next rollout has written meanwhile."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_exchange, args=(r, 2, 29647, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in range(2))
+    for p in procs:
+        p.join(30)
+    for rank, log, calls, n_coll in res:
+        assert n_coll == 4 and calls["all_gather"] == 4          # four reports, four collectives: one each
+        assert calls["all_reduce"] == 2                          # the equal-shard check of the first exchange, once
+        for k, (block, ret, length, n_ag) in enumerate(log):
+            assert block == k and n_ag == k + 1                  # issue() is where the collective is issued
+            for r in range(2):                                   # [world][rows]: rank r's statistics after rollout `block`
+                want_len = (block + 1) * (1 + r)
+                want_ret = sum(0.5 * (b + 1) + 100.0 * r for b in range(block + 1))
+                assert length[r] == [want_len] * 16 and ret[r] == [want_ret] * 16, (rank, block, r)

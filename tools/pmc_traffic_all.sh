@@ -18,5 +18,6 @@ run n16_8192_roll --envs 8192 --rollout 20 --warmup 40
 run n64_4096 --aircraft 64 --envs 4096
 run n64_4096_roll --aircraft 64 --envs 4096 --rollout 20 --warmup 40
 run n64_32768 --aircraft 64 --envs 32768
+run n16_262144 --envs 262144
 python $ROOT/tools/pmc_traffic_table.py $TAG > $ROOT/gpurun_out/pmc_traffic_$TAG.json
 cat $ROOT/gpurun_out/pmc_traffic_$TAG.json

@@ -19,7 +19,7 @@ tag = sys.argv[1]
 WORK = [("n16_65536", 65536, 16, 0, True), ("n16_65536_nohint", 65536, 16, 0, False), ("n16_65536_roll", 65536, 16, 20, False),
         ("n1_65536", 65536, 1, 0, True), ("n1_65536_roll", 65536, 1, 20, False), ("n16_8192", 8192, 16, 0, True),
         ("n16_8192_roll", 8192, 16, 20, False), ("n64_4096", 4096, 64, 0, True), ("n64_4096_roll", 4096, 64, 20, False),
-        ("n64_32768", 32768, 64, 0, True)]
+        ("n64_32768", 32768, 64, 0, True), ("n16_262144", 262144, 16, 0, True)]
 
 
 def avg(d, counter):
@@ -42,10 +42,22 @@ for name, B, N, roll, held in WORK:
     hbm = int(round((fetch * 2 + write) * 1024))
     alg = bench.algorithmic_bytes_per_env_step(N, roll or 1, roll or 1) * B * (roll or 1)
     W = 1 << max(0, (N - 1).bit_length())
-    out.append({"abi": L.ABI_VERSION, "envs": B, "aircraft": N, "rollout": roll, "held_hint": held,
+    ratio = hbm / alg
+    # What the x 2 is calibrated on (MI355X_MICROARCH.md, HBM / rocprofv3 section): streaming reads of 16 bytes per lane.  A
+    # launch whose reads are mostly narrower (4-byte speed, 12-byte action / last-action records, 8-byte lookup cells) or
+    # re-hit lines the Infinity Cache still holds from the previous launch can come out BELOW the algorithmic bytes; such an
+    # entry is a lower bound of the traffic, not evidence that algorithmic bytes were skipped.
+    note = None
+    if ratio < 1.0:
+        note = ("ratio < 1: FETCH_SIZE x 2 is calibrated on 16-byte-per-lane streaming reads; this launch's reads are %s, and "
+                "write-once outputs / re-read state of a %d MB working set are partly absorbed by the 256 MiB Infinity Cache — "
+                "read the figure as a lower bound" % ("mostly 4- / 12-byte records of one-aircraft envs" if N == 1 else
+                "16-byte state records plus 12-byte action records once per %d steps" % (roll or 1),
+                bench.working_set_bytes(B, N, roll or 1) >> 20))
+    out.append({"abi": L.ABI_VERSION, "read_correction_note": note, "envs": B, "aircraft": N, "rollout": roll, "held_hint": held,
                 "kernel": "k_step<%d,false,%s>%s" % (W, "false" if roll else "true", " T=%d hold=%d" % (roll, roll) if roll else ""),
                 "FETCH_SIZE_KB_raw": round(fetch, 1), "WRITE_SIZE_KB": round(write, 1), "hbm_bytes_per_launch": hbm,
-                "algorithmic_bytes_per_launch": alg, "ratio": round(hbm / alg, 4), "dispatches": min(nf, nw),
+                "algorithmic_bytes_per_launch": alg, "ratio": round(ratio, 4), "dispatches": min(nf, nw),
                 "source": "profiles/%s_pmc_traffic.json (tools/pmc_traffic_all.sh %s: two separate rocprofv3 --pmc passes per workload, "
                           "--kernel-trace only; FETCH_SIZE x 2 + WRITE_SIZE, average over the k_step dispatches%s)"
                           % (tag, tag, "; 19 launches in 20 carry ATC_M_ACTIONS_HELD" if held and not roll else "")})
