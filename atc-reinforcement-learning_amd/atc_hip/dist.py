@@ -130,20 +130,26 @@ class StatsExchange:
 
         xch = StatsExchange()
         ...rollout r...        xch.snapshot(env.ep_return, env.ep_length)   # packs the statistics: one [rows, k] int32 tensor
-        ...rollout r + 1 ...   xch.issue()          # all_gather_into_tensor(async_op=True): returns at once; the backend's
-                               <queue the rollout's step launches>          #   stream runs it beside the step kernels
+        ...rollout r + 1 ...   <queue the rollout's step launches>          # the GPU is busy from here on
+                               xch.issue()          # all_gather_into_tensor(async_op=True) from a SIDE stream: the host cost of
+                                                    #   the call (tens of microseconds) and the collective itself run beside
+                                                    #   the step kernels already queued; nothing waits for them
                                ret, length = xch.wait()                    # [world, rows] tensors of rollout r's statistics
 
     The k statistics must be 1-D tensors of one length with 4-byte elements (float32 / int32: `ep_return`, `ep_length` are
     neighbouring words of the per-episode env record); they travel as their bit patterns and come back in their own dtypes.
-    `wait()` makes the CURRENT stream wait for the collective (RCCL) — it does not block the host — so it belongs after the
-    launches that should overlap it.  Not distributed (and not forced): snapshot / wait degrade to a local copy with a leading
+    The collective is issued under a private side stream, so the backend's stream synchronises with THAT (idle) stream and not
+    with the stream the step kernels were queued on (torch's process group makes its stream wait for the caller's current
+    stream: issued on the compute stream after the launches, the collective would start when the last step has finished;
+    issued before them, the host time of the call delays the first launch — measured 41 us per 20-step block on the one-rank
+    RCCL group).  `wait()` makes the side stream, then the CURRENT stream wait for the collective — it does not block the
+    host — so it belongs after the launches that should overlap it.  Not distributed (and not forced): snapshot / wait degrade to a local copy with a leading
     axis of 1 and no collective is issued.  `collectives` counts the collectives issued (tests: one per report)."""
 
     def __init__(self, force=False):
         self.force = bool(force)
         self.collectives = 0
-        self._src = self._dst = self._host = self._work = None
+        self._src = self._dst = self._host = self._work = self._side = None
         self._dtypes = None
         self._pending = False
 
@@ -182,12 +188,23 @@ class StatsExchange:
         assert int(src.shape[0]) == _shard_rows[key], "shard size changed since the first exchange"
         if self._dst is None or self._dst.device != src.device or self._dst.shape[0] != ws * src.shape[0]:
             self._dst = torch.empty((ws * src.shape[0], src.shape[1]), dtype=torch.int32, device=src.device)
-        self._work = dist.all_gather_into_tensor(self._dst, src, async_op=True)
+        if src.is_cuda:
+            if self._side is None or self._side.device != src.device:
+                self._side = torch.cuda.Stream(device=src.device)
+            with torch.cuda.stream(self._side):
+                self._work = dist.all_gather_into_tensor(self._dst, src, async_op=True)
+        else:
+            self._work = dist.all_gather_into_tensor(self._dst, src, async_op=True)
         self.collectives += 1
 
     def wait(self):
         if self._work is not None:
-            self._work.wait()
+            if self._dst.is_cuda:
+                with torch.cuda.stream(self._side):
+                    self._work.wait()
+                torch.cuda.current_stream(self._dst.device).wait_stream(self._side)
+            else:
+                self._work.wait()
             self._work = None
             g = self._dst.view(-1, self._src.shape[0], self._src.shape[1])
         else:

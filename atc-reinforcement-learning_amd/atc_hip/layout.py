@@ -2,7 +2,7 @@
 
 tests/test_abi.py parses the header and checks that every constant here matches it.
 """
-ABI_VERSION = 17
+ABI_VERSION = 18
 BLOB_VERSION = 1013.0
 
 H_VERSION, H_NWORDS, H_N_MVA, H_N_NOISE, H_N_ENTRY, H_OFF_POLY, H_OFF_VERT, H_OFF_ENTRY, H_OFF_GRID, H_N_VERTW = range(10)
@@ -18,6 +18,8 @@ C_ALIGNED_OK = 93
 C_POS_X0, C_POS_Y0, C_POS_SCALE, C_POS_INV = 94, 95, 100, 101   # fixed-point position grid: nm = X0 + fix * 2^-k
 C_FAF_FIX = 124                                                 # FAF on the grid: x (hi, lo), y (hi, lo); fix = hi * 65536 + lo
 POS_MAX_K = 27
+# speed / heading state: 32-bit fixed point (include/atc_step.h, ABI 18): kt = v_fix 2^-23 (unsigned), deg = 180 + phi_fix 2^-23
+V_FIX_SHIFT, PHI_FIX_SHIFT, PHI_FIX_OFFSET = 23, 23, 180.0
 C_TRI_BBOX = 96
 C_NORM_A, C_NORM_B = 104, 114
 C_END = 128

@@ -84,16 +84,16 @@ class AtcVecEnv:
         zs = (lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)) if host_mapped == "io" else z  # noqa: E731
         f32, i32 = torch.float32, torch.int32
         # persistent state (atc_state_t): packed records, see include/atc_step.h
-        self.pos_hp = zs((BN, 4), i32)         # x, y (position-grid counts), h, phi (float bit patterns)
-        self.v = zs(BN, f32)                   # speed
-        self.last_act = zs((BN, 3), f32)       # last accepted v / h / phi targets
+        self.pos_hp = zs((BN, 4), i32)         # x, y (position-grid counts), h (float bit pattern), phi (heading counts)
+        self.v_fix = zs(BN, i32)               # speed counts (unsigned 32-bit, kt = v_fix 2^-23)
+        self.last_act = zs((BN, 3), i32)       # last accepted v / h / phi targets in the state's formats
         self.env = zs((B, L.ENV_WORDS), i32)   # per-step env record
         self.stats = zs((B, L.STAT_WORDS), i32)  # per-episode env record
         self._state = _lib.AtcState(*[self._ptr(getattr(self, n)) for n in _lib.STATE_FIELDS])
         self.pos_origin, self.pos_k = self.compiled.pos_origin, self.compiled.pos_k
         # named views into the records (live memory, usable for reads and in-place writes)
         self.h = self.pos_hp[:, 2:3].view(f32).squeeze(1)
-        self.phi = self.pos_hp[:, 3:4].view(f32).squeeze(1)
+        self.phi_fix = self.pos_hp[:, 3]       # heading counts (deg = 180 + phi_fix 2^-23); `phi` / `v` below are copies in units
         self.timesteps = self.env[:, L.ENV_TIMESTEPS]
         self.actions_taken = self.env[:, L.ENV_ACTIONS_TAKEN]
         self.total_reward = self.env[:, L.ENV_TOTAL_REWARD:L.ENV_TOTAL_REWARD + 1].view(f32).squeeze(1)
@@ -374,6 +374,8 @@ class AtcVecEnv:
 
     # positions live on the sector's 32-bit fixed-point grid (include/atc_step.h "Aircraft positions"):
     # nm = origin + counts * 2^-k.  `x` / `y` are float64 COPIES in nautical miles; write through set_state / set_xy.
+    # Speed and heading are fixed point too (ABI 18): kt = v_fix 2^-23 (unsigned counts), deg = 180 + phi_fix 2^-23; `v` / `phi`
+    # are float64 copies in knots / degrees (exact), written through set_state / set_v / set_phi.
     @property
     def x(self):
         return self.pos_hp[:, 0].to(self.torch.float64) * 2.0 ** -self.pos_k + self.pos_origin[0]
@@ -382,9 +384,27 @@ class AtcVecEnv:
     def y(self):
         return self.pos_hp[:, 1].to(self.torch.float64) * 2.0 ** -self.pos_k + self.pos_origin[1]
 
+    @property
+    def v(self):
+        return (self.v_fix.to(self.torch.int64) & 0xffffffff).to(self.torch.float64) * 2.0 ** -L.V_FIX_SHIFT
+
+    @property
+    def phi(self):
+        return self.phi_fix.to(self.torch.float64) * 2.0 ** -L.PHI_FIX_SHIFT + L.PHI_FIX_OFFSET
+
     def _to_fix(self, value, axis):
         from .scenario import to_fix
         return int(to_fix(float(value), self.pos_origin[axis], self.pos_k))
+
+    @staticmethod
+    def _v_counts(v):
+        """knots -> speed counts as the int32 word that holds the unsigned value"""
+        c = int(min(max(round(float(v) * 2.0 ** L.V_FIX_SHIFT), 0), 2 ** 32 - 1))
+        return c - (1 << 32) if c >= 1 << 31 else c
+
+    @staticmethod
+    def _phi_counts(phi):
+        return int(min(max(round((float(phi) - L.PHI_FIX_OFFSET) * 2.0 ** L.PHI_FIX_SHIFT), -2 ** 31), 2 ** 31 - 1))
 
     def set_xy(self, i, x=None, y=None):
         if x is not None:
@@ -392,20 +412,32 @@ class AtcVecEnv:
         if y is not None:
             self.pos_hp[i, 1] = self._to_fix(y, 1)
 
+    def set_v(self, i, v):
+        self.v_fix[i] = self._v_counts(v)
+
+    def set_phi(self, i, phi):
+        self.phi_fix[i] = self._phi_counts(phi)
+
     def set_state(self, env, slot, x, y, h, phi, v):
         i = env * self.N + slot
         self.set_xy(i, x, y)
-        self.h[i], self.phi[i], self.v[i] = float(h), float(phi), float(v)
+        self.h[i] = float(h)
+        self.set_phi(i, phi)
+        self.set_v(i, v)
 
     def get_last_action(self, env, slot):
-        """AtcGym.last_action (atc_gym.py:86,311) of one aircraft: [v, h, phi] targets last accepted."""
+        """AtcGym.last_action (atc_gym.py:86,311) of one aircraft: [v, h, phi] targets last accepted, in kt / ft / deg."""
         i = env * self.N + slot
-        return [float(c) for c in self.last_act[i]]
+        rec = self.last_act[i].cpu()
+        return [float(int(rec[0]) & 0xffffffff) * 2.0 ** -L.V_FIX_SHIFT, float(rec[1:2].view(self.torch.float32)[0]),
+                float(int(rec[2])) * 2.0 ** -L.PHI_FIX_SHIFT + L.PHI_FIX_OFFSET]
 
     def set_last_action(self, env, slot, value):
         i = env * self.N + slot
-        for c in range(3):
-            self.last_act[i, c] = float(value[c])
+        torch = self.torch
+        rec = torch.tensor([self._v_counts(value[0]), 0, self._phi_counts(value[2])], dtype=torch.int32)
+        rec[1:2].view(torch.float32)[0] = float(value[1])
+        self.last_act[i] = rec.to(self.last_act.device)
 
     def get_state(self, env, slot):
         i = env * self.N + slot

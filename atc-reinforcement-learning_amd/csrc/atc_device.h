@@ -32,25 +32,95 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }  // v_sqrt_f32, 1 ulp
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
-// sin/cos of a heading in DEGREES — the fp32 heading kinematics of include/atc_step.h (shared with the fp32 instantiation
-// of the test oracle, so that positions are bit-identical).  The reduction is exact: k = rint(phi/90), t = phi - 90 k is
-// computed by one fma and is exactly representable (|t| <= 45 + slop, a multiple of ulp(phi)); the polynomials (fitted on
-// |t| <= 46.4 deg) have 8.5e-8 / 8.3e-8 max abs error in fp32 — the accuracy class of libm's sinf/cosf, at ~1/4 of the
-// instructions of a generic radian sincosf (no Payne-Hanek path, no division).  Kinematics: model.py:122-129, 345-348.
-__device__ __forceinline__ void sincos_deg(float phi, float* sn, float* cs) {
-    const float k = rintf(phi * (1.0f / 90.0f));
-    const float t = fmaf(-90.0f, k, phi);
-    const float r = t * kDegToRad;
-    const float r2 = r * r;
-    const float sp = fmaf(fmaf(fmaf(ATC_SIN_C3, r2, ATC_SIN_C2), r2, ATC_SIN_C1), r2, 1.0f);
-    const float s = sp * r;
-    const float c = fmaf(fmaf(fmaf(fmaf(ATC_COS_C4, r2, ATC_COS_C3), r2, ATC_COS_C2), r2, ATC_COS_C1), r2, 1.0f);
-    const uint32_t q = (uint32_t)(int)k;   // quadrant = q mod 4 (two's complement: also right for negative k)
-    const float s1 = (q & 1u) ? c : s;
-    const float c1 = (q & 1u) ? s : c;
-    // sin changes sign in quadrants 2, 3 (bit 1 of q), cos in quadrants 1, 2 (bit 1 of q + 1): the bit moved onto the sign bit
-    *sn = __uint_as_float(__float_as_uint(s1) ^ ((q << 30) & 0x80000000u));
-    *cs = __uint_as_float(__float_as_uint(c1) ^ (((q + 1u) << 30) & 0x80000000u));
+// ---- speed and heading: 32-bit fixed point (include/atc_step.h, ABI 18) -------------------------------------------------
+//   kt = v_fix 2^-23 (unsigned counts),  deg = 180 + phi_fix 2^-23 (signed counts).  Targets, rate limits and the action
+//   discriminator are integer arithmetic; the step's displacement is float64 from the fixed-point state (advance() below).
+constexpr float kFixInv = 1.0f / 8388608.0f;                      // 2^-23 for both
+constexpr uint32_t kVMinFix = 838860800u, kVMaxFix = 2516582400u;  // 100 / 300 kt (model.py:13) in counts
+constexpr uint32_t kVInitFix = 2097152000u;                        // 250 kt (atc_gym.py:348)
+constexpr int kDiscrVFix = 41943040, kDiscrPhiFix = 4194304;       // 5 kt, 0.5 deg (atc_gym.py:84) in counts
+static_assert(ATC_V_FIX_SHIFT == 23 && ATC_PHI_FIX_SHIFT == 23, "fixed-point formats of include/atc_step.h");
+// float64 -> integer exactly as the spec defines it = as the hardware does it: truncation toward zero, saturation at both
+// ends, NaN -> 0 (a C cast is undefined outside the integer's range, so the instructions are named)
+__device__ __forceinline__ int cvt_i32_f64(double x) {
+    int i;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(i) : "v"(x));
+    return i;
+}
+__device__ __forceinline__ uint32_t cvt_u32_f64(double x) {
+    uint32_t i;
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(i) : "v"(x));
+    return i;
+}
+// the fp32 speed / heading every other formula of the reference sees (observation, relative angles, corridor window)
+__device__ __forceinline__ float v_real(uint32_t f) { return (float)f * kFixInv; }
+__device__ __forceinline__ float phi_real(int f) { return fmaf((float)f, kFixInv, ATC_PHI_FIX_OFFSET); }
+// state placed from outside (entry points): nearest count
+__device__ __forceinline__ int phi_store(float p) { return cvt_i32_f64(__builtin_rint(((double)p - (double)ATC_PHI_FIX_OFFSET) * 8388608.0)); }
+
+// Uniform float64 constants of the heading kinematics (include/atc_step.h: ATC_KIN_*) and the step's distance scale — kernel
+// arguments like every other uniform term: a float64 literal cannot be an instruction operand, so written into the code each
+// would be two scalar moves per use (or a register pair held across the step loop); as an argument group the fourteen arrive
+// with two scalar loads.
+struct alignas(16) QKin {
+    double inv180, neg_half_turn;
+    double s0, s1, s2, s3, s4, s5;
+    double c1, c2, c3, c4, c5;
+    double dist_neg;   // -(dt / 3600) 2^(k_pos - 23): position-grid counts per speed count and step, NEGATED (see advance)
+    double pad[2];
+};
+// Airplane.step (model.py:122-129, 345-348) in float64 from the fixed-point state — the spec of include/atc_step.h, shared bit
+// for bit with the fp32 instantiation of the test oracle:  k = rint(phi_fix / (180 2^23)), t = phi_fix - k 180 2^23 (exact),
+// two Horner polynomials in u = t^2 scaled to counts, the distance negated when k is even (phi = 180 (1 + k) + t: an even k is
+// an odd number of half turns — the host passes the NEGATED scale and the sign is flipped back when k is odd: one shift and one
+// xor), and dithered rounding: counts += floor(displacement + u11), u11 = the low 11 bits of the env's time step bit-reversed,
+// as a fraction (van der Corput): the round-off of a constant displacement (a straight leg) cancels to O(log n) counts over n
+// steps instead of adding up.  The dither sits in the low bits of the "magic" addend 1.5 2^41 (assembled from integers); the
+// integer part of the sum is bits 11..42 of the result: one fma and one v_alignbit per axis.
+// a * b + c with the addend c taken from a scalar register pair (v_fma_f64, VOP3: one scalar operand).  Written out because the
+// compiler otherwise picks the two-address form (v_fmac_f64) and copies every uniform coefficient into a vector register pair
+// first: two v_mov per Horner step, twenty per aircraft-step, in a kernel that is bound by instruction issue.
+__device__ __forceinline__ double fma_sc(double a, double b, double c_uniform) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+    return d;
+}
+__device__ __forceinline__ double mul_sc(double a, double b_uniform) {
+    double d;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(b_uniform));
+    return d;
+}
+__device__ __forceinline__ void advance(const QKin& q, int phi_fix, uint32_t v_fix, int t_step, int& x, int& y) {
+    const double pd = (double)phi_fix;
+    const double kd = __builtin_rint(mul_sc(pd, q.inv180));
+    double t;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(t) : "v"(kd), "s"(q.neg_half_turn), "v"(pd));
+    const double u = t * t;
+#ifndef ATC_KIN_ABL
+#define ATC_KIN_ABL 0   // developer-only timing ablations of the float64 kinematics (bit mask); the shipped build uses 0
+#endif
+    // (the two Horner chains are written interleaved: each step waits for the previous one of its own chain only)
+    double sp = fma_sc(u, q.s5, q.s4), cp = fma_sc(u, q.c5, q.c4);
+    if (!(ATC_KIN_ABL & 1)) {
+        sp = fma_sc(sp, u, q.s3);
+        cp = fma_sc(cp, u, q.c3);
+        sp = fma_sc(sp, u, q.s2);
+        cp = fma_sc(cp, u, q.c2);
+        sp = fma_sc(sp, u, q.s1);
+        cp = fma_sc(cp, u, q.c1);
+        sp = fma_sc(sp, u, q.s0);
+    }
+    const double cs = __builtin_fma(cp, u, 1.0);
+    const double sn = sp * t;
+    const double dneg = mul_sc((double)v_fix, q.dist_neg);
+    const uint32_t flip = (uint32_t)cvt_i32_f64(kd) << 31;
+    const double dist = __hiloint2double(__double2hiint(dneg) ^ (int)flip, __double2loint(dneg));
+    const double magic = __hiloint2double((int)ATC_DITHER_MAGIC_HI, (int)(__builtin_bitreverse32((uint32_t)t_step) >> 21));
+    const double rx = __builtin_fma(sn, dist, magic), ry = __builtin_fma(cs, dist, magic);
+    const int nx = (int)__builtin_amdgcn_alignbit((uint32_t)__double2hiint(rx), (uint32_t)__double2loint(rx), 11u);
+    const int ny = (int)__builtin_amdgcn_alignbit((uint32_t)__double2hiint(ry), (uint32_t)__double2loint(ry), 11u);
+    x = __builtin_elementwise_add_sat(x, nx);
+    y = __builtin_elementwise_add_sat(y, ny);
 }
 
 // atan2 in DEGREES (np.degrees(np.arctan2(y, x)), atc_gym.py:289-292) — value-only: octant reduction to a = min/max in
@@ -104,15 +174,6 @@ __device__ __forceinline__ float relative_angle_value(float a1, float a2) {
     const float q = floorf(fmaf(w, 1.0f / 360.0f, 0.5f));
     return fmaf(q, -360.0f, w);
 }
-// v / 3600 (model.py:124), correctly rounded without the IEEE division sequence: q0 = v * RN(1/3600), one fma gives the
-// exact remainder v - 3600 q0, a second folds it back.  Bit-identical to v / 3600.0f for every float with
-// 2^-4 <= |v| < 2^16 and for 0 (checked exhaustively, 1.7e8 values; aircraft speeds are 100..300 kt).
-__device__ __forceinline__ float div3600(float v) {
-    constexpr float r = 1.0f / 3600.0f;
-    const float q0 = v * r;
-    return fmaf(fmaf(-q0, 3600.0f, v), r, q0);
-}
-
 // model.py:318-337 ray_tracing over a closed ring (x,y interleaved in LDS, n vertices, first == last).
 // Same inequality set and evaluation order; the reference's n+1-th iteration re-visits ring[0] from ring[n-1]
 // (identical points for closed rings -> never counted) and is reproduced for rings that are not closed.
@@ -425,17 +486,6 @@ __device__ __forceinline__ float pos_to_real(const float* __restrict__ K, int ax
 __device__ __forceinline__ float pos_to_real(int neg_k, double origin, int p) {
     return (float)(__builtin_ldexp((double)p, neg_k) + origin);
 }
-// model.py:122-129: x += d with d computed in fp32; the grid advances by rint(d 2^k) counts, saturating
-__device__ __forceinline__ int pos_advance(const float* __restrict__ K, int p, float d) {
-    float c = d * K[ATC_C_POS_SCALE];
-    c = fminf(fmaxf(c, -1073741824.0f), 1073741824.0f);
-    return sat_add(p, (int)rintf(c));
-}
-// the same with the displacement already in grid counts (the caller scaled the distance, an exact power-of-two scaling)
-__device__ __forceinline__ int pos_advance_counts(int p, float c) {
-    c = fminf(fmaxf(c, -1073741824.0f), 1073741824.0f);
-    return sat_add(p, (int)rintf(c));
-}
 // entry point (fp32 nm) -> grid
 __device__ __forceinline__ int pos_spawn(const float* __restrict__ K, int axis, float v) {
     float c = (v - K[ATC_C_POS_X0 + axis]) * K[ATC_C_POS_SCALE];
@@ -447,7 +497,9 @@ __device__ __forceinline__ float pos_to_faf(int faf, float pos_inv, int p) { ret
 
 struct Aircraft {
     int x, y;         // position grid counts
-    float h, phi, v;
+    float h;          // altitude [ft]
+    int phi;          // heading, fixed point (deg = 180 + phi 2^-23)
+    uint32_t v;       // speed, fixed point (kt = v 2^-23)
 };
 
 // atc_gym.py:346-348 + model.py:13-52: aircraft k of env e enters at an entry point.
@@ -455,12 +507,12 @@ struct Aircraft {
 // (entry, level) by multiply-shift — no integer division on the reset path.
 __device__ __forceinline__ Aircraft spawn(const float* __restrict__ K, const atc_params_t& p, int e, int k, int episode) {
     Aircraft a;
-    a.v = kVInit;
+    a.v = kVInitFix;
     if (!(p.mode & ATC_M_RANDOM_ENTRY)) {
         const float4 rec = *reinterpret_cast<const float4*>(K + (int)K[ATC_H_OFF_SLOT] + 4 * k);
         a.x = pos_spawn(K, 0, rec.x);
         a.y = pos_spawn(K, 1, rec.y);
-        a.phi = rec.z;
+        a.phi = phi_store(rec.z);
         a.h = rec.w;
         return a;
     }
@@ -471,7 +523,7 @@ __device__ __forceinline__ Aircraft spawn(const float* __restrict__ K, const atc
     const int li = (int)__umulhi((uint32_t)(u >> 32), (uint32_t)(int)rec[ATC_E_NLEV]);
     a.x = pos_spawn(K, 0, rec[ATC_E_X]);
     a.y = pos_spawn(K, 1, rec[ATC_E_Y]);
-    a.phi = rec[ATC_E_PHI];
+    a.phi = phi_store(rec[ATC_E_PHI]);
     a.h = rec[ATC_E_LEV0 + li] * 100.0f;
     return a;
 }

@@ -4,7 +4,8 @@
 //   lane  = one aircraft slot;  W = next_pow2(N) consecutive lanes = one env;  64/W envs per wavefront
 //   (N = 64: one wavefront per env, N = 16: 4 envs per wavefront, N = 1: 64 envs per wavefront).
 //   Aircraft state lives in HBM as packed records indexed env*N + k: pos_hp = (x, y on the 32-bit fixed-point position
-//   grid, h, phi) 16 B, v 4 B, last_act = the three last accepted targets 12 B (written back only when one changed) — a
+//   grid, h as fp32, heading counts) 16 B, speed counts 4 B (speed and heading are 32-bit fixed point too since ABI 18:
+//   include/atc_step.h), last_act = the three last accepted targets 12 B (written back only when one changed) — a
 //   wavefront moves each array with ONE access per lane on consecutive addresses; the per-step env record (4 words) is one
 //   16-byte load that the W lanes of an env share, the per-episode record is touched only when an episode ends.
 //   All per-lane indices are 32-bit offsets from uniform base pointers.
@@ -365,8 +366,18 @@ struct LaneIds {        // who this lane is (one aircraft slot of one env)
 };
 struct LaneState {      // persistent per-aircraft state held in registers
     Aircraft a;
-    float la_v, la_h, la_p;
+    uint32_t la_v;      // last accepted targets (atc_gym.py:86,311) in the state's formats: speed counts,
+    float la_h;         // altitude [ft],
+    int la_p;           // heading counts
     bool la_changed, v_changed;
+};
+struct Targets {        // decoded action of the current step / block (atc_gym.py:318-335) in the state's formats
+    uint32_t v;
+    float h;
+    int p;
+};
+struct Int3 {           // the 12-byte last-action record as stored
+    int a, b, c;
 };
 struct EnvState {       // per-step env record (replicated in the W lanes of the env)
     int t, n_actions;
@@ -391,15 +402,15 @@ struct Mid {            // what the first half of a step hands to the second
 // vector registers — and a multi-step launch would keep them there across its whole step loop.
 // Grouped by the stage that consumes them: a multi-step launch re-reads each group from the kernarg segment right where its
 // stage starts (QGET below) instead of keeping ~70 uniform values alive across the step loop.
-struct alignas(16) QRates {   // first half of the step
-    float dv_hi, dv_lo;   // kAMax * dt, kAMin * dt           (model.py:47-48,75-78)
-    float dh_hi, dh_lo;   // kHDotMax * dt, kHDotMin * dt     (model.py:45-46,97-100)
-    float dp_hi, dp_lo;   // kPhiDotMax * dt, kPhiDotMin * dt (model.py:49-50,113-120)
-    float r_base;         // -0.05 * dt                       (atc_gym.py:137)
-    float dts;            // dt * 2^k: the step's distance comes out in position-grid counts (an exact power-of-two scaling)
-    // _denormalized_action (atc_gym.py:318-335) as target = RN(RN(a * m) + c) [+ c2 for the speed] — see decode_targets
-    float dec_mv, dec_cv, dec_cv2, dec_mh, dec_ch, dec_mp, dec_cp;
-    int pos_neg_k;        // position grid: nm = origin + fix * 2^-k (blob: ATC_C_POS_*)
+struct alignas(16) QRates {   // first half of the step (16 words)
+    // _denormalized_action (atc_gym.py:318-335) for the fixed-point components: counts = trunc(a * m + c) in float64 (m, c the
+    // reference's factor / offset in counts: integers), see decode_targets
+    double dec_mv, dec_cv, dec_mp, dec_cp;
+    float dec_mh, dec_ch;   // altitude target (fp32): RN(a * m) + c, the reference's operation order (see derive())
+    int rate_v, rate_p;     // rint(kAMax dt 2^23), rint(kPhiDotMax dt 2^23): symmetric limits (model.py:47-50,75-78,113-120)
+    float dh_hi, dh_lo;     // kHDotMax * dt, kHDotMin * dt     (model.py:45-46,97-100)
+    float r_base;           // -0.05 * dt                       (atc_gym.py:137)
+    int pos_neg_k;          // position grid: nm = origin + fix * 2^-k (blob: ATC_C_POS_*)
 };
 struct alignas(16) QGrid {    // position conversion + MVA cell lookup
     double pos_x0, pos_y0;
@@ -419,6 +430,7 @@ struct alignas(16) QNorm {
 };
 struct StepDerived {
     QRates r;
+    QKin k;               // float64 heading kinematics + distance scale (32 words)
     QGrid g;
     QScan s;
     ObsConst oc;          // observation / shaping constants
@@ -460,34 +472,46 @@ static StepDerived derive_uncached(const atc_params_t& p, const atc_scenario* s)
     const float* K = s->consts;
     StepDerived q;
     memset(&q, 0, sizeof q);
+    int k_pos;
     {
         int e = 0;
         (void)frexpf(K[ATC_C_POS_SCALE], &e);   // 2^k = 0.5 * 2^(k + 1)
-        q.r.pos_neg_k = -(e - 1);
+        k_pos = e - 1;
+        q.r.pos_neg_k = -k_pos;
     }
     q.g.pos_x0 = (double)K[ATC_C_POS_X0];
     q.g.pos_y0 = (double)K[ATC_C_POS_Y0];
-    q.r.dv_hi = kAMax * p.dt;
-    q.r.dv_lo = kAMin * p.dt;
+    const double dtd = (double)p.dt, fixq = 8388608.0;   // 2^23: speed and heading counts per kt / deg
+    auto rate_fix = [&](float rate) {   // rint(|rate| dt 2^23), saturating (include/atc_step.h)
+        const double r = rint(fabs((double)rate) * dtd * fixq);
+        return r >= 2147483647.0 ? INT32_MAX : (int32_t)r;
+    };
+    q.r.rate_v = rate_fix(kAMax);
+    q.r.rate_p = rate_fix(kPhiDotMax);
     q.r.dh_hi = kHDotMax * p.dt;
     q.r.dh_lo = kHDotMin * p.dt;
-    q.r.dp_hi = kPhiDotMax * p.dt;
-    q.r.dp_lo = kPhiDotMin * p.dt;
     q.r.r_base = -0.05f * p.dt;
-    q.r.dts = p.dt * K[ATC_C_POS_SCALE];
     // atc_gym.py:64-78,318-335: offset (v_min, 0, 0); factor (10, 100, 1) discrete | (v_max - v_min, h_max, 360) continuous.
     //   discrete   : a * fac + off
-    //   continuous : a * fac / 2 + fac / 2 + off.  Halving is exact, so RN(a * fac) / 2 == RN(a * (fac / 2)) (no result here
-    //                is subnormal-sensitive: a sum with fac / 2 + off >= 100 follows) and fac / 2 is exact: the same bits as
-    //                the reference's operation order with one multiplication and one or two additions.
+    //   continuous : a * fac / 2 + fac / 2 + off
+    // Speed and heading (fixed point): counts = a * m + c evaluated as ONE float64 fma — exact for every fp32 action in the
+    // action space (24 x 31 bits) — and truncated; m = the factor, c = the offset relative to the format's origin, in counts.
     const bool discrete = (p.mode & ATC_M_DISCRETE) != 0;
-    q.r.dec_mv = discrete ? 10.0f : (kVMax - kVMin) / 2.0f;
-    q.r.dec_cv = discrete ? kVMin : (kVMax - kVMin) / 2.0f;
-    q.r.dec_cv2 = discrete ? -0.0f : kVMin;   // (x + -0 == x for every x)
+    q.r.dec_mv = (discrete ? 10.0 : (double)(kVMax - kVMin) / 2.0) * fixq;
+    q.r.dec_cv = (discrete ? (double)kVMin : (double)(kVMax - kVMin) / 2.0 + (double)kVMin) * fixq;
+    q.r.dec_mp = (discrete ? 1.0 : 360.0 / 2.0) * fixq;
+    q.r.dec_cp = ((discrete ? 0.0 : 360.0 / 2.0) - (double)ATC_PHI_FIX_OFFSET) * fixq;
+    // Altitude (fp32): halving is exact, so RN(a * fac) / 2 == RN(a * (fac / 2)) and fac / 2 is exact: the same bits as the
+    // reference's operation order with one multiplication and one addition (the discrete form keeps its `+ 0`: it turns a
+    // -0 product into +0, like the reference's `+ offset`).
     q.r.dec_mh = discrete ? 100.0f : kHMax / 2.0f;
     q.r.dec_ch = discrete ? 0.0f : kHMax / 2.0f;
-    q.r.dec_mp = discrete ? 1.0f : 360.0f / 2.0f;
-    q.r.dec_cp = discrete ? 0.0f : 360.0f / 2.0f;
+    // float64 heading kinematics (include/atc_step.h: ATC_KIN_*) and the step's distance scale, NEGATED (see atc::advance)
+    q.k.inv180 = ATC_KIN_INV180;
+    q.k.neg_half_turn = -ATC_KIN_HALF_TURN;
+    q.k.s0 = ATC_KIN_S0; q.k.s1 = ATC_KIN_S1; q.k.s2 = ATC_KIN_S2; q.k.s3 = ATC_KIN_S3; q.k.s4 = ATC_KIN_S4; q.k.s5 = ATC_KIN_S5;
+    q.k.c1 = ATC_KIN_C1; q.k.c2 = ATC_KIN_C2; q.k.c3 = ATC_KIN_C3; q.k.c4 = ATC_KIN_C4; q.k.c5 = ATC_KIN_C5;
+    q.k.dist_neg = -ldexp(dtd / 3600.0, k_pos - ATC_V_FIX_SHIFT);
     q.g.gh = grid_header(s->off_grid ? s->ghdr : nullptr);
     q.s.sep2 = p.sep_nm * p.sep_nm;
     q.s.sep_ft = p.sep_ft;
@@ -576,20 +600,24 @@ __device__ __forceinline__ LaneIds make_ids(uint32_t slot0, int B, int N) {
 // action, outside the action space) yields lo here and hi there — unspecified input either way.
 __device__ __forceinline__ float clamp_rate(float d, float lo, float hi) { return __builtin_amdgcn_fmed3f(d, lo, hi); }
 
-// _denormalized_action (atc_gym.py:318-335): action -> (v, h, phi) targets with the host-evaluated (multiplier, offset)
-// pairs of derive() — bit-identical to the reference's operation order (see there), 7 operations instead of 18.
-// The discrete forms keep their `+ 0` (it turns a -0 product into +0, like the reference's `+ offset`).
-__device__ __forceinline__ Float3 decode_targets(const QRates& q, const Float3& act) {
-    Float3 t;
-    t.a = (act.a * q.dec_mv + q.dec_cv) + q.dec_cv2;
-    t.b = act.b * q.dec_mh + q.dec_ch;
-    t.c = act.c * q.dec_mp + q.dec_cp;
+// _denormalized_action (atc_gym.py:318-335): action -> (v, h, phi) targets in the state's formats with the host-evaluated
+// (multiplier, offset) pairs of derive().  Speed and heading: ONE float64 fma and the saturating, truncating conversion of the
+// hardware (NaN -> 0) — the spec of include/atc_step.h; altitude: fp32, the reference's operation order.
+__device__ __forceinline__ Targets decode_targets(const QRates& q, const Float3& act) {
+    Targets t;
+    t.v = cvt_u32_f64(__builtin_fma((double)act.a, q.dec_mv, q.dec_cv));
+    t.h = act.b * q.dec_mh + q.dec_ch;
+    t.p = cvt_i32_f64(__builtin_fma((double)act.c, q.dec_mp, q.dec_cp));
     return t;
 }
+// max(min(d, r), -r) for integer differences (the symmetric rate limits of speed and heading)
+__device__ __forceinline__ int clamp_sym(int d, int r) { return max(min(d, r), -r); }
+// |d| < D for a wrapped 32-bit difference d (atc_gym.py:305-306 on counts): one addition and one unsigned compare
+__device__ __forceinline__ bool within(int d, int D) { return (uint32_t)(d + (D - 1)) < (uint32_t)(2 * D - 1); }
 
 // ---- first half of AtcGym.step: timestep, rate limits towards the targets, kinematics, MVA floor ---------------------
-__device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const QRates& q, const QGrid& qg,
-                                           const LaneIds& d, float tv, float th, float tp, LaneState& ls, EnvState& es,
+__device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const QRates& q, const QKin& qk, const QGrid& qg,
+                                           const LaneIds& d, uint32_t tv, float th, int tp, LaneState& ls, EnvState& es,
                                            bool repeated, bool all_active, bool track_v) {
     Mid m;
     Aircraft& a = ls.a;
@@ -607,8 +635,11 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     // ---- _action_with_reward x3 (atc_gym.py:139-141,299-335) -> Airplane.action_* (model.py:60-120) ------------------
     // invalid target -> ValueError -> -1 reward, nothing applied, last_action kept (atc_gym.py:303-315); valid -> rate-limited
     // move, actions_taken++ unless |target - last| < discriminator.
-    constexpr float v_min = kVMin, v_max = kVMax, h_min = kHMin, h_max = kHMax;
-    const bool valid_v = !(tv < v_min || tv > v_max);
+    // Speed and heading are 32-bit fixed point (include/atc_step.h): the move is integer arithmetic — exact, like the
+    // reference's float64 — with wrapping differences for the speed (valid speeds and the initial last_action 0 are less than
+    // 2^31 counts apart) and saturating ones for the heading (its targets are not validated: any action is accepted).
+    constexpr float h_min = kHMin, h_max = kHMax;
+    const bool valid_v = !(tv < kVMinFix || tv > kVMaxFix);
     const bool valid_h = !(th < h_min || th > h_max);
     // `plain` (wave-uniform): every lane of the wavefront flies an aircraft under control towards valid targets — the normal
     // case by far (a refused target or a handed-over aircraft in 64 is the exception).  Then nothing is conditional: no
@@ -616,21 +647,19 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     // evaluate the same expressions on the lanes they share.
     // (one lane mask per COMPARE, combined on the scalar unit: the ballot of a compound predicate is materialised per lane and
     // compared again — two vector operations per site)
-    const uint64_t refused = __builtin_amdgcn_ballot_w64(tv < v_min) | __builtin_amdgcn_ballot_w64(tv > v_max) |
+    const uint64_t refused = __builtin_amdgcn_ballot_w64(tv < kVMinFix) | __builtin_amdgcn_ballot_w64(tv > kVMaxFix) |
                              __builtin_amdgcn_ballot_w64(th < h_min) | __builtin_amdgcn_ballot_w64(th > h_max);
     const bool plain = (all_active ? refused : (refused | __builtin_amdgcn_ballot_w64(!active))) == 0ull;
-    // (speed and heading limits are symmetric — kAMin == -kAMax, kPhiDotMin == -kPhiDotMax, checked at compile time below —
-    // so the plain path clamps with ONE scalar operand and its negation; two scalars cost a register move per clamp)
-    static_assert(kAMin == -kAMax && kPhiDotMin == -kPhiDotMax, "symmetric rate limits assumed by the plain path");
+    static_assert(kAMin == -kAMax && kPhiDotMin == -kPhiDotMax, "symmetric rate limits assumed (one count limit each)");
     if (ATC_USUAL(plain)) {
-        const float v_new = a.v + clamp_rate(tv - a.v, -q.dv_hi, q.dv_hi);
+        const uint32_t v_new = a.v + (uint32_t)clamp_sym((int)(tv - a.v), q.rate_v);
         if (track_v) ls.v_changed = ls.v_changed || v_new != a.v;
         a.v = v_new;
         a.h = a.h + clamp_rate(th - a.h, q.dh_lo, q.dh_hi);
-        a.phi = a.phi + clamp_rate(tp - a.phi, -q.dp_hi, q.dp_hi);
+        a.phi = a.phi + clamp_sym(sat_sub(tp, a.phi), q.rate_p);
         if (book) {
-            acts = (!(fabsf(tv - ls.la_v) < kDiscrV) ? 1 : 0) + (!(fabsf(th - ls.la_h) < kDiscrH) ? 1 : 0) +
-                   (!(fabsf(tp - ls.la_p) < kDiscrPhi) ? 1 : 0);
+            acts = (!within((int)(tv - ls.la_v), kDiscrVFix) ? 1 : 0) + (!(fabsf(th - ls.la_h) < kDiscrH) ? 1 : 0) +
+                   (!within(sat_sub(tp, ls.la_p), kDiscrPhiFix) ? 1 : 0);
             ls.la_changed = ls.la_changed || tv != ls.la_v || th != ls.la_h || tp != ls.la_p;
             ls.la_v = tv;
             ls.la_h = th;
@@ -640,13 +669,11 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
         {
             const bool valid = valid_v;
             const bool ok = valid && active;
-            float dd = tv - a.v;
-            dd = clamp_rate(dd, q.dv_lo, q.dv_hi);
-            const float v_new = ok ? a.v + dd : a.v;
+            const uint32_t v_new = ok ? a.v + (uint32_t)clamp_sym((int)(tv - a.v), q.rate_v) : a.v;
             ls.v_changed = ls.v_changed || v_new != a.v;
             a.v = v_new;
             if (book) {
-                acts += (ok && !(fabsf(tv - ls.la_v) < kDiscrV)) ? 1 : 0;
+                acts += (ok && !within((int)(tv - ls.la_v), kDiscrVFix)) ? 1 : 0;
                 ls.la_changed = ls.la_changed || (ok && tv != ls.la_v);
                 ls.la_v = ok ? tv : ls.la_v;
             }
@@ -668,26 +695,23 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
             fl |= valid ? 0u : (uint32_t)ATC_F_INVALID_H;
         }
         {
-            float dd = tp - a.phi;
-            dd = clamp_rate(dd, q.dp_lo, q.dp_hi);
+            const int dd = clamp_sym(sat_sub(tp, a.phi), q.rate_p);
             a.phi = active ? a.phi + dd : a.phi;
             if (book) {
-                acts += (active && !(fabsf(tp - ls.la_p) < kDiscrPhi)) ? 1 : 0;
+                acts += (active && !within(sat_sub(tp, ls.la_p), kDiscrPhiFix)) ? 1 : 0;
                 ls.la_changed = ls.la_changed || (active && tp != ls.la_p);
                 ls.la_p = active ? tp : ls.la_p;
             }
         }
     }
-    // ---- Airplane.step (model.py:122-129): rot_matrix(phi) . [0, (v/3600) dt] ----------------------------------------
-    {
-        // the displacement in grid counts: (sin * (v/3600 * dt)) * 2^k == sin * (v/3600 * (dt * 2^k)) — scaling by a power of
-        // two is exact, so the host folds it into the time step (QRates.dts)
-        const float dist = (plain || active) ? div3600(a.v) * q.dts : 0.0f;
-        float sn, cs;
-        if (ATC_ABLATE & 32) { sn = 0.6f; cs = 0.8f; } else sincos_deg(a.phi, &sn, &cs);
-        a.x = pos_advance_counts(a.x, sn * dist);
-        a.y = pos_advance_counts(a.y, cs * dist);
+    // ---- Airplane.step (model.py:122-129): rot_matrix(phi) . [0, (v/3600) dt], float64 from the fixed-point state -----------
+    // (an aircraft that is not under control does not move: zero speed -> zero displacement -> floor(0 + dither) = 0 counts)
+    uint32_t v_move = a.v;
+    if (!plain) {
+        v_move = active ? a.v : 0u;
+        asm("" : "+v"(v_move));   // (keeps the select on the 32-bit counts: the compiler moved it behind the conversion, onto both halves of the double)
     }
+    if (!(ATC_ABLATE & 32)) advance(qk, a.phi, v_move, es.t, a.x, a.y);
     m.x32 = pos_to_real(q.pos_neg_k, qg.pos_x0, a.x);
     m.y32 = pos_to_real(q.pos_neg_k, qg.pos_y0, a.y);
     // MVA floor, first half: only ISSUE the lookup-cell gather here; nothing until the override chain needs its result
@@ -895,7 +919,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     // (W = 1 has no scan to cover the gather: there the observation goes first)
     constexpr bool kObsFirst = ATC_OBS_FIRST || (ATC_OBS_FIRST_W1 && W == 1 && ONE);
     if (kObsFirst && !(ATC_ABLATE & 8)) {
-        ob = get_state(oc, a.x, a.y, x32, y32, a.h, a.phi, a.v, 0.0f);
+        ob = get_state(oc, a.x, a.y, x32, y32, a.h, phi_real(a.phi), v_real(a.v), 0.0f);
         if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
     }
     // ---- MVA floor (atc_gym.py:146-161), second half ---------------------------------------------------------------------
@@ -932,7 +956,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             fl |= conflict ? (uint32_t)ATC_F_CONFLICT : 0u;
         }
         // ---- win / timeout overrides (atc_gym.py:163-173) ---------------------------------------------------------------
-        if (!(ATC_ABLATE & 4) && inside_corridor(K, qs.tri_bbox, x32, y32, a.h, a.phi)) {
+        if (!(ATC_ABLATE & 4) && inside_corridor(K, qs.tri_bbox, x32, y32, a.h, phi_real(a.phi))) {
             int bonus = (qs.timestep_limit - es.t) * 5;
             bonus = bonus < 0 ? 0 : bonus;
             r = (float)(10000 + bonus);
@@ -958,7 +982,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         } else if (kObsFirst) {
             ob.o[5] = a.h - mva;
         } else {
-            ob = get_state(oc, a.x, a.y, x32, y32, a.h, a.phi, a.v, mva);
+            ob = get_state(oc, a.x, a.y, x32, y32, a.h, phi_real(a.phi), v_real(a.v), mva);
             if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
         }
         // r += pos; r += ang; r += gs (atc_gym.py:179-185, after the override chain) as one addition of the factored sum
@@ -1057,7 +1081,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             ls.v_changed = true;
             const QGrid qg = QGET(g);
             const int neg_k = QGET(r.pos_neg_k);
-            const Obs ob = get_state(QGET(oc), a.x, a.y, pos_to_real(neg_k, qg.pos_x0, a.x), pos_to_real(neg_k, qg.pos_y0, a.y), a.h, a.phi, a.v, 0.0f);
+            const Obs ob = get_state(QGET(oc), a.x, a.y, pos_to_real(neg_k, qg.pos_x0, a.x), pos_to_real(neg_k, qg.pos_y0, a.y), a.h, phi_real(a.phi), v_real(a.v), 0.0f);
 #pragma unroll
             for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = ob.o[c];
         }
@@ -1131,14 +1155,14 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
 __device__ __forceinline__ void store_lane_state(const atc_state_t& st, const LaneIds& d, const LaneState& ls, bool la_live,
                                                  bool v_always) {
     if (d.lane_valid)
-        *at<int4>(st.pos_hp, d.i * 16u) = make_int4(ls.a.x, ls.a.y, __float_as_int(ls.a.h), __float_as_int(ls.a.phi));
+        *at<int4>(st.pos_hp, d.i * 16u) = make_int4(ls.a.x, ls.a.y, __float_as_int(ls.a.h), ls.a.phi);
     // speed and last-action targets are typically constant for many steps (actions are held, the speed reaches its target):
     // written back only by wavefronts in which one of them changed
     // (multi-step launches do not track speed changes per step: one unconditional 4-byte store per aircraft and launch)
-    if ((v_always || __builtin_amdgcn_ballot_w64(ls.v_changed) != 0ull) && d.lane_valid) *at<float>(st.v, d.i * 4u) = ls.a.v;
+    if ((v_always || __builtin_amdgcn_ballot_w64(ls.v_changed) != 0ull) && d.lane_valid) *at<uint32_t>(st.v_fix, d.i * 4u) = ls.a.v;
     if (__builtin_amdgcn_ballot_w64(ls.la_changed) != 0ull && d.lane_valid && la_live) {
-        Float3 la = {ls.la_v, ls.la_h, ls.la_p};
-        *at<Float3>(st.last_act, times12(d.i)) = la;
+        Int3 la = {(int)ls.la_v, __float_as_int(ls.la_h), ls.la_p};
+        *at<Int3>(st.last_act, times12(d.i)) = la;
     }
 }
 template <int W>
@@ -1174,7 +1198,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     const uint32_t hi0 = (W == 64) ? *at<uint32_t>(st.stats, (uint32_t)d.e * (ATC_STAT_WORDS * 4u) + ATC_STAT_MASK_HI * 4u) : 0u;
     EnvState es = {e0.x, e0.y, __int_as_float(e0.z), (uint64_t)(uint32_t)e0.w | ((uint64_t)hi0 << 32)};
     const int4 ps = *at<int4>(st.pos_hp, d.i * 16u);
-    const float v0 = *at<float>(st.v, d.i * 4u);
+    const uint32_t v0 = *at<uint32_t>(st.v_fix, d.i * 4u);
     // ATC_M_ACTIONS_HELD (single-step launches): the caller repeats the previous launch's actions, so an aircraft that was under
     // control then has last_action == its accepted targets and cannot count an action or change the record — the 12-byte
     // record is only read (and written) by envs that were reset since their last step (timesteps == 0), whose aircraft
@@ -1187,9 +1211,9 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     }
     const bool same_actions = ONE && (p.mode & ATC_M_ACTIONS_HELD) != 0;
     const bool la_live = !same_actions || e0.x == 0;
-    Float3 la0 = {0.0f, 0.0f, 0.0f};
-    if (la_live) la0 = *at<Float3>(st.last_act, times12(d.i));
-    LaneState ls = {{ps.x, ps.y, __int_as_float(ps.z), __int_as_float(ps.w), v0}, la0.a, la0.b, la0.c, false, false};
+    Int3 la0 = {0, 0, 0};
+    if (la_live) la0 = *at<Int3>(st.last_act, times12(d.i));
+    LaneState ls = {{ps.x, ps.y, __int_as_float(ps.z), ps.w, v0}, (uint32_t)la0.a, __int_as_float(la0.b), la0.c, false, false};
 
     // A single step is its own instantiation: with the step count a run-time value everything the loop carries (aircraft
     // and env records, output bases, hoisted sector constants) stays live across the whole body — the straight-line form
@@ -1198,7 +1222,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     const float* act_t = actions;   // action block of the current step; a block is held for `hold` steps
     int left = hold;                // steps the current block is still used for
     bool block_start = true;        // this step is the first of its block
-    Float3 tg = {0.0f, 0.0f, 0.0f};   // decoded targets of the current step / block
+    Targets tg = {0u, 0.0f, 0};   // decoded targets of the current step / block
     bool all_active = false, mask_dirty = true;
     QRates qr_next = q.r;   // the rate group of the coming step (multi-step launches fetch it one step ahead, see step_part_b)
     if (!ONE) {
@@ -1260,9 +1284,9 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         if (!ONE && ATC_RARE(step == 0)) act = *at<Float3>(act_t, times12(dl.i));
         if (ONE || !ATC_LOOP_DECODE_ONCE || step == 0) tg = decode_targets(qr, act);
         if (ONE && !la_live) {   // held block: the record equals the accepted targets (components that are refused are not compared)
-            ls.la_v = tg.a;
-            ls.la_h = tg.b;
-            ls.la_p = tg.c;
+            ls.la_v = tg.v;
+            ls.la_h = tg.h;
+            ls.la_p = tg.p;
         }
         // multi-step launches know structurally which steps repeat an action block
         const bool repeated = ONE ? (same_actions && __builtin_amdgcn_ballot_w64(la_live) == 0ull)
@@ -1272,7 +1296,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             all_active = __builtin_amdgcn_ballot_w64(!(dl.lane_valid && ((dl.k < 32 ? ((uint32_t)es.amask >> dl.k) : ((uint32_t)(es.amask >> 32) >> (dl.k - 32))) & 1u))) == 0ull;
             mask_dirty = false;
         }
-        const Mid m = step_part_a(gl, qr, QGET(g), dl, tg.a, tg.b, tg.c, ls, es, repeated, !ONE && all_active, ONE);
+        const Mid m = step_part_a(gl, qr, QGET(k), QGET(g), dl, tg.v, tg.h, tg.p, ls, es, repeated, !ONE && all_active, ONE);
         ATC_STAMP(1);
         Float3 nxt = act;
         const float* act_next = nullptr;   // the next block is fetched during the last step of the current one
@@ -1321,12 +1345,17 @@ k_reset(const float* __restrict__ blob, int B, int N, atc_state_t st, const uint
         if (mask && !mask[e]) continue;
         const int episode = first ? 0 : st.stats[(size_t)e * ATC_STAT_WORDS + ATC_STAT_EPISODES];
         const Aircraft a = spawn(blob, p, e, k, episode);
-        reinterpret_cast<int4*>(st.pos_hp)[i] = make_int4(a.x, a.y, __float_as_int(a.h), __float_as_int(a.phi));
-        st.v[i] = a.v;
-        // atc_gym.py:86: last_action = [0,0,0] once, in __init__ — never on reset (quirk Q7)
-        if (first) st.last_act[3 * (size_t)i] = st.last_act[3 * (size_t)i + 1] = st.last_act[3 * (size_t)i + 2] = 0.0f;
+        reinterpret_cast<int4*>(st.pos_hp)[i] = make_int4(a.x, a.y, __float_as_int(a.h), a.phi);
+        st.v_fix[i] = (int32_t)a.v;
+        // atc_gym.py:86: last_action = [0,0,0] once, in __init__ — never on reset (quirk Q7) — in the state's formats: 0 kt = 0
+        // counts, 0 ft = the bits of 0.0f, 0 deg = the counts of 0 deg
+        if (first) {
+            st.last_act[3 * (size_t)i] = 0;
+            st.last_act[3 * (size_t)i + 1] = __float_as_int(0.0f);
+            st.last_act[3 * (size_t)i + 2] = phi_store(0.0f);
+        }
         if (obs) {  // mva = 0, atc_gym.py:351
-            const Obs ob = get_state(obs_const(blob), a.x, a.y, pos_to_real(blob, 0, a.x), pos_to_real(blob, 1, a.y), a.h, a.phi, a.v, 0.0f);
+            const Obs ob = get_state(obs_const(blob), a.x, a.y, pos_to_real(blob, 0, a.x), pos_to_real(blob, 1, a.y), a.h, phi_real(a.phi), v_real(a.v), 0.0f);
             store_obs(obs + (size_t)i * ATC_OBS_DIM, ob.o);
         }
     }
@@ -1341,7 +1370,7 @@ k_observe(const float* __restrict__ blob, int B, int N, atc_state_t st, const ui
         if (mask && !mask[e]) continue;
         const int4 ps = reinterpret_cast<const int4*>(st.pos_hp)[i];
         const Obs ob = get_state(obs_const(blob), ps.x, ps.y, pos_to_real(blob, 0, ps.x), pos_to_real(blob, 1, ps.y),
-                                 __int_as_float(ps.z), __int_as_float(ps.w), st.v[i], 0.0f);
+                                 __int_as_float(ps.z), phi_real(ps.w), v_real((uint32_t)st.v_fix[i]), 0.0f);
         store_obs(obs + (size_t)i * ATC_OBS_DIM, ob.o);
     }
 }
@@ -1457,7 +1486,7 @@ static int launch_step(const atc_scenario* s, int B, int N, int T, int hold, con
 static int check_env_args(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const atc_params_t* p) {
     if (!s || !st || !p) return fail_arg("null pointer");
     if (B < 1 || N < 1 || N > ATC_MAX_AIRCRAFT) return fail_arg("need B >= 1, 1 <= N <= 64");
-    if (!st->pos_hp || !st->v || !st->last_act || !st->env || !st->stats) return fail_arg("atc_state_t has a null field");
+    if (!st->pos_hp || !st->v_fix || !st->last_act || !st->env || !st->stats) return fail_arg("atc_state_t has a null field");
     if ((unsigned long long)B * N * ATC_OBS_DIM * 4ull >= (1ull << 32) || (unsigned long long)B * 64ull >= (1ull << 32))
         return fail_arg("B*N too large for one launch (B*N*40 bytes must stay below 4 GiB): split the batch");
     return ATC_OK;
@@ -1473,6 +1502,10 @@ static int step_common(const atc_scenario_t* s, int B, int N, int T, int hold, c
     if (!out->obs || !out->reward || !out->done || !out->flags) return fail_arg("obs/reward/done/flags are required");
     if (out->packet && (N != 1 || T != 1)) return fail_arg("atc_out_t.packet is for single steps of single-aircraft envs");
     if (!(p->dt > 0.0f)) return fail_arg("dt must be > 0");
+    // the fixed-point formats of include/atc_step.h: a step's displacement (<= 512 kt) must stay below 2^30 position-grid
+    // counts and the speed's rate limit below 2^31 speed counts — dt up to 51 s for any sector (the reference uses 1 s)
+    if (!(0.1423 * (double)p->dt * (double)s->consts[ATC_C_POS_SCALE] < 1073741824.0) || !((double)kAMax * (double)p->dt < 255.9))
+        return fail_arg("dt too large for the fixed-point state formats (see include/atc_step.h)");
     hipStream_t q = (hipStream_t)stream;
     if (N == 1) return launch_step<1>(s, B, N, T, hold, st, actions, out, p, q);
     if (N == 2) return launch_step<2>(s, B, N, T, hold, st, actions, out, p, q);

@@ -41,8 +41,12 @@ class _AirplaneView:
         if key in ("x", "y"):   # positions live on the device's fixed-point grid (include/atc_step.h)
             self._env._vec.set_xy(0, **{key: float(value)})
             self._env._pos_now = None
-        elif key in ("h", "phi", "v"):
-            getattr(self._env._vec, key)[0] = float(value)
+        elif key == "h":
+            self._env._vec.h[0] = float(value)
+        elif key == "phi":      # speed and heading are fixed point on the device too (ABI 18)
+            self._env._vec.set_phi(0, value)
+        elif key == "v":
+            self._env._vec.set_v(0, value)
         else:
             object.__setattr__(self, key, value)
 

@@ -431,15 +431,16 @@ def measure_collective(D, stats, dev, force, block=None, reps=100):
     out["barrier"] = timed(lambda: D.barrier(force=force))
     if block is not None:
         def with_x():
-            xch.snapshot(*stats())
-            xch.issue()
             block()
+            xch.issue()
             xch.wait()
             torch.cuda.synchronize(dev)
+            xch.snapshot(*stats())   # (the timed loop takes the snapshot outside its window too; here it is in: an upper bound)
 
         def without():
             block()
             torch.cuda.synchronize(dev)
+        xch.snapshot(*stats())
         with_x()
         without()
         reps_b = 30
@@ -663,10 +664,11 @@ def main():
     # HIP events on the stream(s) the kernels are launched on (torch's current stream, or one per sub-batch)
     qs = streams if S > 1 else [torch.cuda.current_stream(dev)]
     # The path's only exchange: ONE packed all-gather of the per-env episode statistics per rollout, asynchronous
-    # (atc_hip.dist.StatsExchange).  Timed block r issues the collective for the statistics of rollout r - 1 (block 0: the
-    # warm-up's) on the backend's stream BEFORE its own launches, queues its K step launches, then waits for the collective:
-    # every timed block contains exactly one exchange, overlapped with its step kernels, and nothing of it sits between the
-    # last step and the end of the window but its completion.
+    # (atc_hip.dist.StatsExchange).  Timed block r queues its K step launches, then issues the collective for the statistics of
+    # rollout r - 1 (block 0: the warm-up's) from a side stream — the backend's stream does not wait for the step kernels, and
+    # the host cost of the call is spent while the GPU works through the queued steps — and waits for it: every timed block
+    # contains exactly one exchange, overlapped with its step kernels; nothing of it sits between the last step and the end
+    # of the window but its completion.
     xch = D.StatsExchange()
     xch.snapshot(*stats())
     blocks = []   # per timed block, max over ranks: (step-window seconds, HIP-event ms, seconds incl. the closing barrier)
@@ -676,13 +678,13 @@ def main():
         ev0 = [torch.cuda.Event(enable_timing=True) for _ in qs]
         ev1 = [torch.cuda.Event(enable_timing=True) for _ in qs]
         t0 = time.perf_counter()
-        xch.issue()
         for e, q in zip(ev0, qs):
             e.record(q)
         run(K, W + rep * K)
         for e, q in zip(ev1, qs):
             e.record(q)
-        gathered = xch.wait()            # rollout r - 1's statistics of every rank (the current stream waits, not the host)
+        xch.issue()                      # from a side stream, behind the launches already queued: host cost and collective overlap them
+        gathered = xch.wait()            # rollout r - 1's statistics of every rank (streams wait, not the host)
         torch.cuda.synchronize(dev)      # every local step AND the overlapped exchange have completed (sub-batch streams joined)
         t1 = time.perf_counter()         # <- the step window closes here, on every rank by its own clock; MAX over ranks below
         xch.snapshot(*stats())           # this rollout's statistics: reported during the next block

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ATC_ABI_VERSION 17
+#define ATC_ABI_VERSION 18
 
 /* ---------------------------------------------------------------------------------------------
  * Scenario blob: one flat array of 32-bit floats (device copy) compiled on the host from the sector
@@ -167,7 +167,8 @@ typedef struct atc_params {
  * (1e-4 nm after 100 steps, measured) — beyond the 1e-5 bar.  Positions are therefore kept as 32-bit FIXED POINT on a
  * per-sector grid: nm = origin + fix * 2^-k, origin integer-valued, k the largest exponent (<= 27) whose range
  * +-2^(31-k) nm covers 1.5 x the sector's half extent (LOWW: origin (36, 42), k = 25: 3e-8 nm = 55 um steps, +-64 nm).
- *   - per-step displacement d (fp32, model.py:122-129) advances the position by rint(d * 2^k) counts, saturating;
+ *   - the per-step displacement (model.py:122-129; float64 from the fixed-point speed and heading, see below) advances the
+ *     position by its value in counts rounded ONCE, saturating;
  *   - the fp32 position every formula of the reference sees is  (float)(origin + fix * 2^-k)  — ONE rounding (evaluated
  *     in float64, exact before the final conversion);
  *   - differences of positions are exact integers: the vector to the FAF (atc_gym.py:289-297) is
@@ -177,28 +178,66 @@ typedef struct atc_params {
  * the LOWW bounding box) is pinned at the range limit: it stays "outside the airspace" exactly like the reference's
  * (model.py:289), only its x / y observation stops growing.
  *
- * fp32 heading kinematics (model.py:122-129, 345-348) — part of the fp32 spec so that every fp32 implementation (the HIP
- * kernels, the fp32 instantiation of the test oracle) produces bit-identical positions:
- *   k = rint(phi / 90) [phi * (1/90) in fp32], t = fma(-90, k, phi) (exact), r = t * (pi/180),
- *   sin r = r * S(r^2), cos r = C(r^2) with the polynomials below (Horner, fmaf), quadrant fix-up by k mod 4.
- *   Max abs error 8.5e-8 (the accuracy class of libm sinf/cosf). */
-#define ATC_SIN_C1 (-0.16666631400585175f)
-#define ATC_SIN_C2 (0.008331366814672947f)
-#define ATC_SIN_C3 (-0.00019439239986240864f)
-#define ATC_COS_C1 (-0.5f)
-#define ATC_COS_C2 (0.04166661575436592f)
-#define ATC_COS_C3 (-0.001388648059219122f)
-#define ATC_COS_C4 (2.436429167573806e-05f)
+ *
+ * Speed and heading (model.py:35-37, 60-129) on the fp32 path — ABI 18.
+ * The reference holds v, phi and the decoded action targets in float64.  As fp32 values they carry the rounding of the
+ * target (1.5e-5 deg at 340 deg, 1.5e-5 kt at 250 kt) for as long as the target is held, and a heading that is 1e-5 deg off
+ * moves the aircraft 5e-6 nm off over a 30 nm leg: next to the FAF, where the bearing to it is ill-conditioned, that was the one
+ * stated exception to the 1e-5 bar of rounds 1-3 (tools/faf_conditioning.py).  Both are therefore 32-bit FIXED POINT, like
+ * the positions, and the step's displacement is evaluated in float64 from them:
+ *   speed    kt  = 200 + v_fix   * 2^-23    (range [-56, 456): the aircraft's [100, 300] and every refusable target)
+ *   heading  deg = 360 + phi_fix * 2^-22    (range [-152, 872): two turns around the action space's [0, 360])
+ *   - a target is  fix = rint(a * m + c)  in float64 (m, c = the reference's factor / offset of atc_gym.py:64-78,318-335
+ *     in counts, both integers), round-half-even, with the action first clamped so that |a m + c| < 2^31 (an action that far
+ *     outside the action space [-1, 1] pins the target at the end of the range: refused for the speed, held for the heading);
+ *   - rate limits (model.py:75-78, 117-120) are exact integer arithmetic: fix += clamp(target - fix, +-rint(rate dt 2^s));
+ *     the "action taken" discriminator (atc_gym.py:84,305-306) compares integer differences with 5 * 2^23 / 0.5 * 2^22;
+ *   - the fp32 speed / heading every other formula of the reference sees (observation, relative angles, corridor window) is
+ *     fmaf((float)fix, 2^-s, offset): exact for every value with <= 24 significant bits, e.g. all integer headings;
+ *   - the altitude stays fp32 (it does not feed the position; 1e-3 ft at 16 000 ft is 5e-8 in observation units).
+ * Heading kinematics (model.py:122-129, 345-348) in float64, shared bit for bit by every fp32 implementation (the HIP
+ * kernels, the fp32 instantiation of the test oracle):
+ *   k = rint(phi_fix * ATC_KIN_INV180)  [(180 * 2^22)^-1, nearest-even],  t = fma(k, -180 * 2^22, phi_fix)  (exact: the
+ *   remainder in counts, |t| <= 90 * 2^22),  u = t * t,
+ *   sin = t * (S0 + u (S1 + u (S2 + u (S3 + u (S4 + u S5))))),  cos = 1 + u (C1 + u (C2 + u (C3 + u (C4 + u C5))))
+ *   (Horner, fma; coefficients below: near-minimax in r = t pi / (180 * 2^22) on |r| <= pi/2, scaled to counts —
+ *   tools/fit_kinematics_f64.py; max error 2.6e-11 / 4.4e-10),  both negated when k is odd;
+ *   distance in position-grid counts  d = fma((double)v_fix, DA, DB)  with  q = (double)dt / 3600,
+ *   DA = q * 2^(k_pos - 23),  DB = (200 q) * 2^k_pos;  x_fix += rint(sin * d),  y_fix += rint(cos * d)  — ONE rounding each
+ *   (fma(sin, d, ATC_FIX_MAGIC), low 32 bits), saturating add.  Requires 0.127 dt 2^k_pos < 2^30 (dt < 63 s at k_pos = 27).
+ * Measured against the float64 reference over the 650 963 steps of tests/golden/g9_wide.npz: positions within a few 1e-7 nm
+ * (the random walk of the 2^-25 nm grid rounding), no near-FAF exception needed. */
+#define ATC_V_FIX_SHIFT 23
+#define ATC_PHI_FIX_SHIFT 23
+#define ATC_PHI_FIX_OFFSET 180.0f
+#define ATC_DITHER_MAGIC_HI 0x42880000u   /* high word of 1.5 * 2^41: the low word's low 11 bits are the dither fraction */
+#define ATC_FIX_MAGIC 6755399441055744.0  /* 1.5 * 2^52: the low 32 bits of fma(a, m, c + MAGIC) are rint(a m + c) */
+#define ATC_FIX_DECODE_LIMIT 2147480000.0 /* |a m + c| after the action clamp */
+#define ATC_KIN_INV180 (0x1.6c16c16c16c17p-31)
+#define ATC_KIN_HALF_TURN 1509949440.0    /* 180 * 2^23 */
+#define ATC_KIN_S0 (0x1.1df46a2514d5fp-29)
+#define ATC_KIN_S1 (-0x1.dbb820c160971p-90)
+#define ATC_KIN_S2 (0x1.dad945dddaa3dp-152)
+#define ATC_KIN_S3 (-0x1.c366787a5df6bp-215)
+#define ATC_KIN_S4 (0x1.f410ee5d4f8bep-279)
+#define ATC_KIN_S5 (-0x1.5a91d219ad65ap-343)
+#define ATC_KIN_C1 (-0x1.3f6a1d6c2409bp-59)
+#define ATC_KIN_C2 (0x1.09b109e7441cbp-120)
+#define ATC_KIN_C3 (-0x1.6198137ae3b3bp-183)
+#define ATC_KIN_C4 (0x1.f762cae337122p-247)
+#define ATC_KIN_C5 (-0x1.a6ebd88a524cfp-311)
 #define ATC_POS_MAX_K 27
 
 /* Persistent environment state (all device pointers).  Aircraft arrays are indexed env * N + k and packed so that a
  * wavefront moves each with one access per lane on consecutive addresses.  Per aircraft-step the step kernel reads
  * 16 + 4 + 12 B and writes 16 + 4 B (+ 12 B only when a last-action target changed). */
 typedef struct atc_state {
-    int32_t* pos_hp;  /* [B*N][4]  x_fix, y_fix (position grid counts, see above), h [ft] and phi [deg, never wrapped]
-                         (model.py:35-36) as float bit patterns — one 16-byte record */
-    float* v;         /* [B*N]     speed [kt] (model.py:37) */
-    float* last_act;  /* [B*N][3]  last accepted v / h / phi targets = AtcGym.last_action (atc_gym.py:86,311) */
+    int32_t* pos_hp;  /* [B*N][4]  x_fix, y_fix (position grid counts, see above), h [ft] as a float bit pattern, phi_fix
+                         (heading, never wrapped, model.py:35-36; fixed point, see above) — one 16-byte record */
+    int32_t* v_fix;   /* [B*N]     speed (model.py:37), fixed point */
+    int32_t* last_act;/* [B*N][3]  last accepted v / h / phi targets = AtcGym.last_action (atc_gym.py:86,311) in the state's
+                         own formats: v_fix, h as a float bit pattern, phi_fix (0 kt / 0 deg of atc_gym.py:86 = the counts
+                         of 0, not the integer 0) */
     int32_t* env;     /* [B][ATC_ENV_WORDS]  per-step env record, see ATC_ENV_* */
     int32_t* stats;   /* [B][ATC_STAT_WORDS] per-episode env record, see ATC_STAT_* (touched only when an episode ends) */
 } atc_state_t;

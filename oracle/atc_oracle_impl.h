@@ -54,20 +54,69 @@ static REAL FN(pos_to_faf)(const REAL* S, int axis, int32_t p) {
     int64_t faf = (int64_t)S[ATC_C_FAF_FIX + 2 * axis] * 65536 + (int64_t)S[ATC_C_FAF_FIX + 2 * axis + 1];
     return (REAL)FN(sat32)(faf - (int64_t)p) * S[ATC_C_POS_INV];
 }
-/* fp32 heading kinematics of include/atc_step.h: exact reduction in degrees + two short polynomials */
-static void FN(sincos_heading)(REAL phi, REAL* sn, REAL* cs) {
-    const float k = rintf(phi * (1.0f / 90.0f));
-    const float t = fmaf(-90.0f, k, phi);
-    const float r = t * (float)(3.14159265358979323846 / 180.0);
-    const float r2 = r * r;
-    const float sp = fmaf(fmaf(fmaf(ATC_SIN_C3, r2, ATC_SIN_C2), r2, ATC_SIN_C1), r2, 1.0f);
-    const float s = sp * r;
-    const float c = fmaf(fmaf(fmaf(fmaf(ATC_COS_C4, r2, ATC_COS_C3), r2, ATC_COS_C2), r2, ATC_COS_C1), r2, 1.0f);
-    const int q = (int)k & 3;
-    const float s1 = (q & 1) ? c : s;
-    const float c1 = (q & 1) ? s : c;
-    *sn = (q & 2) ? -s1 : s1;
-    *cs = ((q + 1) & 2) ? -c1 : c1;
+/* Speed and heading state of the fp32 spec (include/atc_step.h, ABI 18): 32-bit fixed point,
+ *   kt = v_fix 2^-23 (unsigned),  deg = 180 + phi_fix 2^-23 (signed);  targets, rate limits and the action discriminator are
+ *   integer arithmetic, the displacement is float64 from the fixed-point state. */
+typedef int32_t FN(fix_t); /* (the speed's counts are unsigned: stored in the same 32 bits, used through uint32_t) */
+#define ORC_QV 8388608.0 /* 2^ATC_V_FIX_SHIFT */
+#define ORC_QP 8388608.0 /* 2^ATC_PHI_FIX_SHIFT */
+static int32_t FN(clampi)(int32_t d, int32_t lo, int32_t hi) { return d < lo ? lo : (d > hi ? hi : d); }
+/* float64 -> integer as the spec defines it: truncation toward zero, saturation at both ends, NaN -> 0 */
+static int32_t FN(trunc_i32)(double x) {
+    if (!(x == x)) return 0;
+    if (x >= 2147483647.0) return INT32_MAX;
+    if (x <= -2147483648.0) return INT32_MIN;
+    return (int32_t)x;
+}
+static uint32_t FN(trunc_u32)(double x) {
+    if (!(x == x) || x <= 0.0) return 0u;
+    if (x >= 4294967295.0) return UINT32_MAX;
+    return (uint32_t)x;
+}
+typedef struct FN(decode) { double m, c; } FN(decode_t);
+/* target in counts = a * m + c (one fma in float64, m and c integers) */
+static FN(decode_t) FN(decode_consts)(double fac, double add, double offset, double q) {
+    FN(decode_t) d;
+    d.m = fac * q;
+    d.c = (add - offset) * q;
+    return d;
+}
+static int32_t FN(rate_fix)(double rate, double dt, double q) { /* rint(|rate| dt 2^s), saturating */
+    double r = rint(fabs(rate) * dt * q);
+    return r >= 2147483647.0 ? INT32_MAX : (int32_t)r;
+}
+static REAL FN(v_real)(int32_t f) { return (float)(uint32_t)f * (float)(1.0 / ORC_QV); }
+static REAL FN(phi_real)(int32_t f) { return fmaf((float)f, (float)(1.0 / ORC_QP), ATC_PHI_FIX_OFFSET); }
+/* state placed from outside (spawn, fixtures): nearest count */
+static int32_t FN(v_store)(REAL v) { return (int32_t)FN(trunc_u32)(rint((double)v * ORC_QV)); }
+static int32_t FN(phi_store)(REAL p) { return FN(trunc_i32)(rint(((double)p - (double)ATC_PHI_FIX_OFFSET) * ORC_QP)); }
+/* float64 heading kinematics of include/atc_step.h: advances (x, y) by one step's displacement */
+static void FN(advance)(const REAL* S, double dist_a, int32_t phi_fix, int32_t v_fix, int32_t t_step, int32_t* x, int32_t* y) {
+    (void)S;
+    const double pd = (double)phi_fix;
+    const double k = rint(pd * ATC_KIN_INV180);
+    const double t = fma(k, -ATC_KIN_HALF_TURN, pd);
+    const double u = t * t;
+    const double sp = fma(fma(fma(fma(fma(ATC_KIN_S5, u, ATC_KIN_S4), u, ATC_KIN_S3), u, ATC_KIN_S2), u, ATC_KIN_S1), u, ATC_KIN_S0);
+    const double sn = sp * t;
+    const double cs = fma(fma(fma(fma(fma(ATC_KIN_C5, u, ATC_KIN_C4), u, ATC_KIN_C3), u, ATC_KIN_C2), u, ATC_KIN_C1), u, 1.0);
+    double dist = (double)(uint32_t)v_fix * dist_a; /* the step's distance in position-grid counts */
+    if (!(((int32_t)k) & 1)) dist = -dist;         /* phi = 180 (1 + k) + t: an even k is an odd number of half turns */
+    /* Dithered rounding (include/atc_step.h): counts += floor(displacement + u), u = the low 11 bits of the env's time step
+     * bit-reversed, as a fraction (van der Corput sequence).  The rounding errors of a constant displacement — a straight leg
+     * at constant speed — then cancel to O(log n) counts over n steps instead of adding up to n / 4.  One fma against
+     * 1.5 2^41 + u (its bit pattern is assembled from integers), the integer part read from bits 11..42. */
+    uint32_t rb = 0;
+    for (int b = 0; b < 11; ++b) rb |= (((uint32_t)t_step >> b) & 1u) << (10 - b);
+    const uint64_t mb = ((uint64_t)ATC_DITHER_MAGIC_HI << 32) | (uint64_t)rb;
+    double magic_u;
+    memcpy(&magic_u, &mb, sizeof magic_u);
+    double rx = fma(sn, dist, magic_u), ry = fma(cs, dist, magic_u);
+    uint64_t bx, by;
+    memcpy(&bx, &rx, sizeof bx);
+    memcpy(&by, &ry, sizeof by);
+    *x = FN(sat32)((int64_t)*x + (int64_t)(int32_t)(uint32_t)(bx >> 11));
+    *y = FN(sat32)((int64_t)*y + (int64_t)(int32_t)(uint32_t)(by >> 11));
 }
 #else
 typedef double FN(pos_t);
@@ -75,6 +124,11 @@ static double FN(pos_spawn)(const REAL* S, int axis, REAL v) { (void)S; (void)ax
 static REAL FN(pos_to_real)(const REAL* S, int axis, double p) { (void)S; (void)axis; return (REAL)p; }
 static double FN(pos_advance)(const REAL* S, double p, REAL d) { (void)S; return p + (double)d; }
 static REAL FN(pos_to_faf)(const REAL* S, int axis, double p) { return S[ATC_C_FAF_X + axis] - (REAL)p; }
+typedef REAL FN(fix_t);
+static REAL FN(v_real)(REAL f) { return f; }
+static REAL FN(phi_real)(REAL f) { return f; }
+static REAL FN(v_store)(REAL v) { return v; }
+static REAL FN(phi_store)(REAL p) { return p; }
 /* model.py:345-348 rot_matrix: sin / cos of math.radians(phi) */
 static void FN(sincos_heading)(REAL phi, REAL* sn, REAL* cs) {
     REAL pr = phi * (REAL)(3.14159265358979323846 / 180.0);
@@ -220,8 +274,10 @@ static uint64_t FN(draw)(uint64_t seed, uint32_t env, uint32_t episode, uint32_t
 /* ---- structures (host pointers; same field meaning as include/atc_step.h) ----------------------------------------- */
 typedef struct FN(orc_state) {
     FN(pos_t) *x, *y;          /* [B*N] positions: float64 (reference) | 32-bit fixed point (fp32 spec), see pos_t above */
-    REAL *h, *phi, *v;         /* [B*N] */
-    REAL* last_act;            /* [3][B*N] */
+    REAL* h;                   /* [B*N] */
+    FN(fix_t) *phi, *v;        /* [B*N] heading, speed: REAL (reference) | 32-bit fixed point (fp32 spec), see fix_t above */
+    FN(fix_t)* last_act;       /* [3][B*N] last accepted v / h / phi targets in the state's formats (fp32 spec: v_fix, the
+                                  altitude's float bit pattern, phi_fix) */
     int32_t* timesteps;
     int32_t* actions_taken;
     REAL* total_reward;
@@ -319,13 +375,16 @@ static void FN(reset_env)(const REAL* S, int N, const FN(orc_state_t) * st, cons
     int episode = st->episodes[e];
     for (int k = 0; k < N; ++k) {
         int i = e * N + k;
-        REAL sx, sy;
-        FN(spawn)(S, p, e, k, episode, &sx, &sy, &st->h[i], &st->phi[i], &st->v[i]);
+        REAL sx, sy, sphi, sv;
+        FN(spawn)(S, p, e, k, episode, &sx, &sy, &st->h[i], &sphi, &sv);
         st->x[i] = FN(pos_spawn)(S, 0, sx);
         st->y[i] = FN(pos_spawn)(S, 1, sy);
+        st->phi[i] = FN(phi_store)(sphi);
+        st->v[i] = FN(v_store)(sv);
         if (obs) {
             REAL d, pr, gp;
-            FN(get_state)(S, st->x[i], st->y[i], st->h[i], st->phi[i], st->v[i], (REAL)0, obs + (size_t)i * 10, &d, &pr, &gp);
+            FN(get_state)(S, st->x[i], st->y[i], st->h[i], FN(phi_real)(st->phi[i]), FN(v_real)(st->v[i]), (REAL)0,
+                          obs + (size_t)i * 10, &d, &pr, &gp);
         }
     }
     st->total_reward[e] = 0;
@@ -341,9 +400,12 @@ int FN(atc_oracle_reset)(const REAL* S, int B, int N, const FN(orc_state_t) * st
     size_t BN = (size_t)B * N;
     for (int e = 0; e < B; ++e) {
         if (mask && !mask[e]) continue;
-        if (first)
-            for (int k = 0; k < N; ++k)
-                for (int c = 0; c < 3; ++c) st->last_act[(size_t)c * BN + (size_t)e * N + k] = 0;
+        if (first) /* atc_gym.py:86: last_action = [0, 0, 0] — in the state's formats (fp32 spec: the counts of 0 kt / 0 deg) */
+            for (int k = 0; k < N; ++k) {
+                st->last_act[(size_t)0 * BN + (size_t)e * N + k] = FN(v_store)((REAL)0);
+                st->last_act[(size_t)1 * BN + (size_t)e * N + k] = 0; /* 0 ft (fp32 spec: the bit pattern of 0.0f) */
+                st->last_act[(size_t)2 * BN + (size_t)e * N + k] = FN(phi_store)((REAL)0);
+            }
         FN(reset_env)(S, N, st, p, e, obs, first);
     }
     return 0;
@@ -363,6 +425,22 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
     const int n_mva = (int)S[ATC_H_N_MVA];
     const int n_noise = (int)S[ATC_H_N_NOISE];
     const int off_poly = (int)S[ATC_H_OFF_POLY];
+#if ORC_FIXED_POS
+    /* uniform terms of the fixed-point spec (include/atc_step.h, ABI 18), evaluated in float64 from the blob's fp32 constants */
+    const double dtd = (double)p->dt;
+    const FN(decode_t) dec_v = discrete ? FN(decode_consts)((double)fac[0], (double)off[0], 0.0, ORC_QV)
+                                        : FN(decode_consts)((double)fac[0] / 2.0, (double)fac[0] / 2.0 + (double)off[0], 0.0, ORC_QV);
+    const FN(decode_t) dec_p = discrete ? FN(decode_consts)((double)fac[2], (double)off[2], (double)ATC_PHI_FIX_OFFSET, ORC_QP)
+                                        : FN(decode_consts)((double)fac[2] / 2.0, (double)fac[2] / 2.0 + (double)off[2],
+                                                            (double)ATC_PHI_FIX_OFFSET, ORC_QP);
+    const int32_t v_min_fix = FN(v_store)(v_min), v_max_fix = FN(v_store)(v_max);
+    const int32_t rate_v = FN(rate_fix)((double)S[ATC_C_A_MAX], dtd, ORC_QV);      /* model.py:47-48: symmetric */
+    const int32_t rate_p = FN(rate_fix)((double)S[ATC_C_PHIDOT_MAX], dtd, ORC_QP); /* model.py:49-50: symmetric */
+    const int32_t discr_v = (int32_t)((double)S[ATC_C_ACT_DISCR] * ORC_QV), discr_p = (int32_t)((double)S[ATC_C_ACT_DISCR + 2] * ORC_QP);
+    const double qd = dtd / 3600.0;
+    const double dist_a = ldexp(qd, (int)lrint(log2((double)S[ATC_C_POS_SCALE])) - ATC_V_FIX_SHIFT); /* counts per speed count */
+    if (!(0.1423 * dtd * (double)S[ATC_C_POS_SCALE] < 1073741824.0)) return -1; /* 512 kt: the displacement must fit 2^30 counts */
+#endif
 
     /* envs are independent: the all-cores CPU baseline (bench.py) runs this loop under OpenMP; results do not depend on
      * the thread count (no cross-env state) */
@@ -388,6 +466,56 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
                 continue;
             }
             REAL reward = (REAL)-0.05 * dt; /* atc_gym.py:137 */
+#if ORC_FIXED_POS
+            /* fp32 spec (include/atc_step.h, ABI 18): speed / heading targets, rate limits and the discriminator in 32-bit fixed
+             * point; altitude in fp32 as the plain transcription */
+            {
+                const float av = actions[i * 3 + 0], ah = actions[i * 3 + 1], ap = actions[i * 3 + 2];
+                { /* speed: model.py:60-80 */
+                    const uint32_t tgt = FN(trunc_u32)(fma((double)av, dec_v.m, dec_v.c));
+                    if (tgt < (uint32_t)v_min_fix || tgt > (uint32_t)v_max_fix) {
+                        reward -= (REAL)1.0; /* atc_gym.py:312-315 */
+                        fl[k] |= ATC_F_INVALID_V;
+                    } else {
+                        /* (differences of valid speeds and of the initial last_action 0 fit 32 bits: wrapping arithmetic) */
+                        st->v[i] = (int32_t)((uint32_t)st->v[i] + (uint32_t)FN(clampi)((int32_t)(tgt - (uint32_t)st->v[i]), -rate_v, rate_v));
+                        int32_t* la = &st->last_act[(size_t)0 * BN + i];
+                        const int32_t dd = (int32_t)(tgt - (uint32_t)*la);
+                        if (!(dd > -discr_v && dd < discr_v)) st->actions_taken[e] += 1; /* atc_gym.py:305-306 */
+                        *la = (int32_t)tgt;                                               /* atc_gym.py:311 */
+                    }
+                }
+                { /* altitude: model.py:82-102 */
+                    REAL tgt;
+                    if (discrete) tgt = ah * fac[1] + off[1];
+                    else tgt = ah * fac[1] / (REAL)2 + fac[1] / (REAL)2 + off[1];
+                    if (tgt < h_min || tgt > h_max) {
+                        reward -= (REAL)1.0;
+                        fl[k] |= ATC_F_INVALID_H;
+                    } else {
+                        REAL d = tgt - st->h[i];
+                        d = R_MIN(d, S[ATC_C_HDOT_MAX] * dt);
+                        d = R_MAX(d, S[ATC_C_HDOT_MIN] * dt);
+                        st->h[i] = st->h[i] + d;
+                        int32_t* la = &st->last_act[(size_t)1 * BN + i];
+                        float last;
+                        memcpy(&last, la, sizeof last);
+                        if (!(R_ABS(tgt - last) < S[ATC_C_ACT_DISCR + 1])) st->actions_taken[e] += 1;
+                        memcpy(la, &tgt, sizeof tgt);
+                    }
+                }
+                { /* heading: model.py:104-120 — no validation, no wrap */
+                    const int32_t tgt = FN(trunc_i32)(fma((double)ap, dec_p.m, dec_p.c));
+                    st->phi[i] += FN(clampi)(FN(sat32)((int64_t)tgt - (int64_t)st->phi[i]), -rate_p, rate_p);
+                    int32_t* la = &st->last_act[(size_t)2 * BN + i];
+                    const int32_t dd = FN(sat32)((int64_t)tgt - (int64_t)*la);
+                    if (!(dd > -discr_p && dd < discr_p)) st->actions_taken[e] += 1;
+                    *la = tgt;
+                }
+            }
+            /* model.py:122-129 Airplane.step, float64 from the fixed-point state */
+            FN(advance)(S, dist_a, st->phi[i], st->v[i], t, &st->x[i], &st->y[i]);
+#else
             for (int c = 0; c < 3; ++c) {   /* atc_gym.py:139-141 -> _action_with_reward :299-316 */
                 REAL a = actions[i * 3 + c];
                 REAL tgt;
@@ -433,6 +561,7 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
             FN(sincos_heading)(st->phi[i], &sn, &cs);
             st->x[i] = FN(pos_advance)(S, st->x[i], sn * dist);
             st->y[i] = FN(pos_advance)(S, st->y[i], cs * dist);
+#endif
             r[k] = reward;
         }
 
@@ -497,7 +626,8 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
             }
             if (fl[k] & ATC_F_CONFLICT) r[k] = (REAL)p->conflict_reward;
             const REAL px = FN(pos_to_real)(S, 0, st->x[i]), py = FN(pos_to_real)(S, 1, st->y[i]);
-            if (FN(inside_corridor)(S, px, py, st->h[i], st->phi[i])) { /* atc_gym.py:163-169 */
+            const REAL phi_r = FN(phi_real)(st->phi[i]), v_r = FN(v_real)(st->v[i]);
+            if (FN(inside_corridor)(S, px, py, st->h[i], phi_r)) { /* atc_gym.py:163-169 */
                 int bonus = (p->timestep_limit - t) * 5;
                 if (bonus < 0) bonus = 0;
                 r[k] = (REAL)(10000 + bonus);
@@ -510,11 +640,11 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
                 fl[k] |= ATC_F_TIMEOUT;
             }
             REAL d_faf, phi_rel_faf, on_gp;
-            FN(get_state)(S, st->x[i], st->y[i], st->h[i], st->phi[i], st->v[i], mva_h[k], raw, &d_faf, &phi_rel_faf, &on_gp);
+            FN(get_state)(S, st->x[i], st->y[i], st->h[i], phi_r, v_r, mva_h[k], raw, &d_faf, &phi_rel_faf, &on_gp);
             if (p->mode & ATC_M_REWARD_SHAPING) { /* atc_gym.py:179-185 */
                 REAL pos = FN(reward_approach_position)(d_faf, S[ATC_C_PHI_TO_RWY], phi_rel_faf, S[ATC_C_WORLD_DIAG]);
                 r[k] += pos;
-                r[k] += FN(reward_approach_angle)(S[ATC_C_PHI_TO_RWY], phi_rel_faf, st->phi[i], pos);
+                r[k] += FN(reward_approach_angle)(S[ATC_C_PHI_TO_RWY], phi_rel_faf, phi_r, pos);
                 r[k] += FN(reward_glideslope)(st->h[i], on_gp, pos);
             }
             /* extension: noise-abatement areas (no reference code): inside polygon and below its ceiling */

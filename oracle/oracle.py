@@ -77,8 +77,12 @@ class OracleEnv:
         self.pos_origin, self.pos_k = compiled.pos_origin, compiled.pos_k
         pdt = np.int32 if self.fixed else np.float64
         self.px, self.py = np.zeros(BN, pdt), np.zeros(BN, pdt)
-        self.h, self.phi, self.v = (np.zeros(BN, r) for _ in range(3))
-        self.last_act = np.zeros((3, BN), r)
+        # speed / heading: float64 (reference) | 32-bit fixed point (fp32 spec, include/atc_step.h ABI 18: kt = v_fix 2^-23 (unsigned),
+        # deg = 180 + phi_fix 2^-23); `.phi` / `.v` give degrees / knots either way, `.phi_fix` / `.v_fix` the stored counts.
+        # last_act = the last accepted v / h / phi targets in the state's formats (fp32 spec: v_fix, float bits of h, phi_fix)
+        self.h = np.zeros(BN, r)
+        self._phi, self._v = (np.zeros(BN, np.int32 if self.fixed else r) for _ in range(2))
+        self.last_act = np.zeros((3, BN), np.int32 if self.fixed else r)
         self.timesteps = np.zeros(B, np.int32)
         self.actions_taken = np.zeros(B, np.int32)
         self.total_reward = np.zeros(B, r)
@@ -98,7 +102,7 @@ class OracleEnv:
         self.term_obs = np.zeros((B, N, 10), np.float32)
         self.mva = np.zeros((B, N), np.int32)
         self._st = (C.c_void_p * 15)(*[_ptr(a) for a in (
-            self.px, self.py, self.h, self.phi, self.v, self.last_act, self.timesteps, self.actions_taken,
+            self.px, self.py, self.h, self._phi, self._v, self.last_act, self.timesteps, self.actions_taken,
             self.total_reward, self.active_mask, self.win_bits, self.episodes, self.ep_return, self.ep_length,
             self.ep_actions)])
         self._out = (C.c_void_p * 9)(*[_ptr(a) for a in (
@@ -133,10 +137,59 @@ class OracleEnv:
         c = np.rint((float(v) - self.pos_origin[axis]) * 2.0 ** self.pos_k)
         return np.int32(min(max(c, -2.0 ** 31), 2.0 ** 31 - 1))
 
+    V_OFFSET, V_Q, PHI_OFFSET, PHI_Q = 0.0, 2.0 ** 23, 180.0, 2.0 ** 23   # include/atc_step.h: ATC_V_FIX_* / ATC_PHI_FIX_*
+
+    @staticmethod
+    def _fix(value, offset, q, unsigned=False):
+        c = np.rint((float(value) - offset) * q)
+        if unsigned:   # the speed's counts are unsigned 32-bit, stored in the same int32 words
+            return np.uint32(min(max(c, 0.0), 2.0 ** 32 - 1)).astype(np.int32)
+        return np.int32(min(max(c, -2.0 ** 31), 2.0 ** 31 - 1))
+
+    @property
+    def phi(self):
+        """headings in degrees (float64: exact for the fixed-point instantiation)"""
+        return self._phi.astype(np.float64) / self.PHI_Q + self.PHI_OFFSET if self.fixed else self._phi
+
+    @property
+    def v(self):
+        return self._v.view(np.uint32).astype(np.float64) / self.V_Q if self.fixed else self._v
+
+    @property
+    def phi_fix(self):
+        assert self.fixed
+        return self._phi
+
+    @property
+    def v_fix(self):
+        assert self.fixed
+        return self._v
+
     def set_state(self, e, k, x, y, h, phi, v):
         i = e * self.N + k
         self.px[i], self.py[i] = self._to_pos(x, 0), self._to_pos(y, 1)
-        self.h[i], self.phi[i], self.v[i] = h, phi, v
+        self.h[i] = h
+        if self.fixed:
+            self._phi[i], self._v[i] = self._fix(phi, self.PHI_OFFSET, self.PHI_Q), self._fix(v, self.V_OFFSET, self.V_Q, True)
+        else:
+            self._phi[i], self._v[i] = phi, v
+
+    def set_last_action(self, e, k, value):
+        """AtcGym.last_action (atc_gym.py:86,311) of one aircraft from [v, h, phi] in knots / feet / degrees."""
+        i = e * self.N + k
+        if self.fixed:
+            self.last_act[0, i] = self._fix(value[0], self.V_OFFSET, self.V_Q, True)
+            self.last_act[1, i] = np.float32(value[1]).view(np.int32)
+            self.last_act[2, i] = self._fix(value[2], self.PHI_OFFSET, self.PHI_Q)
+        else:
+            self.last_act[:, i] = value
+
+    def get_last_action(self, e, k):
+        i = e * self.N + k
+        if not self.fixed:
+            return [float(c) for c in self.last_act[:, i]]
+        return [float(np.uint32(self.last_act[0, i])) / self.V_Q, float(self.last_act[1, i:i + 1].view(np.float32)[0]),
+                float(self.last_act[2, i]) / self.PHI_Q + self.PHI_OFFSET]
 
     def step(self, actions):
         a = np.ascontiguousarray(np.asarray(actions, dtype=self.dtype).reshape(self.B * self.N * 3))

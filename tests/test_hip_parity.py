@@ -331,11 +331,11 @@ class _HipLockstep:
 def test_wide_fixture_batched():
     """G9: 650 963 reference steps (LOWW / random entries / Simple / UnitTest / Dyadic, dt 1-2-5, discrete, shaping and
     normalisation off, >= 50 wins / MVA busts / timeouts, episodes stepped on past done) replayed through the batched
-    kernel: every integer output of every step exact, rewards and sampled observations within 1e-5 (stated near-FAF
-    exception: helpers.replay_wide)."""
+    kernel: every integer output of every step exact, rewards and sampled observations within 1e-5 — everywhere (the
+    near-FAF exception of rounds 1-3 is retired, helpers.replay_wide)."""
     fx = H.WideFixture()
-    n, near = H.replay_wide(fx, _HipLockstep, obs_tol=1e-5, state_tol=1e-5, rew_tol=1e-5)
-    assert n == len(fx.flags) > 500000 and near < 2e-3 * n
+    n = H.replay_wide(fx, _HipLockstep, obs_tol=1e-5, state_tol=1e-5, rew_tol=1e-5)
+    assert n == len(fx.flags) > 500000
 
 
 def test_atcgym_keeps_flying_after_a_win():
@@ -355,6 +355,10 @@ def test_atcgym_keeps_flying_after_a_win():
         ap.x, ap.y, ap.h, ap.phi, ap.v = ep["init_state"]
         env._vec.timesteps[0] = ep["init_timesteps"]
         env.timesteps = ep["init_timesteps"]
+        # (the fixture's episodes start from their own recorded last_action, not from what the previous episode of this loop
+        # left behind: without this line the float64 oracle itself disagrees with the fixture on the first step of episode 3,
+        # where |target - leftover| = 4.9999999 but |target - recorded| = 13)
+        env.last_action = ep["init_last_action"]
         wins = 0
         for t in range(ep["steps"]):
             row = ep["start"] + t
@@ -473,8 +477,8 @@ def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, sp
     # the fp32 spec (include/atc_step.h: fixed-point position grid, shared heading kinematics, exact rate-limit
     # arithmetic) makes the whole aircraft state BIT-IDENTICAL to the fp32 oracle's
     assert np.array_equal(env.pos_hp[:, 0].cpu().numpy(), orc.px) and np.array_equal(env.pos_hp[:, 1].cpu().numpy(), orc.py)
-    assert np.array_equal(env.h.cpu().numpy(), orc.h) and np.array_equal(env.phi.cpu().numpy(), orc.phi)
-    assert np.array_equal(env.v.cpu().numpy(), orc.v)
+    assert np.array_equal(env.h.cpu().numpy(), orc.h) and np.array_equal(env.phi_fix.cpu().numpy(), orc.phi_fix)
+    assert np.array_equal(env.v_fix.cpu().numpy(), orc.v_fix)
     assert np.array_equal(env.last_act.cpu().numpy(), orc.last_act.T)
     assert np.array_equal(env.ep_actions.cpu().numpy(), orc.ep_actions)
     assert np.allclose(env.ep_return.cpu().numpy(), orc.ep_return, rtol=1e-5, atol=1e-3)
@@ -759,7 +763,7 @@ def test_full_size_rollout_hold(B, N):
         for j in range(launches):
             o = env.rollout(blocks[j][:, :nb].contiguous(), hold=T)
             outs.append({k: v.clone() for k, v in o.items()})
-        state = (env.pos_hp.clone(), env.v.clone(), env.last_act.clone(), env.env.clone())
+        state = (env.pos_hp.clone(), env.v_fix.clone(), env.last_act.clone(), env.env.clone())
         env.close()
         return outs, state
 

@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Where does the fp32 path's position error against the float64 reference come from?  (CPU, numpy, ~10 s.)
 
+ROUND 3 / ABI 17 — kept as the measurement behind that round's conclusion ("the near-FAF exception is a property of fp32 aircraft
+STATE").  Round 4 acted on it: since ABI 18 speed and heading are 32-bit fixed point and the displacement is float64
+(include/atc_step.h); tools/position_error.py measures that specification (profiles/r04_position_error.txt) and the exception
+is retired.  "K" below is the SUPERSEDED ABI-17 specification.
+
 The bearing to the FAF (obs[8], atc_gym.py:289-292) moves by e / d_faf radians for a position error e, so keeping it within
 1e-5 (normalised: 1.8e-3 deg = 3.1e-5 rad) at d_faf = 0.027 nm — the one step of the wide fixture that needs the stated
 exception of tests/helpers.py:replay_wide — takes e < 8.5e-7 nm after the ~700 steps an approach lasts.  This script flies

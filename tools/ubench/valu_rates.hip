@@ -114,12 +114,36 @@ KERNEL(k_add_f64, DECL_D, R16(OP_ADD64), SINK_D)
 KERNEL(k_fma_f64, DECL_D, R16(OP_FMA64), SINK_D)
 #define OP_LDEXP64(i) asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(r[i]) : "v"(k));
 KERNEL(k_ldexp_f64, DECL_D, R16(OP_LDEXP64), SINK_D)
+#define OP_MUL64(i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(r[i]) : "v"(s));
+KERNEL(k_mul_f64, DECL_D, R16(OP_MUL64), SINK_D)
+#define OP_RNDNE64(i) asm volatile("v_rndne_f64 %0, %0" : "+v"(r[i]));
+KERNEL(k_rndne_f64, DECL_D, R16(OP_RNDNE64), SINK_D)
+#define OP_FMA64S(i) asm volatile("v_fma_f64 %0, %0, %1, s[20:21]" : "+v"(r[i]) : "v"(s) : "s20", "s21");
+KERNEL(k_fma_f64_sgpr, DECL_D, R16(OP_FMA64S), SINK_D)
+#define OP_FMA64C1(i) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(r[0]) : "v"(s));
+KERNEL(k_fma_f64_chain1, DECL_D, R16(OP_FMA64C1), SINK_D)
+#define OP_FMA64C2(i) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(r[(i) & 1]) : "v"(s));
+KERNEL(k_fma_f64_chain2, DECL_D, R16(OP_FMA64C2), SINK_D)
 #define DECL_C float r[16]; double q[16]; for (int i = 0; i < 16; ++i) { r[i] = seed + threadIdx.x + i; q[i] = i; } float s = seed
 #define SINK_C double acc = 0; for (int i = 0; i < 16; ++i) acc += q[i] + r[i]; if (acc == 12345.0) out[threadIdx.x] = (float)acc
 #define OP_CVT64(i) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(q[i]) : "v"(r[i]));
 KERNEL(k_cvt_f64_i32, DECL_C, R16(OP_CVT64), SINK_C)
 #define OP_CVT32(i) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(r[i]) : "v"(q[i]));
 KERNEL(k_cvt_f32_f64, DECL_C, R16(OP_CVT32), SINK_C)
+#define OP_CVT64U(i) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(q[i]) : "v"(r[i]));
+KERNEL(k_cvt_f64_u32, DECL_C, R16(OP_CVT64U), SINK_C)
+#define OP_CVT64F(i) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(q[i]) : "v"(r[i]));
+KERNEL(k_cvt_f64_f32, DECL_C, R16(OP_CVT64F), SINK_C)
+#define OP_CVTI64(i) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(r[i]) : "v"(q[i]));
+KERNEL(k_cvt_i32_f64, DECL_C, R16(OP_CVTI64), SINK_C)
+#define OP_CVTU64(i) asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(r[i]) : "v"(q[i]));
+KERNEL(k_cvt_u32_f64, DECL_C, R16(OP_CVTU64), SINK_C)
+#define OP_ALIGNBIT(i) asm volatile("v_alignbit_b32 %0, %0, %1, 11" : "+v"(r[i]) : "v"(s));
+KERNEL(k_alignbit, DECL_F, R16(OP_ALIGNBIT), SINK_F)
+#define OP_BFREV(i) asm volatile("v_bfrev_b32 %0, %0" : "+v"(r[i]));
+KERNEL(k_bfrev, DECL_F, R16(OP_BFREV), SINK_F)
+#define OP_ADDSAT(i) asm volatile("v_add_i32 %0, %0, %1 clamp" : "+v"(r[i]) : "v"(s));
+KERNEL(k_add_i32_clamp, DECL_F, R16(OP_ADDSAT), SINK_F)
 
 template <typename F>
 static void run(const char* name, F kernel, int waves_per_simd, float* out, unsigned long long* cyc, int n_cu) {
@@ -152,8 +176,14 @@ int main() {
     float* out; unsigned long long* cyc;
     hipMalloc(&out, 4096); hipMalloc(&cyc, 64);
     printf("%s, %d CUs\n", prop.name, n_cu);
+    const bool only64 = getenv("ATC_UBENCH_F64") != nullptr;
     for (int w : {1, 2, 4, 8}) {
 #define RUN(k) run(#k, k, w, out, cyc, n_cu)
+        RUN(k_fma); RUN(k_fma_f64); RUN(k_fma_f64_sgpr); RUN(k_fma_f64_chain1); RUN(k_fma_f64_chain2); RUN(k_mul_f64); RUN(k_rndne_f64); RUN(k_add_f64);
+        RUN(k_cvt_f64_i32); RUN(k_cvt_f64_u32); RUN(k_cvt_f64_f32); RUN(k_cvt_i32_f64); RUN(k_cvt_u32_f64); RUN(k_cvt_f32_f64);
+        RUN(k_alignbit); RUN(k_bfrev); RUN(k_add_i32_clamp);
+        printf("\n");
+        if (only64) continue;
         RUN(k_fma); RUN(k_mul); RUN(k_mov); RUN(k_pk_fma); RUN(k_pk_mul); RUN(k_pk_add); RUN(k_rcp); RUN(k_exp); RUN(k_sqrt);
         RUN(k_dpp); RUN(k_cmp); RUN(k_cndmask); RUN(k_med3); RUN(k_mul_lo_u32); RUN(k_mul_u24); RUN(k_cvt_i32_f32); RUN(k_rndne);
         RUN(k_readlane); RUN(k_add_f64); RUN(k_fma_f64); RUN(k_ldexp_f64); RUN(k_cvt_f64_i32); RUN(k_cvt_f32_f64);
