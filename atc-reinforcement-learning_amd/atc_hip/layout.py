@@ -3,10 +3,12 @@
 tests/test_abi.py parses the header and checks that every constant here matches it.
 """
 ABI_VERSION = 18
-BLOB_VERSION = 1013.0
+BLOB_VERSION = 1014.0
 
 H_VERSION, H_NWORDS, H_N_MVA, H_N_NOISE, H_N_ENTRY, H_OFF_POLY, H_OFF_VERT, H_OFF_ENTRY, H_OFF_GRID, H_N_VERTW = range(10)
 H_OFF_SLOT = 10
+H_OFF_SPAWN = 11
+SPAWN_WORDS = 16
 C_RWY_X, C_RWY_Y, C_RWY_H, C_PHI_TO_RWY, C_FAF_X, C_FAF_Y, C_NRM_X, C_NRM_Y = range(16, 24)
 C_FAF_ANGLE, C_GS_TAN, C_FAF_MVA, C_WORLD_DIAG, C_NM_TO_FT = range(24, 29)
 C_V_MIN, C_V_MAX, C_H_MIN, C_H_MAX, C_A_MIN, C_A_MAX, C_HDOT_MIN, C_HDOT_MAX = range(29, 37)

@@ -193,6 +193,62 @@ def _box_records(cx0s, cx1s, cy0s, cy1s, edges, bounds, heights):
     return recs
 
 
+GRID_CELL_LINE = 2.0 ** 23   # cell flag: the cell's first record is a LINE record (see _line_split)
+
+
+def _line_split(recs, cy0s, cy1s, heights):
+    """SPLIT cell: every edge record of the cell whose crossing depends on the point lies on ONE line that runs through the whole
+    cell (no vertex, no second border inside it) — by far the commonest dirty cell.  Then a point more than a margin m to the
+    LEFT of the line crosses all of those edges and a point more than m to the RIGHT crosses none, whatever the rounding of the
+    reference's x-intersection (model.py:331-333): each side has ONE answer, found here by running the cell's record list with
+    the crossing forced.  Returns the LINE record [p1x, p1y, dx/dy, m | left polygon + 1, left height, right polygon + 1,
+    right height] or None.  The kernel evaluates  xl = p1x + (y - p1y) * dx/dy  and answers  x < xl - m -> left,
+    x > xl + m -> right;  only points inside the band walk the ordinary records (which follow the LINE record unchanged)."""
+    line = None
+    m = 0.0
+    for r in recs:
+        fl = int(r[7]) % 16
+        if fl & int(GRID_F_TERM):
+            if r[0] != -_BIG:
+                return None            # polygon bounds cut the cell: the answer depends on more than the side of the line
+            continue
+        if not (r[4] < cy0s and r[5] >= cy1s):
+            return None                # the edge's y tests (model.py:328-329) do not hold for every point of the cell
+        if fl & int(GRID_F_CERTAIN):
+            continue                   # crossed by every point of the cell
+        p1x, p1y, p2x, p2y = r[0:4]
+        slope = (p2x - p1x) / (p2y - p1y)
+        if line is None:
+            line = (p1x, p1y, slope)
+        else:                          # the same geometric line (a border shared by two polygons)?
+            for qx, qy in ((p1x, p1y), (p2x, p2y)):
+                if abs(line[0] + (qy - line[1]) * line[2] - qx) > 1e-9 * max(1.0, abs(qx)):
+                    return None
+        ulp32 = float(np.spacing(np.float32(max(abs(p1x), abs(p1y), abs(p2x), abs(p2y)))))
+        # fp32 x-intersection of the reference's formula (1.5 ulp(y) |dx/dy| + ulp(x)), the kernel's own line evaluation with
+        # an fp32 slope (6e-8 |y - p1y| |dx/dy|, |y - p1y| < 170 nm) and the collinearity tolerance, with room to spare
+        m = max(m, 2e-3 + 8.0 * ulp32 * (1.0 + abs(slope)) + 2e-5 * abs(slope))
+    if line is None:
+        return None
+
+    def side(crossing):
+        inside = False
+        for r in recs:
+            pi, fl = int(r[7]) // 16, int(r[7]) % 16
+            if fl & int(GRID_F_TERM):
+                decide = True
+            else:
+                inside ^= True if (fl & int(GRID_F_CERTAIN)) else crossing
+                decide = bool(fl & int(GRID_F_LAST))
+            if decide:
+                if inside != bool(fl & int(GRID_F_BASE)):
+                    return pi + 1.0, heights[pi]
+                inside = False
+        return 0.0, 0.0
+    left, right = side(True), side(False)
+    return [line[0], line[1], line[2], m, left[0], left[1], right[0], right[1]]
+
+
 def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=(), corridor_bounds=None):
     """Uniform lookup grid for Airspace.find_mva (model.py:282-289) with IDENTICAL results to the ordered polygon scan.
 
@@ -222,8 +278,9 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=(), 
     comparing four bounds per aircraft.
 
     Layout (words): header[8] = x0, y0, inv_cell, nx, ny, offset of the edge pool (from grid start), n_records, 0;
-    cells[ny*nx][2] = (c, first_record | MVA height) with |c| = code + 64 * noise mask + 2^22 * corridor candidate: c > 0 dirty cell, code = n_records
-    (< 64); c <= 0 clean cell, code = polygon + 1 (0 = outside the airspace); pool of 8-word records."""
+    cells[ny*nx][2] = (c, first_record | MVA height) with |c| = code + 64 * noise mask + 2^22 * corridor candidate
+    + 2^23 * split: c > 0 dirty cell, code = n_records (< 64; a split cell's LINE record comes first and is not counted);
+    c <= 0 clean cell, code = polygon + 1 (0 = outside the airspace); pool of 8-word records."""
     if guard is None:
         guard = 1e-3
     x0, y0, x1, y1 = bbox
@@ -277,9 +334,13 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=(), 
                 continue
             cells[j, i, 0] = len(recs)
             cells[j, i, 1] = len(pool) if recs else 0.0   # (0, 0): nothing can match = clean cell outside the airspace
+            split = _line_split(recs, cy0s, cy1s, heights) if recs else None
+            if split is not None:      # LINE record first, the ordinary records behind it
+                cells[j, i, 0] += GRID_CELL_LINE
+                pool.append(split)
             pool.extend(recs)
     assert len(noise_bounds) <= 16, "at most 16 noise-abatement areas"
-    assert cells[:, :, 0].max() < 64
+    assert (np.maximum(cells[:, :, 0], 0.0) % GRID_CELL_LINE).max() < 64
     for j in range(ny):
         cy0s = gy0 + j * cell - slack
         cy1s = gy0 + (j + 1) * cell + slack
@@ -385,6 +446,9 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
     n_entry = len(entrypoints)
     off_slot = (off_entry + n_entry * L.E_WORDS + 3) & ~3  # 16-byte aligned float4 records
     end = off_slot + (4 * L.MAX_AIRCRAFT if n_entry else 0)
+    off_spawn = (end + 15) & ~15   # 64-byte aligned spawn records: 64 lattice slots, then one per entry point
+    n_spawn = (L.MAX_AIRCRAFT + n_entry) if n_entry else 0
+    end = off_spawn + n_spawn * L.SPAWN_WORDS
     grid = None
     off_grid = 0
     if grid_cell is not None and mva_rings:
@@ -404,6 +468,7 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
     b[L.H_OFF_POLY], b[L.H_OFF_VERT], b[L.H_OFF_ENTRY], b[L.H_OFF_GRID] = off_poly, off_vert, off_entry, off_grid
     b[L.H_N_VERTW] = n_vertw
     b[L.H_OFF_SLOT] = off_slot if n_entry else 0
+    b[L.H_OFF_SPAWN] = off_spawn if n_entry else 0
     b[L.C_RWY_X], b[L.C_RWY_Y], b[L.C_RWY_H] = cg["x"], cg["y"], cg["h"]
     b[L.C_PHI_TO_RWY] = cg["phi_to_runway"]
     b[L.C_FAF_X], b[L.C_FAF_Y] = cg["faf"]
@@ -463,6 +528,41 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
     if grid is not None:
         b[off_grid:off_grid + len(grid)] = grid
     assert end < 2 ** 24, "blob offsets must stay exactly representable in fp32"
+    # spawn records (include/atc_step.h: ATC_H_OFF_SPAWN): what AtcGym.reset computes for an aircraft placed at a lattice slot /
+    # an entry point — fixed-point state + the raw reset observation — evaluated here once instead of in every reset of
+    # every env (under the measurement protocol an env of 16 aircraft resets every ~25 steps: the reset is a hot path)
+    spawn_i = np.zeros((n_spawn, L.SPAWN_WORDS), dtype=np.int32)
+    if n_spawn:
+        f32 = np.float32
+        faf_fix = [int(to_fix(cg["faf"][a], (px0, py0)[a], pk)) for a in range(2)]
+        pos_inv = f32(2.0 ** -pk)
+        to_rwy = f32(cg["phi_to_runway"])
+        places = [(entrypoints[k % n_entry], entrypoints[k % n_entry][3][(k // n_entry) % len(entrypoints[k % n_entry][3])] * 100.0)
+                  for k in range(L.MAX_AIRCRAFT)] + [(e, 0.0) for e in entrypoints]
+        for r, ((ex, ey, ephi, _), h) in enumerate(places):
+            fix = []
+            for val, org in ((ex, px0), (ey, py0)):   # csrc/atc_device.h: pos_spawn (fp32 like the device)
+                c = f32(f32(f32(val) - f32(org)) * f32(2.0 ** pk))
+                fix.append(int(np.rint(min(max(float(c), -2147483648.0), 2147483520.0))))
+            phi_fix = int(min(max(np.rint((float(f32(ephi)) - L.PHI_FIX_OFFSET) * 2.0 ** L.PHI_FIX_SHIFT), -2.0 ** 31), 2.0 ** 31 - 1))
+            phi32 = f32(f32(phi_fix) * f32(2.0 ** -L.PHI_FIX_SHIFT) + f32(L.PHI_FIX_OFFSET))   # phi_real (exact for these values)
+            x32, y32 = f32(px0 + fix[0] * 2.0 ** -pk), f32(py0 + fix[1] * 2.0 ** -pk)       # pos_to_real: one rounding
+            tfx = f32(f32(min(max(faf_fix[0] - fix[0], -2 ** 31), 2 ** 31 - 1)) * pos_inv)
+            tfy = f32(f32(min(max(faf_fix[1] - fix[1], -2 ** 31), 2 ** 31 - 1)) * pos_inv)
+            d_faf = f32(math.hypot(float(tfx), float(tfy)))
+            phi_rel_faf = f32(math.degrees(math.atan2(float(tfy), float(tfx))))
+            on_gp = f32(float(f32(318.4)) * float(d_faf) + float(f32(f32(faf_mva) - f32(200.0))))
+            a = f32(f32(phi32 - to_rwy) + f32(180.0))                       # relative_angle (model.py:340-342) in fp32 steps
+            m = f32(math.fmod(float(a), 360.0))
+            if m != 0 and (m < 0):
+                m = f32(m + f32(360.0))
+            rel_rwy = f32(m - f32(180.0))
+            obs = np.array([x32, y32, h, phi32, 250.0, h, on_gp, d_faf, phi_rel_faf, rel_rwy], dtype=np.float32)
+            spawn_i[r, 0], spawn_i[r, 1], spawn_i[r, 3] = fix[0], fix[1], phi_fix
+            spawn_i[r, 2] = np.float32(h).view(np.int32)
+            spawn_i[r, 4:14] = obs.view(np.int32)
+            b[off_spawn + r * L.SPAWN_WORDS:off_spawn + r * L.SPAWN_WORDS + 4] = (fix[0], fix[1], h, phi_fix)
+            b[off_spawn + r * L.SPAWN_WORDS + 4:off_spawn + r * L.SPAWN_WORDS + 14] = obs.astype(np.float64)
 
     meta = dict(
         mva_rings=mva_rings, mva_heights=mva_heights, mva_bounds=bounds[:len(mva_rings)], noise_rings=noise_rings,
@@ -471,4 +571,7 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
         n_mva=len(mva_rings), n_noise=len(noise_rings), n_entry=n_entry, has_grid=grid is not None,
         v_min=v_min, v_max=v_max, h_min=h_min, h_max=h_max, pos_origin=(px0, py0), pos_k=pk,
     )
-    return CompiledSector(b, meta)
+    cs = CompiledSector(b, meta)
+    if n_spawn:   # the device blob carries the records' integer words as 32-bit patterns
+        cs.blob32[off_spawn:off_spawn + n_spawn * L.SPAWN_WORDS].view(np.int32)[:] = spawn_i.ravel()
+    return cs

@@ -224,7 +224,7 @@ __device__ __forceinline__ uint32_t noise_candidates(const float* __restrict__ g
 }
 // the bounds of the corridor's horizontal triangle meet the aircraft's cell (bit 22 of the cell code): only then can
 // Runway.inside_corridor (model.py:198) accept the point
-__device__ __forceinline__ bool corridor_candidate(const MvaCell& c) { return (uint32_t)(int)fabsf(c.cell.x) >= (1u << 22); }
+__device__ __forceinline__ bool corridor_candidate(const MvaCell& c) { return ((uint32_t)(int)fabsf(c.cell.x) & (1u << 22)) != 0u; }
 // The grid header (origin, 1 / cell, columns, rows, record pool) — uniform.  The step kernel receives it with its arguments
 // (evaluated on the host: gfx950 has no scalar float conversion); the query kernel reads it from the blob.
 struct GridHdr {
@@ -288,7 +288,25 @@ __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const fl
         // one L2 round trip per batch instead of one per record.  Indices past the list are clamped (loads stay in
         // bounds) and their records ignored.
         const char* pool = reinterpret_cast<const char*>(grid + gh.off_pool);   // uniform
-        const uint32_t rec0 = 32u * (uint32_t)(int)cell.y;                          // this lane's first record, bytes
+        uint32_t rec0 = 32u * (uint32_t)(int)cell.y;                                // this lane's first record, bytes
+        // SPLIT cell (atc_hip/scenario.py:_line_split — nine dirty cells in ten): one line runs through the whole cell and each
+        // side of it has one answer.  The LINE record holds the line, a margin that covers every rounding of the reference's
+        // x-intersection, and the two answers: one 32-byte fetch, one fma, two compares — no division, no loop.  Only a point
+        // inside the margin band (or in a cell with a vertex or a second border) walks the ordinary records behind it.
+        if ((uint32_t)(int)fabsf(cell.x) & ATC_G_CELL_LINE) {
+            const float4 g = *reinterpret_cast<const float4*>(pool + rec0);          // p1x, p1y, dx/dy, margin
+            const float4 m = *reinterpret_cast<const float4*>(pool + rec0 + 16u);    // left polygon + 1, height, right polygon + 1, height
+            const float xl = fmaf(y - g.y, g.z, g.x);
+            if (x < xl - g.w) {
+                *height = m.y;
+                return (int)m.x - 1;
+            }
+            if (x > xl + g.w) {
+                *height = m.w;
+                return (int)m.z - 1;
+            }
+            rec0 += 32u;
+        }
         bool inside = false;
         for (int base = 0; base < n; base += kBatch) {
             float4 g[kBatch], m[kBatch];
@@ -502,29 +520,43 @@ struct Aircraft {
     uint32_t v;       // speed, fixed point (kt = v 2^-23)
 };
 
-// atc_gym.py:346-348 + model.py:13-52: aircraft k of env e enters at an entry point.
-// Lattice mode reads the per-slot record precomputed in the blob (one 16-byte load); random mode maps a 64-bit draw to
-// (entry, level) by multiply-shift — no integer division on the reset path.
-__device__ __forceinline__ Aircraft spawn(const float* __restrict__ K, const atc_params_t& p, int e, int k, int episode) {
+// atc_gym.py:346-351,365 + model.py:13-52: aircraft k of env e enters at an entry point — from the blob's SPAWN RECORDS
+// (include/atc_step.h: ATC_H_OFF_SPAWN): the fixed-point state and the raw reset observation of an aircraft placed at a lattice
+// slot / an entry point were evaluated once by the sector compiler, so a reset is four 16-byte gathers instead of two position
+// conversions, a heading conversion and a whole _get_state (square root, atan2, modulo).  Under the measurement protocol an
+// env of 16 aircraft resets every ~25 steps — a wavefront meets a reset in one step out of six.
+// Lattice mode reads record k; random mode maps a 64-bit draw to (entry, level) by multiply-shift — no integer division on
+// the reset path —, reads the entry's record and puts the level's altitude into the state and into observation words 2 and 5.
+// obs == nullptr: state only.
+__device__ __forceinline__ Aircraft spawn(const float* __restrict__ K, int off_spawn, const atc_params_t& p, int e, int k,
+                                          int episode, float* obs) {
     Aircraft a;
     a.v = kVInitFix;
-    if (!(p.mode & ATC_M_RANDOM_ENTRY)) {
-        const float4 rec = *reinterpret_cast<const float4*>(K + (int)K[ATC_H_OFF_SLOT] + 4 * k);
-        a.x = pos_spawn(K, 0, rec.x);
-        a.y = pos_spawn(K, 1, rec.y);
-        a.phi = phi_store(rec.z);
-        a.h = rec.w;
-        return a;
+    uint32_t rec = (uint32_t)k;
+    float h_level = 0.0f;
+    const bool random = (p.mode & ATC_M_RANDOM_ENTRY) != 0;
+    if (random) {
+        const uint32_t n_entry = (uint32_t)(int)K[ATC_H_N_ENTRY];
+        const uint64_t u = draw(p.seed, (uint32_t)e, (uint32_t)episode, (uint32_t)k);
+        const int ei = (int)__umulhi((uint32_t)(u & 0xffffffffu), n_entry);
+        const float* er = K + (int)K[ATC_H_OFF_ENTRY] + ei * ATC_E_WORDS;
+        const int li = (int)__umulhi((uint32_t)(u >> 32), (uint32_t)(int)er[ATC_E_NLEV]);
+        h_level = er[ATC_E_LEV0 + li] * 100.0f;
+        rec = (uint32_t)(ATC_MAX_AIRCRAFT + ei);
     }
-    const uint32_t n_entry = (uint32_t)(int)K[ATC_H_N_ENTRY];
-    const uint64_t u = draw(p.seed, (uint32_t)e, (uint32_t)episode, (uint32_t)k);
-    const int ei = (int)__umulhi((uint32_t)(u & 0xffffffffu), n_entry);
-    const float* rec = K + (int)K[ATC_H_OFF_ENTRY] + ei * ATC_E_WORDS;
-    const int li = (int)__umulhi((uint32_t)(u >> 32), (uint32_t)(int)rec[ATC_E_NLEV]);
-    a.x = pos_spawn(K, 0, rec[ATC_E_X]);
-    a.y = pos_spawn(K, 1, rec[ATC_E_Y]);
-    a.phi = phi_store(rec[ATC_E_PHI]);
-    a.h = rec[ATC_E_LEV0 + li] * 100.0f;
+    const char* r = reinterpret_cast<const char*>(K + off_spawn) + rec * (ATC_SPAWN_WORDS * 4u);
+    const int4 st = *reinterpret_cast<const int4*>(r);
+    a.x = st.x;
+    a.y = st.y;
+    a.h = random ? h_level : __int_as_float(st.z);
+    a.phi = st.w;
+    if (obs) {
+        const float4 o0 = *reinterpret_cast<const float4*>(r + 16), o1 = *reinterpret_cast<const float4*>(r + 32);
+        const float2 o2 = *reinterpret_cast<const float2*>(r + 48);
+        obs[0] = o0.x; obs[1] = o0.y; obs[2] = random ? h_level : o0.z; obs[3] = o0.w;
+        obs[4] = o1.x; obs[5] = random ? h_level : o1.y; obs[6] = o1.z; obs[7] = o1.w;
+        obs[8] = o2.x; obs[9] = o2.y;
+    }
     return a;
 }
 

@@ -423,7 +423,8 @@ struct alignas(16) QScan {    // second half: separation scan, override chain
     int timestep_limit;
     float4 tri_bbox;      // bounds of the corridor's horizontal triangle (ATC_C_TRI_BBOX)
     int n_noise;          // number of noise-abatement areas (blob header word; read from the blob inside the step it was a
-    int pad[3];           // dependent scalar load with nothing to hide its latency behind, in every step of every wavefront)
+    int off_spawn;        // dependent scalar load with nothing to hide its latency behind, in every step of every wavefront);
+    int pad[2];           // word offset of the blob's spawn records (ATC_H_OFF_SPAWN)
 };
 struct alignas(16) QNorm {
     float a[ATC_OBS_DIM], b[ATC_OBS_DIM];   // ATC_C_NORM_A / ATC_C_NORM_B
@@ -519,6 +520,7 @@ static StepDerived derive_uncached(const atc_params_t& p, const atc_scenario* s)
     q.s.timestep_limit = p.timestep_limit;
     q.s.tri_bbox = make_float4(K[ATC_C_TRI_BBOX], K[ATC_C_TRI_BBOX + 1], K[ATC_C_TRI_BBOX + 2], K[ATC_C_TRI_BBOX + 3]);
     q.s.n_noise = (int)K[ATC_H_N_NOISE];
+    q.s.off_spawn = (int)K[ATC_H_OFF_SPAWN];
     q.oc = obs_const(K);
     // atc_gym.py:187-189.  Without ATC_M_NORMALIZE the same fma runs with (1, -0): x * 1 + -0 == x for every x, signed
     // zeros included — the step has no branch on the flag and the constants can be requested ahead of the observation.
@@ -750,7 +752,10 @@ __device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, con
 // A by-value kernel argument group where it is needed: the single-step kernel names the argument (the compiler places its
 // kernarg load), a multi-step launch re-reads it from the kernarg segment through this step's opaque zero — a scalar load
 // inside the step instead of registers held (and spilled to vector-register lanes) across the whole step loop.
-#define QGET(member) (ONE ? q.member : kernarg_reread<decltype(q.member)>(offsetof(StepArgs, q) + offsetof(StepDerived, member), zk))
+#ifndef ATC_QGET_REREAD_MIN_W
+#define ATC_QGET_REREAD_MIN_W 1   // developer A/B: multi-step launches of narrower envs name the argument instead of re-reading it
+#endif
+#define QGET(member) ((ONE || W < ATC_QGET_REREAD_MIN_W) ? q.member : kernarg_reread<decltype(q.member)>(offsetof(StepArgs, q) + offsetof(StepDerived, member), zk))
 
 template <int W, bool FULL, bool ONE>
 __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const float* __restrict__ grid,
@@ -781,7 +786,10 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     // sector sees (latency-bound, registers to spare): four per trip (65 536 x 1: 7.4 vs 7.7 us single steps, 4.26 vs 4.44 fused);
     // wider envs two (four cost the fused 65 536 x 16 launch 0.5 us per step)
     constexpr int kWalkBatch = (W == 1) ? 4 : ATC_MVA_BATCH;
-    constexpr bool kResolveAfterScan = ATC_RESOLVE_LATE ? (W >= 16 || (ATC_OBS_FIRST_W1 && W == 1 && ONE)) : (W >= 32);   // (W = 2 .. 8: the unrolled xor scan with the cell
+#ifndef ATC_OBS_FIRST_W1_LOOP
+#define ATC_OBS_FIRST_W1_LOOP 1   // the same order in multi-step launches of one-aircraft envs: 65 536 x 1 fused 3.44-3.45 vs 3.51 us (r04)
+#endif
+    constexpr bool kResolveAfterScan = ATC_RESOLVE_LATE ? (W >= 16 || (ATC_OBS_FIRST_W1 && W == 1 && (ONE || ATC_OBS_FIRST_W1_LOOP))) : (W >= 32);   // (W = 2 .. 8: the unrolled xor scan with the cell
                                                                                    // in flight costs 4 - 22 registers)
     float mva = 0.0f;
     int pi = 0;
@@ -917,7 +925,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     float shaping = 0.0f;
     const ObsConst oc = QGET(oc);
     // (W = 1 has no scan to cover the gather: there the observation goes first)
-    constexpr bool kObsFirst = ATC_OBS_FIRST || (ATC_OBS_FIRST_W1 && W == 1 && ONE);
+    constexpr bool kObsFirst = ATC_OBS_FIRST || (ATC_OBS_FIRST_W1 && W == 1 && (ONE || ATC_OBS_FIRST_W1_LOOP));
     if (kObsFirst && !(ATC_ABLATE & 8)) {
         ob = get_state(oc, a.x, a.y, x32, y32, a.h, phi_real(a.phi), v_real(a.v), 0.0f);
         if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
@@ -1077,13 +1085,8 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             if (FULL && so.term_obs) store_obs(at<float>(so.term_obs, times40(i)), o);
             // (slot through this step's opaque zero: the spawn-record address is then formed here, on the rare path, instead of
             // being carried — and spilled — across the step loop as a 64-bit per-lane pointer)
-            a = spawn(K, p, e, k + zk, episode);
+            a = spawn(K, qs.off_spawn, p, e, k + zk, episode, o);   // state + raw reset observation from the blob's spawn records
             ls.v_changed = true;
-            const QGrid qg = QGET(g);
-            const int neg_k = QGET(r.pos_neg_k);
-            const Obs ob = get_state(QGET(oc), a.x, a.y, pos_to_real(neg_k, qg.pos_x0, a.x), pos_to_real(neg_k, qg.pos_y0, a.y), a.h, phi_real(a.phi), v_real(a.v), 0.0f);
-#pragma unroll
-            for (int c = 0; c < ATC_OBS_DIM; ++c) o[c] = ob.o[c];
         }
         es.total_reward = 0.0f;
         es.n_actions = 0;
@@ -1296,7 +1299,10 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             all_active = __builtin_amdgcn_ballot_w64(!(dl.lane_valid && ((dl.k < 32 ? ((uint32_t)es.amask >> dl.k) : ((uint32_t)(es.amask >> 32) >> (dl.k - 32))) & 1u))) == 0ull;
             mask_dirty = false;
         }
-        const Mid m = step_part_a(gl, qr, QGET(k), QGET(g), dl, tg.v, tg.h, tg.p, ls, es, repeated, !ONE && all_active, ONE);
+#ifndef ATC_KIN_FROM_ARGS
+#define ATC_KIN_FROM_ARGS 1   // 0 (developer A/B): the kinematics constants named as the kernel argument in multi-step launches too
+#endif                        // (the compiler may then keep them in scalar registers across the step loop)
+        const Mid m = step_part_a(gl, qr, ATC_KIN_FROM_ARGS ? QGET(k) : q.k, QGET(g), dl, tg.v, tg.h, tg.p, ls, es, repeated, !ONE && all_active, ONE);
         ATC_STAMP(1);
         Float3 nxt = act;
         const float* act_next = nullptr;   // the next block is fetched during the last step of the current one
@@ -1344,7 +1350,8 @@ k_reset(const float* __restrict__ blob, int B, int N, atc_state_t st, const uint
         const int e = (int)(i / (uint32_t)N), k = (int)(i % (uint32_t)N);
         if (mask && !mask[e]) continue;
         const int episode = first ? 0 : st.stats[(size_t)e * ATC_STAT_WORDS + ATC_STAT_EPISODES];
-        const Aircraft a = spawn(blob, p, e, k, episode);
+        float o[ATC_OBS_DIM];
+        const Aircraft a = spawn(blob, (int)blob[ATC_H_OFF_SPAWN], p, e, k, episode, o);
         reinterpret_cast<int4*>(st.pos_hp)[i] = make_int4(a.x, a.y, __float_as_int(a.h), a.phi);
         st.v_fix[i] = (int32_t)a.v;
         // atc_gym.py:86: last_action = [0,0,0] once, in __init__ — never on reset (quirk Q7) — in the state's formats: 0 kt = 0
@@ -1354,10 +1361,7 @@ k_reset(const float* __restrict__ blob, int B, int N, atc_state_t st, const uint
             st.last_act[3 * (size_t)i + 1] = __float_as_int(0.0f);
             st.last_act[3 * (size_t)i + 2] = phi_store(0.0f);
         }
-        if (obs) {  // mva = 0, atc_gym.py:351
-            const Obs ob = get_state(obs_const(blob), a.x, a.y, pos_to_real(blob, 0, a.x), pos_to_real(blob, 1, a.y), a.h, phi_real(a.phi), v_real(a.v), 0.0f);
-            store_obs(obs + (size_t)i * ATC_OBS_DIM, ob.o);
-        }
+        if (obs) store_obs(obs + (size_t)i * ATC_OBS_DIM, o);   // the raw reset observation (mva = 0, atc_gym.py:351)
     }
 }
 // _get_state(0) of the current state (atc_gym.py:351)
@@ -1532,6 +1536,11 @@ int atc_scenario_create(const float* blob_host, size_t n_words, int device, atc_
     if (n_words < ATC_C_END || blob_host[ATC_H_VERSION] != ATC_BLOB_VERSION || (size_t)blob_host[ATC_H_NWORDS] != n_words)
         return fail_arg("not a scenario blob of this ABI version");
     if ((int)blob_host[ATC_H_N_MVA] > 32) return fail_arg("at most 32 MVA polygons");
+    if ((int)blob_host[ATC_H_N_ENTRY] > 0) {   // the spawn records every reset reads
+        const size_t os = (size_t)blob_host[ATC_H_OFF_SPAWN];
+        if (os == 0 || os % 16 != 0 || os + (size_t)(ATC_MAX_AIRCRAFT + (int)blob_host[ATC_H_N_ENTRY]) * ATC_SPAWN_WORDS > n_words)
+            return fail_arg("spawn records (ATC_H_OFF_SPAWN) missing, misaligned or beyond the blob");
+    }
     if ((int)blob_host[ATC_H_N_NOISE] > 16) return fail_arg("at most 16 noise-abatement areas");
     if (const int og = (int)blob_host[ATC_H_OFF_GRID]) {   // the kernel clamps cell indices into the grid's outermost ring
         if ((size_t)og + ATC_G_HDR > n_words) return fail_arg("lookup grid offset beyond the blob");

@@ -35,7 +35,7 @@ extern "C" {
  * envs/atc/atc_gym.py:45-58,88-110).  Integer fields are stored as exactly representable floats.
  * The float64 master (used by the f64 oracle) has the identical word layout.
  * ------------------------------------------------------------------------------------------- */
-#define ATC_BLOB_VERSION 1013.0f
+#define ATC_BLOB_VERSION 1014.0f
 enum {
     ATC_H_VERSION = 0,   /* ATC_BLOB_VERSION */
     ATC_H_NWORDS = 1,    /* total words */
@@ -49,6 +49,15 @@ enum {
     ATC_H_N_VERTW = 9,   /* words in the vertex pool */
     ATC_H_OFF_SLOT = 10, /* word offset of the slot-lattice spawn table: 64 x (x, y, phi, h) for aircraft slot k =
                             entry k mod n_entry at level (k div n_entry) mod n_levels (the non-random reset) */
+    ATC_H_OFF_SPAWN = 11,/* word offset (64-byte aligned) of the device's SPAWN RECORDS, ATC_SPAWN_WORDS words each: 64 records
+                            for the slot lattice (record k = aircraft slot k), then one per entry point (random resets; the
+                            altitude of those comes from the drawn level).  A record is what AtcGym.reset computes for an
+                            aircraft placed there (atc_gym.py:346-351,365), evaluated once on the host:
+                              words 0..3   x_fix, y_fix (position grid counts), h (float), phi_fix (heading counts) — 32-bit
+                                           PATTERNS in the fp32 device blob (integers are not stored as float values here)
+                              words 4..13  the RAW reset observation _get_state(mva = 0), atc_gym.py:262-277,351
+                              words 14..15 0
+                            The float64 master holds the same quantities as values (nothing reads them there). */
     /* constants block */
     ATC_C_RWY_X = 16, ATC_C_RWY_Y = 17, ATC_C_RWY_H = 18,
     ATC_C_PHI_TO_RWY = 19,                /* (phi_from_runway + 180) % 360, model.py:163,245 */
@@ -91,12 +100,14 @@ enum { ATC_P_MINX = 0, ATC_P_MINY = 1, ATC_P_MAXX = 2, ATC_P_MAXY = 3,
        ATC_P_PENALTY = 7, /* noise-area per-step penalty (0 for MVA polygons) */
        ATC_P_WORDS = 8 };
 /* entry-point record (12 words): x, y, phi, n_levels, levels[8] (flight levels, x100 ft; model.py:309-315) */
+#define ATC_SPAWN_WORDS 16
 enum { ATC_E_X = 0, ATC_E_Y = 1, ATC_E_PHI = 2, ATC_E_NLEV = 3, ATC_E_LEV0 = 4, ATC_E_WORDS = 12, ATC_E_MAXLEV = 8 };
 /* lookup grid (optional acceleration structure for Airspace.find_mva, model.py:282-289; results identical to the
  * ordered polygon scan by construction — see atc_hip/scenario.py:build_grid).  16-byte aligned in the blob.
  *   header 8 words : x0, y0, 1/cell, nx, ny, offset of the edge pool (from grid start), number of edge records, 0
  *   cells  ny*nx*2 : (c, v) with |c| = code + 64 * noise mask (bit q: the bounds of noise-abatement area q meet the cell)
  *                    + 2^22 if the bounds of the corridor's horizontal triangle (ATC_C_TRI_BBOX) meet the cell
+ *                    + 2^23 (ATC_G_CELL_LINE) if the cell is a SPLIT cell, see below
  *                    c > 0  : dirty cell, code = n_records (< 64), v = first record: walk that many edge records
  *                    c <= 0 : clean cell, code = polygon + 1 and v = MVA height — every point has this answer;
  *                             code = 0: outside the airspace
@@ -108,6 +119,10 @@ enum { ATC_E_X = 0, ATC_E_Y = 1, ATC_E_PHI = 2, ATC_E_NLEV = 3, ATC_E_LEV0 = 4, 
  *                    code = 16 * polygon index + flags                                                                */
 enum { ATC_G_X0 = 0, ATC_G_Y0 = 1, ATC_G_INV = 2, ATC_G_NX = 3, ATC_G_NY = 4, ATC_G_OFF_POOL = 5, ATC_G_NREC = 6,
        ATC_G_HDR = 8, ATC_GE_WORDS = 8 };
+#define ATC_G_CELL_LINE (1u << 23) /* |c| flag of a SPLIT cell: its first record (not counted in `code`) is a LINE record
+                                      G = p1x, p1y, dx/dy, margin   M = left polygon + 1, left height, right polygon + 1, right height:
+                                      xl = p1x + (y - p1y) dx/dy;  x < xl - margin -> the left answer, x > xl + margin -> the right
+                                      one (polygon + 1 = 0: outside the airspace), else walk the `code` ordinary records behind it */
 #define ATC_GE_TERM 1    /* terminator: (crossing parity xor BASE) and the bounds test (model.py:286-287) decide now */
 #define ATC_GE_CERTAIN 2 /* the cell lies entirely left of this edge: crossing iff the two y tests pass */
 #define ATC_GE_LAST 4    /* last edge of a polygon whose bounds contain the whole cell: parity xor BASE decides now */

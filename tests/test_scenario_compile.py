@@ -47,7 +47,25 @@ def test_blob_layout_roundtrip():
         assert np.array_equal(ring[0], ring[-1])
         nverts += n
     assert nverts == 123  # closed-ring vertex counts of LOWW sum to 123
-    assert np.array_equal(c.blob32, b.astype(np.float32))
+    # the device blob is the float32 image of the master — except the integer words of the spawn records, which are 32-bit
+    # PATTERNS there (include/atc_step.h: ATC_H_OFF_SPAWN)
+    sp, n_sp = int(b[L.H_OFF_SPAWN]), L.MAX_AIRCRAFT + int(b[L.H_N_ENTRY])
+    assert sp % 16 == 0 and sp + n_sp * L.SPAWN_WORDS <= len(b)
+    img = b.astype(np.float32)
+    keep = np.ones(len(b), bool)
+    recs = sp + L.SPAWN_WORDS * np.arange(n_sp)
+    for w in (0, 1, 3):
+        keep[recs + w] = False
+    assert np.array_equal(c.blob32[keep], img[keep])
+    ints = c.blob32.view(np.int32)
+    for r in recs:   # counts as patterns == counts as values in the master; the observation words are plain floats
+        assert [int(ints[r]), int(ints[r + 1]), int(ints[r + 3])] == [int(b[r]), int(b[r + 1]), int(b[r + 3])]
+    # record 0 = the reference's default reset (scenarios.py:205-207, atc_gym.py:347-351): (10, 51) at 15 000 ft heading 90, 250 kt
+    o = c.blob32[sp + 4:sp + 14]
+    assert list(o[:6]) == [10.0, 51.0, 15000.0, 90.0, 250.0, 15000.0]
+    fx, fy = c.corridor["faf"]
+    assert abs(o[7] - np.hypot(fx - 10, fy - 51)) < 1e-5 and abs(o[8] - np.degrees(np.arctan2(fy - 51, fx - 10))) < 1e-5
+    assert o[9] == ((90 - 340 + 180) % 360) - 180 and abs(o[6] - (318.4 * o[7] + c.faf_mva - 200)) < 1e-3
     # every integer-valued field survives the float32 device copy
     for idx in (L.H_NWORDS, L.H_OFF_POLY, L.H_OFF_VERT, L.H_OFF_ENTRY):
         assert float(c.blob32[idx]) == b[idx]
@@ -81,6 +99,15 @@ def _walk_grid(b, g, tabs, tabs_h, x, y):
         return code - 1
     n = code
     pool = g + int(b[g + L.G_OFF_POOL])
+    if int(abs(b[c])) & (1 << 23):   # split cell: LINE record first (csrc/atc_device.h: mva_resolve)
+        r = b[pool + v * L.GE_WORDS: pool + (v + 1) * L.GE_WORDS]
+        xl = (y - r[1]) * r[2] + r[0]
+        for cond, k in ((x < xl - r[3], 4), (x > xl + r[3], 6)):
+            if cond:
+                if r[k] > 0:
+                    assert r[k + 1] == tabs_h[int(r[k]) - 1]
+                return int(r[k]) - 1
+        v += 1
     inside = False
     for e in range(n):
         r = b[pool + (v + e) * L.GE_WORDS: pool + (v + e + 1) * L.GE_WORDS]
@@ -125,6 +152,8 @@ def test_grid_matches_ordered_scan_on_host(scen, cell):
             t = rng.uniform(0, 1, 12)[:, None]
             pts.append(ring[k][None, :] * (1 - t) + ring[k + 1][None, :] * t + rng.normal(0, 2e-4, (12, 2)))
             pts.append(ring[k][None, :] + rng.normal(0, 1e-5, (3, 2)))
+            # either side of a split cell's margin band (a few 1e-3 nm: atc_hip/scenario.py:_line_split) and inside it
+            pts.append(ring[k][None, :] * (1 - t) + ring[k + 1][None, :] * t + rng.normal(0, 4e-3, (12, 2)))
     pts = np.concatenate(pts)
     n_dirty = 0
     for x, y in pts:
@@ -139,7 +168,7 @@ def test_grid_matches_ordered_scan_on_host(scen, cell):
     # and the marked cells are few
     nx, ny = int(b[g + L.G_NX]), int(b[g + L.G_NY])
     tb = b[L.C_TRI_BBOX:L.C_TRI_BBOX + 4]
-    cand = (codes >> 22).reshape(ny, nx)
+    cand = ((codes >> 22) & 1).reshape(ny, nx)
     for x in np.linspace(tb[0], tb[2], 41):
         for y in np.linspace(tb[1], tb[3], 41):
             assert cand[int((y - b[g + L.G_Y0]) * b[g + L.G_INV]), int((x - b[g + L.G_X0]) * b[g + L.G_INV])] == 1
@@ -147,7 +176,11 @@ def test_grid_matches_ordered_scan_on_host(scen, cell):
     border = np.concatenate([cells.reshape(ny, nx, 2)[0].ravel(), cells.reshape(ny, nx, 2)[-1].ravel(),
                              cells.reshape(ny, nx, 2)[:, 0].ravel(), cells.reshape(ny, nx, 2)[:, -1].ravel()])
     assert not border.any()   # the outermost ring: clean, outside, no candidates of any kind
-    print(scen, cell, 'dirty cells', n_dirty, 'of', len(cells), 'records per dirty cell %.2f' % ((codes & 63)[cells[:, 0] > 0].mean()))
+    n_split = int(((codes >> 23) & 1)[cells[:, 0] > 0].sum())
+    if scen == "LOWW":
+        assert n_split > (0.6 if cell <= 0.5 else 0.4) * n_dirty     # most dirty cells of a real sector are cut by one line only
+    print(scen, cell, 'dirty cells', n_dirty, 'of', len(cells), 'split', n_split,
+          'records per dirty cell %.2f' % ((codes & 63)[cells[:, 0] > 0].mean()))
 
 
 @pytest.mark.parametrize("cell", [0.125, 0.25, 0.5, 1.0])
