@@ -5,10 +5,10 @@ lengths) once per report interval — `torch.distributed` backend "nccl" (= RCCL
 SubprocVecEnv's pipe per worker + Monitor CSVs, learning/atc-gym-stable-baselines.py:69-80.)
 
 Round 4: the exchange is ONE collective per report (the statistics packed into one [rows, k] 32-bit tensor) and it is
-ASYNCHRONOUS — `StatsExchange`: a snapshot at the end of a rollout, the all-gather issued on the backend's own stream while the
-next rollout's step kernels are already being queued, the wait after they are queued.  A 20-step rollout is 0.4 ms of GPU
-work; two blocking all-gathers and a barrier inside that window would have cost a fifth of it on a path that has no
-step-path communication at all.
+ASYNCHRONOUS — `StatsExchange`: a snapshot at the end of a rollout, the all-gather issued from a side stream so that it runs
+beside whatever the caller does next (the bench: the closing barrier and the next rollout's start-up), the wait where the
+result is needed.  A 20-step rollout is 0.4 ms of GPU work; two blocking all-gathers and a barrier inside that window would
+have cost a fifth of it on a path that has no step-path communication at all.
 
 Works on CPU tensors with the gloo backend too (tests/test_dist_gloo.py, world_size 2)."""
 import os

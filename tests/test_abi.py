@@ -104,7 +104,10 @@ def test_integration_stub_runs():
     from envs.atc import atc_gym
     env = atc_gym.AtcGym()
     s0 = env.reset()
-    assert np.array_equal(ns["out"]["obs"].cpu().numpy(), s0)
+    # (atc_reset reads the raw reset observation from the sector's spawn record — evaluated in float64 by the compiler —,
+    # AtcGym.reset places the aircraft and asks atc_observe, the device's fp32 _get_state: the parity bar, not bit equality)
+    o0 = ns["out"]["obs"].cpu().numpy()
+    assert np.all(np.abs(o0 - s0) <= 1e-5 * np.maximum(1.0, np.abs(s0)))
     rng = np.random.default_rng(2)
     for t in range(200):
         if t % 20 == 0:
