@@ -268,9 +268,25 @@ __device__ __forceinline__ MvaCell mva_cell_load(const float* __restrict__ grid,
     }
     return c;
 }
+// A dirty cell's first record (the LINE record of a split cell), requested ahead of its use: the second dependent L2 round trip of
+// the lookup then overlaps the observation arithmetic instead of stalling the wavefront (clean cells request nothing).
+struct MvaPre {
+    float4 g, m;
+};
+__device__ __forceinline__ MvaPre mva_prefetch(const float* __restrict__ grid, const GridHdr& gh, const MvaCell& c) {
+    MvaPre p;
+    p.g = p.m = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (grid && c.cell.x > 0.0f) {
+        const char* pool = reinterpret_cast<const char*>(grid + gh.off_pool);
+        const uint32_t rec0 = 32u * (uint32_t)(int)c.cell.y;
+        p.g = *reinterpret_cast<const float4*>(pool + rec0);
+        p.m = *reinterpret_cast<const float4*>(pool + rec0 + 16u);
+    }
+    return p;
+}
 template <int kBatch = ATC_MVA_BATCH>
 __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const float* __restrict__ grid, const GridHdr& gh,
-                                           const MvaCell& c, float x, float y, float* height) {
+                                           const MvaCell& c, float x, float y, float* height, const MvaPre* pre = nullptr) {
     *height = 0.0f;
     if (grid) {
         const float2 cell = c.cell;
@@ -294,8 +310,9 @@ __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const fl
         // x-intersection, and the two answers: one 32-byte fetch, one fma, two compares — no division, no loop.  Only a point
         // inside the margin band (or in a cell with a vertex or a second border) walks the ordinary records behind it.
         if ((uint32_t)(int)fabsf(cell.x) & ATC_G_CELL_LINE) {
-            const float4 g = *reinterpret_cast<const float4*>(pool + rec0);          // p1x, p1y, dx/dy, margin
-            const float4 m = *reinterpret_cast<const float4*>(pool + rec0 + 16u);    // left polygon + 1, height, right polygon + 1, height
+            // (p1x, p1y, dx/dy, margin | left polygon + 1, height, right polygon + 1, height; already requested by mva_prefetch?)
+            const float4 g = pre ? pre->g : *reinterpret_cast<const float4*>(pool + rec0);
+            const float4 m = pre ? pre->m : *reinterpret_cast<const float4*>(pool + rec0 + 16u);
             const float xl = fmaf(y - g.y, g.z, g.x);
             if (x < xl - g.w) {
                 *height = m.y;

@@ -575,7 +575,11 @@ struct StepOut {        // per-step output bases (uniform pointers)
 #endif
 };
 
-template <int W>
+// ALLV ("all valid"): the launch's slots are all aircraft — N == W and B * W a multiple of the workgroup size (every BASELINE
+// configuration) — so the validity flags are compile-time true: no clamped indices, no validity terms in the active masks, no
+// exec-mask regions around the stores, the full-wavefront observation store unconditionally.  Fused 65 536 x 16: 11.9 vs 12.3 us
+// per step, 8 192 x 16 2.55 vs 2.70 (r04, same box).  Chosen by the host per launch; other shapes take the general kernels.
+template <int W, bool ALLV>
 __device__ __forceinline__ LaneIds make_ids(uint32_t slot0, int B, int N) {
     LaneIds d;
     d.tid = threadIdx.x;
@@ -583,9 +587,15 @@ __device__ __forceinline__ LaneIds make_ids(uint32_t slot0, int B, int N) {
     d.slot0 = slot0;
     const uint32_t slots = (uint32_t)B * (uint32_t)W;
     const uint32_t slot = slot0 + d.tid;
+    d.k = (int)(slot % W);
+    if (ALLV) {
+        d.env_valid = d.lane_valid = d.wave_full = true;
+        d.e = (int)(slot / W);
+        d.i = slot;   // N == W: env * N + k
+        return d;
+    }
     d.env_valid = slot < slots;
     d.e = d.env_valid ? (int)(slot / W) : B - 1;  // clamped: loads stay in bounds, results are never stored
-    d.k = (int)(slot % W);
     d.lane_valid = d.env_valid && d.k < N;
     d.i = d.lane_valid ? (uint32_t)d.e * (uint32_t)N + (uint32_t)d.k : (uint32_t)B * (uint32_t)N - 1u;
     if (ATC_ABLATE & 64) {  // developer-only "no HBM traffic" timing: every workgroup works on the first 256 aircraft
@@ -925,7 +935,18 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     float shaping = 0.0f;
     const ObsConst oc = QGET(oc);
     // (W = 1 has no scan to cover the gather: there the observation goes first)
-    constexpr bool kObsFirst = ATC_OBS_FIRST || (ATC_OBS_FIRST_W1 && W == 1 && (ONE || ATC_OBS_FIRST_W1_LOOP));
+    // A dirty cell's first record (the LINE record of a split cell) is requested BEFORE the observation arithmetic, which then comes
+    // before the resolve: the lookup's second dependent L2 trip overlaps ~100 instructions instead of stalling the wavefront.
+    // Measured per width and launch form (r04, same box, two rounds): single steps of 16-aircraft envs 17.81 vs 18.03 us at
+    // 65 536 envs, one-aircraft envs 6.58-6.61 vs 6.60-6.67 single / 3.42 vs 3.47-3.50 fused; NOT the fused 16-aircraft launch
+    // (8 B scratch under its 80-register bound: 2.73-2.77 vs 2.66 us at 8 192 envs) and not the 64-aircraft kernels (8.50 vs 8.30).
+#ifndef ATC_MVA_PREFETCH
+#define ATC_MVA_PREFETCH(W, ONE) ((W) == 1 || ((ONE) && (W) == 16))
+#endif
+    constexpr bool kPrefetch = ATC_MVA_PREFETCH(W, ONE) && kResolveAfterScan;
+    constexpr bool kObsFirst = ATC_OBS_FIRST || kPrefetch || (ATC_OBS_FIRST_W1 && W == 1 && (ONE || ATC_OBS_FIRST_W1_LOOP));
+    MvaPre pre;
+    if (kPrefetch) pre = mva_prefetch(grid, QGET(g.gh), m.cell);
     if (kObsFirst && !(ATC_ABLATE & 8)) {
         ob = get_state(oc, a.x, a.y, x32, y32, a.h, phi_real(a.phi), v_real(a.v), 0.0f);
         if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
@@ -933,7 +954,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     // ---- MVA floor (atc_gym.py:146-161), second half ---------------------------------------------------------------------
     if (kResolveAfterScan) {
         float hgt = 0.0f;
-        pi = (ATC_ABLATE & 1) ? 0 : mva_resolve<kWalkBatch>(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt);
+        pi = (ATC_ABLATE & 1) ? 0 : mva_resolve<kWalkBatch>(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt, kPrefetch ? &pre : nullptr);
         mva = hgt;                                 // atc_gym.py:161: mva = 0 outside (mva_resolve leaves the height at 0)
         fl |= noise_areas(K, grid, qs.n_noise, m.cell, x32, y32, a.h);
     }
@@ -1178,7 +1199,7 @@ __device__ __forceinline__ void store_env_state(const atc_state_t& st, const Lan
     }
 }
 
-template <int W, bool FULL, bool ONE>  // ONE: single-step launch (T == 1)
+template <int W, bool FULL, bool ONE, bool ALLV>  // ONE: single-step launch (T == 1); ALLV: every slot is an aircraft (make_ids)
 __global__ void __launch_bounds__(kBlock, (ONE ? ATC_MIN_WAVES : ((FULL || W <= 8 || W >= 32) ? ATC_MIN_WAVES_LOOP - 1 : ATC_MIN_WAVES_LOOP)))
 k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int hold, atc_state_t st,
        const float* __restrict__ actions, atc_out_t out, atc_params_t p, StepDerived q, InlineAction ia) {
@@ -1194,7 +1215,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     const unsigned long long t_launch = __builtin_amdgcn_s_memtime();
 #endif
     const uint32_t BN = (uint32_t)B * (uint32_t)N;      // host guarantees B*N*40 bytes < 4 GiB: 32-bit lane offsets
-    const LaneIds d = make_ids<W>(blockIdx.x * kBlock, B, N);
+    const LaneIds d = make_ids<W, ALLV>(blockIdx.x * kBlock, B, N);
 
     // ---- load persistent state (16-byte records; the W lanes of an env share the env record) -------------------------
     const int4 e0 = *at<int4>(st.env, (uint32_t)d.e * (ATC_ENV_WORDS * 4u));
@@ -1455,7 +1476,7 @@ static size_t lds_bytes(const atc_scenario*, bool pair_scan, bool step_kernel = 
     return w * sizeof(float);
 }
 
-template <int W, bool FULL, bool ONE>
+template <int W, bool FULL, bool ONE, bool ALLV>
 static int launch_step2(const atc_scenario* s, int B, int N, int T, int hold, const atc_state_t* st, const float* actions,
                         const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
 #ifdef ATC_LDS_PAD_LOOP   // developer A/B builds: cap the multi-step launch's workgroups per CU through its LDS allocation
@@ -1464,11 +1485,11 @@ static int launch_step2(const atc_scenario* s, int B, int N, int T, int hold, co
     const size_t lds = lds_bytes(s, W >= 32, true);
 #endif
     if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<W, FULL, ONE>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<W, FULL, ONE, ALLV>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long long slots = (long long)B * W;
     const int grid = (int)((slots + kBlock - 1) / kBlock);  // one workgroup per 256 slots, no grid-stride loop
-    hipLaunchKernelGGL((k_step<W, FULL, ONE>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->off_grid, B, N, T, hold, *st, actions, *out, *p, derive(*p, s), inline_action());
+    hipLaunchKernelGGL((k_step<W, FULL, ONE, ALLV>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->off_grid, B, N, T, hold, *st, actions, *out, *p, derive(*p, s), inline_action());
     HIP_TRY(hipGetLastError());
     return ATC_OK;
 }
@@ -1476,14 +1497,19 @@ template <int W>
 static int launch_step(const atc_scenario* s, int B, int N, int T, int hold, const atc_state_t* st, const float* actions,
                        const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
     const bool full = out->raw_obs || out->ac_reward || out->min_sep || out->term_obs || out->packet;
+    // every slot of the launch is an aircraft: the fast variant then runs its all-valid instantiation (make_ids)
+    const bool allv = !full && N == W && ((long long)B * W) % kBlock == 0 && !(ATC_ABLATE & 64);
     // Multi-step launches keep the state in registers across the steps; the run-time step loop costs the kernel its
     // occupancy (4 wavefronts per SIMD against 5-7 for the straight-line single step) but issuing T single-step launches
     // instead is slower at every size (65 536 x 16, T = 20, [T, ...] outputs: 35.0 vs 27.1 us per step).
-    if (T > 1)
-        return full ? launch_step2<W, true, false>(s, B, N, T, hold, st, actions, out, p, stream)
-                    : launch_step2<W, false, false>(s, B, N, T, hold, st, actions, out, p, stream);
-    return full ? launch_step2<W, true, true>(s, B, N, 1, 1, st, actions, out, p, stream)
-                : launch_step2<W, false, true>(s, B, N, 1, 1, st, actions, out, p, stream);
+    if (T > 1) {
+        if (full) return launch_step2<W, true, false, false>(s, B, N, T, hold, st, actions, out, p, stream);
+        return allv ? launch_step2<W, false, false, true>(s, B, N, T, hold, st, actions, out, p, stream)
+                    : launch_step2<W, false, false, false>(s, B, N, T, hold, st, actions, out, p, stream);
+    }
+    if (full) return launch_step2<W, true, true, false>(s, B, N, 1, 1, st, actions, out, p, stream);
+    return allv ? launch_step2<W, false, true, true>(s, B, N, 1, 1, st, actions, out, p, stream)
+                : launch_step2<W, false, true, false>(s, B, N, 1, 1, st, actions, out, p, stream);
 }
 
 // argument checks shared by every entry point that touches the env state

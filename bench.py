@@ -769,7 +769,8 @@ def main():
                        "rank_seeds": [int(v) for v in rank_seeds.reshape(-1).tolist()]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_step<%d, false, %s>" % (1 << max(0, (N - 1).bit_length()), "false" if args.rollout else "true"),
+                         "kernel": "k_step<%d, false, %s, %s>" % (1 << max(0, (N - 1).bit_length()), "false" if args.rollout else "true",
+                                                                  "true" if (N & (N - 1)) == 0 and (B // S * N) % 256 == 0 else "false"),
                          "avg_launch_ms": launch_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "concurrent_launches": S,
                          "working_set_bytes": working_set_bytes(B, N, T), "fits_infinity_cache": working_set_bytes(B, N, T) <= INFINITY_CACHE_BYTES,

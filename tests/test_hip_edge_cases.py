@@ -538,3 +538,37 @@ def test_envs_with_different_parameters_interleaved_on_one_thread():
         assert np.array_equal(env.pos_hp[:, 0].cpu().numpy(), orc.px) and np.array_equal(env.h.cpu().numpy(), orc.h)
         assert np.array_equal(env.timesteps.cpu().numpy(), orc.timesteps)
         env.close()
+
+
+@pytest.mark.parametrize("N", [1, 16, 64])
+def test_all_valid_instantiation_equals_general_kernels(N):
+    """A batch that is a whole number of workgroups of aircraft slots runs the ALL-VALID kernel instantiation (every validity flag a
+    compile-time constant: csrc/atc_step.hip make_ids<W, ALLV>); one env more and the launch takes the general kernels.  The envs
+    the two batches share must come out bit-identical — single steps (with the held-action hint) and atc_rollout_hold — and a
+    batch with the optional outputs (FULL kernels, never all-valid) must agree with both."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+    scn = scenarios.LOWWDense() if N == 64 else scenarios.LOWW(random_entrypoints=N > 1)
+    B = 2 * max(1, 256 // N) * (4 if N == 1 else 1)
+    envs = [AtcVecEnv(B, N, scenario=scn, seed=9), AtcVecEnv(B + 1, N, scenario=scn, seed=9),
+            AtcVecEnv(B, N, scenario=scn, seed=9, want_raw_obs=True)]
+    g = torch.Generator(device="cpu").manual_seed(N)
+    for t in range(120):
+        if t % 20 == 0:
+            a = (torch.rand((B + 1, N, 3), generator=g) * 2 - 1).cuda()
+        res = [e.step(a[:e.B].contiguous(), held=t % 20 != 0) for e in envs]
+        for o, r, d, info in res[1:]:
+            assert torch.equal(res[0][0], o[:B]) and torch.equal(res[0][1], r[:B]) and torch.equal(res[0][2], d[:B])
+            assert torch.equal(res[0][3]["flags"], info["flags"][:B])
+    for j in range(3):
+        blocks = (torch.rand((1, B + 1, N, 3), generator=g) * 2 - 1).cuda()
+        outs = [e.rollout(blocks[:, :e.B].contiguous(), hold=20) for e in envs[:2]]
+        for k in ("obs", "reward", "done", "flags"):
+            assert torch.equal(outs[0][k], outs[1][k][:, :B]), k
+    for name in ("pos_hp", "v_fix", "last_act"):
+        assert torch.equal(getattr(envs[0], name), getattr(envs[1], name)[:B * N]), name
+    assert torch.equal(envs[0].env, envs[1].env[:B]) and torch.equal(envs[0].stats, envs[1].stats[:B])
+    assert int(envs[0].episodes.sum()) > B      # episodes ended and restarted inside the comparison
+    for e in envs:
+        e.close()

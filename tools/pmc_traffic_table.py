@@ -55,7 +55,8 @@ for name, B, N, roll, held in WORK:
                 "16-byte state records plus 12-byte action records once per %d steps" % (roll or 1),
                 bench.working_set_bytes(B, N, roll or 1) >> 20))
     out.append({"abi": L.ABI_VERSION, "read_correction_note": note, "envs": B, "aircraft": N, "rollout": roll, "held_hint": held,
-                "kernel": "k_step<%d,false,%s>%s" % (W, "false" if roll else "true", " T=%d hold=%d" % (roll, roll) if roll else ""),
+                "kernel": "k_step<%d,false,%s,%s>%s" % (W, "false" if roll else "true", "true" if N == W and (B * W) % 256 == 0 else "false",
+                                                     " T=%d hold=%d" % (roll, roll) if roll else ""),
                 "FETCH_SIZE_KB_raw": round(fetch, 1), "WRITE_SIZE_KB": round(write, 1), "hbm_bytes_per_launch": hbm,
                 "algorithmic_bytes_per_launch": alg, "ratio": round(ratio, 4), "dispatches": min(nf, nw),
                 "source": "profiles/%s_pmc_traffic.json (tools/pmc_traffic_all.sh %s: two separate rocprofv3 --pmc passes per workload, "
