@@ -269,20 +269,73 @@ __device__ __forceinline__ MvaCell mva_cell_load(const float* __restrict__ grid,
     return c;
 }
 // A dirty cell's first record (the LINE record of a split cell), requested ahead of its use: the second dependent L2 round trip of
-// the lookup then overlaps the observation arithmetic instead of stalling the wavefront (clean cells request nothing).
+// the lookup then overlaps the observation arithmetic instead of stalling the wavefront.  Wave-uniform: if any lane's cell is dirty,
+// EVERY lane requests a record (lanes in clean cells record 0 — one shared cache line): no per-lane branch around the loads.
 struct MvaPre {
     float4 g, m;
 };
+__device__ __forceinline__ uint32_t first_record(const MvaCell& c) {   // byte offset in the pool (0 for clean cells)
+    return (c.cell.x > 0.0f) ? 32u * (uint32_t)(int)c.cell.y : 0u;
+}
 __device__ __forceinline__ MvaPre mva_prefetch(const float* __restrict__ grid, const GridHdr& gh, const MvaCell& c) {
     MvaPre p;
     p.g = p.m = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (grid && c.cell.x > 0.0f) {
+    if (grid && __builtin_amdgcn_ballot_w64(c.cell.x > 0.0f) != 0ull) {
         const char* pool = reinterpret_cast<const char*>(grid + gh.off_pool);
-        const uint32_t rec0 = 32u * (uint32_t)(int)c.cell.y;
+        const uint32_t rec0 = first_record(c);
         p.g = *reinterpret_cast<const float4*>(pool + rec0);
         p.m = *reinterpret_cast<const float4*>(pool + rec0 + 16u);
     }
     return p;
+}
+// The walk of a dirty cell's ordinary records (rec0 = its first, n of them): the reference's crossing test per edge record, polygon by
+// polygon in priority order (see above).  Returns the polygon index (-1: none) and its height.
+template <int kBatch>
+__device__ __forceinline__ int mva_walk(const char* __restrict__ pool, uint32_t rec0, int n, float x, float y, float* height) {
+    *height = 0.0f;
+    bool inside = false;
+    // Records are fetched in batches of kBatch (both 16-byte halves of each, all loads issued before the first use):
+    // one L2 round trip per batch instead of one per record.  Indices past the list are clamped (loads stay in
+    // bounds) and their records ignored.
+    for (int base = 0; base < n; base += kBatch) {
+        float4 g[kBatch], m[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int e = min(base + u, n - 1);
+            g[u] = *reinterpret_cast<const float4*>(pool + (rec0 + 32u * (uint32_t)e));
+            m[u] = *reinterpret_cast<const float4*>(pool + (rec0 + 32u * (uint32_t)e + 16u));
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            if (base + u < n) {
+                const int code = (int)m[u].w;
+                bool decide, ok = true;
+                if (code & ATC_GE_TERM) {  // g = polygon bounds (model.py:286)
+                    decide = true;
+                    ok = g[u].x <= x && x <= g[u].z && g[u].y <= y && y <= g[u].w;
+                } else {
+                    // the three cheap tests of model.py:328-330 (m.x / m.y = min / max of the edge's y, precomputed)
+                    if (y > m[u].x && y <= m[u].y && x <= fmaxf(g[u].x, g[u].z)) {
+                        bool cross = (code & ATC_GE_CERTAIN) != 0;
+                        if (!cross) {
+                            const float xints = (y - g[u].y) * (g[u].z - g[u].x) / (g[u].w - g[u].y) + g[u].x;
+                            cross = (g[u].x == g[u].z) || x <= xints;
+                        }
+                        inside = inside != cross;
+                    }
+                    decide = (code & ATC_GE_LAST) != 0;
+                }
+                if (decide) {
+                    if ((inside != ((code & ATC_GE_BASE) != 0)) && ok) {
+                        *height = m[u].z;
+                        return code >> 4;
+                    }
+                    inside = false;
+                }
+            }
+        }
+    }
+    return -1;
 }
 template <int kBatch = ATC_MVA_BATCH>
 __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const float* __restrict__ grid, const GridHdr& gh,
@@ -290,80 +343,41 @@ __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const fl
     *height = 0.0f;
     if (grid) {
         const float2 cell = c.cell;
-        const int code = (int)fabsf(cell.x) & 63;
-        if (!(cell.x > 0.0f)) {  // clean cell: polygon + 1 (0 = outside the airspace), height
-            *height = cell.y;
-            return code - 1;
-        }
-        const int n = code;
+        const uint32_t bits = (uint32_t)(int)fabsf(cell.x);
+        const int code = (int)(bits & 63u);
+        const bool dirty = cell.x > 0.0f;
+        int res = code - 1;               // clean cell: polygon + 1 (0 = outside the airspace), height
+        float h = dirty ? 0.0f : cell.y;
 #ifdef ATC_ABLATE_WALK
-        *height = 3000.0f;  // developer-only timing ablation: dirty cells answered without walking their edge list
-        return 1;
+        if (dirty) { res = 1; h = 3000.0f; }  // developer-only timing ablation: dirty cells answered without their records
+        *height = h;
+        return res;
 #endif
-        // Records are fetched in batches of kBatch (both 16-byte halves of each, all loads issued before the first use):
-        // one L2 round trip per batch instead of one per record.  Indices past the list are clamped (loads stay in
-        // bounds) and their records ignored.
-        const char* pool = reinterpret_cast<const char*>(grid + gh.off_pool);   // uniform
-        uint32_t rec0 = 32u * (uint32_t)(int)cell.y;                                // this lane's first record, bytes
-        // SPLIT cell (atc_hip/scenario.py:_line_split — nine dirty cells in ten): one line runs through the whole cell and each
-        // side of it has one answer.  The LINE record holds the line, a margin that covers every rounding of the reference's
-        // x-intersection, and the two answers: one 32-byte fetch, one fma, two compares — no division, no loop.  Only a point
-        // inside the margin band (or in a cell with a vertex or a second border) walks the ordinary records behind it.
-        if ((uint32_t)(int)fabsf(cell.x) & ATC_G_CELL_LINE) {
+        // Some lane's cell is cut by a border (wave-uniform test; nine wavefronts in ten at the headline size).  SPLIT cells
+        // (atc_hip/scenario.py:_line_split — four dirty cells in five) are answered by their LINE record: the line, a margin that
+        // covers every rounding of the reference's x-intersection, and the answer of either side — one 32-byte fetch, one fma, two
+        // compares, selects; written for the whole wavefront without a per-lane branch (lanes in clean cells evaluate record 0 and
+        // discard the result).  Only a point inside the margin band, or in a cell with a vertex or a second border, walks the
+        // ordinary records behind it — behind a second wave-uniform test.
+        if (__builtin_amdgcn_ballot_w64(dirty) != 0ull) {
+            const char* pool = reinterpret_cast<const char*>(grid + gh.off_pool);   // uniform
+            const uint32_t rec0 = first_record(c);
             // (p1x, p1y, dx/dy, margin | left polygon + 1, height, right polygon + 1, height; already requested by mva_prefetch?)
             const float4 g = pre ? pre->g : *reinterpret_cast<const float4*>(pool + rec0);
             const float4 m = pre ? pre->m : *reinterpret_cast<const float4*>(pool + rec0 + 16u);
             const float xl = fmaf(y - g.y, g.z, g.x);
-            if (x < xl - g.w) {
-                *height = m.y;
-                return (int)m.x - 1;
-            }
-            if (x > xl + g.w) {
-                *height = m.w;
-                return (int)m.z - 1;
-            }
-            rec0 += 32u;
-        }
-        bool inside = false;
-        for (int base = 0; base < n; base += kBatch) {
-            float4 g[kBatch], m[kBatch];
-#pragma unroll
-            for (int u = 0; u < kBatch; ++u) {
-                const int e = min(base + u, n - 1);
-                g[u] = *reinterpret_cast<const float4*>(pool + (rec0 + 32u * (uint32_t)e));
-                m[u] = *reinterpret_cast<const float4*>(pool + (rec0 + 32u * (uint32_t)e + 16u));
-            }
-#pragma unroll
-            for (int u = 0; u < kBatch; ++u) {
-                if (base + u < n) {
-                    const int code = (int)m[u].w;
-                    bool decide, ok = true;
-                    if (code & ATC_GE_TERM) {  // g = polygon bounds (model.py:286)
-                        decide = true;
-                        ok = g[u].x <= x && x <= g[u].z && g[u].y <= y && y <= g[u].w;
-                    } else {
-                        // the three cheap tests of model.py:328-330 (m.x / m.y = min / max of the edge's y, precomputed)
-                        if (y > m[u].x && y <= m[u].y && x <= fmaxf(g[u].x, g[u].z)) {
-                            bool cross = (code & ATC_GE_CERTAIN) != 0;
-                            if (!cross) {
-                                const float xints = (y - g[u].y) * (g[u].z - g[u].x) / (g[u].w - g[u].y) + g[u].x;
-                                cross = (g[u].x == g[u].z) || x <= xints;
-                            }
-                            inside = inside != cross;
-                        }
-                        decide = (code & ATC_GE_LAST) != 0;
-                    }
-                    if (decide) {
-                        if ((inside != ((code & ATC_GE_BASE) != 0)) && ok) {
-                            *height = m[u].z;
-                            return code >> 4;
-                        }
-                        inside = false;
-                    }
-                }
+            const bool line = dirty && (bits & ATC_G_CELL_LINE) != 0u;
+            const bool left = x < xl - g.w, right = x > xl + g.w;
+            const bool decided = line && (left || right);
+            res = decided ? (int)(left ? m.x : m.z) - 1 : res;
+            h = decided ? (left ? m.y : m.w) : h;
+            const bool walk = dirty && !decided;
+            if (__builtin_amdgcn_ballot_w64(walk) != 0ull) {
+                if (walk) res = mva_walk<kBatch>(pool, rec0 + (line ? 32u : 0u), code, x, y, &h);
             }
         }
-        return -1;
+        *height = h;
+        return res;
     }
     const float* tab = K + (int)K[ATC_H_OFF_POLY];
     const int n_mva = (int)K[ATC_H_N_MVA];
