@@ -15,16 +15,25 @@ from . import lib as _lib
 
 
 def auto_grid_cell(num_envs, num_aircraft):
-    """Cell size [nm] of the MVA lookup grid for a batch: 0.125 nm while the batch is at most 262 144 aircraft slots, 0.25 nm
-    beyond.  A finer grid puts fewer aircraft into cells an edge passes through (whose edge lists every wavefront holding such
-    an aircraft has to walk — the longest dependent chain of a step), which is what a small, latency-bound batch feels
-    (65 536 x 1: 6.8 vs 7.3 us single steps, 3.5 vs 3.9 fused; 8 192 x 16: 2.7 vs 2.9 fused); a large batch is bound by HBM
-    or instruction issue and only pays for the bigger table in each XCD's L2 (3 MB vs 0.9 MB for LOWW; 65 536 x 16: 18.3 vs
-    18.1 us).  Results do not depend on the cell size (the lookup is exact for any)."""
+    """Cell size [nm] of the MVA lookup grid for a batch, by its number of aircraft slots (envs x next_pow2(aircraft)):
+        4 096 .. 131 072 slots   0.0625 nm   (65 536 x 1, 8 192 x 16)
+        up to 262 144 slots      0.125 nm    (4 096 x 64; and the tiny batches below 4 096 slots, whose step is a launch latency)
+        beyond                   0.25 nm     (65 536 x 16)
+    A finer grid puts fewer aircraft into cells a border passes through — whose records are a second dependent L2 round trip
+    for the wavefront holding such an aircraft, the longest chain of a step — which is what a small, latency-bound batch feels
+    (round 4, split cells in place: 65 536 x 1 fused 3.04 / 3.35 / 3.71 / 4.33 us per step at 0.0625 / 0.125 / 0.25 / 0.5 nm, single
+    steps 5.93 / 6.29 / 6.68 / 6.97; 8 192 x 16 fused 2.42 / 2.51 / 2.87 / 3.3); a large batch is bound by HBM or instruction issue
+    and only pays for the bigger table (LOWW: 11.6 MB at 0.0625 nm — it lives in the Infinity Cache —, 3.2 MB at 0.125, 0.9 MB at
+    0.25; 65 536 x 16: 17.7 us single steps at 0.125 against 17.6 at 0.25, 4 096 x 64 the same at every size).  The sector
+    compiler takes 5 s for LOWW at 0.0625 nm (1.4 s at 0.125), once per process and sector.  Results do not depend on the cell
+    size (the lookup is exact for any)."""
     w = 1
     while w < int(num_aircraft):
         w *= 2
-    return 0.125 if int(num_envs) * w <= 262144 else 0.25
+    slots = int(num_envs) * w
+    if 4096 <= slots <= 131072:
+        return 0.0625
+    return 0.125 if slots <= 262144 else 0.25
 
 
 class AtcVecEnv:

@@ -53,6 +53,9 @@ def _case(seed):
     if pick < 2:
         kw["grid_cell"] = 0.125 if pick == 0 else "auto"
         comp = scenarios.compile_scenario(scn, grid_cell=0.125)
+    elif pick == 2 and kind != "Dense":   # 0.0625 nm: what `auto` picks from 4 096 aircraft slots up (bigger than this sweep's batches)
+        kw["grid_cell"] = 0.0625
+        comp = scenarios.compile_scenario(scn, grid_cell=0.125)
     # round 4, drawn last again: a quarter of the cases whose aircraft count is a power of two get a batch that is a whole number of
     # workgroups — the launches then run the all-valid kernel instantiations (csrc/atc_step.hip: make_ids<W, ALLV>), the others
     # the general ones

@@ -77,7 +77,7 @@ class TestReferenceModelTests:
 
 
 # ------------------------------------------------------------------------------------------------ G3 / G4 / G5 lattices
-@pytest.mark.parametrize("grid_cell", [None, 0.125, 0.5, 1.0])
+@pytest.mark.parametrize("grid_cell", [None, 0.0625, 0.125, 0.5, 1.0])
 @pytest.mark.parametrize("scen", ["LOWW", "Simple"])
 def test_mva_lattice_golden(scen, grid_cell):
     g = H.golden_npz("g3_mva.npz")
@@ -88,7 +88,7 @@ def test_mva_lattice_golden(scen, grid_cell):
     assert np.array_equal(got, g[scen + "_lattice"])
 
 
-@pytest.mark.parametrize("grid_cell", [None, 0.125, 0.25, 0.5, 2.0])
+@pytest.mark.parametrize("grid_cell", [None, 0.0625, 0.125, 0.25, 0.5, 2.0])
 @pytest.mark.parametrize("scen", ["LOWW", "Simple", "Sliver"])
 def test_mva_bitexact_vs_oracle_dense_and_edges(scen, grid_cell):
     """1.5 M random points + points hugging every polygon edge/vertex (within a few fp32 ulps): the polygon index must be
@@ -162,7 +162,7 @@ def test_shaping_golden():
     assert np.max(np.abs(out[:, 2] - g["gs"])) <= 1e-5
 
 
-@pytest.mark.parametrize("grid_cell", [None, 0.125, 0.25, 0.5, 1.0])
+@pytest.mark.parametrize("grid_cell", [None, 0.0625, 0.125, 0.25, 0.5, 1.0])
 def test_tiebreak_points_exact(grid_cell):
     """G8: sector with integer / dyadic vertices (the fp32 blob holds exactly the reference's polygons): vertices, edge
     points, shared borders, overlapping polygons and points 2^-10 nm either side of every edge must get the REFERENCE's

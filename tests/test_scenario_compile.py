@@ -135,7 +135,7 @@ def _walk_grid(b, g, tabs, tabs_h, x, y):
     return -1
 
 
-@pytest.mark.parametrize("scen,cell", [("LOWW", 0.5), ("LOWW", 1.0), ("Simple", 0.5), ("LOWW", 0.25), ("LOWW", 0.125), ("Simple", 0.125)])
+@pytest.mark.parametrize("scen,cell", [("LOWW", 0.5), ("LOWW", 1.0), ("Simple", 0.5), ("LOWW", 0.25), ("LOWW", 0.125), ("Simple", 0.125), ("LOWW", 0.0625)])
 def test_grid_matches_ordered_scan_on_host(scen, cell):
     """Edge-list lookup grid == ordered polygon scan on random points, points hugging every edge, and the golden lattice
     (host check of the compiler; the device walk is checked bit-for-bit against the oracle in the gpu tests)."""
@@ -183,7 +183,7 @@ def test_grid_matches_ordered_scan_on_host(scen, cell):
           'records per dirty cell %.2f' % ((codes & 63)[cells[:, 0] > 0].mean()))
 
 
-@pytest.mark.parametrize("cell", [0.125, 0.25, 0.5, 1.0])
+@pytest.mark.parametrize("cell", [0.0625, 0.125, 0.25, 0.5, 1.0])
 def test_sliver_edges_fp32_walk_matches_fp32_oracle(cell):
     """the device walks the lookup grid in fp32 from fp32-rounded vertices; for a near-horizontal LONG edge the
     fp32 x-intersection is ~2.5e-3 nm off the float64 line the grid builder classifies boxes against.  The walk emulated in
@@ -218,7 +218,8 @@ def test_grid_cell_by_batch_size_and_compile_cache():
     object for an equal sector description and a new one when anything differs."""
     from atc_hip.vec_env import auto_grid_cell
     from envs.atc import scenarios
-    assert auto_grid_cell(1, 1) == 0.125 and auto_grid_cell(65536, 1) == 0.125 and auto_grid_cell(8192, 16) == 0.125
+    assert auto_grid_cell(1, 1) == 0.125 and auto_grid_cell(65536, 1) == 0.0625 and auto_grid_cell(8192, 16) == 0.0625
+    assert auto_grid_cell(255, 16) == 0.125 and auto_grid_cell(256, 16) == 0.0625 and auto_grid_cell(8193, 16) == 0.125
     assert auto_grid_cell(4096, 64) == 0.125 and auto_grid_cell(4096, 33) == 0.125   # 33 aircraft occupy 64 slots
     assert auto_grid_cell(65536, 16) == 0.25 and auto_grid_cell(4097, 64) == 0.25
     a = scenarios.compile_scenario(scenarios.LOWW(), grid_cell=0.5)
