@@ -172,3 +172,55 @@ def replay_wide(fx, make_backend, obs_tol, state_tol, rew_tol, max_envs=4096):
             be.close()
     assert total == len(fx.flags)
     return total
+
+
+# ---------------------------------------------------------------------------------------------- extension known answers
+# Hand-computed outcomes of ONE step for the build-defined multi-aircraft semantics (separation, hand-over,
+# override order, per-aircraft rewards summed per env), with reward shaping OFF so that every reward is a small exact sum:
+# base -0.05 dt per aircraft (atc_gym.py:137), -1 per refused target (:312-315), -50 outside (:156-161), -200 below the MVA
+# (:149-153), the conflict reward for a lost separation (extension), 10000 + 5 (limit - t) for the corridor (:163-169), -200
+# for a time-out (:171-173), in the chain's order.  Nothing here comes from the oracle or the kernels; the one borrowed fact is
+# the REFERENCE's verdict that WIN_STATE + WIN_ACTION is inside the corridor after the step (row 523257 of tests/golden/g9_wide.npz).
+WIN_STATE = (48.49859896879164, 33.44283053975357, 2700.0003457069397, 344.0000009536743, 200.0)
+WIN_ACTION = (0.0, -0.8578947186470032, 0.9111111164093018)
+FAR_A = (20.0, 60.0, 15000.0, 90.0, 250.0)      # inside the airspace (the reference's lattice G3: MVA 3500 / 2700 ft there),
+FAR_B = (55.0, 70.0, 21000.0, 20.0, 220.0)      # far above it and > 20 nm from each other and from everything placed below
+
+
+def hold_action(state):
+    """The continuous action whose targets are the state's own speed / altitude / heading (nothing changes but the position)."""
+    x, y, h, phi, v = state
+    return ((v - 200.0) / 100.0, h / 19000.0 - 1.0, phi / 180.0 - 1.0)
+
+
+def extension_known_answers():
+    """[(name, params, timesteps before the step, [(state, action)] per aircraft, expected)] with expected =
+    {flags: [...], ac_reward: [...], done: bool, mask_after: int}; params = dict(timestep_limit, conflict_reward)."""
+    W, C, O_, B, T = F_WON, F_CONFLICT, F_OUTSIDE, F_BELOW_MVA, F_TIMEOUT
+    near0, near1 = (30.0, 60.0, 15000.0, 0.0, 250.0), (32.0, 60.0, 15500.0, 0.0, 250.0)          # 2 nm, 500 ft
+    low0, low1 = (30.0, 60.0, 1000.0, 0.0, 250.0), (32.0, 60.0, 1200.0, 0.0, 250.0)                # below every MVA (>= 2600 ft)
+    out0 = (1.0, 1.0, 15000.0, 90.0, 250.0)                                                       # outside LOWW's bounds
+    k = []
+    k.append(("conflict pair + bystander", {}, 0, [(near0, hold_action(near0)), (near1, hold_action(near1)), (FAR_A, hold_action(FAR_A))],
+              dict(flags=[C, C, 0], ac_reward=[-200.0, -200.0, -0.05], done=True, mask_after=0b111)))
+    k.append(("conflict overrides below-MVA", dict(conflict_reward=-123.0), 0,
+              [(low0, hold_action(low0)), (low1, hold_action(low1)), (FAR_A, hold_action(FAR_A))],
+              dict(flags=[B | C, B | C, 0], ac_reward=[-123.0, -123.0, -0.05], done=True, mask_after=0b111)))
+    k.append(("below-MVA alone", {}, 0, [(low0, hold_action(low0)), (FAR_A, hold_action(FAR_A)), (FAR_B, hold_action(FAR_B))],
+              dict(flags=[B, 0, 0], ac_reward=[-200.0, -0.05, -0.05], done=True, mask_after=0b111)))
+    k.append(("outside the airspace", {}, 0, [(out0, hold_action(out0)), (FAR_A, hold_action(FAR_A)), (FAR_B, hold_action(FAR_B))],
+              dict(flags=[O_, 0, 0], ac_reward=[-50.0, -0.05, -0.05], done=True, mask_after=0b111)))
+    k.append(("time-out ends every aircraft", dict(timestep_limit=5), 5,
+              [(near0, hold_action(near0)), (FAR_A, hold_action(FAR_A)), (FAR_B, hold_action(FAR_B))],
+              dict(flags=[T, T, T], ac_reward=[-200.0, -200.0, -200.0], done=True, mask_after=0b111)))
+    k.append(("win + conflict: two aircraft on the same winning state", {}, 0, [(WIN_STATE, WIN_ACTION), (WIN_STATE, WIN_ACTION), (FAR_A, hold_action(FAR_A))],
+              dict(flags=[W | C, W | C, 0], ac_reward=[10000.0 + 5 * 5999, 10000.0 + 5 * 5999, -0.05], done=True, mask_after=0b100)))
+    k.append(("win hands over, env continues", {}, 0, [(WIN_STATE, WIN_ACTION), (FAR_A, hold_action(FAR_A)), (FAR_B, hold_action(FAR_B))],
+              dict(flags=[W, 0, 0], ac_reward=[10000.0 + 5 * 5999, -0.05, -0.05], done=False, mask_after=0b110)))
+    k.append(("time-out overrides the win", dict(timestep_limit=40), 40, [(WIN_STATE, WIN_ACTION), (FAR_A, hold_action(FAR_A)), (FAR_B, hold_action(FAR_B))],
+              dict(flags=[W | T, T, T], ac_reward=[-200.0, -200.0, -200.0], done=True, mask_after=0b110)))
+    k.append(("win bonus runs out at the limit", dict(timestep_limit=6000), 5999, [(WIN_STATE, WIN_ACTION), (FAR_A, hold_action(FAR_A)), (FAR_B, hold_action(FAR_B))],
+              dict(flags=[W, 0, 0], ac_reward=[10000.0, -0.05, -0.05], done=False, mask_after=0b110)))
+    k.append(("refused targets cost 1 each and change nothing", {}, 0, [(FAR_A, (1.5, -1.2, 0.0)), (FAR_B, hold_action(FAR_B)), (near0, hold_action(near0))],
+              dict(flags=[F_INVALID_V | F_INVALID_H, 0, 0], ac_reward=[-2.05, -0.05, -0.05], done=False, mask_after=0b111)))
+    return k

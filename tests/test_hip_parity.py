@@ -604,6 +604,44 @@ def test_separation_known_answers():
     env.close()
 
 
+def test_extension_known_answers():
+    """The hand-computed one-step outcomes of helpers.extension_known_answers (override order, per-aircraft rewards and their env
+    sum, termination, hand-over masks; nothing in them comes from the oracle) through the batched kernel — all cases as the
+    envs of batches that share their parameters."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import model, scenarios
+    cases = H.extension_known_answers()
+    groups = {}
+    for c in cases:
+        groups.setdefault(tuple(sorted(c[1].items())), []).append(c)
+    for params, cs in groups.items():
+        env = AtcVecEnv(len(cs), 3, sim_parameters=model.SimParameters(1, reward_shaping=False),
+                        scenario=scenarios.LOWW(random_entrypoints=True), auto_reset=False, want_ac_reward=True, **dict(params))
+        a = np.zeros((len(cs), 3, 3), np.float32)
+        for b, (name, _, t0, aircraft, want) in enumerate(cs):
+            for k, (st, act) in enumerate(aircraft):
+                env.set_state(b, k, *st)
+                a[b, k] = act
+            env.timesteps[b] = t0
+        obs, rew, done, info = env.step(a)
+        fl = info["flags"].cpu().numpy()
+        acr = info["aircraft_reward"].cpu().numpy()
+        mask = env.active_mask.cpu().numpy()
+        for b, (name, _, t0, aircraft, want) in enumerate(cs):
+            assert [int(f) for f in fl[b]] == want["flags"], name
+            assert np.allclose(acr[b], want["ac_reward"], rtol=0, atol=2e-3), (name, acr[b])
+            assert abs(float(rew[b]) - sum(want["ac_reward"])) <= 4e-3, name
+            assert bool(done[b]) == want["done"] and int(mask[b]) == want["mask_after"], name
+        names = [c[0] for c in cs]
+        if "win hands over, env continues" in names:
+            b = names.index("win hands over, env continues")
+            obs, rew, done, info = env.step(a)
+            assert int(info["flags"][b, 0]) == H.F_INACTIVE and bool((obs[b, :10] == 0).all())
+            assert float(info["aircraft_reward"][b, 0]) == 0.0 and abs(float(rew[b]) + 0.10) < 1e-6 and not bool(done[b])
+        env.close()
+
+
 def test_noise_abatement_area_penalty():
     """Aircraft inside a noise polygon below its ceiling pays the per-step penalty and is flagged; above the ceiling or
     outside the polygon it is not (extension; checked against the oracle's definition)."""

@@ -140,3 +140,24 @@ def test_thread_count_does_not_change_results():
     O.set_threads(1)
     for u, v in zip(outs[0], outs[1]):
         assert np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_extension_known_answers(dtype):
+    """Hand-computed one-step outcomes of the multi-aircraft semantics (helpers.extension_known_answers): override order,
+    per-aircraft rewards and their env sum, termination, hand-over masks — on both instantiations of the oracle."""
+    for name, params, t0, aircraft, want in H.extension_known_answers():
+        env = _env("LOWW_random", 1, len(aircraft), dtype, shaping=False, **params)
+        for k, (st, _) in enumerate(aircraft):
+            env.set_state(0, k, *st)
+        env.timesteps[0] = t0
+        a = np.array([[act for _, act in aircraft]], dtype=np.float32)
+        env.step(a)
+        assert [int(f) for f in env.flags[0]] == want["flags"], name
+        assert np.allclose(env.ac_reward[0], want["ac_reward"], rtol=0, atol=2e-3 if dtype == np.float32 else 1e-9), (name, env.ac_reward[0])
+        assert abs(env.reward[0] - sum(want["ac_reward"])) <= (4e-3 if dtype == np.float32 else 1e-9), name
+        assert bool(env.done[0]) == want["done"] and int(env.active_mask[0]) == want["mask_after"], name
+        if name == "win hands over, env continues":   # the next step: a handed-over aircraft is inactive — zero observation, zero reward
+            env.step(a)
+            assert int(env.flags[0, 0]) == H.F_INACTIVE and np.all(env.obs[0, 0] == 0) and env.ac_reward[0, 0] == 0
+            assert abs(env.reward[0] - (-0.10)) < 1e-6 and not env.done[0]
