@@ -165,6 +165,11 @@ class StatsExchange:
             self._src[:, c].copy_(t.view(torch.int32))
         self._pending = True
 
+    def rearm(self):
+        """Marks the last snapshot as unreported again (measurement loops that exchange the same snapshot repeatedly)."""
+        assert self._src is not None, "snapshot() first"
+        self._pending = True
+
     def issue(self):
         assert self._pending, "snapshot() first"
         self._pending = False

@@ -421,7 +421,7 @@ def measure_collective(D, stats, dev, force, block=None, reps=100):
     xch = D.StatsExchange(force=force)
 
     def packed():
-        xch._pending = True      # (re-arm the snapshot taken below: the timed loop takes its snapshots outside the window too)
+        xch.rearm()      # (re-arm the snapshot taken below: the timed loop takes its snapshots outside the window too)
         xch.issue()
         xch.wait()
         torch.cuda.synchronize(dev)
@@ -434,7 +434,7 @@ def measure_collective(D, stats, dev, force, block=None, reps=100):
     if block is not None:
         def with_x():            # queue the block's launches, issue from the side stream, wait, synchronize
             block()
-            xch._pending = True
+            xch.rearm()
             xch.issue()
             xch.wait()
             torch.cuda.synchronize(dev)
@@ -459,7 +459,7 @@ def measure_collective(D, stats, dev, force, block=None, reps=100):
                 t0 = time.perf_counter()
                 block()
                 t1 = time.perf_counter()
-                xch._pending = True
+                xch.rearm()
                 xch.issue()
                 t2 = time.perf_counter()
                 xch.wait()

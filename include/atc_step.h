@@ -188,11 +188,10 @@ typedef struct atc_params {
  *     in float64, exact before the final conversion);
  *   - differences of positions are exact integers: the vector to the FAF (atc_gym.py:289-297) is
  *     (float)(faf_fix - fix) * 2^-k, accurate to fp32 RELATIVE precision however close the aircraft is to the FAF.
- * Worst-case accumulated rounding over a 6 000-step episode: 6 000 * 2^-26 nm = 9e-5 nm (3e-6 in normalised units);
+ * Accumulated rounding over a 6 000-step episode: <= 1.04e-6 nm measured against the float64 reference (dithered rounding, below);
  * half the bytes of a float64 pair.  An aircraft that is flown on, without reset, beyond the grid range (>= 24 nm outside
  * the LOWW bounding box) is pinned at the range limit: it stays "outside the airspace" exactly like the reference's
  * (model.py:289), only its x / y observation stops growing.
- *
  *
  * Speed and heading (model.py:35-37, 60-129) on the fp32 path — ABI 18.
  * The reference holds v, phi and the decoded action targets in float64.  As fp32 values they carry the rounding of the
@@ -200,34 +199,48 @@ typedef struct atc_params {
  * moves the aircraft 5e-6 nm off over a 30 nm leg: next to the FAF, where the bearing to it is ill-conditioned, that was the one
  * stated exception to the 1e-5 bar of rounds 1-3 (tools/faf_conditioning.py).  Both are therefore 32-bit FIXED POINT, like
  * the positions, and the step's displacement is evaluated in float64 from them:
- *   speed    kt  = 200 + v_fix   * 2^-23    (range [-56, 456): the aircraft's [100, 300] and every refusable target)
- *   heading  deg = 360 + phi_fix * 2^-22    (range [-152, 872): two turns around the action space's [0, 360])
- *   - a target is  fix = rint(a * m + c)  in float64 (m, c = the reference's factor / offset of atc_gym.py:64-78,318-335
- *     in counts, both integers), round-half-even, with the action first clamped so that |a m + c| < 2^31 (an action that far
- *     outside the action space [-1, 1] pins the target at the end of the range: refused for the speed, held for the heading);
- *   - rate limits (model.py:75-78, 117-120) are exact integer arithmetic: fix += clamp(target - fix, +-rint(rate dt 2^s));
- *     the "action taken" discriminator (atc_gym.py:84,305-306) compares integer differences with 5 * 2^23 / 0.5 * 2^22;
+ *   speed    kt  = v_fix * 2^-23            UNSIGNED counts, [0, 512): the aircraft's [100, 300] and every refusable target
+ *   heading  deg = 180 + phi_fix * 2^-23    signed counts, [-76, 436): the action space's [0, 360] and 76 deg either side
+ *   - a target is  counts = trunc(a * m + c):  ONE float64 fma on the fp32 action (m, c = the reference's factor / offset of
+ *     atc_gym.py:64-78,318-335 in counts, both integers; exact for every fp32 action: 24 x 31 bits) and the conversion to
+ *     uint32 (speed) / int32 (heading) that TRUNCATES toward zero, SATURATES at both ends and maps NaN to 0 (gfx950:
+ *     v_cvt_u32_f64 / v_cvt_i32_f64).  An action far outside the action space [-1, 1] therefore pins the target at the end of
+ *     the format's range: refused for the speed like any target outside [100, 300] kt, held there for the heading (the
+ *     reference, which does not validate headings, would turn on);
+ *   - rate limits (model.py:75-78, 117-120) are exact integer arithmetic:  fix += clamp(target - fix, +-rint(rate dt 2^23))
+ *     (wrapping 32-bit difference for the speed — valid speeds, and the initial last_action 0, are < 2^31 counts apart —,
+ *     saturating for the heading); the "action taken" discriminator (atc_gym.py:84,305-306) compares the same integer
+ *     differences with 5 * 2^23 / 0.5 * 2^23 counts;
  *   - the fp32 speed / heading every other formula of the reference sees (observation, relative angles, corridor window) is
- *     fmaf((float)fix, 2^-s, offset): exact for every value with <= 24 significant bits, e.g. all integer headings;
- *   - the altitude stays fp32 (it does not feed the position; 1e-3 ft at 16 000 ft is 5e-8 in observation units).
+ *     (float)v_fix * 2^-23  /  fmaf((float)phi_fix, 2^-23, 180):  exact for every value with <= 24 significant bits, e.g. all
+ *     integer speeds and headings;
+ *   - the altitude stays fp32 (it does not feed the position; 1e-3 ft at 16 000 ft is 5e-8 in observation units);
+ *   - state placed from outside (entry points, fixtures) is the NEAREST count.
  * Heading kinematics (model.py:122-129, 345-348) in float64, shared bit for bit by every fp32 implementation (the HIP
  * kernels, the fp32 instantiation of the test oracle):
- *   k = rint(phi_fix * ATC_KIN_INV180)  [(180 * 2^22)^-1, nearest-even],  t = fma(k, -180 * 2^22, phi_fix)  (exact: the
- *   remainder in counts, |t| <= 90 * 2^22),  u = t * t,
+ *   k = rint(phi_fix * ATC_KIN_INV180)  [(180 * 2^23)^-1, nearest-even],  t = fma(k, -180 * 2^23, phi_fix)  (exact: the
+ *   remainder in counts, |t| <= 90 * 2^23),  u = t * t,
  *   sin = t * (S0 + u (S1 + u (S2 + u (S3 + u (S4 + u S5))))),  cos = 1 + u (C1 + u (C2 + u (C3 + u (C4 + u C5))))
- *   (Horner, fma; coefficients below: near-minimax in r = t pi / (180 * 2^22) on |r| <= pi/2, scaled to counts —
- *   tools/fit_kinematics_f64.py; max error 2.6e-11 / 4.4e-10),  both negated when k is odd;
- *   distance in position-grid counts  d = fma((double)v_fix, DA, DB)  with  q = (double)dt / 3600,
- *   DA = q * 2^(k_pos - 23),  DB = (200 q) * 2^k_pos;  x_fix += rint(sin * d),  y_fix += rint(cos * d)  — ONE rounding each
- *   (fma(sin, d, ATC_FIX_MAGIC), low 32 bits), saturating add.  Requires 0.127 dt 2^k_pos < 2^30 (dt < 63 s at k_pos = 27).
- * Measured against the float64 reference over the 650 963 steps of tests/golden/g9_wide.npz: positions within a few 1e-7 nm
- * (the random walk of the 2^-25 nm grid rounding), no near-FAF exception needed. */
+ *   (Horner, every step one fma; coefficients below: near-minimax in r = t pi / (180 * 2^23) on |r| <= pi/2, scaled to
+ *   counts — tools/fit_kinematics_f64.py; max error 2.6e-11 / 4.4e-10);
+ *   distance in position-grid counts  d = (double)v_fix * DA,  DA = ((double)dt / 3600) * 2^(k_pos - 23),  NEGATED when k is
+ *   even (phi = 180 (1 + k) + t: an even k is an odd number of half turns);
+ *   DITHERED ROUNDING:  x_fix += floor(sin * d + u11),  y_fix += floor(cos * d + u11)  (saturating adds), u11 = the low 11 bits of
+ *   the env's time step (after its increment, atc_gym.py:135) bit-reversed, as a fraction in [0, 1) — the van der Corput
+ *   sequence.  Plain rounding repeats the SAME round-off every step of a straight leg at constant speed (measured: up to
+ *   7.8e-6 nm per episode); dithered, the round-offs of a constant displacement cancel to O(log n) counts over n steps.
+ *   Evaluated as  r = fma(sin, d, M)  with M = the float64 whose high word is ATC_DITHER_MAGIC_HI (1.5 * 2^41) and whose low
+ *   word is u11, i.e. M = 1.5 * 2^41 + u11 * 2^-11 (2^-11 is the last place of a float64 of that magnitude); the integer part of r is
+ *   bits 11..42 of its pattern:  counts = (int32)(bits(r) >> 11).
+ *   Requires 0.1423 dt 2^k_pos < 2^30 (512 kt: the displacement must fit 2^30 counts) and 5 dt < 256 (the speed's rate limit in
+ *   counts): dt <= 51 s for any sector; atc_step refuses larger steps.
+ * Measured against the float64 reference over the 650 963 steps of tests/golden/g9_wide.npz (tools/position_error.py):
+ * positions within 1.5e-7 nm (median) / 1.04e-6 nm (maximum, 6 000-step episodes), speed and heading within one count;
+ * the fixture replays at the plain 1e-5 bar everywhere — no near-FAF exception. */
 #define ATC_V_FIX_SHIFT 23
 #define ATC_PHI_FIX_SHIFT 23
 #define ATC_PHI_FIX_OFFSET 180.0f
 #define ATC_DITHER_MAGIC_HI 0x42880000u   /* high word of 1.5 * 2^41: the low word's low 11 bits are the dither fraction */
-#define ATC_FIX_MAGIC 6755399441055744.0  /* 1.5 * 2^52: the low 32 bits of fma(a, m, c + MAGIC) are rint(a m + c) */
-#define ATC_FIX_DECODE_LIMIT 2147480000.0 /* |a m + c| after the action clamp */
 #define ATC_KIN_INV180 (0x1.6c16c16c16c17p-31)
 #define ATC_KIN_HALF_TURN 1509949440.0    /* 180 * 2^23 */
 #define ATC_KIN_S0 (0x1.1df46a2514d5fp-29)

@@ -50,7 +50,7 @@ def v_copy():
 
 def v_xch():
     block()
-    xch._pending = True
+    xch.rearm()
     xch.issue()
     xch.wait()
 
@@ -58,13 +58,13 @@ def v_xch():
 def v_serial():
     block()
     torch.cuda.synchronize()
-    xch._pending = True
+    xch.rearm()
     xch.issue()
     xch.wait()
 
 
 def v_xch_first():
-    xch._pending = True
+    xch.rearm()
     xch.issue()
     block()
     xch.wait()
