@@ -8,10 +8,11 @@
  *   REAL = double (suffix _f64): the reference as it is — Python floats, libm; pinned against the golden vectors captured
  *     from the imported reference (integer outputs exact, state within 1e-11);
  *   REAL = float (suffix _f32): the fp32 restatement — the same operation order in float with libm's float functions,
- *     EXCEPT the two choices include/atc_step.h fixes for every fp32 implementation ("Aircraft positions": the fixed-point
- *     position grid and the polynomial heading kinematics).  With those shared, the HIP kernels' aircraft state and every
+ *     EXCEPT the choices include/atc_step.h fixes for every fp32 implementation ("Aircraft positions", "Speed and heading":
+ *     the fixed-point position grid; since ABI 18 the fixed-point speed / heading state with its integer rate limits, the
+ *     truncating target conversion, the float64 heading kinematics and the dithered rounding).  With those shared, the HIP kernels' aircraft state and every
  *     integer output match this instantiation bit for bit; it is itself pinned against the same golden vectors (integer
- *     outputs exact, fp32 values within 1e-5).
+ *     outputs exact, fp32 values within 1e-5 — everywhere: the near-FAF exception of rounds 1-3 is retired).
  * Scalar, compiled with -ffp-contract=off.
  *
  * Pinned by: tests/golden/{g1..g9,model_test_known_answers} (see tests/test_oracle_golden.py): 48 080 + 650 963 reference
