@@ -859,10 +859,12 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             constexpr int H = W / 2;   // distances 1 .. H
             constexpr int U = 4;       // partners per LDS batch
-            // lanes that are the FIRST element of a conflicting pair (`first`) ... or the second: the mask of distance d rotated by
-            // d inside each group.  The distances are visited from H down to 1 and the rotations accumulated Horner-style —
-            // acc = rot1(acc | mask_d) — so every distance costs one rotation by ONE (constant shifts) instead of one by d.
-            uint64_t first = 0, acc = 0;
+            // lanes that are the FIRST element of a conflicting pair, or the second: the mask of distance d rotated by d inside each
+            // group.  Round 4: a lost separation is RARE (it ends the episode), so the four compare masks of an LDS batch are only
+            // ored into the result — and into one "anything?" word — on the common path; the rotations run behind a wave-uniform
+            // test, with variable shifts, in the few batches that found a pair (rounds 2-3 rotated every mask, Horner-style by one:
+            // 6-7 scalar operations per partner, 216 per wavefront-step at W = 64; now ~3).
+            uint64_t hit = 0;
             const v2f xs2 = {xs, xs}, ys2 = {y32, y32}, hs2 = {a.h, a.h};
             const float sep_ft = qs.sep_ft;
 #pragma unroll 1   // (fully unrolled, the 2 H compare masks stay live together: 140-220 spilled SGPRs)
@@ -877,37 +879,30 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
                     // only read for partner pairs some lane of the wavefront is horizontally close to
                     if (FULL || !ATC_NEAR_FIRST_LDS) qh[u] = v2f{q0[2 * P], q0[2 * P + 1]};
                 }
+                uint64_t mk[U];   // mk[2 u + w]: distance d0 + 2 u + w
 #pragma unroll
                 for (int u = U / 2 - 1; u >= 0; --u) {
                     const v2f dx = xs2 - qx[u], dy = ys2 - qy[u];
                     const v2f d2 = __builtin_elementwise_fma(dx, dx, dy * dy);
-                    uint64_t mk[2];
                     if (FULL || !ATC_NEAR_FIRST_LDS) {
                         const v2f dh = hs2 - qh[u];
                         // (two ballots anded as scalars: the compare masks themselves — a ballot of the anded predicate is
                         // materialised per lane and compared again)
-                        mk[0] = __builtin_amdgcn_ballot_w64(d2[0] < sep2) & __builtin_amdgcn_ballot_w64(fabsf(dh[0]) < sep_ft);
-                        mk[1] = __builtin_amdgcn_ballot_w64(d2[1] < sep2) & __builtin_amdgcn_ballot_w64(fabsf(dh[1]) < sep_ft);
+                        mk[2 * u] = __builtin_amdgcn_ballot_w64(d2[0] < sep2) & __builtin_amdgcn_ballot_w64(fabsf(dh[0]) < sep_ft);
+                        mk[2 * u + 1] = __builtin_amdgcn_ballot_w64(d2[1] < sep2) & __builtin_amdgcn_ballot_w64(fabsf(dh[1]) < sep_ft);
                     } else {
-                        mk[0] = __builtin_amdgcn_ballot_w64(d2[0] < sep2);
-                        mk[1] = __builtin_amdgcn_ballot_w64(d2[1] < sep2);
-                        if ((mk[0] | mk[1]) != 0ull) {   // wave-uniform
+                        mk[2 * u] = __builtin_amdgcn_ballot_w64(d2[0] < sep2);
+                        mk[2 * u + 1] = __builtin_amdgcn_ballot_w64(d2[1] < sep2);
+                        if ((mk[2 * u] | mk[2 * u + 1]) != 0ull) {   // wave-uniform
                             const float* q0 = own + d0 + 2 * u;
                             const v2f dh = hs2 - v2f{q0[2 * P], q0[2 * P + 1]};
-                            mk[0] &= __builtin_amdgcn_ballot_w64(fabsf(dh[0]) < sep_ft);
-                            mk[1] &= __builtin_amdgcn_ballot_w64(fabsf(dh[1]) < sep_ft);
+                            mk[2 * u] &= __builtin_amdgcn_ballot_w64(fabsf(dh[0]) < sep_ft);
+                            mk[2 * u + 1] &= __builtin_amdgcn_ballot_w64(fabsf(dh[1]) < sep_ft);
                         }
                     }
+                    if (FULL) {   // diagnostic minimum separation: the partner needs the VALUE -> LDS float minimum
 #pragma unroll
-                    for (int w = 1; w >= 0; --w) {
-                        first |= mk[w];
-                        const uint64_t t = acc | mk[w];
-                        if (W == 64) {
-                            acc = (t << 1) | (t >> 63);
-                        } else {  // two groups of 32 lanes: rotate inside each half
-                            acc = ((t << 1) & 0xfffffffefffffffeull) | ((t >> 31) & 0x0000000100000001ull);
-                        }
-                        if (FULL) {   // diagnostic minimum separation: the partner needs the VALUE -> LDS float minimum
+                        for (int w = 1; w >= 0; --w) {
                             const int dd = d0 + 2 * u + w;   // uniform (H is a multiple of U: no tail)
                             min_d2 = fminf(min_d2, d2[w]);
                             // d^2 >= 0: the IEEE order of non-negative floats is the order of their bit patterns
@@ -915,8 +910,24 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
                         }
                     }
                 }
+                uint64_t any = mk[0];
+#pragma unroll
+                for (int j = 1; j < U; ++j) any |= mk[j];
+                if (ATC_RARE(any != 0ull)) {   // some pair of this batch lost its separation: both of its lanes are marked
+                    hit |= any;
+#pragma unroll
+                    for (int j = 0; j < U; ++j) {
+                        const int dd = d0 + j;   // 1 .. W / 2, uniform
+                        const uint64_t t = mk[j];
+                        if (W == 64) {
+                            hit |= (t << dd) | (t >> (64 - dd));
+                        } else {  // two groups of 32 lanes: rotate inside each half
+                            const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+                            hit |= (uint64_t)((lo << dd) | (lo >> (32 - dd))) | ((uint64_t)((hi << dd) | (hi >> (32 - dd))) << 32);
+                        }
+                    }
+                }
             }
-            const uint64_t hit = first | acc;
             if ((hit >> lane) & 1ull) margin = -1.0f;
             if (FULL) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
