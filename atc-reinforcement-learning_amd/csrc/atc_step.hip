@@ -555,7 +555,19 @@ __device__ __forceinline__ T kernarg_reread(size_t byte_off, int opaque_zero) {
     // for scalar loads (a byte-wise copy from an address with an opaque term became per-lane vector loads).
     typedef __attribute__((address_space(4))) const char* karg_ptr;
     typedef __attribute__((address_space(4))) const T* typed_ptr;
+#ifndef ATC_KERNARG_OPAQUE_PTR
+#define ATC_KERNARG_OPAQUE_PTR 1
+#endif
+#if ATC_KERNARG_OPAQUE_PTR
+    // Round 4: the BASE POINTER is made opaque (an empty asm tied to the step's opaque zero), the member's offset stays an
+    // immediate of the scalar load.  Rounds 2-3 added `opaque_zero * alignof(T)` to the address: five scalar instructions of
+    // 64-bit address arithmetic per re-read (shift, negate, add with carry — one chain per alignment), ~40 per wavefront-step.
+    karg_ptr base = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(base) : "s"(opaque_zero));
+    return *(typed_ptr)(base + byte_off);
+#else
     return *(typed_ptr)((karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + byte_off + (size_t)opaque_zero * alignof(T));
+#endif
 #else
     T v;
     __builtin_memset(&v, 0, sizeof(T));
