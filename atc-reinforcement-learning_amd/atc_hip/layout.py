@@ -2,7 +2,7 @@
 
 tests/test_abi.py parses the header and checks that every constant here matches it.
 """
-ABI_VERSION = 18
+ABI_VERSION = 19
 BLOB_VERSION = 1014.0
 
 H_VERSION, H_NWORDS, H_N_MVA, H_N_NOISE, H_N_ENTRY, H_OFF_POLY, H_OFF_VERT, H_OFF_ENTRY, H_OFF_GRID, H_N_VERTW = range(10)
@@ -22,6 +22,11 @@ C_FAF_FIX = 124                                                 # FAF on the gri
 POS_MAX_K = 27
 # speed / heading state: 32-bit fixed point (include/atc_step.h, ABI 18): kt = v_fix 2^-23 (unsigned), deg = 180 + phi_fix 2^-23
 V_FIX_SHIFT, PHI_FIX_SHIFT, PHI_FIX_OFFSET = 23, 23, 180.0
+# ABI 19: the heading is unbounded like the reference's (model.py:104-120) — a 32-bit field that SATURATES (INT32_MIN / INT32_MAX =
+# "WIDE") in front of the exact integer-valued float64 counts in atc_state_t.phi_wide[i][0] ([1]: the last heading target)
+PHI_WIDE_WORDS = 4
+PHI_LIMIT = 2.0 ** 52
+I32_MIN, I32_MAX = -2 ** 31, 2 ** 31 - 1
 C_TRI_BBOX = 96
 C_NORM_A, C_NORM_B = 104, 114
 C_END = 128
@@ -39,7 +44,7 @@ OBS_DIM = 10
 ACT_DIM = 3
 
 F_BELOW_MVA, F_OUTSIDE, F_WON, F_TIMEOUT = 1, 2, 4, 8
-F_INVALID_V, F_INVALID_H, F_CONFLICT, F_NOISE, F_INACTIVE = 16, 32, 64, 128, 256
+F_INVALID_V, F_INVALID_H, F_CONFLICT, F_NOISE, F_INACTIVE, F_PHI_LIMIT = 16, 32, 64, 128, 256, 512
 F_TERMINAL = F_BELOW_MVA | F_OUTSIDE | F_TIMEOUT | F_CONFLICT  # episode-ending on their own (WON: when all handed over)
 
 M_REWARD_SHAPING, M_NORMALIZE, M_DISCRETE, M_AUTO_RESET, M_RANDOM_ENTRY, M_KEEP_ACTIVE, M_ACTIONS_HELD = 1, 2, 4, 8, 16, 32, 64

@@ -28,7 +28,7 @@ class AtcParams(C.Structure):
                 ("reserved1", C.c_float)]
 
 
-STATE_FIELDS = ("pos_hp", "v_fix", "last_act", "env", "stats")
+STATE_FIELDS = ("pos_hp", "v_fix", "last_act", "env", "stats", "phi_wide")
 OUT_FIELDS = ("obs", "raw_obs", "reward", "ac_reward", "done", "flags", "min_sep", "term_obs", "packet")
 
 

@@ -98,7 +98,6 @@ class AtcVecEnv:
         self.last_act = zs((BN, 3), i32)       # last accepted v / h / phi targets in the state's formats
         self.env = zs((B, L.ENV_WORDS), i32)   # per-step env record
         self.stats = zs((B, L.STAT_WORDS), i32)  # per-episode env record
-        self._state = _lib.AtcState(*[self._ptr(getattr(self, n)) for n in _lib.STATE_FIELDS])
         self.pos_origin, self.pos_k = self.compiled.pos_origin, self.compiled.pos_k
         # named views into the records (live memory, usable for reads and in-place writes)
         self.h = self.pos_hp[:, 2:3].view(f32).squeeze(1)
@@ -123,6 +122,11 @@ class AtcVecEnv:
         if want_packet and not (self.host_mapped and N == 1):
             raise ValueError("want_packet needs host_mapped=True and num_aircraft=1")
         self.packet = z((B, L.PKT_CHUNKS, 4), i32) if want_packet else None
+        # exact heading counts / last heading target of aircraft whose 32-bit heading fields are saturated ("WIDE", ABI 19): the
+        # reference's heading is unbounded (model.py:104-120).  Untouched while headings stay inside (-76, 436) deg.
+        # (allocated after everything a step streams through, so that those tensors sit where they would without it)
+        self.phi_wide = zs((BN, L.PHI_WIDE_WORDS), torch.float64)
+        self._state = _lib.AtcState(*[self._ptr(getattr(self, n)) for n in _lib.STATE_FIELDS])
         # twin of `params` with ATC_M_ACTIONS_HELD set: what step(held=True) and the held launchers pass.  A persistent object,
         # refreshed by seed() / refresh_params(), so that pre-bound launchers see parameter changes like plain launches do
         self._params_held = type(self.params).from_buffer_copy(self.params)
@@ -398,8 +402,15 @@ class AtcVecEnv:
         return (self.v_fix.to(self.torch.int64) & 0xffffffff).to(self.torch.float64) * 2.0 ** -L.V_FIX_SHIFT
 
     @property
+    def phi_counts(self):
+        """exact heading counts as float64 (integer-valued): the 32-bit field, or the side record where that is saturated"""
+        f = self.phi_fix
+        wide = (f == L.I32_MIN) | (f == L.I32_MAX)
+        return self.torch.where(wide, self.phi_wide[:, 0], f.to(self.torch.float64))
+
+    @property
     def phi(self):
-        return self.phi_fix.to(self.torch.float64) * 2.0 ** -L.PHI_FIX_SHIFT + L.PHI_FIX_OFFSET
+        return self.phi_counts * 2.0 ** -L.PHI_FIX_SHIFT + L.PHI_FIX_OFFSET
 
     def _to_fix(self, value, axis):
         from .scenario import to_fix
@@ -413,7 +424,15 @@ class AtcVecEnv:
 
     @staticmethod
     def _phi_counts(phi):
-        return int(min(max(round((float(phi) - L.PHI_FIX_OFFSET) * 2.0 ** L.PHI_FIX_SHIFT), -2 ** 31), 2 ** 31 - 1))
+        """degrees -> (32-bit field, exact counts): the field saturates, the exact counts are clamped to +-2^52 (include/atc_step.h)"""
+        P = int(min(max(round((float(phi) - L.PHI_FIX_OFFSET) * 2.0 ** L.PHI_FIX_SHIFT), -L.PHI_LIMIT), L.PHI_LIMIT))
+        return min(max(P, L.I32_MIN), L.I32_MAX), P
+
+    def _put_phi(self, field, i, col, phi):
+        f, P = self._phi_counts(phi)
+        field[i] = f
+        if f in (L.I32_MIN, L.I32_MAX):
+            self.phi_wide[i, col] = float(P)
 
     def set_xy(self, i, x=None, y=None):
         if x is not None:
@@ -422,10 +441,15 @@ class AtcVecEnv:
             self.pos_hp[i, 1] = self._to_fix(y, 1)
 
     def set_v(self, i, v):
+        # The speed's rate limit is a wrapping 32-bit difference (include/atc_step.h): exact while the speed lies within 256 kt
+        # of every acceptable target [100, 300] kt, i.e. inside [44, 356] kt.  The reference's constructor refuses anything outside
+        # [100, 300] (model.py:22-23); a speed poked in from outside (env._airplane.v = ...) is refused beyond the format's range.
+        if not 44.0 <= float(v) <= 356.0:
+            raise ValueError("invalid velocity: the device's speed format holds 44 .. 356 kt (an Airplane has 100 .. 300)")
         self.v_fix[i] = self._v_counts(v)
 
     def set_phi(self, i, phi):
-        self.phi_fix[i] = self._phi_counts(phi)
+        self._put_phi(self.phi_fix, i, 0, phi)
 
     def set_state(self, env, slot, x, y, h, phi, v):
         i = env * self.N + slot
@@ -438,15 +462,21 @@ class AtcVecEnv:
         """AtcGym.last_action (atc_gym.py:86,311) of one aircraft: [v, h, phi] targets last accepted, in kt / ft / deg."""
         i = env * self.N + slot
         rec = self.last_act[i].cpu()
+        lp = int(rec[2])
+        if lp in (L.I32_MIN, L.I32_MAX):
+            lp = float(self.phi_wide[i, 1])
         return [float(int(rec[0]) & 0xffffffff) * 2.0 ** -L.V_FIX_SHIFT, float(rec[1:2].view(self.torch.float32)[0]),
-                float(int(rec[2])) * 2.0 ** -L.PHI_FIX_SHIFT + L.PHI_FIX_OFFSET]
+                float(lp) * 2.0 ** -L.PHI_FIX_SHIFT + L.PHI_FIX_OFFSET]
 
     def set_last_action(self, env, slot, value):
         i = env * self.N + slot
         torch = self.torch
-        rec = torch.tensor([self._v_counts(value[0]), 0, self._phi_counts(value[2])], dtype=torch.int32)
+        f, P = self._phi_counts(value[2])
+        rec = torch.tensor([self._v_counts(value[0]), 0, f], dtype=torch.int32)
         rec[1:2].view(torch.float32)[0] = float(value[1])
         self.last_act[i] = rec.to(self.last_act.device)
+        if f in (L.I32_MIN, L.I32_MAX):
+            self.phi_wide[i, 1] = float(P)
 
     def get_state(self, env, slot):
         i = env * self.N + slot

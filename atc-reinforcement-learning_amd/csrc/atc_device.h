@@ -55,6 +55,25 @@ __device__ __forceinline__ uint32_t cvt_u32_f64(double x) {
 // the fp32 speed / heading every other formula of the reference sees (observation, relative angles, corridor window)
 __device__ __forceinline__ float v_real(uint32_t f) { return (float)f * kFixInv; }
 __device__ __forceinline__ float phi_real(int f) { return fmaf((float)f, kFixInv, ATC_PHI_FIX_OFFSET); }
+// ---- the unbounded heading (include/atc_step.h, ABI 19): exact counts behind a saturating 32-bit field ------------------
+// A heading (or last heading target) whose 32-bit field is INT32_MIN / INT32_MAX is WIDE: its exact counts are the integer-valued
+// float64 side word atc_state_t.phi_wide[i][0] ([1] for the last target).  Everything below runs only in wavefronts that hold such
+// an aircraft or receive a heading target beyond the 32-bit range — behind wave-uniform tests, off the step's straight line.
+// All of it is float64 arithmetic on integers below 2^53: exact, and one instruction per operation on gfx950.
+__device__ __forceinline__ bool is_wide(int f) { return f == INT32_MAX || f == INT32_MIN; }
+// heading target in counts: trunc(a m + c) clamped to +-2^52, NaN -> 0 (the spec of include/atc_step.h)
+__device__ __forceinline__ double phi_target_wide(double x, bool* clamped) {
+    x = (x == x) ? __builtin_trunc(x) : 0.0;
+    *clamped = __builtin_fabs(x) > ATC_PHI_LIMIT;
+    return __builtin_fmin(__builtin_fmax(x, -ATC_PHI_LIMIT), ATC_PHI_LIMIT);
+}
+// a WIDE heading wrapped to within half a turn of zero: what the kinematics and every relative angle use (they are periodic)
+__device__ __forceinline__ int phi_wrap(double P) {
+    const double k = __builtin_rint(P * ATC_PHI_INV_TURN);
+    return cvt_i32_f64(__builtin_fma(k, -ATC_PHI_TURN, P));
+}
+// observation word 3 (atc_gym.py:269) of a WIDE heading: exact in float64, ONE rounding
+__device__ __forceinline__ float phi_obs_wide(double P) { return (float)((double)ATC_PHI_FIX_OFFSET + P * (1.0 / 8388608.0)); }
 // state placed from outside (entry points): nearest count
 __device__ __forceinline__ int phi_store(float p) { return cvt_i32_f64(__builtin_rint(((double)p - (double)ATC_PHI_FIX_OFFSET) * 8388608.0)); }
 
@@ -596,7 +615,8 @@ struct Obs {
     float d_faf, phi_rel_faf, on_gp;
 };
 // atc_gym.py:262-297 _get_state.  (px, py) = grid position, (x, y) = its fp32 value
-__device__ __forceinline__ Obs get_state(const ObsConst& c, int px, int py, float x, float y, float h, float phi, float v,
+// phi: the heading the relative angle sees; phi_obs: observation word 3 — the same number unless the heading is WIDE
+__device__ __forceinline__ Obs get_state(const ObsConst& c, int px, int py, float x, float y, float h, float phi, float phi_obs, float v,
                                          float mva) {
     Obs r;
     const float to_faf_x = pos_to_faf(c.faf_x, c.pos_inv, px);
@@ -607,7 +627,7 @@ __device__ __forceinline__ Obs get_state(const ObsConst& c, int px, int py, floa
     r.o[0] = x;
     r.o[1] = y;
     r.o[2] = h;
-    r.o[3] = phi;
+    r.o[3] = phi_obs;
     r.o[4] = v;
     r.o[5] = h - mva;
     r.o[6] = r.on_gp;

@@ -70,6 +70,12 @@ static int fail_hip(hipError_t e, const char* what) {
         if (_e != hipSuccess) return fail_hip(_e, #expr); \
     } while (0)
 
+#ifndef ATC_WIDE_WAIT_INSIDE
+#define ATC_WIDE_WAIT_INSIDE 1
+#endif
+#ifndef ATC_WABL
+#define ATC_WABL 0
+#endif
 #ifndef ATC_BLOCK
 #define ATC_BLOCK 256
 #endif
@@ -429,7 +435,10 @@ struct alignas(16) QScan {    // second half: separation scan, override chain
 struct alignas(16) QNorm {
     float a[ATC_OBS_DIM], b[ATC_OBS_DIM];   // ATC_C_NORM_A / ATC_C_NORM_B
 };
-struct StepDerived {
+#ifndef ATC_Q_ALIGN
+#define ATC_Q_ALIGN 64
+#endif
+struct alignas(ATC_Q_ALIGN) StepDerived {
     QRates r;
     QKin k;               // float64 heading kinematics + distance scale (32 words)
     QGrid g;
@@ -575,6 +584,38 @@ __device__ __forceinline__ T kernarg_reread(size_t byte_off, int opaque_zero) {
 #endif
 }
 
+// base of atc_state_t.phi_wide on the rare paths that need it: the named argument in single-step launches, a kernarg re-read in
+// multi-step ones (like the per-episode record's base: nothing about it is carried across the step loop)
+template <bool ONE>
+__device__ __forceinline__ double* wide_base(double* named, int zk) {
+    return ONE ? named : kernarg_reread<double*>(offsetof(StepArgs, st) + offsetof(atc_state_t, phi_wide), zk);
+}
+// WIDE headings (include/atc_step.h, ABI 19) exist only in wavefronts that are not `plain`; their wrapped counts and observation
+// word 3 were left in word 2 of the side record by the first half of this step (step_part_a) — 4-byte loads behind a second
+// wave-uniform test, no arithmetic and as few registers as possible where the observation's registers are all live.
+// WORD 0: the wrapped counts (what kinematics and angles use in place of phi_fix), WORD 1: observation word 3 as a bit pattern.
+template <bool ONE, int WORD>
+__device__ __forceinline__ int wide_view(bool plain, int phi, double* named, int zk, uint32_t i, int dflt) {
+    int r = dflt;
+    if (ATC_RARE(!plain)) {
+        if ((__builtin_amdgcn_ballot_w64(phi == INT32_MAX) | __builtin_amdgcn_ballot_w64(phi == INT32_MIN)) != 0ull) {
+            if (is_wide(phi)) r = *at<int>(wide_base<ONE>(named, zk), i * 32u + (16u + 4u * WORD));   // (B N 40 < 4 GiB is guaranteed)
+#if ATC_WIDE_WAIT_INSIDE
+            // The load is WAITED FOR here, inside the rare block: left pending, the join below would carry "r may be in flight" into
+            // the step's straight line, where the first use of r waits for every earlier vector load as well (one counter, in
+            // order) — e.g. the lookup-cell records requested ahead of the observation arithmetic that is meant to cover them.
+            asm volatile("" : "+v"(r));
+#endif
+        }
+    }
+    return r;
+}
+// the heading's counts as kinematics and angles see them (both are periodic in the heading)
+template <bool ONE>
+__device__ __forceinline__ int heading_counts(bool plain, int phi, double* named, int zk, uint32_t i) {
+    return wide_view<ONE, 0>(plain, phi, named, zk, i, phi);
+}
+
 struct StepOut {        // per-step output bases (uniform pointers)
     float* obs;
     uint16_t* flags;
@@ -637,12 +678,13 @@ __device__ __forceinline__ Targets decode_targets(const QRates& q, const Float3&
 // max(min(d, r), -r) for integer differences (the symmetric rate limits of speed and heading)
 __device__ __forceinline__ int clamp_sym(int d, int r) { return max(min(d, r), -r); }
 // |d| < D for a wrapped 32-bit difference d (atc_gym.py:305-306 on counts): one addition and one unsigned compare
-__device__ __forceinline__ bool within(int d, int D) { return (uint32_t)(d + (D - 1)) < (uint32_t)(2 * D - 1); }
+__device__ __forceinline__ bool within(int d, int D) { return (uint32_t)d + (uint32_t)(D - 1) < (uint32_t)(2 * D - 1); }
 
 // ---- first half of AtcGym.step: timestep, rate limits towards the targets, kinematics, MVA floor ---------------------
+template <bool ONE>
 __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const QRates& q, const QKin& qk, const QGrid& qg,
-                                           const LaneIds& d, uint32_t tv, float th, int tp, LaneState& ls, EnvState& es,
-                                           bool repeated, bool all_active, bool track_v) {
+                                           const LaneIds& d, uint32_t tv, float th, int tp, float act_p, LaneState& ls, EnvState& es,
+                                           bool repeated, bool all_active, bool track_v, double* wide_named, int zk) {
     Mid m;
     Aircraft& a = ls.a;
     // `repeated` (wave-uniform): this step repeats the previous step's actions and no env of the wavefront was reset in
@@ -671,9 +713,18 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     // evaluate the same expressions on the lanes they share.
     // (one lane mask per COMPARE, combined on the scalar unit: the ballot of a compound predicate is materialised per lane and
     // compared again — two vector operations per site)
+    // ... and a heading target beyond the 32-bit range (the saturated conversion, include/atc_step.h ABI 19) takes the general
+    // form too, like a lane whose heading or last heading target is WIDE already (`all_active` vouches that none is)
     const uint64_t refused = __builtin_amdgcn_ballot_w64(tv < kVMinFix) | __builtin_amdgcn_ballot_w64(tv > kVMaxFix) |
-                             __builtin_amdgcn_ballot_w64(th < h_min) | __builtin_amdgcn_ballot_w64(th > h_max);
-    const bool plain = (all_active ? refused : (refused | __builtin_amdgcn_ballot_w64(!active))) == 0ull;
+                             __builtin_amdgcn_ballot_w64(th < h_min) | __builtin_amdgcn_ballot_w64(th > h_max) |
+                             ((ATC_WABL & 32) ? 0ull : (__builtin_amdgcn_ballot_w64(tp == INT32_MAX) | __builtin_amdgcn_ballot_w64(tp == INT32_MIN)));
+    uint64_t special = refused;
+    if ((ATC_WABL & 64) && !all_active) special |= __builtin_amdgcn_ballot_w64(!active);
+    else if (!all_active) {
+        const int hi = book ? max(a.phi, ls.la_p) : a.phi, lo = book ? min(a.phi, ls.la_p) : a.phi;
+        special |= __builtin_amdgcn_ballot_w64(!active) | __builtin_amdgcn_ballot_w64(hi == INT32_MAX) | __builtin_amdgcn_ballot_w64(lo == INT32_MIN);
+    }
+    const bool plain = special == 0ull;
     static_assert(kAMin == -kAMax && kPhiDotMin == -kPhiDotMax, "symmetric rate limits assumed (one count limit each)");
     if (ATC_USUAL(plain)) {
         const uint32_t v_new = a.v + (uint32_t)clamp_sym((int)(tv - a.v), q.rate_v);
@@ -719,12 +770,43 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
             fl |= valid ? 0u : (uint32_t)ATC_F_INVALID_H;
         }
         {
+            // heading (model.py:104-120: no validation, no wrap).  The 32-bit saturating form is exact while heading, target and last
+            // target are inside the 32-bit range; lanes where one is not redo the move in 64-bit counts with the side array
+            // (include/atc_step.h, ABI 19) — in the few wavefronts that hold such a lane.
             const int dd = clamp_sym(sat_sub(tp, a.phi), q.rate_p);
-            a.phi = active ? a.phi + dd : a.phi;
+            int phi_new = active ? a.phi + dd : a.phi;
+            bool counted = active && !within(sat_sub(tp, ls.la_p), kDiscrPhiFix);
+            int la_new = active ? tp : ls.la_p;
+            // (lanes without an aircraft compute on a clamped copy of the batch's last one: they must not write its side record)
+            const bool wide = d.lane_valid && (is_wide(tp) || is_wide(a.phi) || (book && is_wide(ls.la_p)));
+            if (!(ATC_WABL & 1) && ATC_RARE(__builtin_amdgcn_ballot_w64(wide) != 0ull)) {
+                if (wide) {
+                    double* w = at<double>(wide_base<ONE>(wide_named, zk), d.i * 32u);
+                    bool lim;
+                    const double T = phi_target_wide(__builtin_fma((double)act_p, q.dec_mp, q.dec_cp), &lim);
+                    const double P = is_wide(a.phi) ? w[0] : (double)a.phi;
+                    const double rate = (double)q.rate_p;
+                    // (a handed-over aircraft keeps its heading; its views are refreshed all the same: they are scratch)
+                    const double Pn = active ? P + __builtin_fmin(__builtin_fmax(T - P, -rate), rate) : P;
+                    phi_new = cvt_i32_f64(Pn);   // saturating: sat32
+                    if (is_wide(phi_new)) {   // the exact counts, and their views for the rest of this step (wide_view)
+                        w[0] = Pn;
+                        *reinterpret_cast<int2*>(w + 2) = make_int2(phi_wrap(Pn), __float_as_int(phi_obs_wide(Pn)));
+                    }
+                    if (book && active) {
+                        const double L = is_wide(ls.la_p) ? w[1] : (double)ls.la_p;
+                        counted = !(__builtin_fabs(T - L) < (double)kDiscrPhiFix);
+                        la_new = cvt_i32_f64(T);
+                        if (is_wide(la_new)) w[1] = T;
+                    }
+                    fl |= (lim && active) ? (uint32_t)ATC_F_PHI_LIMIT : 0u;
+                }
+            }
+            a.phi = phi_new;
             if (book) {
-                acts += (active && !within(sat_sub(tp, ls.la_p), kDiscrPhiFix)) ? 1 : 0;
-                ls.la_changed = ls.la_changed || (active && tp != ls.la_p);
-                ls.la_p = active ? tp : ls.la_p;
+                acts += counted ? 1 : 0;
+                ls.la_changed = ls.la_changed || (active && la_new != ls.la_p);
+                ls.la_p = la_new;
             }
         }
     }
@@ -735,7 +817,9 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
         v_move = active ? a.v : 0u;
         asm("" : "+v"(v_move));   // (keeps the select on the 32-bit counts: the compiler moved it behind the conversion, onto both halves of the double)
     }
-    if (!(ATC_ABLATE & 32)) advance(qk, a.phi, v_move, es.t, a.x, a.y);
+    // (the kinematics are periodic in the heading: a WIDE one goes in wrapped — read back from the side record's scratch word)
+    const int phi_k = heading_counts<ONE>(plain, a.phi, wide_named, zk, d.i);
+    if (!(ATC_ABLATE & 32)) advance(qk, phi_k, v_move, es.t, a.x, a.y);
     m.x32 = pos_to_real(q.pos_neg_k, qg.pos_x0, a.x);
     m.y32 = pos_to_real(q.pos_neg_k, qg.pos_y0, a.y);
     // MVA floor, first half: only ISSUE the lookup-cell gather here; nothing until the override chain needs its result
@@ -783,7 +867,7 @@ template <int W, bool FULL, bool ONE>
 __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const float* __restrict__ grid,
                                             const atc_params_t& p, const StepDerived& q, const QScan& qs, int zk, int N,
                                             const LaneIds& d, const Mid& m, LaneState& ls,
-                                            EnvState& es, const StepOut& so, int32_t* stp, float4* pos, float* obs_stage,
+                                            EnvState& es, const StepOut& so, int32_t* stp, double* wide_named, float4* pos, float* obs_stage,
                                             const float* act_next, Float3& a_next, QRates& qr_next) {
     Aircraft& a = ls.a;
     const bool active = m.active;
@@ -971,7 +1055,11 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     MvaPre pre;
     if (kPrefetch) pre = mva_prefetch(grid, QGET(g.gh), m.cell);
     if (kObsFirst && !(ATC_ABLATE & 8)) {
-        ob = get_state(oc, a.x, a.y, x32, y32, a.h, phi_real(a.phi), v_real(a.v), 0.0f);
+        // (observation word 3 first, then the heading for the angles — each its own rare look-up for a WIDE heading, before the rest
+        // of the observation occupies its registers)
+        const float phi_f = phi_real(heading_counts<ONE>(m.plain, a.phi, wide_named, zk, i));
+        const float phi_o = __int_as_float(wide_view<ONE, 1>(m.plain, a.phi, wide_named, zk, i, __float_as_int(phi_f)));
+        ob = get_state(oc, a.x, a.y, x32, y32, a.h, phi_f, phi_o, v_real(a.v), 0.0f);
         if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
     }
     // ---- MVA floor (atc_gym.py:146-161), second half ---------------------------------------------------------------------
@@ -1008,7 +1096,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             fl |= conflict ? (uint32_t)ATC_F_CONFLICT : 0u;
         }
         // ---- win / timeout overrides (atc_gym.py:163-173) ---------------------------------------------------------------
-        if (!(ATC_ABLATE & 4) && inside_corridor(K, qs.tri_bbox, x32, y32, a.h, phi_real(a.phi))) {
+        if (!(ATC_ABLATE & 4) && inside_corridor(K, qs.tri_bbox, x32, y32, a.h, phi_real(heading_counts<ONE>(m.plain, a.phi, wide_named, zk, i)))) {
             int bonus = (qs.timestep_limit - es.t) * 5;
             bonus = bonus < 0 ? 0 : bonus;
             r = (float)(10000 + bonus);
@@ -1034,7 +1122,9 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         } else if (kObsFirst) {
             ob.o[5] = a.h - mva;
         } else {
-            ob = get_state(oc, a.x, a.y, x32, y32, a.h, phi_real(a.phi), v_real(a.v), mva);
+            const float phi_f = phi_real(heading_counts<ONE>(m.plain, a.phi, wide_named, zk, i));
+            const float phi_o = __int_as_float(wide_view<ONE, 1>(m.plain, a.phi, wide_named, zk, i, __float_as_int(phi_f)));
+            ob = get_state(oc, a.x, a.y, x32, y32, a.h, phi_f, phi_o, v_real(a.v), mva);
             if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
         }
         // r += pos; r += ang; r += gs (atc_gym.py:179-185, after the override chain) as one addition of the factored sum
@@ -1340,13 +1430,16 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
                                   : (ATC_LOOP_SKIP_BOOK && !block_start && __builtin_amdgcn_ballot_w64(es.t == 0) == 0ull);
         // ... and whether every lane's aircraft is under control: re-established after the steps in which a mask can change
         if (!ONE && ATC_LOOP_ALLACT && ATC_RARE(mask_dirty)) {
-            all_active = __builtin_amdgcn_ballot_w64(!(dl.lane_valid && ((dl.k < 32 ? ((uint32_t)es.amask >> dl.k) : ((uint32_t)(es.amask >> 32) >> (dl.k - 32))) & 1u))) == 0ull;
+            // (and no lane's heading or last heading target is WIDE: include/atc_step.h ABI 19 — such lanes take the general form)
+            all_active = (__builtin_amdgcn_ballot_w64(!(dl.lane_valid && ((dl.k < 32 ? ((uint32_t)es.amask >> dl.k) : ((uint32_t)(es.amask >> 32) >> (dl.k - 32))) & 1u))) |
+                          __builtin_amdgcn_ballot_w64(max(ls.a.phi, ls.la_p) == INT32_MAX) | __builtin_amdgcn_ballot_w64(min(ls.a.phi, ls.la_p) == INT32_MIN)) == 0ull;
             mask_dirty = false;
         }
 #ifndef ATC_KIN_FROM_ARGS
 #define ATC_KIN_FROM_ARGS 1   // 0 (developer A/B): the kinematics constants named as the kernel argument in multi-step launches too
 #endif                        // (the compiler may then keep them in scalar registers across the step loop)
-        const Mid m = step_part_a(gl, qr, ATC_KIN_FROM_ARGS ? QGET(k) : q.k, QGET(g), dl, tg.v, tg.h, tg.p, ls, es, repeated, !ONE && all_active, ONE);
+        const Mid m = step_part_a<ONE>(gl, qr, ATC_KIN_FROM_ARGS ? QGET(k) : q.k, QGET(g), dl, tg.v, tg.h, tg.p, act.c, ls, es, repeated, !ONE && all_active, ONE,
+                                       st.phi_wide, zk);
         ATC_STAMP(1);
         Float3 nxt = act;
         const float* act_next = nullptr;   // the next block is fetched during the last step of the current one
@@ -1357,7 +1450,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             act_t += (size_t)BN * 3;
             if (step + 1 < n_steps) act_next = act_t;
         }
-        const bool quiet = step_part_b<W, FULL, ONE>(Kl, gl, pl, q, qs, zk, N, dl, m, ls, es, so, stats_l, pos, obs_stage, act_next, nxt, qr_next);
+        const bool quiet = step_part_b<W, FULL, ONE>(Kl, gl, pl, q, qs, zk, N, dl, m, ls, es, so, stats_l, st.phi_wide, pos, obs_stage, act_next, nxt, qr_next);
         if (ATC_RARE(!quiet)) mask_dirty = true;
         if (ATC_LOOP_DECODE_ONCE) {
             if (act_next) tg = decode_targets(QGET(r), nxt);
@@ -1417,8 +1510,14 @@ k_observe(const float* __restrict__ blob, int B, int N, atc_state_t st, const ui
         const int e = (int)(i / (uint32_t)N);
         if (mask && !mask[e]) continue;
         const int4 ps = reinterpret_cast<const int4*>(st.pos_hp)[i];
+        float ang = phi_real(ps.w), o3 = ang;
+        if (is_wide(ps.w)) {   // (include/atc_step.h, ABI 19: the exact counts are in the side record)
+            const double P = st.phi_wide[4 * (size_t)i];
+            ang = phi_real(phi_wrap(P));
+            o3 = phi_obs_wide(P);
+        }
         const Obs ob = get_state(obs_const(blob), ps.x, ps.y, pos_to_real(blob, 0, ps.x), pos_to_real(blob, 1, ps.y),
-                                 __int_as_float(ps.z), phi_real(ps.w), v_real((uint32_t)st.v_fix[i]), 0.0f);
+                                 __int_as_float(ps.z), ang, o3, v_real((uint32_t)st.v_fix[i]), 0.0f);
         store_obs(obs + (size_t)i * ATC_OBS_DIM, ob.o);
     }
 }
@@ -1539,7 +1638,7 @@ static int launch_step(const atc_scenario* s, int B, int N, int T, int hold, con
 static int check_env_args(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const atc_params_t* p) {
     if (!s || !st || !p) return fail_arg("null pointer");
     if (B < 1 || N < 1 || N > ATC_MAX_AIRCRAFT) return fail_arg("need B >= 1, 1 <= N <= 64");
-    if (!st->pos_hp || !st->v_fix || !st->last_act || !st->env || !st->stats) return fail_arg("atc_state_t has a null field");
+    if (!st->pos_hp || !st->v_fix || !st->last_act || !st->env || !st->stats || !st->phi_wide) return fail_arg("atc_state_t has a null field");
     if ((unsigned long long)B * N * ATC_OBS_DIM * 4ull >= (1ull << 32) || (unsigned long long)B * 64ull >= (1ull << 32))
         return fail_arg("B*N too large for one launch (B*N*40 bytes must stay below 4 GiB): split the batch");
     return ATC_OK;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ATC_ABI_VERSION 18
+#define ATC_ABI_VERSION 19
 
 /* ---------------------------------------------------------------------------------------------
  * Scenario blob: one flat array of 32-bit floats (device copy) compiled on the host from the sector
@@ -142,7 +142,9 @@ enum {
     ATC_F_INVALID_H = 1u << 5, /* atc_gym.py:312-315 via model.py:91-94 */
     ATC_F_CONFLICT = 1u << 6,  /* extension: 3 nm / 1000 ft separation lost (README.md:51) */
     ATC_F_NOISE = 1u << 7,     /* extension: inside a noise-abatement area below its ceiling (README.md:62) */
-    ATC_F_INACTIVE = 1u << 8   /* extension: aircraft already handed over (won earlier in this episode) */
+    ATC_F_INACTIVE = 1u << 8,  /* extension: aircraft already handed over (won earlier in this episode) */
+    ATC_F_PHI_LIMIT = 1u << 9  /* the heading target of this step lay beyond +-2^52 counts (|a_phi| > 2.98e6) and was clamped there:
+                                  the format's one remaining bound on the reference's unvalidated heading (model.py:104-120) */
 };
 
 /* params.mode bits */
@@ -193,27 +195,48 @@ typedef struct atc_params {
  * the LOWW bounding box) is pinned at the range limit: it stays "outside the airspace" exactly like the reference's
  * (model.py:289), only its x / y observation stops growing.
  *
- * Speed and heading (model.py:35-37, 60-129) on the fp32 path — ABI 18.
+ * Speed and heading (model.py:35-37, 60-129) on the fp32 path — ABI 18; unbounded heading: ABI 19.
  * The reference holds v, phi and the decoded action targets in float64.  As fp32 values they carry the rounding of the
  * target (1.5e-5 deg at 340 deg, 1.5e-5 kt at 250 kt) for as long as the target is held, and a heading that is 1e-5 deg off
  * moves the aircraft 5e-6 nm off over a 30 nm leg: next to the FAF, where the bearing to it is ill-conditioned, that was the one
  * stated exception to the 1e-5 bar of rounds 1-3 (tools/faf_conditioning.py).  Both are therefore 32-bit FIXED POINT, like
  * the positions, and the step's displacement is evaluated in float64 from them:
  *   speed    kt  = v_fix * 2^-23            UNSIGNED counts, [0, 512): the aircraft's [100, 300] and every refusable target
- *   heading  deg = 180 + phi_fix * 2^-23    signed counts, [-76, 436): the action space's [0, 360] and 76 deg either side
+ *   heading  deg = 180 + P * 2^-23          signed counts P.  The reference never validates or wraps a heading (model.py:104-120:
+ *                                           a continuous action a_phi = 3 turns the aircraft on to 720 deg), so P is NOT a 32-bit
+ *                                           quantity: |P| <= 2^52 (+-5.4e8 deg).  What is STORED is two-level (ABI 19):
+ *                                             phi_fix = sat32(P) in the 16-byte aircraft record — for -2^31 < P < 2^31 - 1, i.e.
+ *                                               headings in (-76, 436) deg: the action space's [0, 360] and 76 deg either side,
+ *                                               this IS the heading and nothing else is read or written;
+ *                                             a record whose phi_fix is INT32_MIN / INT32_MAX is WIDE: its exact P is the
+ *                                               integer-valued float64 atc_state_t.phi_wide[i][0] (written by the step that
+ *                                               left the 32-bit range; float64 holds every integer up to 2^53).
+ *                                           The last accepted heading target (last_action[2], atc_gym.py:311) is stored the same way:
+ *                                           sat32 in last_act[i][2], exact value in phi_wide[i][1] when that is saturated.
  *   - a target is  counts = trunc(a * m + c):  ONE float64 fma on the fp32 action (m, c = the reference's factor / offset of
- *     atc_gym.py:64-78,318-335 in counts, both integers; exact for every fp32 action: 24 x 31 bits) and the conversion to
- *     uint32 (speed) / int32 (heading) that TRUNCATES toward zero, SATURATES at both ends and maps NaN to 0 (gfx950:
- *     v_cvt_u32_f64 / v_cvt_i32_f64).  An action far outside the action space [-1, 1] therefore pins the target at the end of
- *     the format's range: refused for the speed like any target outside [100, 300] kt, held there for the heading (the
- *     reference, which does not validate headings, would turn on);
+ *     atc_gym.py:64-78,318-335 in counts, both integers; exact for every fp32 action: 24 x 31 bits), truncated toward zero,
+ *     NaN -> 0.  The speed's target is converted to uint32 SATURATING (gfx950: v_cvt_u32_f64): an action far outside the action
+ *     space pins it at the end of the format's range, where it is refused like any target outside [100, 300] kt.  The heading's
+ *     target is clamped to +-2^52 counts (|a_phi| <= 2.98e6 continuous, 5.4e8 discrete) — the one bound left: an aircraft-step
+ *     whose heading target was clamped carries ATC_F_PHI_LIMIT; the aircraft still turns towards it at the rate limit, and all
+ *     that differs from the reference is its action counter when two successive targets are BOTH beyond the bound and differ
+ *     (tests/test_oracle_golden.py pins that step).
  *   - rate limits (model.py:75-78, 117-120) are exact integer arithmetic:  fix += clamp(target - fix, +-rint(rate dt 2^23))
- *     (wrapping 32-bit difference for the speed — valid speeds, and the initial last_action 0, are < 2^31 counts apart —,
- *     saturating for the heading); the "action taken" discriminator (atc_gym.py:84,305-306) compares the same integer
- *     differences with 5 * 2^23 / 0.5 * 2^23 counts;
- *   - the fp32 speed / heading every other formula of the reference sees (observation, relative angles, corridor window) is
- *     (float)v_fix * 2^-23  /  fmaf((float)phi_fix, 2^-23, 180):  exact for every value with <= 24 significant bits, e.g. all
- *     integer speeds and headings;
+ *     (wrapping 32-bit difference for the speed — speeds an Airplane can have, [100, 300] kt (model.py:22-23: the constructor
+ *     raises outside), and the initial last_action 0 are < 2^31 counts apart; a speed placed from outside must lie inside
+ *     [44, 356] kt, within 256 kt of every acceptable target: the host mirror's set_v refuses others —, exact for the heading: the 32-bit saturating
+ *     form gives the same result whenever target and heading are both inside the 32-bit range, which is what the kernels
+ *     evaluate for such lanes); the "action taken" discriminator (atc_gym.py:84,305-306) compares the same integer differences
+ *     with 5 * 2^23 / 0.5 * 2^23 counts;
+ *   - what the heading feeds: the kinematics and every relative angle / the corridor window are periodic in the heading, the
+ *     observation's raw heading (atc_gym.py:269) is not.  A heading inside the 32-bit range is used as it is:
+ *       fp32 heading = fmaf((float)phi_fix, 2^-23, 180),  kinematics from phi_fix (below).
+ *     A WIDE heading P is first wrapped, in float64 like the kinematics' own reduction:  Pw = fma(rint(P * ATC_PHI_INV_TURN),
+ *       -ATC_PHI_TURN, P)  (exact: the remainder of P modulo 360 deg in counts, |Pw| <= 180 deg within a count):
+ *       kinematics, relative angles and the corridor window use Pw exactly like a phi_fix;  observation word 3 is
+ *       (float)(180 + P 2^-23) evaluated in float64 (exact) and rounded once — the float32 of the reference's float64 heading.
+ *   - the fp32 speed every other formula of the reference sees is (float)v_fix * 2^-23; both conversions are exact for every value
+ *     with <= 24 significant bits, e.g. all integer speeds and headings;
  *   - the altitude stays fp32 (it does not feed the position; 1e-3 ft at 16 000 ft is 5e-8 in observation units);
  *   - state placed from outside (entry points, fixtures) is the NEAREST count.
  * Heading kinematics (model.py:122-129, 345-348) in float64, shared bit for bit by every fp32 implementation (the HIP
@@ -243,6 +266,9 @@ typedef struct atc_params {
 #define ATC_DITHER_MAGIC_HI 0x42880000u   /* high word of 1.5 * 2^41: the low word's low 11 bits are the dither fraction */
 #define ATC_KIN_INV180 (0x1.6c16c16c16c17p-31)
 #define ATC_KIN_HALF_TURN 1509949440.0    /* 180 * 2^23 */
+#define ATC_PHI_TURN 3019898880.0         /* 360 * 2^23: a full turn in heading counts */
+#define ATC_PHI_INV_TURN (0x1.6c16c16c16c17p-32)   /* RN(1 / ATC_PHI_TURN) */
+#define ATC_PHI_LIMIT 4503599627370496.0  /* 2^52: heading targets are clamped to +-this (ATC_F_PHI_LIMIT) */
 #define ATC_KIN_S0 (0x1.1df46a2514d5fp-29)
 #define ATC_KIN_S1 (-0x1.dbb820c160971p-90)
 #define ATC_KIN_S2 (0x1.dad945dddaa3dp-152)
@@ -261,13 +287,21 @@ typedef struct atc_params {
  * 16 + 4 + 12 B and writes 16 + 4 B (+ 12 B only when a last-action target changed). */
 typedef struct atc_state {
     int32_t* pos_hp;  /* [B*N][4]  x_fix, y_fix (position grid counts, see above), h [ft] as a float bit pattern, phi_fix
-                         (heading, never wrapped, model.py:35-36; fixed point, see above) — one 16-byte record */
+                         (heading, never wrapped, model.py:35-36; fixed point, INT32_MIN / INT32_MAX = WIDE: see above and
+                         phi_wide) — one 16-byte record */
     int32_t* v_fix;   /* [B*N]     speed (model.py:37), fixed point */
     int32_t* last_act;/* [B*N][3]  last accepted v / h / phi targets = AtcGym.last_action (atc_gym.py:86,311) in the state's
                          own formats: v_fix, h as a float bit pattern, phi_fix (0 kt / 0 deg of atc_gym.py:86 = the counts
                          of 0, not the integer 0) */
     int32_t* env;     /* [B][ATC_ENV_WORDS]  per-step env record, see ATC_ENV_* */
     int32_t* stats;   /* [B][ATC_STAT_WORDS] per-episode env record, see ATC_STAT_* (touched only when an episode ends) */
+    double* phi_wide; /* [B*N][4]  side record of aircraft whose 32-bit heading fields are saturated (see "Speed and heading": WIDE):
+                         word 0 = exact heading counts, word 1 = exact last heading target (integer-valued float64, valid while
+                         phi_fix / last_act[i][2] is INT32_MIN / INT32_MAX), word 2 = scratch of the step kernel (the wrapped
+                         counts and observation word 3 of word 0, handed from the first half of a step to the second), word 3
+                         reserved.  Never read or written for an aircraft whose heading and heading targets stay inside
+                         (-76, 436) deg — every action inside the action space —, so it costs memory (32 B per aircraft), not
+                         traffic; contents are unspecified while the 32-bit field is in range. */
 } atc_state_t;
 /* per-step env record (4 x 32-bit words; float fields are stored by bit pattern) */
 enum {

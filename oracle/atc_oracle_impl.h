@@ -74,6 +74,32 @@ static uint32_t FN(trunc_u32)(double x) {
     if (x >= 4294967295.0) return UINT32_MAX;
     return (uint32_t)x;
 }
+/* Heading counts are 64-bit (include/atc_step.h, ABI 19): target = trunc(a m + c) clamped to +-2^52, NaN -> 0 */
+#define ORC_PHI_LIMIT 4503599627370496.0 /* 2^52 */
+static int64_t FN(trunc_i64_phi)(double x, int* clamped) {
+    *clamped = 0;
+    if (!(x == x)) return 0;
+    x = trunc(x);
+    if (x > ORC_PHI_LIMIT) { *clamped = 1; x = ORC_PHI_LIMIT; }
+    if (x < -ORC_PHI_LIMIT) { *clamped = 1; x = -ORC_PHI_LIMIT; }
+    return (int64_t)x;
+}
+static int FN(is_wide)(int32_t f) { return f == INT32_MAX || f == INT32_MIN; }
+/* the exact counts of a stored (32-bit field, 64-bit side word) pair, and back */
+static int64_t FN(phi_load)(int32_t f, int64_t wide) { return FN(is_wide)(f) ? wide : (int64_t)f; }
+static void FN(phi_put)(int64_t P, int32_t* f, int64_t* wide) {
+    *f = FN(sat32)(P);
+    if (FN(is_wide)(*f)) *wide = P;
+}
+/* a WIDE heading wrapped into [-W/2, W/2), W = 360 2^23 (include/atc_step.h): what kinematics and relative angles use */
+#define ORC_PHI_TURN 3019898880ll
+static int32_t FN(phi_wrap)(int64_t P) {
+    int64_t a = P + ORC_PHI_TURN / 2, q = a / ORC_PHI_TURN;
+    if (a % ORC_PHI_TURN < 0) q -= 1; /* floor division */
+    return (int32_t)(P - q * ORC_PHI_TURN);
+}
+/* the heading as kinematics / angles see it, and observation word 3 (atc_gym.py:269) */
+static int32_t FN(phi_eff)(int32_t f, int64_t wide) { return FN(is_wide)(f) ? FN(phi_wrap)(wide) : f; }
 typedef struct FN(decode) { double m, c; } FN(decode_t);
 /* target in counts = a * m + c (one fma in float64, m and c integers) */
 static FN(decode_t) FN(decode_consts)(double fac, double add, double offset, double q) {
@@ -88,6 +114,9 @@ static int32_t FN(rate_fix)(double rate, double dt, double q) { /* rint(|rate| d
 }
 static REAL FN(v_real)(int32_t f) { return (float)(uint32_t)f * (float)(1.0 / ORC_QV); }
 static REAL FN(phi_real)(int32_t f) { return fmaf((float)f, (float)(1.0 / ORC_QP), ATC_PHI_FIX_OFFSET); }
+static REAL FN(phi_obs)(int32_t f, int64_t wide) {
+    return FN(is_wide)(f) ? (float)((double)ATC_PHI_FIX_OFFSET + (double)wide * (1.0 / ORC_QP)) : FN(phi_real)(f);
+}
 /* state placed from outside (spawn, fixtures): nearest count */
 static int32_t FN(v_store)(REAL v) { return (int32_t)FN(trunc_u32)(rint((double)v * ORC_QV)); }
 static int32_t FN(phi_store)(REAL p) { return FN(trunc_i32)(rint(((double)p - (double)ATC_PHI_FIX_OFFSET) * ORC_QP)); }
@@ -130,6 +159,8 @@ static REAL FN(v_real)(REAL f) { return f; }
 static REAL FN(phi_real)(REAL f) { return f; }
 static REAL FN(v_store)(REAL v) { return v; }
 static REAL FN(phi_store)(REAL p) { return p; }
+static REAL FN(phi_eff)(REAL f, int64_t wide) { (void)wide; return f; }
+static REAL FN(phi_obs)(REAL f, int64_t wide) { (void)wide; return f; }
 /* model.py:345-348 rot_matrix: sin / cos of math.radians(phi) */
 static void FN(sincos_heading)(REAL phi, REAL* sn, REAL* cs) {
     REAL pr = phi * (REAL)(3.14159265358979323846 / 180.0);
@@ -288,6 +319,8 @@ typedef struct FN(orc_state) {
     REAL* ep_return;
     int32_t* ep_length;
     int32_t* ep_actions;       /* actions_taken of the last finished episode */
+    int64_t* phi_wide;         /* [B*N][2] fp32 spec only: exact heading counts / last heading target of WIDE aircraft
+                                  (include/atc_step.h, atc_state_t.phi_wide) */
 } FN(orc_state_t);
 
 typedef struct FN(orc_out) {
@@ -304,8 +337,10 @@ typedef struct FN(orc_out) {
 
 /* atc_gym.py:262-277 _get_state -> float32[10]; also returns the full-precision d_faf / phi_rel_faf / on_gp used by the
  * shaping rewards (atc_gym.py:179-185 read self._d_faf etc., which are not rounded to float32). */
-static void FN(get_state)(const REAL* S, FN(pos_t) px, FN(pos_t) py, REAL h, REAL phi, REAL v, REAL mva, float* obs10,
+static void FN(get_state)(const REAL* S, FN(pos_t) px, FN(pos_t) py, REAL h, REAL phi, REAL phi_obs, REAL v, REAL mva, float* obs10,
                           REAL* d_faf, REAL* phi_rel_faf, REAL* on_gp) {
+    /* phi: the heading the relative angle sees; phi_obs: observation word 3 — the same number in the reference, the wrapped /
+     * unwrapped pair of a WIDE heading in the fp32 spec (include/atc_step.h) */
     REAL x = FN(pos_to_real)(S, 0, px), y = FN(pos_to_real)(S, 1, py);
     REAL to_faf_x = FN(pos_to_faf)(S, 0, px);  /* faf - position, atc_gym.py:289-297 */
     REAL to_faf_y = FN(pos_to_faf)(S, 1, py);
@@ -316,7 +351,7 @@ static void FN(get_state)(const REAL* S, FN(pos_t) px, FN(pos_t) py, REAL h, REA
     obs10[0] = (float)x;
     obs10[1] = (float)y;
     obs10[2] = (float)h;
-    obs10[3] = (float)phi;
+    obs10[3] = (float)phi_obs;
     obs10[4] = (float)v;
     obs10[5] = (float)(h - mva);
     obs10[6] = (float)*on_gp;
@@ -384,8 +419,8 @@ static void FN(reset_env)(const REAL* S, int N, const FN(orc_state_t) * st, cons
         st->v[i] = FN(v_store)(sv);
         if (obs) {
             REAL d, pr, gp;
-            FN(get_state)(S, st->x[i], st->y[i], st->h[i], FN(phi_real)(st->phi[i]), FN(v_real)(st->v[i]), (REAL)0,
-                          obs + (size_t)i * 10, &d, &pr, &gp);
+            FN(get_state)(S, st->x[i], st->y[i], st->h[i], FN(phi_real)(st->phi[i]), FN(phi_real)(st->phi[i]), FN(v_real)(st->v[i]),
+                          (REAL)0, obs + (size_t)i * 10, &d, &pr, &gp);
         }
     }
     st->total_reward[e] = 0;
@@ -505,17 +540,23 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
                         memcpy(la, &tgt, sizeof tgt);
                     }
                 }
-                { /* heading: model.py:104-120 — no validation, no wrap */
-                    const int32_t tgt = FN(trunc_i32)(fma((double)ap, dec_p.m, dec_p.c));
-                    st->phi[i] += FN(clampi)(FN(sat32)((int64_t)tgt - (int64_t)st->phi[i]), -rate_p, rate_p);
+                { /* heading: model.py:104-120 — no validation, no wrap: 64-bit counts (include/atc_step.h, ABI 19) */
+                    int clamped;
+                    const int64_t tgt = FN(trunc_i64_phi)(fma((double)ap, dec_p.m, dec_p.c), &clamped);
+                    if (clamped) fl[k] |= ATC_F_PHI_LIMIT;
+                    int64_t* wide = st->phi_wide + 2 * i;
+                    const int64_t P = FN(phi_load)(st->phi[i], wide[0]);
+                    int64_t d = tgt - P;
+                    d = d > (int64_t)rate_p ? (int64_t)rate_p : (d < -(int64_t)rate_p ? -(int64_t)rate_p : d);
+                    FN(phi_put)(P + d, &st->phi[i], &wide[0]);
                     int32_t* la = &st->last_act[(size_t)2 * BN + i];
-                    const int32_t dd = FN(sat32)((int64_t)tgt - (int64_t)*la);
-                    if (!(dd > -discr_p && dd < discr_p)) st->actions_taken[e] += 1;
-                    *la = tgt;
+                    const int64_t dd = tgt - FN(phi_load)(*la, wide[1]);
+                    if (!(dd > -(int64_t)discr_p && dd < (int64_t)discr_p)) st->actions_taken[e] += 1;
+                    FN(phi_put)(tgt, la, &wide[1]);
                 }
             }
             /* model.py:122-129 Airplane.step, float64 from the fixed-point state */
-            FN(advance)(S, dist_a, st->phi[i], st->v[i], t, &st->x[i], &st->y[i]);
+            FN(advance)(S, dist_a, FN(phi_eff)(st->phi[i], st->phi_wide[2 * i]), st->v[i], t, &st->x[i], &st->y[i]);
 #else
             for (int c = 0; c < 3; ++c) {   /* atc_gym.py:139-141 -> _action_with_reward :299-316 */
                 REAL a = actions[i * 3 + c];
@@ -627,7 +668,12 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
             }
             if (fl[k] & ATC_F_CONFLICT) r[k] = (REAL)p->conflict_reward;
             const REAL px = FN(pos_to_real)(S, 0, st->x[i]), py = FN(pos_to_real)(S, 1, st->y[i]);
-            const REAL phi_r = FN(phi_real)(st->phi[i]), v_r = FN(v_real)(st->v[i]);
+#if ORC_FIXED_POS
+            const REAL phi_r = FN(phi_real)(FN(phi_eff)(st->phi[i], st->phi_wide[2 * i])), v_r = FN(v_real)(st->v[i]);
+            const REAL phi_o = FN(phi_obs)(st->phi[i], st->phi_wide[2 * i]);
+#else
+            const REAL phi_r = st->phi[i], phi_o = st->phi[i], v_r = st->v[i];
+#endif
             if (FN(inside_corridor)(S, px, py, st->h[i], phi_r)) { /* atc_gym.py:163-169 */
                 int bonus = (p->timestep_limit - t) * 5;
                 if (bonus < 0) bonus = 0;
@@ -641,7 +687,7 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
                 fl[k] |= ATC_F_TIMEOUT;
             }
             REAL d_faf, phi_rel_faf, on_gp;
-            FN(get_state)(S, st->x[i], st->y[i], st->h[i], phi_r, v_r, mva_h[k], raw, &d_faf, &phi_rel_faf, &on_gp);
+            FN(get_state)(S, st->x[i], st->y[i], st->h[i], phi_r, phi_o, v_r, mva_h[k], raw, &d_faf, &phi_rel_faf, &on_gp);
             if (p->mode & ATC_M_REWARD_SHAPING) { /* atc_gym.py:179-185 */
                 REAL pos = FN(reward_approach_position)(d_faf, S[ATC_C_PHI_TO_RWY], phi_rel_faf, S[ATC_C_WORLD_DIAG]);
                 r[k] += pos;

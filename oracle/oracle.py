@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liboracle_atc.so")
 
 M_REWARD_SHAPING, M_NORMALIZE, M_DISCRETE, M_AUTO_RESET, M_RANDOM_ENTRY, M_KEEP_ACTIVE = 1, 2, 4, 8, 16, 32
+F_PHI_LIMIT = 1 << 9
 
 
 class Params(C.Structure):
@@ -101,10 +102,13 @@ class OracleEnv:
         self.min_sep = np.zeros(B, r)
         self.term_obs = np.zeros((B, N, 10), np.float32)
         self.mva = np.zeros((B, N), np.int32)
-        self._st = (C.c_void_p * 15)(*[_ptr(a) for a in (
+        # exact 64-bit heading counts / last heading target of WIDE aircraft (include/atc_step.h, atc_state_t.phi_wide); the
+        # float64 instantiation (the reference as it is) never touches it
+        self.phi_wide = np.zeros((BN, 2), np.int64)
+        self._st = (C.c_void_p * 16)(*[_ptr(a) for a in (
             self.px, self.py, self.h, self._phi, self._v, self.last_act, self.timesteps, self.actions_taken,
             self.total_reward, self.active_mask, self.win_bits, self.episodes, self.ep_return, self.ep_length,
-            self.ep_actions)])
+            self.ep_actions, self.phi_wide)])
         self._out = (C.c_void_p * 9)(*[_ptr(a) for a in (
             self.obs, self.raw_obs, self.reward, self.ac_reward, self.done, self.flags, self.min_sep, self.term_obs,
             self.mva)])
@@ -146,10 +150,28 @@ class OracleEnv:
             return np.uint32(min(max(c, 0.0), 2.0 ** 32 - 1)).astype(np.int32)
         return np.int32(min(max(c, -2.0 ** 31), 2.0 ** 31 - 1))
 
+    I32_MIN, I32_MAX = -2 ** 31, 2 ** 31 - 1
+
+    @property
+    def phi_counts(self):
+        """exact 64-bit heading counts (the 32-bit field, or phi_wide where that is saturated: include/atc_step.h, ABI 19)"""
+        assert self.fixed
+        p = self._phi.astype(np.int64)
+        wide = (self._phi == self.I32_MIN) | (self._phi == self.I32_MAX)
+        return np.where(wide, self.phi_wide[:, 0], p)
+
     @property
     def phi(self):
         """headings in degrees (float64: exact for the fixed-point instantiation)"""
-        return self._phi.astype(np.float64) / self.PHI_Q + self.PHI_OFFSET if self.fixed else self._phi
+        return self.phi_counts.astype(np.float64) / self.PHI_Q + self.PHI_OFFSET if self.fixed else self._phi
+
+    def _put_phi(self, field, i, col, deg):
+        """stores a heading [deg] as (sat32 counts, exact counts in phi_wide[:, col] when saturated)"""
+        P = int(np.rint((float(deg) - self.PHI_OFFSET) * self.PHI_Q))
+        P = min(max(P, -2 ** 52), 2 ** 52)
+        field[i] = min(max(P, self.I32_MIN), self.I32_MAX)
+        if field[i] in (self.I32_MIN, self.I32_MAX):
+            self.phi_wide[i, col] = P
 
     @property
     def v(self):
@@ -170,7 +192,8 @@ class OracleEnv:
         self.px[i], self.py[i] = self._to_pos(x, 0), self._to_pos(y, 1)
         self.h[i] = h
         if self.fixed:
-            self._phi[i], self._v[i] = self._fix(phi, self.PHI_OFFSET, self.PHI_Q), self._fix(v, self.V_OFFSET, self.V_Q, True)
+            self._put_phi(self._phi, i, 0, phi)
+            self._v[i] = self._fix(v, self.V_OFFSET, self.V_Q, True)
         else:
             self._phi[i], self._v[i] = phi, v
 
@@ -180,7 +203,7 @@ class OracleEnv:
         if self.fixed:
             self.last_act[0, i] = self._fix(value[0], self.V_OFFSET, self.V_Q, True)
             self.last_act[1, i] = np.float32(value[1]).view(np.int32)
-            self.last_act[2, i] = self._fix(value[2], self.PHI_OFFSET, self.PHI_Q)
+            self._put_phi(self.last_act[2], i, 1, value[2])
         else:
             self.last_act[:, i] = value
 
@@ -188,8 +211,11 @@ class OracleEnv:
         i = e * self.N + k
         if not self.fixed:
             return [float(c) for c in self.last_act[:, i]]
+        lp = int(self.last_act[2, i])
+        if lp in (self.I32_MIN, self.I32_MAX):
+            lp = int(self.phi_wide[i, 1])
         return [float(np.uint32(self.last_act[0, i])) / self.V_Q, float(self.last_act[1, i:i + 1].view(np.float32)[0]),
-                float(self.last_act[2, i]) / self.PHI_Q + self.PHI_OFFSET]
+                float(lp) / self.PHI_Q + self.PHI_OFFSET]
 
     def step(self, actions):
         a = np.ascontiguousarray(np.asarray(actions, dtype=self.dtype).reshape(self.B * self.N * 3))

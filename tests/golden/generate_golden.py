@@ -23,6 +23,9 @@ inputs + expected outputs of the AtcGym.step() hot path as small fixtures:
                       and state every 16th step and on the last step of every episode): LOWW / LOWW_random / Simple /
                       UnitTest, dt 1/2/5, continuous and discrete, shaping x normalisation off, >= 50 each of win /
                       below-MVA / timeout terminals, episodes stepped on past `done` (incl. past a win)
+  g11_unbounded.npz   actions outside the action space, replayed by the reference: sustained a_phi up to +-3 (heading to 720 / -360
+                      deg), headings wound to +-5 500 deg and back, un-clipped random actions, discrete heading indices beyond 360;
+                      the same compact form as g9
   model_test_known_answers.json  the 8 known answers of the reference's own envs/atc/model_test.py
 
 Usage:
@@ -784,8 +787,53 @@ def gen_model_test():
         json.dump(cases, f, indent=1)
 
 
+# ----------------------------------------------------------------------------------------------- G11
+def gen_g11():
+    """Actions OUTSIDE the action space (the reference enforces nothing: Box(-1, 1) is not applied by step(), atc_gym.py:128-141;
+    Airplane.action_phi validates nothing and never wraps, model.py:104-120): sustained a_phi in {+-1.2, +-1.43, +-2, +-3} with
+    a_v / a_h in and out of range alongside, headings wound up to several thousand degrees and back, un-clipped
+    random continuous actions, discrete heading indices beyond MultiDiscrete's 360 — every episode stepped on past `done` so
+    that the heading passes -76 / 436 deg (the 32-bit range of the fp32 state format) and reaches +-360 / 720 and beyond."""
+    rec = WideRecorder(stride=8)
+    env = make_env()
+    # Every episode flies on for at most 240 s after its first `done` (an aircraft that leaves the sector stays within the 24 nm
+    # the fp32 position grid reaches beyond the bounding box, include/atc_step.h "Aircraft positions").
+    # 1. sustained out-of-range heading actions from the reset state
+    for k, ap in enumerate((1.2, -1.2, 1.43, -1.43, 2.0, -2.0, 3.0, -3.0)):
+        for av, ah in ((0.0, 0.0), (1.5, -1.2), (-0.3, 0.4)):
+            acts = np.tile(f32([av, ah, ap]), (1400, 1))
+            rec.run(env, acts, "LOWW", 1, True, True, False, extra_after_done=240)
+    # 2. wind the heading up in circles (radius 1.3 nm: the position stays put) and unwind it again through zero
+    inits = interior_states(np.random.default_rng(41000), env, 6, 9000.0, 14000.0)
+    for k, st in enumerate(inits):
+        up = (30.0, 12.5, 7.25, -31.0, 11.37, -6.6)[k]
+        t1, t2 = 180.0 + 180.0 * up, 180.0 - 180.0 * up            # the two heading targets (atc_gym.py:333-335)
+        n1, n2 = int(abs(t1 - st[3]) / 3) + 8, int(abs(t2 - t1) / 3) + 8   # turning all the way at 3 deg / s, then 8 s straight
+        acts = np.concatenate([np.tile(f32([0.0, 0.1, up]), (n1, 1)), np.tile(f32([0.2, 0.1, -up]), (n2, 1)),
+                               np.tile(f32([0.2, 0.1, 0.25]), (140, 1))])
+        rec.run(env, acts, "LOWW", 1, True, True, False, init_state=st, extra_after_done=len(acts))
+    # 3. un-clipped random continuous actions (what an un-squashed Gaussian policy emits), held 20 steps
+    for scen, dt, n_eps, seed0, horizon in (("LOWW_random", 1, 40, 42000, 1500), ("LOWW_random", 5, 16, 43000, 600),
+                                            ("Simple", 2, 12, 44000, 800)):
+        e2 = make_env(scen, dt=dt)
+        its = interior_states(np.random.default_rng(seed0 + 500), e2, n_eps, 8000.0, 15000.0)
+        for k in range(n_eps):
+            rng = np.random.default_rng(seed0 + k)
+            nb = horizon // 20
+            a = np.stack([rng.uniform(-1.2, 1.2, nb), rng.uniform(-0.4, 1.1, nb), rng.uniform(-4.0, 4.0, nb)], 1)
+            a[rng.uniform(size=nb) < 0.15, 2] *= 6.0   # now and then far out
+            rec.run(e2, np.repeat(f32(a), 20, 0), scen, dt, True, True, False, init_state=its[k], extra_after_done=240 // dt)
+    # 4. discrete action space, heading indices outside [0, 360) (atc_gym.py:329-330: index * 1 + 0, never validated)
+    e3 = make_env("LOWW", discrete=True)
+    for k, idx in enumerate((500, -90, 1000, -700, 436, 437, -76, -77)):
+        acts = np.tile(np.array([15.0, 120.0, float(idx)]), (1400, 1))
+        rec.run(e3, acts, "LOWW", 1, True, True, True, extra_after_done=240)
+    rec.save(os.path.join(HERE, "g11_unbounded.npz"))
+    return rec
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "mt", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "mt", "g8", "g9", "g10", "g11"]
     if "g1" in which:
         gen_g1()
     if "mt" in which:
@@ -818,6 +866,14 @@ if __name__ == "__main__":
         r = gen_g9()
         fl, dn = np.asarray(r.flags), np.asarray(r.done)
         print("g9 episodes", len(r.ep), "steps", len(fl), "sampled rows", len(r.samp_rows))
+        for name, bit in (("below", 1), ("outside", 2), ("won", 4), ("timeout", 8), ("inv_v", 16), ("inv_h", 32)):
+            print(name, int(((fl & bit) != 0).sum()), "terminal:", int((((fl & bit) != 0) & (dn != 0)).sum()))
+    if "g11" in which:
+        r = gen_g11()
+        fl, dn = np.asarray(r.flags), np.asarray(r.done)
+        phi = np.asarray(r.state)[:, 3]
+        print("g11 episodes", len(r.ep), "steps", len(fl), "sampled rows", len(r.samp_rows), "heading range", phi.min(), phi.max(),
+              "rows beyond [-76, 436):", int(((phi < -76) | (phi >= 436)).sum()))
         for name, bit in (("below", 1), ("outside", 2), ("won", 4), ("timeout", 8), ("inv_v", 16), ("inv_h", 32)):
             print(name, int(((fl & bit) != 0).sum()), "terminal:", int((((fl & bit) != 0) & (dn != 0)).sum()))
     print("done")

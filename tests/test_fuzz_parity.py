@@ -62,6 +62,10 @@ def _case(seed):
     if int(rng.integers(4)) == 0 and (N & (N - 1)) == 0:
         per = max(1, 256 // N)
         kw["B"] = per * max(1, kw["B"] // per // (4 if N == 1 else 1))
+    # round 5, drawn last: a tenth of the cases carry actions OUTSIDE the action space (U(-4, 4) and beyond) — the reference
+    # enforces none (atc_gym.py:128-141) and never validates or wraps a heading (model.py:104-120)
+    if int(rng.integers(10)) == 0:
+        kw["wild"] = float(rng.choice([0.05, 0.3, 1.0]))
     return scn, comp, kw
 
 

@@ -98,7 +98,7 @@ def test_argument_errors_are_reported_not_raised_from_c():
     assert L.atc_rollout_hold(env.sector.handle, 4, 2, 10, 4, C.byref(st), a.data_ptr(), C.byref(out), C.byref(p), stream) == -1
     assert b"multiple of hold" in L.atc_last_error()
     assert L.atc_rollout_hold(env.sector.handle, 4, 2, 3, 0, C.byref(st), a.data_ptr(), C.byref(out), C.byref(p), stream) == -1
-    bad = lib.AtcState(st.pos_hp, None, st.last_act, st.env, st.stats)
+    bad = lib.AtcState(st.pos_hp, None, st.last_act, st.env, st.stats, st.phi_wide)
     assert L.atc_step(env.sector.handle, 4, 2, C.byref(bad), a.data_ptr(), C.byref(out), C.byref(p), stream) == -1
     assert b"null" in L.atc_last_error()
     too_big = 2 ** 27  # 2^27 x 64 aircraft x 40 B >> 4 GiB
@@ -205,7 +205,7 @@ def test_fast_and_full_kernel_variants_agree(N):
             dn = d2 != 0
             if bool(dn.any()):
                 assert torch.equal(out["term_obs"][t][dn], i2["terminal_observation"][dn])
-    for name in ("pos_hp", "v_fix", "last_act", "env", "stats"):
+    for name in ("pos_hp", "v_fix", "last_act", "env", "stats", "phi_wide"):
         assert torch.equal(getattr(fast, name), getattr(full, name)) and torch.equal(getattr(roll, name), getattr(full, name)), name
     for e in (fast, full, roll):
         e.close()
@@ -230,7 +230,7 @@ def test_rollout_with_held_actions_equals_single_steps(N, T, hold):
             o, r, d, info = one.step(blocks[t // hold])
             assert torch.equal(out["obs"][t], o) and torch.equal(out["reward"][t], r), (launch, t)
             assert torch.equal(out["done"][t], d) and torch.equal(out["flags"][t], info["flags"]), (launch, t)
-    for name in ("pos_hp", "v_fix", "last_act", "env", "stats"):
+    for name in ("pos_hp", "v_fix", "last_act", "env", "stats", "phi_wide"):
         assert torch.equal(getattr(one, name), getattr(roll, name)), name
     assert N < 16 or int(one.episodes.sum()) > B
     one.close()
@@ -303,7 +303,7 @@ def test_host_mapped_buffers_match_device_buffers(B, N):
         o2, r2, d2, i2 = hst.step(pinned if t % 2 else acts)  # pinned actions are read in place, others are uploaded
         assert torch.equal(o1.cpu(), o2) and torch.equal(r1.cpu(), r2) and torch.equal(d1.cpu(), d2)
         assert torch.equal(i1["flags"].cpu(), i2["flags"]) and torch.equal(i1["original_state"].cpu(), i2["original_state"])
-    for name in ("pos_hp", "v_fix", "last_act", "env", "stats"):
+    for name in ("pos_hp", "v_fix", "last_act", "env", "stats", "phi_wide"):
         assert torch.equal(getattr(dev, name).cpu(), getattr(hst, name)), name
     assert int(hst.episodes.sum()) > 0
     # a pageable host pointer is rejected by the library, not dereferenced
@@ -434,7 +434,7 @@ def test_held_actions_hint_changes_nothing(N, hold):
                 o2, r2, d2, i2 = hint.obs, hint.reward, hint.done, {"flags": hint.flags}
             assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(d, d2), (block, k)
             assert torch.equal(info["flags"], i2["flags"]), (block, k)
-            for name in ("pos_hp", "v_fix", "last_act", "env", "stats"):
+            for name in ("pos_hp", "v_fix", "last_act", "env", "stats", "phi_wide"):
                 assert torch.equal(getattr(plain, name), getattr(hint, name)), (name, block, k)
             handed_over += int(slot0_inactive.sum()) if t == 1 else 0
             if k == 0:
@@ -488,7 +488,7 @@ def test_held_hint_after_a_multi_step_launch():
             ra = a.step(blocks[2])
             rb = b.step(blocks[2], held=True)
             assert all(torch.equal(x, y) for x, y in zip(ra[:3], rb[:3])), (rnd, k)
-        for name in ("pos_hp", "v_fix", "last_act", "env", "stats"):
+        for name in ("pos_hp", "v_fix", "last_act", "env", "stats", "phi_wide"):
             assert torch.equal(getattr(a, name), getattr(b, name)), (name, rnd)
     a.close()
     b.close()

@@ -338,6 +338,67 @@ def test_wide_fixture_batched():
     assert n == len(fx.flags) > 500000
 
 
+def test_unbounded_heading_fixture_batched():
+    """G11: actions outside the action space as the REFERENCE replays them (tests/golden/generate_golden.py:gen_g11) — sustained
+    a_phi up to +-3 (headings to 720 / -360 deg), headings wound to +-5 500 deg and back, un-clipped random actions, discrete
+    indices beyond 360 — through the batched kernel at g9's bars.  ABI 18's heading format ended at 436 / -76 deg; ABI 19 keeps
+    the exact counts behind the saturating 32-bit field (include/atc_step.h)."""
+    fx = H.WideFixture("g11_unbounded.npz")
+    n = H.replay_wide(fx, _HipLockstep, obs_tol=1e-5, state_tol=1e-5, rew_tol=1e-5)
+    assert n == len(fx.flags) > 90000
+    phi = fx.state[:, 3]
+    assert phi.max() >= 5000 and phi.min() <= -5000
+
+
+def test_unbounded_heading_single_env():
+    """The same through the drop-in AtcGym (one env, packet polling): the four +-3 / +-2 episodes of G11 step by step."""
+    from envs.atc import atc_gym
+    fx = H.WideFixture("g11_unbounded.npz")
+    eps = [ep for ep in fx.episodes if ep["scen"] == "LOWW" and not ep["discrete"] and ep["init_timesteps"] == 0
+           and abs(float(fx.action[ep["start"], 2])) >= 2.0 and ep["init_state"][:2] == [10.0, 51.0]][:6]
+    assert len(eps) >= 4
+    env = atc_gym.AtcGym()
+    for ep in eps:
+        env.reset()
+        for t in range(ep["steps"]):
+            row = ep["start"] + t
+            obs, rew, done, info = env.step(fx.action[row].astype(np.float32))
+            assert bool(done) == bool(fx.done[row]) and env.actions_taken == fx.actions_taken[row], (row, t)
+            assert abs(rew - fx.reward[row]) <= 1e-5 * max(1.0, abs(fx.reward[row])), (row, t)
+            si = fx.samp_index[row]
+            if si >= 0:
+                assert np.all(np.abs(obs - fx.obs[si]) <= 1e-5), (row, t, obs, fx.obs[si])
+                assert abs(env._airplane.phi - fx.state[si][3]) <= 1e-5
+    env.close()
+
+
+def test_heading_bound_flag_on_device():
+    """ATC_F_PHI_LIMIT: the one bound left (heading targets beyond +-2^52 counts, |a_phi| > 2.98e6) is flagged on the step that
+    clamps — same flags, counters and state as the fp32 oracle (tests/test_oracle_golden.py pins what the clamp changes
+    against the reference)."""
+    from atc_hip.vec_env import AtcVecEnv
+    from oracle import oracle as O
+    comp = H.compiled("LOWW", 0.5)
+    env = AtcVecEnv(64, 1, scenario=H.make_scenario("LOWW"), auto_reset=False, keep_active=True, grid_cell=0.5)
+    orc = O.OracleEnv(comp, 64, 1, O.make_params(keep_active=True), np.float32)
+    a = np.zeros((64, 1, 3), np.float32)
+    a[:, 0, 2] = np.concatenate([np.linspace(-1, 1, 16), [1.4222, 1.4223, -1.4223, 3.0, -3.0, 100.0, 2.9e6, 2.99e6, 4e6, -4e6,
+                                                         1e30, -1e30, np.inf, -np.inf, np.nan, 5e6], np.linspace(-9e6, 9e6, 32)])
+    for t in range(12):
+        if t == 6:
+            a[:, 0, 2] *= -0.5
+        obs, rew, done, info = env.step(a)
+        orc.step(a)
+        fl = info["flags"].cpu().numpy().astype(np.uint16)
+        assert np.array_equal(fl, orc.flags), t
+        assert np.array_equal(env.actions_taken.cpu().numpy(), orc.actions_taken), t
+        assert np.array_equal(env.phi_counts.cpu().numpy(), orc.phi_counts.astype(np.float64)), t
+        on = obs.cpu().numpy().reshape(64, 1, 10)
+        assert np.all(np.abs(on - orc.obs) <= 1e-5 * np.maximum(1.0, np.abs(orc.obs))), t
+    assert int((fl & 512 != 0).sum()) >= 10 and int((fl & 512 == 0).sum()) >= 20
+    env.close()
+
+
 def test_atcgym_keeps_flying_after_a_win():
     """The reference has no inactive state (atc_gym.py:128-192): stepping on after a win without reset keeps simulating
     the aircraft, which can win again (learning/atc-gym-compute-performance.py never resets).  Checked against the g9
@@ -374,13 +435,16 @@ def test_atcgym_keeps_flying_after_a_win():
 # ------------------------------------------------------------------------------------------------ batched vs fp32 oracle
 def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, spawn="lattice", hold=20, grid_cell=0.5,
                    use_rollout=0, timestep_limit=6000, full=True, shaping=True, normalize=True, sep_nm=3.0,
-                   keep_active=False, held_hint=False, rollout_hold=1):
+                   keep_active=False, held_hint=False, rollout_hold=1, wild=0.0):
     """full=False drives the fast kernel variant (obs / reward / done / flags only), full=True the one with every optional
     output; everything the variant produces is compared with the fp32 oracle.  held_hint: single steps that repeat the
     previous step's action array are launched with ATC_M_ACTIONS_HELD (must change nothing).
     rollout_hold > 1 (with use_rollout): the multi-step launches go through atc_rollout_hold — one action block per
     `rollout_hold` steps (frame skip, learning/atc-gym-demo.py:18-19), whose repeated steps skip the last-action bookkeeping
-    inside the kernel; the oracle is stepped once per step with the block's actions."""
+    inside the kernel; the oracle is stepped once per step with the block's actions.
+    wild > 0: that fraction of the drawn action COMPONENTS lies outside the action space — U(-4, 4) (a tenth of those a further
+    factor 50 out): the reference enforces no Box (atc_gym.py:128-141); speed / altitude targets beyond their limits are refused,
+    heading targets are never validated and headings leave the state format's 32-bit range (include/atc_step.h, ABI 19)."""
     torch = _torch()
     from atc_hip.vec_env import AtcVecEnv
     from envs.atc import model
@@ -415,6 +479,11 @@ def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, sp
                     act = np.floor(rng.uniform(0, 1, (B, N, 3)) * np.array([20, 380, 360])).astype(np.float32)
                 else:
                     act = rng.uniform(-1.05, 1.05, (B, N, 3)).astype(np.float32)
+                if wild > 0.0:   # (drawn after the regular actions: a case without wild draws keeps its stream)
+                    out_of_space = rng.uniform(-4.0, 4.0, (B, N, 3)) * np.where(rng.uniform(size=(B, N, 3)) < 0.1, 50.0, 1.0)
+                    if discrete:
+                        out_of_space = np.floor(out_of_space * np.array([20, 380, 360]))
+                    act = np.where(rng.uniform(size=(B, N, 3)) < wild, out_of_space, act).astype(np.float32)
             acts.append(act)
         if use_rollout and rollout_hold > 1:
             assert all(acts[c] is acts[c - c % rollout_hold] for c in range(chunk))   # blocks are constant by construction
@@ -478,6 +547,10 @@ def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, sp
     # arithmetic) makes the whole aircraft state BIT-IDENTICAL to the fp32 oracle's
     assert np.array_equal(env.pos_hp[:, 0].cpu().numpy(), orc.px) and np.array_equal(env.pos_hp[:, 1].cpu().numpy(), orc.py)
     assert np.array_equal(env.h.cpu().numpy(), orc.h) and np.array_equal(env.phi_fix.cpu().numpy(), orc.phi_fix)
+    # ... the exact counts of WIDE headings / last heading targets (beyond the 32-bit fields, ABI 19) included
+    assert np.array_equal(env.phi_counts.cpu().numpy(), orc.phi_counts.astype(np.float64))
+    la_wide = np.isin(orc.last_act[2], (-2 ** 31, 2 ** 31 - 1))
+    assert np.array_equal(env.phi_wide[:, 1].cpu().numpy()[la_wide], orc.phi_wide[la_wide, 1])
     assert np.array_equal(env.v_fix.cpu().numpy(), orc.v_fix)
     assert np.array_equal(env.last_act.cpu().numpy(), orc.last_act.T)
     assert np.array_equal(env.ep_actions.cpu().numpy(), orc.ep_actions)
@@ -542,6 +615,27 @@ def test_rollout_hold_matches_oracle(N, B, T, rh, hold, full):
     n_done, seen = _run_vs_oracle(scn, scenarios.compile_scenario(scn, grid_cell=0.5), B=B, N=N, steps=12 * T, seed=100 + N + T,
                                   use_rollout=T, rollout_hold=rh, hold=hold, full=full, spawn="lattice")
     assert n_done > 0
+
+
+@pytest.mark.parametrize("N,B,kw", [
+    (1, 2048, dict()), (1, 2048, dict(use_rollout=20, rollout_hold=20, full=False)), (1, 1000, dict(discrete=True, dt=5.0, hold=5)),
+    (16, 256, dict(held_hint=True)), (16, 256, dict(use_rollout=20, rollout_hold=20, full=False)),
+    (16, 300, dict(use_rollout=20, rollout_hold=4, full=True)), (16, 256, dict(full=False, held_hint=True, timestep_limit=100000)),
+    (5, 200, dict(use_rollout=8)), (64, 64, dict(full=False)), (64, 64, dict(use_rollout=20, rollout_hold=20, full=False)),
+    (33, 64, dict(wild=1.0, dt=5.0))])
+def test_actions_outside_the_action_space_vs_oracle(N, B, kw):
+    """A third of all action components outside [-1, 1] (U(-4, 4), some 50 x further): refused speed / altitude targets, heading
+    targets and headings beyond the 32-bit field (WIDE, include/atc_step.h ABI 19) in every kernel variant — single steps with
+    and without the held hint, fused launches with held blocks, all-valid and general instantiations, DPP / xor / LDS scans.  Every
+    step's flags / done exact, obs / rewards within 1e-5, the final state — exact 64-bit heading counts included — bit-identical."""
+    from envs.atc import scenarios
+    scn = scenarios.LOWWDense() if N > 16 else scenarios.LOWW(random_entrypoints=True)
+    kw = dict(dict(wild=0.33, steps=400, seed=700 + N + B), **kw)
+    if kw.get("use_rollout"):
+        kw["steps"] = (kw["steps"] // kw["use_rollout"]) * kw["use_rollout"]
+        kw.setdefault("hold", max(kw.get("rollout_hold", 1), 20 if kw.get("rollout_hold", 1) in (1, 20) else 8))
+    n_done, seen = _run_vs_oracle(scn, scenarios.compile_scenario(scn, grid_cell=0.5), B=B, N=N, **kw)
+    assert n_done > 0 and (seen & H.F_INVALID_V) and (seen & H.F_INVALID_H)
 
 
 def test_flying_on_beyond_the_position_grid():
