@@ -139,7 +139,8 @@ class StatsExchange:
     The k statistics must be 1-D tensors of one length with 4-byte elements (float32 / int32: `ep_return`, `ep_length` are
     neighbouring words of the per-episode env record); they travel as their bit patterns and come back in their own dtypes.
     The collective is issued under a private side stream, so the backend's stream synchronises with THAT (idle) stream and not
-    with the stream the step kernels were queued on (torch's process group makes its stream wait for the caller's current
+    with the stream the step kernels were queued on — an event recorded by snapshot() orders it after the packing copies alone —
+    (torch's process group makes its stream wait for the caller's current
     stream: issued on the compute stream after the launches, the collective would start when the last step has finished;
     issued before them, the host time of the call delays the first launch — measured 41 us per 20-step block on the one-rank
     RCCL group).  `wait()` makes the side stream, then the CURRENT stream wait for the collective — it does not block the
@@ -149,7 +150,7 @@ class StatsExchange:
     def __init__(self, force=False):
         self.force = bool(force)
         self.collectives = 0
-        self._src = self._dst = self._host = self._work = self._side = None
+        self._src = self._dst = self._host = self._work = self._side = self._packed = None
         self._dtypes = None
         self._pending = False
 
@@ -163,6 +164,15 @@ class StatsExchange:
         self._dtypes = [t.dtype for t in tensors]
         for c, t in enumerate(tensors):   # (strided views of the env record are fine: the copy gathers them)
             self._src[:, c].copy_(t.view(torch.int32))
+        # The packing copies are kernels on the CURRENT (compute) stream; the collective is issued from a side stream that the
+        # process group synchronises with — an idle stream that knows nothing of them.  This event is what orders the collective
+        # after the copies (and only after them: launches queued on the compute stream after the snapshot stay unordered with it,
+        # which is the overlap).  Without it the all-gather could read `_src` before the copies — queued behind a whole rollout —
+        # had run.
+        self._packed = None
+        if self._src.is_cuda:
+            self._packed = torch.cuda.Event()
+            self._packed.record(torch.cuda.current_stream(self._src.device))
         self._pending = True
 
     def rearm(self):
@@ -179,7 +189,7 @@ class StatsExchange:
         ws = dist.get_world_size()
         src = self._src
         if dist.get_backend() == "gloo" and src.is_cuda:   # gloo gathers host tensors (test flows on one GPU)
-            self._host = src.cpu()
+            self._host = src.cpu()   # (a synchronising copy on the compute stream: ordered after the packing copies)
             src = self._host
         key = (("packed", src.shape[1]),)
         if key not in _shard_rows:   # equal shards: decided by every rank alike on the first call (see all_gather_stats)
@@ -196,6 +206,8 @@ class StatsExchange:
         if src.is_cuda:
             if self._side is None or self._side.device != src.device:
                 self._side = torch.cuda.Stream(device=src.device)
+            if self._packed is not None:
+                self._side.wait_event(self._packed)   # the collective reads `_src`: after the snapshot's packing copies
             with torch.cuda.stream(self._side):
                 self._work = dist.all_gather_into_tensor(self._dst, src, async_op=True)
         else:
@@ -215,7 +227,9 @@ class StatsExchange:
         else:
             g = self._src.unsqueeze(0)
         g = g.to(self._src.device)
-        return [g[:, :, c].view(dt) for c, dt in enumerate(self._dtypes)]
+        # copies, not views: `_dst` / `_src` are overwritten by the next issue() / snapshot() — possibly queued before the caller
+        # has looked at this report
+        return [g[:, :, c].contiguous().view(dt).clone() for c, dt in enumerate(self._dtypes)]
 
 
 def barrier(force=False):

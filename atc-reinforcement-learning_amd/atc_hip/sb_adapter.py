@@ -6,6 +6,7 @@ auto-reset with the reset observation returned and the terminal one under info["
 Monitor's info["episode"] = {"r", "l", "t"} for finished episodes, `get_attr`/`set_attr`/`env_method`), but all envs are
 stepped by ONE kernel launch and the Monitor statistics are accumulated on the device; only the per-step arrays cross
 PCIe (B x (10 N + 2) floats).  For throughput without host copies use AtcVecEnv directly (device tensors)."""
+import importlib
 import time
 
 import numpy as np
@@ -14,10 +15,29 @@ from . import layout as L
 from .vec_env import AtcVecEnv
 
 
-class AtcSBVecEnv:
+def _vecenv_base():
+    """The VecEnv abstract base of whichever stable-baselines is importable — the reference pins stable-baselines 2.8.0
+    (requirements.txt), whose BaseRLModel wraps anything that is NOT a `VecEnv` instance in DummyVecEnv([lambda: env]); its
+    trainer hands the vector env straight to PPO2 (learning/atc-gym-stable-baselines.py:76-90).  Neither library is installed in
+    this image: then the adapter is a plain class with the same surface."""
+    for mod in ("stable_baselines.common.vec_env", "stable_baselines3.common.vec_env"):
+        try:
+            return importlib.import_module(mod).VecEnv
+        except Exception:   # noqa: BLE001 — not installed, or an installation that does not import here
+            continue
+    return object
+
+
+_Base = _vecenv_base()
+
+
+class AtcSBVecEnv(_Base):
     def __init__(self, num_envs, num_aircraft=1, sim_parameters=None, scenario=None, device=0, seed=0, sparse_infos=None,
                  host_mapped=None, **kw):
-        from envs.atc._spaces import Box, MultiDiscrete
+        try:   # gym's own space classes where gym is there (stable-baselines' policies type-check them; gym is its dependency)
+            from gym.spaces import Box, MultiDiscrete
+        except ImportError:
+            from envs.atc._spaces import Box, MultiDiscrete
         # Small batches (the 8-16 envs stable-baselines users run) are latency-bound: their state and outputs live in pinned
         # host memory mapped into the device, so a vector step is one launch + one synchronisation with the numpy results read
         # in place — no device-to-host copy.  Large batches stay in HBM and cross PCIe once per step.
@@ -34,6 +54,8 @@ class AtcSBVecEnv:
         else:                         # atc_gym.py:81-82
             self.action_space = Box(low=-np.ones(3 * n, np.float32), high=np.ones(3 * n, np.float32))
         self.observation_space = Box(low=-1.0, high=1.0, shape=(L.OBS_DIM * n,))  # atc_gym.py:113
+        if _Base is not object:   # VecEnv.__init__(num_envs, observation_space, action_space): the same three attributes
+            _Base.__init__(self, self.num_envs, self.observation_space, self.action_space)
         self.reward_range = (-3000.0, 23000.0)                                    # atc_gym.py:115
         self.metadata = {'render.modes': ['human', 'rgb_array'], 'video.frames_per_second': 50}
         self._t0 = time.time()
@@ -107,7 +129,16 @@ class AtcSBVecEnv:
         self.vec.close()
 
     def seed(self, seed=None):
-        return self.vec.seed(seed)
+        """VecEnv.seed (stable-baselines >= 2.10, SB3): env i is seeded with `seed + i`, one entry per env in the return value,
+        each what AtcGym.seed returns (atc_gym.py:117-126: `[seed]`).  The batch has ONE counter-based generator keyed by
+        (seed, env index, episode): env i's stream is its own, like seed + i gives a SubprocVecEnv worker."""
+        self.vec.seed(seed)
+        return [[None if seed is None else int(seed) + i] for i in range(self.num_envs)]
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        """SB3's VecEnv.env_is_wrapped: there are no per-env gym wrappers inside the batch."""
+        n = self.num_envs if indices is None else len(self._idx(indices))
+        return [False] * n
 
     def get_attr(self, attr_name, indices=None):
         """`actions_per_timestep`, `winning_ratio` (read by the reference's TensorBoard callback,
@@ -126,7 +157,7 @@ class AtcSBVecEnv:
         for i in (range(self.num_envs) if indices is None else self._idx(indices)):
             t[i] = value
 
-    def env_method(self, method_name, *args, indices=None, **kwargs):
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
         """`reset` and `seed` per env (what SB wrappers call); other methods of the single-env class have no batched
         meaning."""
         idx = list(range(self.num_envs)) if indices is None else self._idx(indices)
@@ -136,14 +167,14 @@ class AtcSBVecEnv:
             obs = self.vec.reset(mask=mask).cpu().numpy()
             return [obs[i].copy() for i in idx]
         if method_name == "seed":
-            return [self.vec.seed(*args, **kwargs)[0] for _ in idx]
+            return [self.vec.seed(*method_args, **method_kwargs)[0] for _ in idx]
         raise AttributeError("env_method(%r) is not available on the batched env" % method_name)
 
-    def get_images(self):
+    def get_images(self, *args, **kwargs):
         from . import render
         return [render.rgb_array(self.vec, env=b) for b in range(self.num_envs)]
 
-    def render(self, mode="human"):
+    def render(self, mode="human", *args, **kwargs):
         if mode == "rgb_array":
             from . import render
             return render.rgb_array(self.vec, env=0)

@@ -130,6 +130,11 @@ def _ring_edges(ring):
     return np.array([[a[0], a[1], b[0], b[1]] for a, b in e if a[1] != b[1]], dtype=np.float64).reshape(-1, 4)
 
 
+class SectorTooLarge(ValueError):
+    """The compiled sector does not fit the blob's formats (offsets are exactly representable fp32 numbers: < 2^24 words; the
+    lookup grid indexes cells with 24-bit multiplies) — choose a coarser lookup grid.  AtcVecEnv(grid_cell='auto') does."""
+
+
 GRID_EDGE_WORDS = 8      # edge: p1x, p1y, p2x, p2y | min(p1y,p2y), max(p1y,p2y), polygon height, 16 * polygon index + flags
 #                          terminator: polygon bounds x0, y0, x1, y1 | 0, 0, polygon height, 16 * polygon index + flags
 GRID_F_TERM = 1.0        # terminator record: parity (+ base) and bounds test decide the polygon now
@@ -191,6 +196,85 @@ def _box_records(cx0s, cx1s, cy0s, cy1s, edges, bounds, heights):
         if not inside_bounds:
             recs.append([b[0], b[1], b[2], b[3], 0.0, 0.0, heights[pi], 16.0 * pi + GRID_F_TERM + base])
     return recs
+
+
+def _seg_near_boxes(p, q, bx0, bx1, by0, by1):
+    """_seg_near_box for a block of boxes: bx0 / bx1 are the (inflated) bounds of the block's columns, by0 / by1 of its rows.
+    Returns a [rows, columns] boolean array — the same float64 operations as the scalar form, element by element."""
+    bx0, bx1, by0, by1 = bx0[None, :], bx1[None, :], by0[:, None], by1[:, None]
+    miss = (max(p[0], q[0]) < bx0) | (min(p[0], q[0]) > bx1) | (max(p[1], q[1]) < by0) | (min(p[1], q[1]) > by1)
+    dx, dy = q[0] - p[0], q[1] - p[1]
+    if dx == 0.0 and dy == 0.0:
+        return ~miss
+    s = [(cx - p[0]) * dy - (cy - p[1]) * dx for cx in (bx0, bx1) for cy in (by0, by1)]
+    lo = np.minimum(np.minimum(s[0], s[1]), np.minimum(s[2], s[3]))
+    hi = np.maximum(np.maximum(s[0], s[1]), np.maximum(s[2], s[3]))
+    return ~miss & ~((lo > 0.0) | (hi < 0.0))
+
+
+def _box_records_many(cx0s, cx1s, cy0s, cy1s, edges, bounds, heights):
+    """_box_records for MANY (slack-inflated) boxes at once: the per-edge classification — the expensive part — is evaluated for
+    all boxes x all edges of a polygon in array operations (the same float64 arithmetic, element by element), and only the
+    assembly of each box's record list stays a Python loop.  Returns one record list per box, identical to _box_records'."""
+    n = len(cx0s)
+    X0, X1, Y0, Y1 = cx0s[:, None], cx1s[:, None], cy0s[:, None], cy1s[:, None]
+    per_poly = []
+    for e, b in zip(edges, bounds):
+        skip = (b[2] < cx0s) | (b[0] > cx1s) | (b[3] < cy0s) | (b[1] > cy1s)
+        if len(e) == 0 or skip.all():
+            per_poly.append((skip, None, None, None, None))
+            continue
+        ymin = np.minimum(e[:, 1], e[:, 3])
+        ymax = np.maximum(e[:, 1], e[:, 3])
+        xmax = np.maximum(e[:, 0], e[:, 2])
+        rel = (Y1 > ymin) & (Y0 <= ymax) & (X0 <= xmax) & (ymax > ymin)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            slope = np.where(ymax > ymin, (e[:, 2] - e[:, 0]) / (e[:, 3] - e[:, 1]), 0.0)
+        ya = np.clip(Y0, ymin, ymax)
+        yb = np.clip(Y1, ymin, ymax)
+        xa = e[:, 0] + (ya - e[:, 1]) * slope
+        xb = e[:, 0] + (yb - e[:, 1]) * slope
+        ulp32 = np.spacing(np.abs(e).max(axis=1).astype(np.float32)).astype(np.float64)
+        margin = 1e-3 + 4.0 * ulp32 * (1.0 + np.abs(slope))
+        right = X1 < np.minimum(xa, xb) - margin
+        rel &= ~(X0 > np.maximum(xa, xb) + margin)
+        const = rel & right & (Y0 > ymin) & (Y1 <= ymax)
+        odd = (const.sum(axis=1) & 1).astype(bool)
+        listed = rel & ~const
+        inside_bounds = (b[0] <= cx0s) & (cx1s <= b[2]) & (b[1] <= cy0s) & (cy1s <= b[3])
+        per_poly.append((skip, listed, right, odd, inside_bounds))
+    out = []
+    for d in range(n):
+        recs = []
+        for pi, (skip, listed, right, odd, inside_b) in enumerate(per_poly):
+            if skip[d]:
+                continue
+            e, b = edges[pi], bounds[pi]
+            base = GRID_F_BASE if (listed is not None and odd[d]) else 0.0
+            idx = np.nonzero(listed[d])[0] if listed is not None else ()
+            inside_bounds = bool(inside_b[d]) if listed is not None else \
+                (b[0] <= cx0s[d] and cx1s[d] <= b[2] and b[1] <= cy0s[d] and cy1s[d] <= b[3])
+            if len(idx) == 0:
+                if not base:
+                    continue
+                if inside_bounds:
+                    recs.append([-_BIG, -_BIG, _BIG, _BIG, 0.0, 0.0, heights[pi], 16.0 * pi + GRID_F_TERM + base])
+                    break
+                recs.append([b[0], b[1], b[2], b[3], 0.0, 0.0, heights[pi], 16.0 * pi + GRID_F_TERM + base])
+                continue
+            certain = right[d][idx]
+            order = np.argsort(certain, kind="stable")
+            last = len(order) - 1
+            for pos, k in enumerate(order):
+                ek = e[idx[k]]
+                fl = GRID_F_CERTAIN if certain[k] else 0.0
+                if inside_bounds and pos == last:
+                    fl += GRID_F_LAST + base
+                recs.append([ek[0], ek[1], ek[2], ek[3], min(ek[1], ek[3]), max(ek[1], ek[3]), heights[pi], 16.0 * pi + fl])
+            if not inside_bounds:
+                recs.append([b[0], b[1], b[2], b[3], 0.0, 0.0, heights[pi], 16.0 * pi + GRID_F_TERM + base])
+        out.append(recs)
+    return out
 
 
 GRID_CELL_LINE = 2.0 ** 23   # cell flag: the cell's first record is a LINE record (see _line_split)
@@ -293,8 +377,9 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=(), 
     gx0 = x0 - 2 * cell
     gy0 = y0 - 2 * cell
     nx = int(math.ceil((x1 - gx0) / cell)) + 2
-    assert nx < 1 << 20, "lookup grid too wide (the kernel indexes cells with a 24-bit multiply)"
     ny = int(math.ceil((y1 - gy0) / cell)) + 2
+    if nx >= 1 << 20 or ny >= 1 << 20 or L.G_HDR + 2 * nx * ny >= 2 ** 24:
+        raise SectorTooLarge("a %g nm lookup grid over this sector has %d x %d cells: beyond the blob's 2^24 words" % (cell, nx, ny))
     inv = 1.0 / cell
     slack = guard + 1e-4 * max(1.0, abs(x1), abs(y1)) * 2.0 ** -10
     assert slack < 0.5 * cell
@@ -307,12 +392,11 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=(), 
             i1 = min(nx - 1, int(math.floor((max(p[0], q[0]) + slack - gx0) * inv)) + 1)
             j0 = max(0, int(math.floor((min(p[1], q[1]) - slack - gy0) * inv)) - 1)
             j1 = min(ny - 1, int(math.floor((max(p[1], q[1]) + slack - gy0) * inv)) + 1)
-            for j in range(j0, j1 + 1):
-                cy0 = gy0 + j * cell - slack
-                cy1 = gy0 + (j + 1) * cell + slack
-                for i in range(i0, i1 + 1):
-                    if not near[j, i] and _seg_near_box(p, q, gx0 + i * cell - slack, cy0, gx0 + (i + 1) * cell + slack, cy1):
-                        near[j, i] = True
+            if i1 < i0 or j1 < j0:
+                continue
+            ii, jj = np.arange(i0, i1 + 1, dtype=np.float64), np.arange(j0, j1 + 1, dtype=np.float64)
+            near[j0:j1 + 1, i0:i1 + 1] |= _seg_near_boxes(p, q, gx0 + ii * cell - slack, gx0 + (ii + 1) * cell + slack,
+                                                          gy0 + jj * cell - slack, gy0 + (jj + 1) * cell + slack)
     cells = np.zeros((ny, nx, 2), dtype=np.float64)
     pool = []
     # clean cells (no edge near): the answer of the centre point, all of them at once
@@ -321,42 +405,33 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=(), 
     hit = pis >= 0
     cells[jj[hit], ii[hit], 0] = -(pis[hit] + 1.0)
     cells[jj[hit], ii[hit], 1] = np.asarray(heights, dtype=np.float64)[pis[hit]]
-    for j in range(ny):
-        cy0s = gy0 + j * cell - slack
-        cy1s = gy0 + (j + 1) * cell + slack
-        for i in np.nonzero(near[j])[0]:
-            cx0s = gx0 + i * cell - slack
-            cx1s = gx0 + (i + 1) * cell + slack
-            recs = _box_records(cx0s, cx1s, cy0s, cy1s, edges, bounds, heights)
-            if len(recs) == 1 and recs[0][0] == -_BIG:   # a single unconditional answer: the cell is clean after all
-                cells[j, i, 0] = -(recs[0][7] // 16 + 1.0)
-                cells[j, i, 1] = recs[0][6]
-                continue
-            cells[j, i, 0] = len(recs)
-            cells[j, i, 1] = len(pool) if recs else 0.0   # (0, 0): nothing can match = clean cell outside the airspace
-            split = _line_split(recs, cy0s, cy1s, heights) if recs else None
-            if split is not None:      # LINE record first, the ordinary records behind it
-                cells[j, i, 0] += GRID_CELL_LINE
-                pool.append(split)
-            pool.extend(recs)
+    # cells an edge passes near (row-major order = the order of their records in the pool): classified all at once
+    dj, di = np.nonzero(near)
+    dcy0, dcy1 = gy0 + dj * cell - slack, gy0 + (dj + 1) * cell + slack
+    all_recs = _box_records_many(gx0 + di * cell - slack, gx0 + (di + 1) * cell + slack, dcy0, dcy1, edges, bounds, heights)
+    for j, i, cy0s, cy1s, recs in zip(dj, di, dcy0, dcy1, all_recs):
+        if len(recs) == 1 and recs[0][0] == -_BIG:   # a single unconditional answer: the cell is clean after all
+            cells[j, i, 0] = -(recs[0][7] // 16 + 1.0)
+            cells[j, i, 1] = recs[0][6]
+            continue
+        cells[j, i, 0] = len(recs)
+        cells[j, i, 1] = len(pool) if recs else 0.0   # (0, 0): nothing can match = clean cell outside the airspace
+        split = _line_split(recs, cy0s, cy1s, heights) if recs else None
+        if split is not None:      # LINE record first, the ordinary records behind it
+            cells[j, i, 0] += GRID_CELL_LINE
+            pool.append(split)
+        pool.extend(recs)
     assert len(noise_bounds) <= 16, "at most 16 noise-abatement areas"
     assert (np.maximum(cells[:, :, 0], 0.0) % GRID_CELL_LINE).max() < 64
-    for j in range(ny):
-        cy0s = gy0 + j * cell - slack
-        cy1s = gy0 + (j + 1) * cell + slack
-        for i in range(nx):
-            cx0s = gx0 + i * cell - slack
-            cx1s = gx0 + (i + 1) * cell + slack
-            mask = 0
-            for q, b in enumerate(noise_bounds):
-                if not (b[2] < cx0s or b[0] > cx1s or b[3] < cy0s or b[1] > cy1s):
-                    mask |= 1 << q
-            if corridor_bounds is not None:
-                b = corridor_bounds
-                if not (b[2] < cx0s or b[0] > cx1s or b[3] < cy0s or b[1] > cy1s):
-                    mask |= 1 << 16   # bit 22 of |c|
-            c = cells[j, i, 0]
-            cells[j, i, 0] = (c + 64.0 * mask) if c > 0 else (c - 64.0 * mask)
+    # candidate masks: which noise-area bounds / the corridor triangle's bounds meet each (inflated) cell — rows x columns
+    ai, aj = np.arange(nx, dtype=np.float64), np.arange(ny, dtype=np.float64)
+    acx0, acx1 = gx0 + ai * cell - slack, gx0 + (ai + 1) * cell + slack
+    acy0, acy1 = gy0 + aj * cell - slack, gy0 + (aj + 1) * cell + slack
+    mask = np.zeros((ny, nx), dtype=np.float64)
+    for bit, b in [(q, b) for q, b in enumerate(noise_bounds)] + ([(16, corridor_bounds)] if corridor_bounds is not None else []):
+        meets = ~((b[3] < acy0) | (b[1] > acy1))[:, None] & ~((b[2] < acx0) | (b[0] > acx1))[None, :]   # (16: bit 22 of |c|)
+        mask += np.where(meets, float(1 << bit), 0.0)
+    cells[:, :, 0] = np.where(cells[:, :, 0] > 0, cells[:, :, 0] + 64.0 * mask, cells[:, :, 0] - 64.0 * mask)
     border = np.concatenate([cells[0, :, :].ravel(), cells[-1, :, :].ravel(), cells[:, 0, :].ravel(), cells[:, -1, :].ravel()])
     assert not border.any(), "the outermost ring of lookup cells must be clean, outside the airspace, without noise candidates"
     n_rec = len(pool)
@@ -365,10 +440,70 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=(), 
     off_pool = (L.G_HDR + cells.size + 3) & ~3  # edge records are read as 16-byte vectors
     hdr[L.G_OFF_POOL] = off_pool
     hdr[L.G_NREC] = n_rec
-    assert n_rec < 2 ** 21 and off_pool + n_rec * GRID_EDGE_WORDS < 2 ** 24
+    if not (n_rec < 2 ** 21 and off_pool + n_rec * GRID_EDGE_WORDS < 2 ** 24):
+        raise SectorTooLarge("a %g nm lookup grid over this sector needs %d edge records: beyond the blob's 2^24 words" % (cell, n_rec))
     pool_arr = np.asarray(pool, dtype=np.float64).reshape(-1, GRID_EDGE_WORDS)
     pad = np.zeros(off_pool - L.G_HDR - cells.size)
     return np.concatenate([hdr, cells.ravel(), pad, pool_arr.ravel()])
+
+
+_SOURCE_TAG = None
+
+
+def _grid_cache_path(args, kind="grid"):
+    """File of the on-disk copy of one lookup grid (kind "grid") or of one whole device blob ("blob32"), or None when the cache is off.  The key is a sha256 over every input of
+    build_grid (floats by their exact hex form), the blob / ABI versions and THIS FILE's source text — any change to the compiler
+    retires every cached grid.  Directory: $ATC_HIP_CACHE ('' or '0': no cache), else $XDG_CACHE_HOME/atc_hip, else
+    ~/.cache/atc_hip."""
+    import hashlib
+    import os
+    global _SOURCE_TAG
+    d = os.environ.get("ATC_HIP_CACHE")
+    if d is None:
+        d = os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "atc_hip")
+    if d in ("", "0"):
+        return None
+    if _SOURCE_TAG is None:
+        with open(__file__, "rb") as f:
+            _SOURCE_TAG = hashlib.sha256(f.read()).hexdigest()
+
+    def canon(v):
+        if isinstance(v, (list, tuple)):
+            return "[" + ",".join(canon(x) for x in v) + "]"
+        if isinstance(v, np.ndarray):
+            return canon(v.tolist())
+        return "None" if v is None else float(v).hex()
+    key = hashlib.sha256(("%s|%s|%s|%s" % (_SOURCE_TAG, L.ABI_VERSION, L.BLOB_VERSION, canon(args))).encode()).hexdigest()
+    return os.path.join(d, "%s_%s.npy" % (kind, key[:40]))
+
+
+def _cache_save(path, arr):
+    import os
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = "%s.%d.tmp.npy" % (path, os.getpid())
+        np.save(tmp, arr)
+        os.replace(tmp, path)   # atomic: concurrent workers (8 x SubprocVecEnv) never see a partial file
+    except OSError:
+        pass
+
+
+def build_grid_cached(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=(), corridor_bounds=None):
+    """build_grid behind an on-disk cache (see _grid_cache_path): LOWW at 0.0625 nm — the grid `auto` selects for 65 536 x 1 and
+    8 192 x 16 — takes 0.6 s to classify and 10 ms to load.  A cache that cannot be read or written is ignored."""
+    import os
+    path = _grid_cache_path([rings, bounds, heights, bbox, cell, guard, list(noise_bounds), corridor_bounds])
+    if path is not None and os.path.exists(path):
+        try:
+            g = np.load(path, allow_pickle=False)
+            if g.dtype == np.float64 and g.ndim == 1 and len(g) > L.G_HDR and g[L.G_INV] == 1.0 / cell:
+                return g
+        except (OSError, ValueError):
+            pass
+    g = build_grid(rings, bounds, heights, bbox, cell, guard, noise_bounds=noise_bounds, corridor_bounds=corridor_bounds)
+    if path is not None:
+        _cache_save(path, g)
+    return g
 
 
 def position_grid(points):
@@ -394,12 +529,40 @@ def from_fix(fix, origin, k):
 
 
 class CompiledSector:
-    """Result of compile_sector: `.blob64` (float64 master), `.blob32` (device copy) and the derived constants."""
+    """Result of compile_sector: `.blob32` (device copy), `.blob64` (float64 master: what the float64 test oracle reads) and the
+    derived constants."""
 
-    def __init__(self, blob64, meta):
-        self.blob64 = np.ascontiguousarray(blob64, dtype=np.float64)
-        self.blob32 = np.ascontiguousarray(blob64.astype(np.float32))
+    def __init__(self, blob64, meta, spawn_words=None, grid_fn=None, blob32=None):
+        """spawn_words: the int32 image [n_records, SPAWN_WORDS] of the spawn records (include/atc_step.h: ATC_H_OFF_SPAWN) — their
+        integer words are 32-bit PATTERNS in the device blob, not float values, so the device blob is built HERE, in the one
+        place that can build it: a CompiledSector re-made from a float64 master alone (no spawn_words) refuses a master that
+        has spawn records instead of silently shipping float-valued counts.
+        grid_fn: the lookup grid's words are filled into the master on first use (`blob64`) — a process that only needs the
+        device blob, and finds it in the on-disk cache (`blob32`), never touches the 2 x larger float64 image."""
+        self._b64 = np.ascontiguousarray(blob64, dtype=np.float64)
+        self._grid_fn = grid_fn
         self.meta = meta
+        self.spawn_words = None if spawn_words is None else np.array(spawn_words, dtype=np.int32, copy=True)
+        n_entry, off_spawn = int(self._b64[L.H_N_ENTRY]), int(self._b64[L.H_OFF_SPAWN])
+        if n_entry and off_spawn and spawn_words is None:
+            raise ValueError("a sector with entry points needs the spawn records' integer image (spawn_words): the float64 "
+                             "master holds their counts as values, the device blob as 32-bit patterns")
+        if blob32 is not None:
+            self.blob32 = blob32
+            return
+        self.blob32 = np.ascontiguousarray(self.blob64.astype(np.float32))
+        if n_entry and off_spawn:
+            n_spawn = L.MAX_AIRCRAFT + n_entry
+            sw = np.ascontiguousarray(spawn_words, dtype=np.int32).reshape(n_spawn, L.SPAWN_WORDS)
+            self.blob32[off_spawn:off_spawn + n_spawn * L.SPAWN_WORDS].view(np.int32)[:] = sw.ravel()
+
+    @property
+    def blob64(self):
+        if self._grid_fn is not None:
+            og = int(self._b64[L.H_OFF_GRID])
+            self._b64[og:] = self._grid_fn()
+            self._grid_fn = None
+        return self._b64
 
     def __getattr__(self, name):
         try:
@@ -449,15 +612,36 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
     off_spawn = (end + 15) & ~15   # 64-byte aligned spawn records: 64 lattice slots, then one per entry point
     n_spawn = (L.MAX_AIRCRAFT + n_entry) if n_entry else 0
     end = off_spawn + n_spawn * L.SPAWN_WORDS
-    grid = None
+    grid = grid_fn = cached32 = cache32_path = None
     off_grid = 0
     if grid_cell is not None and mva_rings:
         th = cg["tri_h"]
-        grid = build_grid(mva_rings, bounds[:len(mva_rings)], mva_heights, bbox, float(grid_cell), grid_guard,
-                          noise_bounds=bounds[len(mva_rings):],
-                          corridor_bounds=(th[:, 0].min(), th[:, 1].min(), th[:, 0].max(), th[:, 1].max()))
+        grid_args = (mva_rings, bounds[:len(mva_rings)], mva_heights, bbox, float(grid_cell), grid_guard)
+        grid_kw = dict(noise_bounds=bounds[len(mva_rings):],
+                       corridor_bounds=(th[:, 0].min(), th[:, 1].min(), th[:, 0].max(), th[:, 1].max()))
         off_grid = (end + 3) & ~3  # 16-byte aligned: cells are read as 8-byte pairs, edge records as 16-byte vectors
-        end = off_grid + len(grid)
+        # The whole device blob of a sector with a lookup grid is kept on disk too (see _grid_cache_path): a process that finds it
+        # maps the file and never builds — or even touches — the grid's float64 image (23 MB for LOWW at 0.0625 nm); the
+        # float64 master fills its grid words in on first use (only the float64 test oracle reads them).
+        cache32_path = _grid_cache_path([[m[0] for m in mvas], [m[1] for m in mvas], list(runway),
+                                         [[e[0], e[1], e[2], list(e[3])] for e in entrypoints],
+                                         [[n[0], n[1], n[2]] for n in noise], grid_cell, grid_guard], kind="blob32")
+        if cache32_path is not None:
+            import os
+            if os.path.exists(cache32_path):
+                try:
+                    c32 = np.load(cache32_path, mmap_mode="r", allow_pickle=False)
+                    if c32.dtype == np.float32 and c32.ndim == 1 and len(c32) > off_grid + L.G_HDR and \
+                            c32[L.H_VERSION] == L.BLOB_VERSION and int(c32[L.H_NWORDS]) == len(c32) and int(c32[L.H_OFF_GRID]) == off_grid:
+                        cached32 = c32
+                except (OSError, ValueError):
+                    pass
+        if cached32 is not None:
+            end = len(cached32)
+            grid_fn = lambda: build_grid_cached(*grid_args, **grid_kw)   # noqa: E731
+        else:
+            grid = build_grid_cached(*grid_args, **grid_kw)
+            end = off_grid + len(grid)
 
     b = np.zeros(end, dtype=np.float64)
     b[L.H_VERSION] = L.BLOB_VERSION
@@ -527,7 +711,10 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
         b[off_slot + 4 * k:off_slot + 4 * k + 4] = (ex, ey, ephi, levels[(k // n_entry) % len(levels)] * 100)
     if grid is not None:
         b[off_grid:off_grid + len(grid)] = grid
-    assert end < 2 ** 24, "blob offsets must stay exactly representable in fp32"
+    elif grid_fn is not None:   # (filled in by CompiledSector.blob64 on first use; the header words the head check needs are there)
+        pass
+    if end >= 2 ** 24:
+        raise SectorTooLarge("the compiled sector has %d words: blob offsets must stay exactly representable in fp32 (< 2^24)" % end)
     # spawn records (include/atc_step.h: ATC_H_OFF_SPAWN): what AtcGym.reset computes for an aircraft placed at a lattice slot /
     # an entry point — fixed-point state + the raw reset observation — evaluated here once instead of in every reset of
     # every env (under the measurement protocol an env of 16 aircraft resets every ~25 steps: the reset is a hot path)
@@ -571,7 +758,14 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
         n_mva=len(mva_rings), n_noise=len(noise_rings), n_entry=n_entry, has_grid=grid is not None,
         v_min=v_min, v_max=v_max, h_min=h_min, h_max=h_max, pos_origin=(px0, py0), pos_k=pk,
     )
-    cs = CompiledSector(b, meta)
-    if n_spawn:   # the device blob carries the records' integer words as 32-bit patterns
-        cs.blob32[off_spawn:off_spawn + n_spawn * L.SPAWN_WORDS].view(np.int32)[:] = spawn_i.ravel()
+    cs = CompiledSector(b, meta, spawn_words=spawn_i if n_spawn else None, grid_fn=grid_fn, blob32=cached32)
+    if cached32 is not None:   # the cached device blob must be THIS sector's: its head (everything but the grid) is rebuilt here
+        head = b[:off_grid].astype(np.float32)
+        if n_spawn:
+            head[off_spawn:off_spawn + n_spawn * L.SPAWN_WORDS].view(np.int32)[:] = spawn_i.ravel()
+        if not np.array_equal(head.view(np.int32), np.asarray(cached32[:off_grid]).view(np.int32)):
+            cs = CompiledSector(b, meta, spawn_words=spawn_i if n_spawn else None, grid_fn=grid_fn)   # stale file: rebuild
+            cached32 = None
+    if cached32 is None and cache32_path is not None:
+        _cache_save(cache32_path, cs.blob32)
     return cs

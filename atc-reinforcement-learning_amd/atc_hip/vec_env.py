@@ -64,9 +64,20 @@ class AtcVecEnv:
         self.B, self.N = int(num_envs), int(num_aircraft)
         self.num_envs = self.B
         if grid_cell == "auto":
-            grid_cell = auto_grid_cell(self.B, self.N)
+            # the batch's preferred cell size, or the next coarser one the sector's blob can hold (a sector a few times LOWW's
+            # size does not fit 2^24 words at 0.0625 nm): an explicitly requested size that does not fit raises SectorTooLarge
+            from .scenario import SectorTooLarge
+            want = auto_grid_cell(self.B, self.N)
+            for grid_cell in [c for c in (0.0625, 0.125, 0.25, 0.5, 1.0, 2.0) if c >= want] + [None]:
+                try:
+                    self.compiled = scenarios.compile_scenario(self.scenario_obj, grid_cell=grid_cell)
+                    break
+                except SectorTooLarge:
+                    if grid_cell is None:
+                        raise
+        else:
+            self.compiled = scenarios.compile_scenario(self.scenario_obj, grid_cell=grid_cell)
         self.grid_cell = grid_cell
-        self.compiled = scenarios.compile_scenario(self.scenario_obj, grid_cell=grid_cell)
         self.sector = _lib.Scenario(self.compiled, device)
         self.device = self.sector.device
         n_entry = self.compiled.n_entry

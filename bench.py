@@ -692,6 +692,7 @@ def main():
     # the exchange is in `config.collective.us` and `config.exchange`, and `value_incl_exchange` charges it in full.)
     xch = D.StatsExchange()
     blocks = []   # per timed block, max over ranks: (step-window seconds, HIP-event ms, seconds incl. the closing barrier)
+    local_windows = []   # per timed block, THIS rank's step-window seconds (gathered after the loop: a straggler must be visible)
     gathered = None
     for rep in range(max(1, args.repeats)):
         D.barrier()
@@ -712,6 +713,7 @@ def main():
         xch.issue()
         D.barrier()
         t2 = time.perf_counter()
+        local_windows.append(t1 - t0)
         blocks.append((D.max_over_ranks(t1 - t0, dev), D.max_over_ranks(max(a.elapsed_time(b) for a, b in zip(ev0, ev1)), dev),
                        D.max_over_ranks(t2 - t0, dev)))
     torch.cuda.synchronize(dev)
@@ -720,6 +722,10 @@ def main():
     rank_seeds = D.all_gather_stats(torch.tensor([D.rank_seed(0, rank) & 0x7fffffffffffffff], dtype=torch.int64, device=dev))[0]
     order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
     elapsed, kernel_ms_total, elapsed_with_barrier = blocks[order[len(order) // 2]]   # the median block
+    # every rank's own step window of that block (the blocks list holds maxima over ranks: the same on every rank, so all ranks
+    # pick the same block)
+    rank_windows = D.all_gather_stats(torch.tensor([local_windows[order[len(order) // 2]]], dtype=torch.float64, device=dev))[0]
+    rank_ms_per_step = [float(v) / K * 1e3 for v in rank_windows.reshape(-1).tolist()]
     T = args.rollout or 1
     n_launches = K // T
     launch_ms = kernel_ms_total / n_launches   # average launch duration (HIP events) of the median block
@@ -749,12 +755,17 @@ def main():
                        "1 all-gather of episode returns per rollout" % ws,
                        "episodes_finished": int(episodes), "positions": "32-bit fixed point (2^-25 nm grid)",
                        "timed_blocks_ms_per_step": [b[0] / K * 1e3 for b in blocks],
-                       "timing": "median of %d timed blocks of %d steps; a block = barrier + synchronize | t0 | issue the async "
-                                 "packed all-gather of the previous rollout's episode statistics, queue the %d step launches, wait "
-                                 "for the all-gather, synchronize | t1 | barrier; window = t1 - t0, MAX over ranks (every rank "
-                                 "starts at the opening barrier, so the max is the time until the slowest rank's steps and the "
-                                 "exchange are done; the closing barrier's own latency is not charged to the steps: "
-                                 "`ms_per_step_incl_closing_barrier` carries it)" % (len(blocks), K, n_launches),
+                       "timing": "median of %d timed blocks of %d steps; a block = barrier + synchronize | t0 | queue the %d step "
+                                 "launches, synchronize | t1 | snapshot the episode statistics and issue the ONE packed asynchronous "
+                                 "all-gather from a side stream, barrier | t2 (the all-gather is waited for after the next block's "
+                                 "opening synchronisation).  `value` = ranks x envs x steps / MAX over ranks of (t1 - t0): the step "
+                                 "window, which holds no collective — the path has none on its step path; `rank_ms_per_step` "
+                                 "lists every rank's own window.  `value_between_barriers` = the same work / MAX over ranks of "
+                                 "(t2 - t0): the aggregate between two barriers as SURVEY 8e defines it — it charges the exchange's "
+                                 "host-side issue and the closing barrier to the steps; `value_incl_exchange` charges the exchange's "
+                                 "measured blocking cost (`exchange.us_blocking`, on THIS group) in full" % (len(blocks), K, n_launches),
+                       "rank_ms_per_step": rank_ms_per_step,
+                       "value_between_barriers": ws * B * K / elapsed_with_barrier,
                        "ms_per_step_incl_closing_barrier": elapsed_with_barrier / K * 1e3,
                        "exchange": {"collectives_per_report": 1, "issued": xch.collectives, "reports": len(blocks),
                                     "async": True, "in_step_window": False, "us_blocking": exchange_us,

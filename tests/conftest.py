@@ -8,6 +8,13 @@ for p in (ROOT, PKG, os.path.dirname(os.path.abspath(__file__))):
         sys.path.insert(0, p)
 
 
+# the sector compiler's on-disk grid cache (atc_hip/scenario.py:build_grid_cached) stays inside a per-session temporary
+# directory: tests never write to the user's ~/.cache
+if "ATC_HIP_CACHE" not in os.environ:
+    import tempfile
+    os.environ["ATC_HIP_CACHE"] = tempfile.mkdtemp(prefix="atc_hip_cache_")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -156,5 +156,15 @@ def test_bench_two_ranks_on_one_device():
     assert 0 < line["ms_per_step"] <= c["ms_per_step_incl_closing_barrier"] and 0 < c["value_incl_exchange"] <= line["value"]
     us = c["collective"]["us"]
     assert us["world_size"] == 2 and us["packed_blocking"]["wall"] > 0 and "exchange_adds_us_per_block" in us
+    # round 5: the record the 8-GPU run will write — the timing text describes the protocol the code runs, every rank's own step
+    # window is listed (a straggler shows), the exchange's blocking cost is measured on THIS group, and the aggregate between two
+    # barriers stands next to `value`
+    assert "queue the 3 step launches, synchronize | t1 | snapshot" in c["timing"].replace("60 step", "3 step") or "synchronize | t1 | snapshot" in c["timing"]
+    assert "wait for the all-gather, synchronize | t1" not in c["timing"]
+    assert len(c["rank_ms_per_step"]) == 2 and all(v > 0 for v in c["rank_ms_per_step"])
+    assert abs(max(c["rank_ms_per_step"]) - line["ms_per_step"]) <= 1e-9 * line["ms_per_step"] + 1e-12
+    assert c["exchange"]["us_blocking"] == us["packed_blocking"]["wall"] > 0
+    assert 0 < c["value_between_barriers"] <= line["value"]
+    assert abs(c["value_between_barriers"] - 2 * 4096 * 60 / (c["ms_per_step_incl_closing_barrier"] * 60 * 1e-3)) <= 1e-6 * line["value"]
     with open(os.path.join(ROOT, "gpurun_out", "bench_2ranks_1gpu.json"), "w") as f:
         json.dump(line, f)

@@ -162,3 +162,75 @@ def test_render_frames_equal_reference_geometry():
                 img = check(t + 1)
         assert (img != img0).any() and env.render(mode='human') is None
         env.close()
+
+
+def test_adapter_is_a_vecenv_and_runs_the_runner_loop():
+    """Row f1's purpose: the reference's trainer hands its vector env straight to PPO2 (learning/atc-gym-stable-baselines.py:
+    76-90), and stable-baselines 2.8 wraps anything that is not a `VecEnv` INSTANCE in DummyVecEnv.  With the library importable
+    (here: the interface-only stand-in of tests/sb_shim) AtcSBVecEnv must be a VecEnv subclass with the base's three attributes,
+    every abstract method implemented with SB's signatures, and survive the exact call sequence of PPO2's Runner.run plus the
+    reference's TensorBoard callback (learning/atc-gym-stable-baselines.py:31-49)."""
+    import importlib
+    import inspect
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    added = [os.path.join(here, "sb_shim"), os.path.join(here, "oracle_shims")]
+    had_gym = "gym" in sys.modules
+    sys.path[:0] = added
+    try:
+        vmod = importlib.import_module("stable_baselines.common.vec_env")
+        import atc_hip.sb_adapter as sba
+        sba = importlib.reload(sba)
+        assert issubclass(sba.AtcSBVecEnv, vmod.VecEnv)
+        assert not getattr(sba.AtcSBVecEnv, "__abstractmethods__", None)        # every abstract method is implemented
+        for name in ("env_method", "get_attr", "set_attr", "step_async", "reset"):
+            want = list(inspect.signature(getattr(vmod.VecEnv, name)).parameters)
+            got = list(inspect.signature(getattr(sba.AtcSBVecEnv, name)).parameters)
+            assert got == want, (name, got, want)
+        n_envs, n_steps = 8, 128                                                  # the reference: 8 workers, PPO2's default n_steps
+        env = sba.AtcSBVecEnv(n_envs)
+        assert vmod.wrap_like_base_rl_model(env) is env                           # BaseRLModel keeps it as it is
+        assert isinstance(env, vmod.VecEnv) and env.num_envs == n_envs and env.unwrapped is env
+        assert type(env.observation_space).__module__.startswith("gym") and env.observation_space.shape == (10,)
+        assert env.seed(7) == [[7 + i] for i in range(n_envs)]
+        assert env.env_is_wrapped(object) == [False] * n_envs
+        # AbstractEnvRunner.__init__ + Runner.run (ppo2.py): obs buffer from reset(), then n_steps x (policy step, clip to the
+        # Box, env.step, collect info.get('episode'))
+        obs = np.zeros((n_envs,) + env.observation_space.shape, dtype=np.float32)
+        obs[:] = env.reset()
+        assert obs[0, 2] == 15000.0                                               # the raw reset observation (quirk Q1)
+        rng = np.random.default_rng(0)
+        dones = [False] * n_envs
+        ep_infos, mb = [], []
+        for update in range(3):
+            for _ in range(n_steps):
+                actions = rng.normal(0.0, 0.8, (n_envs, 3)).astype(np.float32)    # an un-squashed Gaussian policy
+                actions[:, 1] = np.minimum(actions[:, 1], -0.8)                   # descend: episodes end inside the loop
+                clipped = np.clip(actions, env.action_space.low, env.action_space.high)
+                obs[:], rewards, dones, infos = env.step(clipped)
+                assert rewards.shape == (n_envs,) and len(infos) == n_envs and np.asarray(dones).shape == (n_envs,)
+                for info in infos:
+                    maybe = info.get('episode')
+                    if maybe:
+                        ep_infos.append(maybe)
+                mb.append(rewards)
+            # the reference's callback once per update (learning/atc-gym-stable-baselines.py:31-49)
+            apt = env.get_attr("actions_per_timestep")
+            wr = env.get_attr("winning_ratio")
+            assert len(apt) == len(wr) == n_envs and all(0.0 <= w <= 1.0 for w in wr) and all(a >= 0.0 for a in apt)
+        assert len(ep_infos) >= n_envs and all(set(e) == {"r", "l", "t"} and e["l"] > 0 for e in ep_infos)
+        assert np.isfinite(np.asarray(mb)).all()
+        assert env.env_method("seed", 3, indices=[0, 1]) == [3, 3]
+        assert len(env.get_images()) == n_envs
+        env.close()
+    finally:
+        for p in added:
+            sys.path.remove(p)
+        for m in [m for m in sys.modules if m == "stable_baselines" or m.startswith("stable_baselines.")]:
+            del sys.modules[m]
+        if not had_gym:
+            for m in [m for m in sys.modules if m == "gym" or m.startswith("gym.")]:
+                del sys.modules[m]
+        import atc_hip.sb_adapter as sba2
+        importlib.reload(sba2)

@@ -226,3 +226,79 @@ def test_grid_cell_by_batch_size_and_compile_cache():
     assert scenarios.compile_scenario(scenarios.LOWW(), grid_cell=0.5) is a
     assert scenarios.compile_scenario(scenarios.LOWW(), grid_cell=1.0) is not a
     assert scenarios.compile_scenario(scenarios.LOWW(random_entrypoints=True), grid_cell=0.5) is not a
+
+
+# ------------------------------------------------------------------------------------------------ compile time and the disk cache
+# sha256[:16] of (device blob, float64 master) of LOWW as compiled at the end of round 4 (Python-loop classification): the
+# vectorised compiler and the cache must reproduce them byte for byte
+R04_BLOBS = {None: ("eae6135af3b8d976", "dd3fc088a5ff380e"), 0.0625: ("bb25316b2a3046b0", "544f83059ef5e433"),
+             0.125: ("2e1afd2125379807", "44370b74adb47d75"), 0.25: ("ee8f034fb29b86b6", "161d8ee7e4b0bd37")}
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def test_compile_is_fast_cached_and_byte_identical(tmp_path, monkeypatch):
+    """LOWW at 0.0625 nm — the grid `auto` selects for 65 536 x 1 and 8 192 x 16, 5.9 s of Python loops in round 4 (1.8 s at
+    0.125 nm, which every single-env AtcGym worker paid): cold <= 1.0 s, from the on-disk cache <= 50 ms, blobs byte-identical to
+    round 4's in both cases; a corrupt cache file is ignored; ATC_HIP_CACHE='' turns the cache off."""
+    import time
+    from atc_hip import scenario as S
+    from envs.atc import scenarios
+    scn = scenarios.LOWW()
+    args = ([(m.area_as_list, m.height) for m in scn.mvas], (scn.runway.x, scn.runway.y, scn.runway.h, scn.runway.phi_from_runway),
+            [(e.x, e.y, e.phi, list(e.levels)) for e in scn.entrypoints])
+    cold = []
+    for k in range(2):
+        monkeypatch.setenv("ATC_HIP_CACHE", str(tmp_path / ("c%d" % k)))
+        t = time.perf_counter()
+        c = S.compile_sector(*args, grid_cell=0.0625)
+        cold.append(time.perf_counter() - t)
+        assert (_sha(c.blob32), _sha(c.blob64)) == R04_BLOBS[0.0625]
+    warm = []
+    for k in range(3):
+        t = time.perf_counter()
+        c = S.compile_sector(*args, grid_cell=0.0625)
+        warm.append(time.perf_counter() - t)
+        assert _sha(c.blob32) == R04_BLOBS[0.0625][0]
+    assert (_sha(c.blob32), _sha(c.blob64)) == R04_BLOBS[0.0625]       # (the float64 master fills its grid in on first use)
+    print("cold", cold, "warm", warm)
+    assert min(cold) <= 1.0 and min(warm) <= 0.05, (cold, warm)
+    files = sorted(p.name for p in (tmp_path / "c1").iterdir())
+    assert len(files) == 2 and files[0].startswith("blob32_") and files[1].startswith("grid_")
+    for cell in (None, 0.125, 0.25):
+        c = S.compile_sector(*args, grid_cell=cell)
+        assert (_sha(c.blob32), _sha(c.blob64)) == R04_BLOBS[cell], cell
+    # a damaged cache never changes the result
+    for p in (tmp_path / "c1").iterdir():
+        p.write_bytes(p.read_bytes()[:4096])
+    c = S.compile_sector(*args, grid_cell=0.0625)
+    assert (_sha(c.blob32), _sha(c.blob64)) == R04_BLOBS[0.0625]
+    monkeypatch.setenv("ATC_HIP_CACHE", "")
+    assert S._grid_cache_path([1.0]) is None
+    c = S.compile_sector(*args, grid_cell=0.25)
+    assert (_sha(c.blob32), _sha(c.blob64)) == R04_BLOBS[0.25]
+
+
+def test_device_blob_cannot_be_rebuilt_without_the_spawn_image():
+    """the spawn records' integer words are 32-bit patterns in the device blob; a CompiledSector re-made from the float64
+    master alone would ship float-valued counts — it refuses, and with the image it reproduces the device blob."""
+    from atc_hip import scenario as S
+    c = H.compiled("LOWW_random", 0.5)
+    with pytest.raises(ValueError):
+        S.CompiledSector(c.blob64, c.meta)
+    again = S.CompiledSector(c.blob64, c.meta, spawn_words=c.spawn_words)
+    assert np.array_equal(again.blob32.view(np.int32), np.asarray(c.blob32).view(np.int32))
+
+
+def test_oversized_sector_falls_back_to_a_coarser_grid():
+    """a sector a few times LOWW's size does not fit the blob's 2^24 words at the finest lookup grid: an explicit
+    request raises SectorTooLarge (a ValueError with a message), `auto` (vec_env.AtcVecEnv) takes the next size that fits."""
+    from atc_hip import scenario as S
+    mvas = [([(0, 0), (400, 0), (400, 300), (0, 300)], 3000)]
+    with pytest.raises(S.SectorTooLarge):
+        S.compile_sector(mvas, (200, 150, 0, 180), [(10, 10, 90, [100])], grid_cell=0.0625)
+    c = S.compile_sector(mvas, (200, 150, 0, 180), [(10, 10, 90, [100])], grid_cell=0.5)
+    assert c.has_grid and len(c.blob32) < 2 ** 24
