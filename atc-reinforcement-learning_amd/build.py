@@ -14,8 +14,11 @@ SRC = os.path.join(HERE, "csrc", "atc_step.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "atc_device.h"), os.path.join(os.path.dirname(HERE), "include", "atc_step.h")]
 OUT = os.path.join(HERE, "atc_hip", "libatcstep.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -amdgpu-kernarg-preload-count=16: the first 64 bytes of the kernel arguments (sector pointer, batch shape, the state record
+# pointers) arrive in scalar registers with the wavefront instead of through a first scalar-load round trip (gfx950 supports the
+# preload; measured r05: 8 192 x 16 fused 2.34 vs 2.47 us per step, 65 536 x 1 2.98 vs 3.04, the other launches unchanged)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def needs_build():

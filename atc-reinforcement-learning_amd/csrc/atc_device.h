@@ -109,29 +109,35 @@ __device__ __forceinline__ double mul_sc(double a, double b_uniform) {
     asm("v_mul_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(b_uniform));
     return d;
 }
+// VG: the constants of `q` live in VECTOR registers (the latency-bound instantiation for batches of at most two wavefronts per
+// SIMD, csrc/atc_step.hip: LAT): plain fma / mul then take them as they are — the scalar-operand forms below exist to keep the
+// compiler from copying SCALAR constants into vector register pairs.
+template <bool VG = false>
 __device__ __forceinline__ void advance(const QKin& q, int phi_fix, uint32_t v_fix, int t_step, int& x, int& y) {
     const double pd = (double)phi_fix;
-    const double kd = __builtin_rint(mul_sc(pd, q.inv180));
+    const double kd = __builtin_rint(VG ? pd * q.inv180 : mul_sc(pd, q.inv180));
     double t;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(t) : "v"(kd), "s"(q.neg_half_turn), "v"(pd));
+    if (VG) t = __builtin_fma(kd, q.neg_half_turn, pd);
+    else asm("v_fma_f64 %0, %1, %2, %3" : "=v"(t) : "v"(kd), "s"(q.neg_half_turn), "v"(pd));
     const double u = t * t;
+    auto fma_c = [](double a, double b, double c) { return VG ? __builtin_fma(a, b, c) : fma_sc(a, b, c); };
 #ifndef ATC_KIN_ABL
 #define ATC_KIN_ABL 0   // developer-only timing ablations of the float64 kinematics (bit mask); the shipped build uses 0
 #endif
     // (the two Horner chains are written interleaved: each step waits for the previous one of its own chain only)
-    double sp = fma_sc(u, q.s5, q.s4), cp = fma_sc(u, q.c5, q.c4);
+    double sp = fma_c(u, q.s5, q.s4), cp = fma_c(u, q.c5, q.c4);
     if (!(ATC_KIN_ABL & 1)) {
-        sp = fma_sc(sp, u, q.s3);
-        cp = fma_sc(cp, u, q.c3);
-        sp = fma_sc(sp, u, q.s2);
-        cp = fma_sc(cp, u, q.c2);
-        sp = fma_sc(sp, u, q.s1);
-        cp = fma_sc(cp, u, q.c1);
-        sp = fma_sc(sp, u, q.s0);
+        sp = fma_c(sp, u, q.s3);
+        cp = fma_c(cp, u, q.c3);
+        sp = fma_c(sp, u, q.s2);
+        cp = fma_c(cp, u, q.c2);
+        sp = fma_c(sp, u, q.s1);
+        cp = fma_c(cp, u, q.c1);
+        sp = fma_c(sp, u, q.s0);
     }
     const double cs = __builtin_fma(cp, u, 1.0);
     const double sn = sp * t;
-    const double dneg = mul_sc((double)v_fix, q.dist_neg);
+    const double dneg = VG ? (double)v_fix * q.dist_neg : mul_sc((double)v_fix, q.dist_neg);
     const uint32_t flip = (uint32_t)cvt_i32_f64(kd) << 31;
     const double dist = __hiloint2double(__double2hiint(dneg) ^ (int)flip, __double2loint(dneg));
     const double magic = __hiloint2double((int)ATC_DITHER_MAGIC_HI, (int)(__builtin_bitreverse32((uint32_t)t_step) >> 21));

@@ -110,11 +110,21 @@ constexpr int kBlock = ATC_BLOCK;
 #endif
 #if ATC_TRACE
 // one row of 8 stamps per wavefront AND step (row = wavefront * steps + step)
-#define ATC_STAMP(n) do { if (lane == 0 && trow) trow[(n)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define ATC_STAMP_B(n) do { unsigned long long* trow = so.trace; ATC_STAMP(n); } while (0)
+#ifndef ATC_TRACE_MODE
+#define ATC_TRACE_MODE 0   // 0: the step's phases (tools/trace_rollout.py); 1: stamps 1..5 dissect the step's first phase instead
+#endif
+#define ATC_STAMP_AT(row, n) do { if ((threadIdx.x & 63) == 0 && (row)) (row)[(n)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ATC_STAMP(n) do { if (ATC_TRACE_MODE == 0) ATC_STAMP_AT(trow, n); } while (0)
+#define ATC_STAMP_B(n) do { if (ATC_TRACE_MODE == 0) ATC_STAMP_AT(so.trace, n); } while (0)
+#define ATC_STAMP_TOP(row, n) do { if (ATC_TRACE_MODE == 1) ATC_STAMP_AT(row, n); } while (0)
+#define ATC_TRACE_PARAM , unsigned long long* trace_row
+#define ATC_TRACE_PASS(x) , (x)
 #else
 #define ATC_STAMP(n) do {} while (0)
 #define ATC_STAMP_B(n) do {} while (0)
+#define ATC_STAMP_TOP(row, n) do {} while (0)
+#define ATC_TRACE_PARAM
+#define ATC_TRACE_PASS(x)
 #endif
 #ifndef ATC_NEAR_FIRST_LDS
 #define ATC_NEAR_FIRST_LDS 0   // N > 16 fast variant: horizontal test first, altitude plane only for close pairs: 459 vs 503 VALU
@@ -447,6 +457,41 @@ struct alignas(ATC_Q_ALIGN) StepDerived {
     int pad[2];
     QNorm n;
 };
+// LAT — the latency-bound instantiation of the multi-step kernels, for launches of at most two wavefronts per SIMD (65 536 x 1,
+// 8 192 x 16: every BASELINE configuration but the headline and 4 096 x 64).  There a step IS one wavefront's serial instruction
+// chain and the vector register file is all but empty, so the uniform FLOATING-POINT terms of StepDerived (~80 words) are copied
+// into vector registers once per launch — every lane holds the same value — and the step loop reads them as ordinary operands:
+// no kernarg re-read (a scalar load and its wait: ~45 cycles for a wavefront alone, 17 per step at W = 1), no scalar register
+// spilled to lanes, no constant-bus limit.  Integer terms that steer scalar control flow stay scalar.
+__device__ __forceinline__ float vg(float x) {
+    float r;
+    asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(x));
+    return r;
+}
+__device__ __forceinline__ double vg(double x) {
+    int lo, hi;
+    asm("v_mov_b32 %0, %1" : "=v"(lo) : "s"(__double2loint(x)));
+    asm("v_mov_b32 %0, %1" : "=v"(hi) : "s"(__double2hiint(x)));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ StepDerived to_vector_registers(const StepDerived& q) {
+    StepDerived v = q;
+    v.r.dec_mv = vg(q.r.dec_mv); v.r.dec_cv = vg(q.r.dec_cv); v.r.dec_mp = vg(q.r.dec_mp); v.r.dec_cp = vg(q.r.dec_cp);
+    v.r.dec_mh = vg(q.r.dec_mh); v.r.dec_ch = vg(q.r.dec_ch);
+    v.r.dh_hi = vg(q.r.dh_hi); v.r.dh_lo = vg(q.r.dh_lo); v.r.r_base = vg(q.r.r_base);
+    v.k.inv180 = vg(q.k.inv180); v.k.neg_half_turn = vg(q.k.neg_half_turn);
+    v.k.s0 = vg(q.k.s0); v.k.s1 = vg(q.k.s1); v.k.s2 = vg(q.k.s2); v.k.s3 = vg(q.k.s3); v.k.s4 = vg(q.k.s4); v.k.s5 = vg(q.k.s5);
+    v.k.c1 = vg(q.k.c1); v.k.c2 = vg(q.k.c2); v.k.c3 = vg(q.k.c3); v.k.c4 = vg(q.k.c4); v.k.c5 = vg(q.k.c5);
+    v.k.dist_neg = vg(q.k.dist_neg);
+    v.g.pos_x0 = vg(q.g.pos_x0); v.g.pos_y0 = vg(q.g.pos_y0);
+    v.g.gh.x0 = vg(q.g.gh.x0); v.g.gh.y0 = vg(q.g.gh.y0); v.g.gh.inv = vg(q.g.gh.inv);
+    v.s.sep2 = vg(q.s.sep2); v.s.sep_ft = vg(q.s.sep_ft); v.s.conflict_reward = vg(q.s.conflict_reward);
+    v.oc.pos_inv = vg(q.oc.pos_inv); v.oc.to_rwy = vg(q.oc.to_rwy); v.oc.on_gp_c = vg(q.oc.on_gp_c); v.oc.sig_a = vg(q.oc.sig_a);
+#pragma unroll
+    for (int c = 0; c < ATC_OBS_DIM; ++c) { v.n.a[c] = vg(q.n.a[c]); v.n.b[c] = vg(q.n.b[c]); }
+    return v;
+}
+
 // atc_step_packet: the ONE env's action by value, a kernel argument of its own (no read over the host link on the device side)
 struct InlineAction {
     float v, h, p;
@@ -681,10 +726,10 @@ __device__ __forceinline__ int clamp_sym(int d, int r) { return max(min(d, r), -
 __device__ __forceinline__ bool within(int d, int D) { return (uint32_t)d + (uint32_t)(D - 1) < (uint32_t)(2 * D - 1); }
 
 // ---- first half of AtcGym.step: timestep, rate limits towards the targets, kinematics, MVA floor ---------------------
-template <bool ONE>
+template <bool ONE, bool LAT>
 __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const QRates& q, const QKin& qk, const QGrid& qg,
                                            const LaneIds& d, uint32_t tv, float th, int tp, float act_p, LaneState& ls, EnvState& es,
-                                           bool repeated, bool all_active, bool track_v, double* wide_named, int zk) {
+                                           bool repeated, bool all_active, bool track_v, double* wide_named, int zk ATC_TRACE_PARAM) {
     Mid m;
     Aircraft& a = ls.a;
     // `repeated` (wave-uniform): this step repeats the previous step's actions and no env of the wavefront was reset in
@@ -810,6 +855,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
             }
         }
     }
+    ATC_STAMP_TOP(trace_row, 2);
     // ---- Airplane.step (model.py:122-129): rot_matrix(phi) . [0, (v/3600) dt], float64 from the fixed-point state -----------
     // (an aircraft that is not under control does not move: zero speed -> zero displacement -> floor(0 + dither) = 0 counts)
     uint32_t v_move = a.v;
@@ -819,7 +865,8 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     }
     // (the kinematics are periodic in the heading: a WIDE one goes in wrapped — read back from the side record's scratch word)
     const int phi_k = heading_counts<ONE>(plain, a.phi, wide_named, zk, d.i);
-    if (!(ATC_ABLATE & 32)) advance(qk, phi_k, v_move, es.t, a.x, a.y);
+    if (!(ATC_ABLATE & 32)) advance<LAT>(qk, phi_k, v_move, es.t, a.x, a.y);
+    ATC_STAMP_TOP(trace_row, 3);
     m.x32 = pos_to_real(q.pos_neg_k, qg.pos_x0, a.x);
     m.y32 = pos_to_real(q.pos_neg_k, qg.pos_y0, a.y);
     // MVA floor, first half: only ISSUE the lookup-cell gather here; nothing until the override chain needs its result
@@ -830,6 +877,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     m.acts = acts;
     m.repeated = repeated;
     m.plain = plain;
+    ATC_STAMP_TOP(trace_row, 4);
     return m;
 }
 
@@ -861,9 +909,9 @@ __device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, con
 #ifndef ATC_QGET_REREAD_MIN_W
 #define ATC_QGET_REREAD_MIN_W 1   // developer A/B: multi-step launches of narrower envs name the argument instead of re-reading it
 #endif
-#define QGET(member) ((ONE || W < ATC_QGET_REREAD_MIN_W) ? q.member : kernarg_reread<decltype(q.member)>(offsetof(StepArgs, q) + offsetof(StepDerived, member), zk))
+#define QGET(member) ((ONE || LAT || W < ATC_QGET_REREAD_MIN_W) ? q.member : kernarg_reread<decltype(q.member)>(offsetof(StepArgs, q) + offsetof(StepDerived, member), zk))
 
-template <int W, bool FULL, bool ONE>
+template <int W, bool FULL, bool ONE, bool LAT>
 __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const float* __restrict__ grid,
                                             const atc_params_t& p, const StepDerived& q, const QScan& qs, int zk, int N,
                                             const LaneIds& d, const Mid& m, LaneState& ls,
@@ -1062,6 +1110,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         ob = get_state(oc, a.x, a.y, x32, y32, a.h, phi_f, phi_o, v_real(a.v), 0.0f);
         if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
     }
+    ATC_STAMP_TOP(so.trace, 5);
     // ---- MVA floor (atc_gym.py:146-161), second half ---------------------------------------------------------------------
     if (kResolveAfterScan) {
         float hgt = 0.0f;
@@ -1231,11 +1280,19 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     ATC_STAMP_B(5);
     // Multi-step launches: the NEXT step's rate group is requested here, with the observation store still ahead — requested at
     // the top of the step that uses it, its latency was a stall before the first instruction of the kinematics.
-    if (!ONE) {
+    if (!ONE && !LAT) {
         int zn;
         asm volatile("s_mov_b32 %0, 0" : "=s"(zn));
         qr_next = kernarg_reread<QRates>(offsetof(StepArgs, q) + offsetof(StepDerived, r), zn);
     }
+#ifndef ATC_ACT_WAIT_INSIDE
+#define ATC_ACT_WAIT_INSIDE 1
+#endif
+    // The next block's action (requested above, behind the MVA gathers) is WAITED FOR here, in the step that requested it and ahead
+    // of this step's stores: left pending across the loop's back edge, "the action may be in flight" reaches the loop header, and the
+    // decode at the top of EVERY step waits for every earlier vector-memory operation — one counter, in order — i.e. for the
+    // previous step's observation stores to complete.  By now the load has long arrived.
+    if (ATC_ACT_WAIT_INSIDE && ATC_RARE(act_next != nullptr)) asm volatile("" : "+v"(a_next.a), "+v"(a_next.b), "+v"(a_next.c));
     // ---- observation store: [aircraft][10] rows are 40 B apart, so per-lane stores would scatter 8-byte pieces over 20
     //      cache lines per instruction; a full wavefront instead transposes its 64 x 10 block through LDS and writes 2 560
     //      contiguous bytes as 16-byte stores.
@@ -1312,10 +1369,18 @@ __device__ __forceinline__ void store_env_state(const atc_state_t& st, const Lan
     }
 }
 
-template <int W, bool FULL, bool ONE, bool ALLV>  // ONE: single-step launch (T == 1); ALLV: every slot is an aircraft (make_ids)
-__global__ void __launch_bounds__(kBlock, (ONE ? ATC_MIN_WAVES : ((FULL || W <= 8 || W >= 32) ? ATC_MIN_WAVES_LOOP - 1 : ATC_MIN_WAVES_LOOP)))
+#ifndef ATC_LAT_WAVES
+#define ATC_LAT_WAVES 2   // wavefronts per SIMD the latency-bound instantiation is register-budgeted for (<= 256 VGPRs)
+#endif
+// ONE: single-step launch (T == 1); ALLV: every slot is an aircraft (make_ids); LAT: latency-bound multi-step instantiation (above)
+template <int W, bool FULL, bool ONE, bool ALLV, bool LAT = false>
+__global__ void __launch_bounds__(kBlock, (LAT ? ATC_LAT_WAVES : ONE ? ATC_MIN_WAVES : ((FULL || W <= 8 || W >= 32) ? ATC_MIN_WAVES_LOOP - 1 : ATC_MIN_WAVES_LOOP)))
 k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int hold, atc_state_t st,
-       const float* __restrict__ actions, atc_out_t out, atc_params_t p, StepDerived q, InlineAction ia) {
+       const float* __restrict__ actions, atc_out_t out, atc_params_t p, StepDerived q_arg, InlineAction ia) {
+    static_assert(!LAT || (!ONE && !FULL), "LAT is an instantiation of the fast multi-step kernels");
+    StepDerived q_vec;
+    if (LAT) q_vec = to_vector_registers(q_arg);
+    const StepDerived& q = LAT ? q_vec : q_arg;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4* pos = reinterpret_cast<float4*>(smem);                    // [2 kBlock] pair-scan staging (W >= 32)
     float* obs_stage = smem + (W >= 32 ? 2 * kBlock * 4 : 0);  // [4 waves][64 x 10] obs transpose
@@ -1328,6 +1393,24 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     const unsigned long long t_launch = __builtin_amdgcn_s_memtime();
 #endif
     const uint32_t BN = (uint32_t)B * (uint32_t)N;      // host guarantees B*N*40 bytes < 4 GiB: 32-bit lane offsets
+#ifndef ATC_KARG_PREFETCH
+// single-step launches of envs of up to 16 aircraft (r05, same box: 8 192 x 16 5.15 vs 5.34 us, 65 536 x 16 17.53 vs 17.60, 65 536 x 1
+// 6.03 vs 6.13 with the argument preload; 4 096 x 64 8.0 vs 7.8 and the multi-step launches no better: off there)
+#define ATC_KARG_PREFETCH(W, ONE) ((ONE) && (W) <= 16)
+#endif
+    int karg_touch = 0;
+    if (ATC_KARG_PREFETCH(W, ONE)) {
+        // Touch every 64-byte line of the kernarg segment NOW, in one burst of scalar loads: the step reads its ~530 bytes of
+        // arguments at a dozen places, each just ahead of its use — in a wavefront that is the first of its dispatch on its scalar
+        // cache every one of those is a miss on the step's serial chain; requested together up front the misses overlap and the
+        // later reads hit.
+#if __HIP_DEVICE_COMPILE__
+        typedef __attribute__((address_space(4))) const int* karg_ip;
+        karg_ip kb = (karg_ip)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma unroll
+        for (int ln = 1; ln < (int)((sizeof(StepArgs) + 63) / 64); ++ln) karg_touch ^= kb[16 * ln];
+#endif
+    }
     const LaneIds d = make_ids<W, ALLV>(blockIdx.x * kBlock, B, N);
 
     // ---- load persistent state (16-byte records; the W lanes of an env share the env record) -------------------------
@@ -1362,7 +1445,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     Targets tg = {0u, 0.0f, 0};   // decoded targets of the current step / block
     bool all_active = false, mask_dirty = true;
     QRates qr_next = q.r;   // the rate group of the coming step (multi-step launches fetch it one step ahead, see step_part_b)
-    if (!ONE) {
+    if (!ONE && !LAT) {
         int zn;
         asm volatile("s_mov_b32 %0, 0" : "=s"(zn));
         qr_next = kernarg_reread<QRates>(offsetof(StepArgs, q) + offsetof(StepDerived, r), zn);
@@ -1438,8 +1521,9 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
 #ifndef ATC_KIN_FROM_ARGS
 #define ATC_KIN_FROM_ARGS 1   // 0 (developer A/B): the kinematics constants named as the kernel argument in multi-step launches too
 #endif                        // (the compiler may then keep them in scalar registers across the step loop)
-        const Mid m = step_part_a<ONE>(gl, qr, ATC_KIN_FROM_ARGS ? QGET(k) : q.k, QGET(g), dl, tg.v, tg.h, tg.p, act.c, ls, es, repeated, !ONE && all_active, ONE,
-                                       st.phi_wide, zk);
+        ATC_STAMP_TOP(trow, 1);
+        const Mid m = step_part_a<ONE, LAT>(gl, qr, ATC_KIN_FROM_ARGS ? QGET(k) : q.k, QGET(g), dl, tg.v, tg.h, tg.p, act.c, ls, es, repeated, !ONE && all_active, ONE,
+                                       st.phi_wide, zk ATC_TRACE_PASS(trow));
         ATC_STAMP(1);
         Float3 nxt = act;
         const float* act_next = nullptr;   // the next block is fetched during the last step of the current one
@@ -1450,7 +1534,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             act_t += (size_t)BN * 3;
             if (step + 1 < n_steps) act_next = act_t;
         }
-        const bool quiet = step_part_b<W, FULL, ONE>(Kl, gl, pl, q, qs, zk, N, dl, m, ls, es, so, stats_l, st.phi_wide, pos, obs_stage, act_next, nxt, qr_next);
+        const bool quiet = step_part_b<W, FULL, ONE, LAT>(Kl, gl, pl, q, qs, zk, N, dl, m, ls, es, so, stats_l, st.phi_wide, pos, obs_stage, act_next, nxt, qr_next);
         if (ATC_RARE(!quiet)) mask_dirty = true;
         if (ATC_LOOP_DECODE_ONCE) {
             if (act_next) tg = decode_targets(QGET(r), nxt);
@@ -1458,6 +1542,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             act = nxt;
         }
         ATC_STAMP(6);
+        ATC_STAMP_TOP(trow, 6);
     }
     // ---- write back persistent state -----------------------------------------------------------------------------------
     atc_state_t st_end = st;
@@ -1471,6 +1556,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     }
     store_lane_state(st_end, d, ls, la_live, !ONE);
     store_env_state<W>(st_end, d, es, hi0);
+    if (ATC_KARG_PREFETCH(W, ONE)) asm volatile("" ::"s"(karg_touch));   // (keeps the touches alive; nothing waits for them before here)
 #if ATC_TRACE
     if (lane == 0 && trace) trace[((size_t)(blockIdx.x * (kBlock / 64) + (tid >> 6)) * n_steps + (n_steps - 1)) * 8 + 7] = __builtin_amdgcn_s_memtime();
 #endif
@@ -1598,7 +1684,7 @@ static size_t lds_bytes(const atc_scenario*, bool pair_scan, bool step_kernel = 
     return w * sizeof(float);
 }
 
-template <int W, bool FULL, bool ONE, bool ALLV>
+template <int W, bool FULL, bool ONE, bool ALLV, bool LAT = false>
 static int launch_step2(const atc_scenario* s, int B, int N, int T, int hold, const atc_state_t* st, const float* actions,
                         const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
 #ifdef ATC_LDS_PAD_LOOP   // developer A/B builds: cap the multi-step launch's workgroups per CU through its LDS allocation
@@ -1607,11 +1693,11 @@ static int launch_step2(const atc_scenario* s, int B, int N, int T, int hold, co
     const size_t lds = lds_bytes(s, W >= 32, true);
 #endif
     if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<W, FULL, ONE, ALLV>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<W, FULL, ONE, ALLV, LAT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long long slots = (long long)B * W;
     const int grid = (int)((slots + kBlock - 1) / kBlock);  // one workgroup per 256 slots, no grid-stride loop
-    hipLaunchKernelGGL((k_step<W, FULL, ONE, ALLV>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->off_grid, B, N, T, hold, *st, actions, *out, *p, derive(*p, s), inline_action());
+    hipLaunchKernelGGL((k_step<W, FULL, ONE, ALLV, LAT>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->off_grid, B, N, T, hold, *st, actions, *out, *p, derive(*p, s), inline_action());
     HIP_TRY(hipGetLastError());
     return ATC_OK;
 }
@@ -1626,6 +1712,12 @@ static int launch_step(const atc_scenario* s, int B, int N, int T, int hold, con
     // instead is slower at every size (65 536 x 16, T = 20, [T, ...] outputs: 35.0 vs 27.1 us per step).
     if (T > 1) {
         if (full) return launch_step2<W, true, false, false>(s, B, N, T, hold, st, actions, out, p, stream);
+#ifndef ATC_LAT
+#define ATC_LAT 1   // developer A/B: 0 = never choose the latency-bound instantiation
+#endif
+        // at most ATC_LAT_WAVES wavefronts per SIMD: the latency-bound instantiation (uniform terms in vector registers)
+        const bool lat = ATC_LAT && allv && ((long long)B * W + 63) / 64 <= (long long)ATC_LAT_WAVES * 4 * s->n_cu;
+        if (lat) return launch_step2<W, false, false, true, true>(s, B, N, T, hold, st, actions, out, p, stream);
         return allv ? launch_step2<W, false, false, true>(s, B, N, T, hold, st, actions, out, p, stream)
                     : launch_step2<W, false, false, false>(s, B, N, T, hold, st, actions, out, p, stream);
     }

@@ -572,3 +572,34 @@ def test_all_valid_instantiation_equals_general_kernels(N):
     assert int(envs[0].episodes.sum()) > B      # episodes ended and restarted inside the comparison
     for e in envs:
         e.close()
+
+
+@pytest.mark.parametrize("N,big", [(1, 131072 + 256), (16, 8192 + 256), (64, 2048 + 4)])
+def test_latency_bound_instantiation_equals_the_throughput_kernels(N, big):
+    """Multi-step launches of at most two wavefronts per SIMD run the LATENCY-BOUND instantiation (uniform floating-point terms in
+    vector registers, csrc/atc_step.hip: LAT), bigger all-valid batches the throughput instantiation, other shapes the general
+    kernels.  The envs three such batches share (same env indices, same seed: same spawn draws) must come out bit-identical over
+    several atc_rollout_hold launches with resets inside."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+    scn = scenarios.LOWWDense() if N == 64 else scenarios.LOWW(random_entrypoints=N > 1)
+    small = 2 * max(1, 256 // N) * (4 if N == 1 else 1)
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    W = 1 << max(0, (N - 1).bit_length())
+    assert (big * W + 63) // 64 > 2 * 4 * n_cu >= (small * W + 63) // 64, "batch sizes no longer straddle the LAT threshold"
+    envs = [AtcVecEnv(small, N, scenario=scn, seed=5), AtcVecEnv(big, N, scenario=scn, seed=5), AtcVecEnv(big + 1, N, scenario=scn, seed=5)]
+    g = torch.Generator(device="cpu").manual_seed(N)
+    for j in range(6):
+        blocks = (torch.rand((2, big + 1, N, 3), generator=g) * 2.1 - 1.05).cuda()
+        outs = [e.rollout(blocks[:, :e.B].contiguous(), hold=10) for e in envs]
+        for k in ("obs", "reward", "done", "flags"):
+            assert torch.equal(outs[0][k], outs[1][k][:, :small]), (k, "latency-bound vs throughput")
+            assert torch.equal(outs[1][k], outs[2][k][:, :big]), (k, "throughput vs general")
+    for name in ("pos_hp", "v_fix", "last_act"):
+        assert torch.equal(getattr(envs[0], name), getattr(envs[1], name)[:small * N]), name
+        assert torch.equal(getattr(envs[1], name), getattr(envs[2], name)[:big * N]), name
+    assert torch.equal(envs[0].env, envs[1].env[:small]) and torch.equal(envs[0].stats, envs[1].stats[:small])
+    assert int(envs[0].episodes.sum()) > small
+    for e in envs:
+        e.close()

@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "atc-reinforcement-learning_amd", "csrc", "atc_step.hip")
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-fPIC", "-shared",
        "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/atc_usage.so", SRC] + sys.argv[1:]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
