@@ -76,6 +76,12 @@ static int fail_hip(hipError_t e, const char* what) {
 #ifndef ATC_WABL
 #define ATC_WABL 0
 #endif
+#ifndef ATC_LAT_CARRY_REFUSED
+#define ATC_LAT_CARRY_REFUSED 1   // latency-bound instantiation: the refused-target mask of a held action block is carried across its steps
+#endif
+#ifndef ATC_LAT_DECODE_ONCE
+#define ATC_LAT_DECODE_ONCE 1     // ... and so are the decoded targets (three vector registers it has to spare)
+#endif
 #ifndef ATC_BLOCK
 #define ATC_BLOCK 256
 #endif
@@ -474,8 +480,19 @@ __device__ __forceinline__ double vg(double x) {
     asm("v_mov_b32 %0, %1" : "=v"(hi) : "s"(__double2hiint(x)));
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ int vg(int x) {
+    int r;
+    asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(x));
+    return r;
+}
 __device__ __forceinline__ StepDerived to_vector_registers(const StepDerived& q) {
     StepDerived v = q;
+    // (integers that are only ever VALU operands — limits, grid dimensions, the FAF's grid coordinates — go along: each frees a scalar
+    // register the loop would otherwise spill to a vector-register lane and read back with v_readlane)
+    v.r.rate_v = vg(q.r.rate_v); v.r.rate_p = vg(q.r.rate_p); v.r.pos_neg_k = vg(q.r.pos_neg_k);
+    v.g.gh.nx = vg(q.g.gh.nx); v.g.gh.nx_last = vg(q.g.gh.nx_last); v.g.gh.ny_last = vg(q.g.gh.ny_last);
+    v.oc.faf_x = vg(q.oc.faf_x); v.oc.faf_y = vg(q.oc.faf_y);
+    v.s.timestep_limit = vg(q.s.timestep_limit);
     v.r.dec_mv = vg(q.r.dec_mv); v.r.dec_cv = vg(q.r.dec_cv); v.r.dec_mp = vg(q.r.dec_mp); v.r.dec_cp = vg(q.r.dec_cp);
     v.r.dec_mh = vg(q.r.dec_mh); v.r.dec_ch = vg(q.r.dec_ch);
     v.r.dh_hi = vg(q.r.dh_hi); v.r.dh_lo = vg(q.r.dh_lo); v.r.r_base = vg(q.r.r_base);
@@ -655,6 +672,26 @@ __device__ __forceinline__ int wide_view(bool plain, int phi, double* named, int
     }
     return r;
 }
+// Latency-bound instantiation: ONE look-up per step (both words, kept in the vector registers it has to spare) instead of one
+// wave-uniform test per use site — a not-taken scalar branch is ~20 cycles of a lone wavefront's chain.
+struct WideWords {
+    int counts, obs_bits;
+};
+template <bool ONE>
+__device__ __forceinline__ WideWords wide_words(bool plain, int phi, double* named, int zk, uint32_t i) {
+    WideWords w = {phi, __float_as_int(phi_real(phi))};
+    if (ATC_RARE(!plain)) {
+        if ((__builtin_amdgcn_ballot_w64(phi == INT32_MAX) | __builtin_amdgcn_ballot_w64(phi == INT32_MIN)) != 0ull) {
+            if (is_wide(phi)) {
+                const int2 v = *at<int2>(wide_base<ONE>(named, zk), i * 32u + 16u);
+                w.counts = v.x;
+                w.obs_bits = v.y;
+            }
+            asm volatile("" : "+v"(w.counts), "+v"(w.obs_bits));   // (waited for here, inside the rare block: see wide_view)
+        }
+    }
+    return w;
+}
 // the heading's counts as kinematics and angles see them (both are periodic in the heading)
 template <bool ONE>
 __device__ __forceinline__ int heading_counts(bool plain, int phi, double* named, int zk, uint32_t i) {
@@ -729,7 +766,8 @@ __device__ __forceinline__ bool within(int d, int D) { return (uint32_t)d + (uin
 template <bool ONE, bool LAT>
 __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const QRates& q, const QKin& qk, const QGrid& qg,
                                            const LaneIds& d, uint32_t tv, float th, int tp, float act_p, LaneState& ls, EnvState& es,
-                                           bool repeated, bool all_active, bool track_v, double* wide_named, int zk ATC_TRACE_PARAM) {
+                                           bool repeated, bool all_active, bool track_v, double* wide_named, int zk,
+                                           uint64_t& refused_blk, bool refused_known ATC_TRACE_PARAM) {
     Mid m;
     Aircraft& a = ls.a;
     // `repeated` (wave-uniform): this step repeats the previous step's actions and no env of the wavefront was reset in
@@ -760,9 +798,15 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     // compared again — two vector operations per site)
     // ... and a heading target beyond the 32-bit range (the saturated conversion, include/atc_step.h ABI 19) takes the general
     // form too, like a lane whose heading or last heading target is WIDE already (`all_active` vouches that none is)
-    const uint64_t refused = __builtin_amdgcn_ballot_w64(tv < kVMinFix) | __builtin_amdgcn_ballot_w64(tv > kVMaxFix) |
-                             __builtin_amdgcn_ballot_w64(th < h_min) | __builtin_amdgcn_ballot_w64(th > h_max) |
-                             ((ATC_WABL & 32) ? 0ull : (__builtin_amdgcn_ballot_w64(tp == INT32_MAX) | __builtin_amdgcn_ballot_w64(tp == INT32_MIN)));
+    // (the latency-bound multi-step instantiation carries this mask across the steps of a held action block: the targets do not
+    // change inside one — six compares and five scalar ORs fewer on a lone wavefront's chain)
+    uint64_t refused = refused_blk;
+    if (!(LAT && ATC_LAT_CARRY_REFUSED) || !refused_known) {
+        refused = __builtin_amdgcn_ballot_w64(tv < kVMinFix) | __builtin_amdgcn_ballot_w64(tv > kVMaxFix) |
+                  __builtin_amdgcn_ballot_w64(th < h_min) | __builtin_amdgcn_ballot_w64(th > h_max) |
+                  ((ATC_WABL & 32) ? 0ull : (__builtin_amdgcn_ballot_w64(tp == INT32_MAX) | __builtin_amdgcn_ballot_w64(tp == INT32_MIN)));
+        refused_blk = refused;
+    }
     uint64_t special = refused;
     if ((ATC_WABL & 64) && !all_active) special |= __builtin_amdgcn_ballot_w64(!active);
     else if (!all_active) {
@@ -770,6 +814,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
         special |= __builtin_amdgcn_ballot_w64(!active) | __builtin_amdgcn_ballot_w64(hi == INT32_MAX) | __builtin_amdgcn_ballot_w64(lo == INT32_MIN);
     }
     const bool plain = special == 0ull;
+    int phi_k;   // the heading as the kinematics see it (a WIDE heading wrapped: they are periodic)
     static_assert(kAMin == -kAMax && kPhiDotMin == -kPhiDotMax, "symmetric rate limits assumed (one count limit each)");
     if (ATC_USUAL(plain)) {
         const uint32_t v_new = a.v + (uint32_t)clamp_sym((int)(tv - a.v), q.rate_v);
@@ -777,6 +822,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
         a.v = v_new;
         a.h = a.h + clamp_rate(th - a.h, q.dh_lo, q.dh_hi);
         a.phi = a.phi + clamp_sym(sat_sub(tp, a.phi), q.rate_p);
+        phi_k = a.phi;
         if (book) {
             acts = (!within((int)(tv - ls.la_v), kDiscrVFix) ? 1 : 0) + (!(fabsf(th - ls.la_h) < kDiscrH) ? 1 : 0) +
                    (!within(sat_sub(tp, ls.la_p), kDiscrPhiFix) ? 1 : 0);
@@ -822,6 +868,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
             int phi_new = active ? a.phi + dd : a.phi;
             bool counted = active && !within(sat_sub(tp, ls.la_p), kDiscrPhiFix);
             int la_new = active ? tp : ls.la_p;
+            phi_k = phi_new;
             // (lanes without an aircraft compute on a clamped copy of the batch's last one: they must not write its side record)
             const bool wide = d.lane_valid && (is_wide(tp) || is_wide(a.phi) || (book && is_wide(ls.la_p)));
             if (!(ATC_WABL & 1) && ATC_RARE(__builtin_amdgcn_ballot_w64(wide) != 0ull)) {
@@ -834,9 +881,11 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
                     // (a handed-over aircraft keeps its heading; its views are refreshed all the same: they are scratch)
                     const double Pn = active ? P + __builtin_fmin(__builtin_fmax(T - P, -rate), rate) : P;
                     phi_new = cvt_i32_f64(Pn);   // saturating: sat32
+                    phi_k = phi_new;
                     if (is_wide(phi_new)) {   // the exact counts, and their views for the rest of this step (wide_view)
+                        phi_k = phi_wrap(Pn);
                         w[0] = Pn;
-                        *reinterpret_cast<int2*>(w + 2) = make_int2(phi_wrap(Pn), __float_as_int(phi_obs_wide(Pn)));
+                        *reinterpret_cast<int2*>(w + 2) = make_int2(phi_k, __float_as_int(phi_obs_wide(Pn)));
                     }
                     if (book && active) {
                         const double L = is_wide(ls.la_p) ? w[1] : (double)ls.la_p;
@@ -864,7 +913,6 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
         asm("" : "+v"(v_move));   // (keeps the select on the 32-bit counts: the compiler moved it behind the conversion, onto both halves of the double)
     }
     // (the kinematics are periodic in the heading: a WIDE one goes in wrapped — read back from the side record's scratch word)
-    const int phi_k = heading_counts<ONE>(plain, a.phi, wide_named, zk, d.i);
     if (!(ATC_ABLATE & 32)) advance<LAT>(qk, phi_k, v_move, es.t, a.x, a.y);
     ATC_STAMP_TOP(trace_row, 3);
     m.x32 = pos_to_real(q.pos_neg_k, qg.pos_x0, a.x);
@@ -945,6 +993,8 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
 #endif
     constexpr bool kResolveAfterScan = ATC_RESOLVE_LATE ? (W >= 16 || (ATC_OBS_FIRST_W1 && W == 1 && (ONE || ATC_OBS_FIRST_W1_LOOP))) : (W >= 32);   // (W = 2 .. 8: the unrolled xor scan with the cell
                                                                                    // in flight costs 4 - 22 registers)
+    WideWords ww = {0, 0};
+    if (LAT) ww = wide_words<ONE>(m.plain, a.phi, wide_named, zk, i);
     float mva = 0.0f;
     int pi = 0;
     if (!kResolveAfterScan) {
@@ -1105,8 +1155,8 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     if (kObsFirst && !(ATC_ABLATE & 8)) {
         // (observation word 3 first, then the heading for the angles — each its own rare look-up for a WIDE heading, before the rest
         // of the observation occupies its registers)
-        const float phi_f = phi_real(heading_counts<ONE>(m.plain, a.phi, wide_named, zk, i));
-        const float phi_o = __int_as_float(wide_view<ONE, 1>(m.plain, a.phi, wide_named, zk, i, __float_as_int(phi_f)));
+        const float phi_f = phi_real(LAT ? ww.counts : heading_counts<ONE>(m.plain, a.phi, wide_named, zk, i));
+        const float phi_o = __int_as_float(LAT ? ww.obs_bits : wide_view<ONE, 1>(m.plain, a.phi, wide_named, zk, i, __float_as_int(phi_f)));
         ob = get_state(oc, a.x, a.y, x32, y32, a.h, phi_f, phi_o, v_real(a.v), 0.0f);
         if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
     }
@@ -1145,7 +1195,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             fl |= conflict ? (uint32_t)ATC_F_CONFLICT : 0u;
         }
         // ---- win / timeout overrides (atc_gym.py:163-173) ---------------------------------------------------------------
-        if (!(ATC_ABLATE & 4) && inside_corridor(K, qs.tri_bbox, x32, y32, a.h, phi_real(heading_counts<ONE>(m.plain, a.phi, wide_named, zk, i)))) {
+        if (!(ATC_ABLATE & 4) && inside_corridor(K, qs.tri_bbox, x32, y32, a.h, phi_real(LAT ? ww.counts : heading_counts<ONE>(m.plain, a.phi, wide_named, zk, i)))) {
             int bonus = (qs.timestep_limit - es.t) * 5;
             bonus = bonus < 0 ? 0 : bonus;
             r = (float)(10000 + bonus);
@@ -1171,8 +1221,8 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         } else if (kObsFirst) {
             ob.o[5] = a.h - mva;
         } else {
-            const float phi_f = phi_real(heading_counts<ONE>(m.plain, a.phi, wide_named, zk, i));
-            const float phi_o = __int_as_float(wide_view<ONE, 1>(m.plain, a.phi, wide_named, zk, i, __float_as_int(phi_f)));
+            const float phi_f = phi_real(LAT ? ww.counts : heading_counts<ONE>(m.plain, a.phi, wide_named, zk, i));
+            const float phi_o = __int_as_float(LAT ? ww.obs_bits : wide_view<ONE, 1>(m.plain, a.phi, wide_named, zk, i, __float_as_int(phi_f)));
             ob = get_state(oc, a.x, a.y, x32, y32, a.h, phi_f, phi_o, v_real(a.v), mva);
             if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
         }
@@ -1443,12 +1493,27 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     int left = hold;                // steps the current block is still used for
     bool block_start = true;        // this step is the first of its block
     Targets tg = {0u, 0.0f, 0};   // decoded targets of the current step / block
+    uint64_t refused_blk = 0ull;  // LAT: which lanes' speed / altitude / heading targets of the current block are refused or beyond range
+    bool refused_known = false;
     bool all_active = false, mask_dirty = true;
     QRates qr_next = q.r;   // the rate group of the coming step (multi-step launches fetch it one step ahead, see step_part_b)
     if (!ONE && !LAT) {
         int zn;
         asm volatile("s_mov_b32 %0, 0" : "=s"(zn));
         qr_next = kernarg_reread<QRates>(offsetof(StepArgs, q) + offsetof(StepDerived, r), zn);
+    }
+#ifndef ATC_LOOP_STATE_WAIT
+#define ATC_LOOP_STATE_WAIT 1
+#endif
+    if (!ONE && ATC_LOOP_STATE_WAIT) {
+        // The state loads are WAITED FOR here, before the step loop.  Left pending, "a state register may still be in flight" is
+        // merged into the loop header from the pre-header, and the compiler guards the first use of each in the loop body with a
+        // wait that — one counter for loads and stores, in order — also waits for the PREVIOUS step's stores in every later step.
+        asm volatile("" : "+v"(ls.a.x), "+v"(ls.a.y), "+v"(ls.a.h), "+v"(ls.a.phi), "+v"(ls.a.v));
+        asm volatile("" : "+v"(ls.la_v), "+v"(ls.la_h), "+v"(ls.la_p), "+v"(es.t), "+v"(es.n_actions), "+v"(es.total_reward));
+        uint32_t m_lo = (uint32_t)es.amask, m_hi = (uint32_t)(es.amask >> 32);
+        asm volatile("" : "+v"(m_lo), "+v"(m_hi));
+        es.amask = (uint64_t)m_lo | ((uint64_t)m_hi << 32);
     }
     for (int step = 0; step < n_steps; ++step) {
 #if ATC_TRACE
@@ -1502,7 +1567,8 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         const QRates qr = qr_next;
         const QScan qs = QGET(s);   // (requested here, consumed after the kinematics)
         if (!ONE && ATC_RARE(step == 0)) act = *at<Float3>(act_t, times12(dl.i));
-        if (ONE || !ATC_LOOP_DECODE_ONCE || step == 0) tg = decode_targets(qr, act);
+        constexpr bool kDecodeOnce = ATC_LOOP_DECODE_ONCE || (LAT && ATC_LAT_DECODE_ONCE);
+        if (ONE || !kDecodeOnce || step == 0) tg = decode_targets(qr, act);
         if (ONE && !la_live) {   // held block: the record equals the accepted targets (components that are refused are not compared)
             ls.la_v = tg.v;
             ls.la_h = tg.h;
@@ -1523,7 +1589,8 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
 #endif                        // (the compiler may then keep them in scalar registers across the step loop)
         ATC_STAMP_TOP(trow, 1);
         const Mid m = step_part_a<ONE, LAT>(gl, qr, ATC_KIN_FROM_ARGS ? QGET(k) : q.k, QGET(g), dl, tg.v, tg.h, tg.p, act.c, ls, es, repeated, !ONE && all_active, ONE,
-                                       st.phi_wide, zk ATC_TRACE_PASS(trow));
+                                       st.phi_wide, zk, refused_blk, refused_known ATC_TRACE_PASS(trow));
+        refused_known = true;
         ATC_STAMP(1);
         Float3 nxt = act;
         const float* act_next = nullptr;   // the next block is fetched during the last step of the current one
@@ -1531,16 +1598,14 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         if (!ONE && ATC_RARE(--left == 0)) {   // (the block length is fetched again here, at block ends, not kept — or re-fetched — every step)
             left = kernarg_reread<int>(offsetof(StepArgs, hold), zk);
             block_start = true;
+            refused_known = false;
             act_t += (size_t)BN * 3;
             if (step + 1 < n_steps) act_next = act_t;
         }
         const bool quiet = step_part_b<W, FULL, ONE, LAT>(Kl, gl, pl, q, qs, zk, N, dl, m, ls, es, so, stats_l, st.phi_wide, pos, obs_stage, act_next, nxt, qr_next);
         if (ATC_RARE(!quiet)) mask_dirty = true;
-        if (ATC_LOOP_DECODE_ONCE) {
-            if (act_next) tg = decode_targets(QGET(r), nxt);
-        } else {
-            act = nxt;
-        }
+        if (kDecodeOnce && act_next) tg = decode_targets(QGET(r), nxt);
+        act = nxt;
         ATC_STAMP(6);
         ATC_STAMP_TOP(trow, 6);
     }
