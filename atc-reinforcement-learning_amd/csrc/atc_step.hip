@@ -79,6 +79,9 @@ static int fail_hip(hipError_t e, const char* what) {
 #ifndef ATC_LAT_CARRY_REFUSED
 #define ATC_LAT_CARRY_REFUSED 1   // latency-bound instantiation: the refused-target mask of a held action block is carried across its steps
 #endif
+#ifndef ATC_CARRY_REFUSED_ALL
+#define ATC_CARRY_REFUSED_ALL 1   // the throughput multi-step kernels carry the mask as well (r05: 65 536 x 16 fused -2 %); 0: developer A/B
+#endif
 #ifndef ATC_LAT_DECODE_ONCE
 #define ATC_LAT_DECODE_ONCE 1     // ... and so are the decoded targets (three vector registers it has to spare)
 #endif
@@ -801,7 +804,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     // (the latency-bound multi-step instantiation carries this mask across the steps of a held action block: the targets do not
     // change inside one — six compares and five scalar ORs fewer on a lone wavefront's chain)
     uint64_t refused = refused_blk;
-    if (!(LAT && ATC_LAT_CARRY_REFUSED) || !refused_known) {
+    if (!((LAT || ATC_CARRY_REFUSED_ALL) && ATC_LAT_CARRY_REFUSED) || !refused_known) {
         refused = __builtin_amdgcn_ballot_w64(tv < kVMinFix) | __builtin_amdgcn_ballot_w64(tv > kVMaxFix) |
                   __builtin_amdgcn_ballot_w64(th < h_min) | __builtin_amdgcn_ballot_w64(th > h_max) |
                   ((ATC_WABL & 32) ? 0ull : (__builtin_amdgcn_ballot_w64(tp == INT32_MAX) | __builtin_amdgcn_ballot_w64(tp == INT32_MIN)));
@@ -1559,8 +1562,9 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
 #endif
         };
 #ifndef ATC_LOOP_DECODE_ONCE
-#define ATC_LOOP_DECODE_ONCE 0   // 1: carry the DECODED targets of a held block across its steps (7 operations fewer per step, but
-#endif                           // a second re-read site of the rate group: 331.9 vs 331.2 VALU, 11.50 vs 11.46 us — no gain)
+#define ATC_LOOP_DECODE_ONCE 1   // carry the DECODED targets of a held block across its steps (7 operations fewer per step).  Round 3: no
+#endif                           // gain (a second re-read site of the rate group); round 5, next to the carried refused-target mask:
+                                 // 65 536 x 16 fused 11.8-12.0 -> 11.6-11.8 us, 4 096 x 64 5.32-5.35 -> 5.14-5.23
 #ifndef ATC_LOOP_ALLACT
 #define ATC_LOOP_ALLACT 1        // carry "every lane's aircraft is under control" across the steps (re-established after steps that
 #endif                           // can change a mask): 325.5 vs 331.2 VALU per wavefront-step, 11.37 vs 11.46 us at 65 536 x 16
