@@ -1518,6 +1518,18 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         asm volatile("" : "+v"(m_lo), "+v"(m_hi));
         es.amask = (uint64_t)m_lo | ((uint64_t)m_hi << 32);
     }
+#ifndef ATC_LOOP_RUNPTR
+#define ATC_LOOP_RUNPTR 0
+#endif
+    // Developer A/B (r05, rejected): 1 = the four per-step output bases RUN along (one 64-bit scalar add each per step), 2 = computed
+    // from the step and made opaque.  As `base + step * stride` the compiler hoists the per-lane invariant part — three 64-bit per-lane
+    // pointers (flags, reward, done) — and adds the step's offset with 64-bit vector arithmetic after two 64-bit scalar multiplies;
+    // either alternative costs 10-14 more spilled scalar registers and no time is gained (profiles/r05_experiments.txt: ab_rp).
+    constexpr bool kRunPtr = ATC_LOOP_RUNPTR == 1 && !ONE && !FULL;
+    float* run_obs = out.obs;
+    uint16_t* run_flags = out.flags;
+    float* run_reward = out.reward;
+    uint8_t* run_done = out.done;
     for (int step = 0; step < n_steps; ++step) {
 #if ATC_TRACE
         unsigned long long* trow = trace ? trace + ((size_t)(blockIdx.x * (kBlock / 64) + (tid >> 6)) * n_steps + step) * 8 : nullptr;
@@ -1551,7 +1563,14 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             if (ATC_LOOP_OPAQUE & 1) { dl.i += zv; dl.e += (int)zv; dl.k += (int)zv; dl.tid += (int)zv; dl.lane += (int)zv; dl.slot0 += (uint32_t)zs; }
             if (ATC_LOOP_OPAQUE & 2) { Kl = K + zs; gl = grid ? grid + zs : nullptr; }
         }
-        StepOut so = {outl.obs + sBN * ATC_OBS_DIM, outl.flags + sBN, outl.reward + sB, outl.done + sB,
+        if (kRunPtr && ATC_LOOP_RUNPTR == 1) asm volatile("" : "+s"(run_obs), "+s"(run_flags), "+s"(run_reward), "+s"(run_done));
+        if (ATC_LOOP_RUNPTR == 2 && !ONE && !FULL) {   // variant: bases computed from the step, then made opaque
+            run_obs = outl.obs + sBN * ATC_OBS_DIM; run_flags = outl.flags + sBN; run_reward = outl.reward + sB; run_done = outl.done + sB;
+            asm volatile("" : "+s"(run_flags), "+s"(run_reward), "+s"(run_done));
+        }
+        constexpr bool kOpaque = (ATC_LOOP_RUNPTR == 2 && !ONE && !FULL);
+        StepOut so = {(kRunPtr || kOpaque) ? run_obs : outl.obs + sBN * ATC_OBS_DIM, (kRunPtr || kOpaque) ? run_flags : outl.flags + sBN,
+                      (kRunPtr || kOpaque) ? run_reward : outl.reward + sB, (kRunPtr || kOpaque) ? run_done : outl.done + sB,
                       FULL && outl.raw_obs ? outl.raw_obs + sBN * ATC_OBS_DIM : nullptr,
                       FULL && outl.ac_reward ? outl.ac_reward + sBN : nullptr,
                       FULL && outl.min_sep ? outl.min_sep + sB : nullptr,
@@ -1612,6 +1631,12 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         act = nxt;
         ATC_STAMP(6);
         ATC_STAMP_TOP(trow, 6);
+        if (kRunPtr) {
+            run_obs += (size_t)BN * ATC_OBS_DIM;
+            run_flags += BN;
+            run_reward += (uint32_t)B;
+            run_done += (uint32_t)B;
+        }
     }
     // ---- write back persistent state -----------------------------------------------------------------------------------
     atc_state_t st_end = st;
