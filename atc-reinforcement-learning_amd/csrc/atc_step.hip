@@ -1158,8 +1158,8 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     if (kObsFirst && !(ATC_ABLATE & 8)) {
         // (observation word 3 first, then the heading for the angles — each its own rare look-up for a WIDE heading, before the rest
         // of the observation occupies its registers)
-        const float phi_f = phi_real(LAT ? ww.counts : heading_counts<ONE>(m.plain, a.phi, wide_named, zk, i));
-        const float phi_o = __int_as_float(LAT ? ww.obs_bits : wide_view<ONE, 1>(m.plain, a.phi, wide_named, zk, i, __float_as_int(phi_f)));
+        const WideWords wo = LAT ? ww : wide_words<ONE>(m.plain, a.phi, wide_named, zk, i);   // (ONE test for both words)
+        const float phi_f = phi_real(wo.counts), phi_o = __int_as_float(wo.obs_bits);
         ob = get_state(oc, a.x, a.y, x32, y32, a.h, phi_f, phi_o, v_real(a.v), 0.0f);
         if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
     }
@@ -1224,8 +1224,8 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         } else if (kObsFirst) {
             ob.o[5] = a.h - mva;
         } else {
-            const float phi_f = phi_real(LAT ? ww.counts : heading_counts<ONE>(m.plain, a.phi, wide_named, zk, i));
-            const float phi_o = __int_as_float(LAT ? ww.obs_bits : wide_view<ONE, 1>(m.plain, a.phi, wide_named, zk, i, __float_as_int(phi_f)));
+            const WideWords wo = LAT ? ww : wide_words<ONE>(m.plain, a.phi, wide_named, zk, i);
+            const float phi_f = phi_real(wo.counts), phi_o = __int_as_float(wo.obs_bits);
             ob = get_state(oc, a.x, a.y, x32, y32, a.h, phi_f, phi_o, v_real(a.v), mva);
             if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
         }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""How far do the positions of the fp32 specification (include/atc_step.h, ABI 18: fixed-point speed / heading state, float64
+"""How far do the positions of the fp32 specification (include/atc_step.h, ABI 18 / 19: fixed-point speed / heading state, float64
 kinematics, dithered rounding on the 2^-25 nm grid) drift from the float64 reference?  (CPU, the two instantiations of the test
 oracle side by side over every episode of tests/golden/g9_wide.npz: 650 963 steps, episodes of up to 6 000 steps.)
 
@@ -16,7 +16,7 @@ import numpy as np
 import helpers as H
 import test_oracle_golden as T
 
-fx = H.WideFixture()
+fx = H.WideFixture(sys.argv[1] if len(sys.argv) > 1 else "g9_wide.npz")   # e.g. g11_unbounded.npz: headings beyond the 32-bit field (ABI 19)
 errs, perr, verr, ages = [], [], [], []
 for (scen, dt, shaping, normalize, discrete), eps in fx.groups().items():
     B = len(eps)
