@@ -11,7 +11,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "atc-reinforcement-learning_amd")]
 import numpy as np
 import torch
 from atc_hip import lib as _binding
-_binding.use_library(os.path.join(ROOT, "build_variants", "libatcstep_trace.so"))
+_binding.use_library(os.environ.get("ATC_TRACE_LIB") or os.path.join(ROOT, "build_variants", "libatcstep_trace.so"))
 from atc_hip.vec_env import AtcVecEnv
 from envs.atc import scenarios
 

@@ -10,7 +10,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "atc-reinforcement-learning_amd")]
 import numpy as np
 import torch
 from atc_hip import lib as _binding
-_binding.use_library(os.path.join(ROOT, "build_variants", "libatcstep_trace.so"))
+_binding.use_library(os.environ.get("ATC_TRACE_LIB") or os.path.join(ROOT, "build_variants", "libatcstep_trace.so"))
 from atc_hip.vec_env import AtcVecEnv
 from envs.atc import scenarios
 
@@ -51,6 +51,11 @@ tick = 1e-3 / GHZ
 print("launch %.1f us = %.2f us per step (HIP events); stamps in cycles, converted at %.2f GHz" % (launch_us, launch_us / T, GHZ))
 names = ["top: decode + kinematics (+ first loads in step 0)", "mva resolve + pair scan", "overrides + corridor",
          "obs + shaping + normalise", "reductions, flag/reward stores, auto-reset (+ next action fetch)", "obs transpose + store"]
+if os.environ.get("ATC_TRACE_MODE") == "1":   # a library built with -DATC_TRACE_MODE=1: stamps 1..5 dissect the first phase
+    names = ["loop top: output bases, decode, masks (stamp 0 -> 1)", "first half up to the rate limits (1 -> 2)",
+             "float64 kinematics (2 -> 3)", "position -> fp32, lookup cell address, gather issued (3 -> 4)",
+             "second half up to the lookup resolve: scan, observation-first arithmetic (4 -> 5)",
+             "resolve, override chain, normalisation, reductions, stores, auto-reset (5 -> 6)"]
 life = (raw[:, T - 1, 7] - raw[:, 0, 0]) * tick
 print("wave lifetime: mean %.1f us, per step %.2f us" % (life.mean(), life.mean() / T))
 for label, sl in (("step 0", slice(0, 1)), ("steps 1..T-1", slice(1, T))):
