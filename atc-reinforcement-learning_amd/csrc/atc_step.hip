@@ -74,8 +74,8 @@ static int fail_hip(hipError_t e, const char* what) {
 #define ATC_WIDE_WAIT_INSIDE 1
 #endif
 #ifndef ATC_WABL
-#define ATC_WABL 0
-#endif
+#define ATC_WABL 0   // developer-only timing ablations of the WIDE-heading code (bit mask: 1 the 64-bit move, 32 / 64 the range tests
+#endif               // of target / state): profiles/r05_experiments.txt ab1, ab3; the shipped build uses 0
 #ifndef ATC_LAT_CARRY_REFUSED
 #define ATC_LAT_CARRY_REFUSED 1   // latency-bound instantiation: the refused-target mask of a held action block is carried across its steps
 #endif
@@ -126,12 +126,14 @@ constexpr int kBlock = ATC_BLOCK;
 #define ATC_STAMP(n) do { if (ATC_TRACE_MODE == 0) ATC_STAMP_AT(trow, n); } while (0)
 #define ATC_STAMP_B(n) do { if (ATC_TRACE_MODE == 0) ATC_STAMP_AT(so.trace, n); } while (0)
 #define ATC_STAMP_TOP(row, n) do { if (ATC_TRACE_MODE == 1) ATC_STAMP_AT(row, n); } while (0)
+#define ATC_STAMP_END(row, n) do { if (ATC_TRACE_MODE == 2) ATC_STAMP_AT(row, n); } while (0)   // mode 2: the step's LAST phase dissected
 #define ATC_TRACE_PARAM , unsigned long long* trace_row
 #define ATC_TRACE_PASS(x) , (x)
 #else
 #define ATC_STAMP(n) do {} while (0)
 #define ATC_STAMP_B(n) do {} while (0)
 #define ATC_STAMP_TOP(row, n) do {} while (0)
+#define ATC_STAMP_END(row, n) do {} while (0)
 #define ATC_TRACE_PARAM
 #define ATC_TRACE_PASS(x)
 #endif
@@ -1171,6 +1173,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         mva = hgt;                                 // atc_gym.py:161: mva = 0 outside (mva_resolve leaves the height at 0)
         fl |= noise_areas(K, grid, qs.n_noise, m.cell, x32, y32, a.h);
     }
+    ATC_STAMP_END(so.trace, 1);
     // ---- the override chain (atc_gym.py:146-173) -----------------------------------------------------------------------
     // `quiet` (wave-uniform): nothing of it applies to any lane of this wavefront — every aircraft under control with accepted
     // targets (plain), inside the airspace at or above its MVA, no separation lost, no time-out, outside the bounds of the
@@ -1210,6 +1213,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         }
     }
     ATC_STAMP_B(3);
+    ATC_STAMP_END(so.trace, 2);
     // ---- observation, shaping, noise areas, normalisation (atc_gym.py:175-189) ------------------------------------------
     // (multi-step launches: the normalisation constants are requested here, a hundred vector operations ahead of their use —
     // requested where they are used, the scalar load's whole latency was a stall)
@@ -1261,6 +1265,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     }
 
     ATC_STAMP_B(4);
+    ATC_STAMP_END(so.trace, 3);
     // ---- per-env reductions over the W lanes of the group ----------------------------------------------------------------
     const float env_r = group_sum<W>(r);
     const int env_acts = m.repeated ? 0 : group_sum_i<W>(acts);
@@ -1331,6 +1336,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     }
 
     ATC_STAMP_B(5);
+    ATC_STAMP_END(so.trace, 4);
     // Multi-step launches: the NEXT step's rate group is requested here, with the observation store still ahead — requested at
     // the top of the step that uses it, its latency was a stall before the first instruction of the kinematics.
     if (!ONE && !LAT) {
@@ -1384,6 +1390,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     } else if (d.lane_valid) {
         store_obs(at<float>(so.obs, times40(i)), o);
     }
+    ATC_STAMP_END(so.trace, 5);
     // ---- flag word, reward, done: last.  The compiler guards the observation's staging registers with a wait for ALL vector
     //      memory operations (one counter for loads and stores; the auto-reset path's loads merge in above) — issued before the
     //      observation, these three small stores were waited for there, a store round trip in every step.  Here the next such
@@ -1631,6 +1638,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         act = nxt;
         ATC_STAMP(6);
         ATC_STAMP_TOP(trow, 6);
+        ATC_STAMP_END(trow, 6);
         if (kRunPtr) {
             run_obs += (size_t)BN * ATC_OBS_DIM;
             run_flags += BN;

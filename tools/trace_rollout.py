@@ -51,6 +51,10 @@ tick = 1e-3 / GHZ
 print("launch %.1f us = %.2f us per step (HIP events); stamps in cycles, converted at %.2f GHz" % (launch_us, launch_us / T, GHZ))
 names = ["top: decode + kinematics (+ first loads in step 0)", "mva resolve + pair scan", "overrides + corridor",
          "obs + shaping + normalise", "reductions, flag/reward stores, auto-reset (+ next action fetch)", "obs transpose + store"]
+if os.environ.get("ATC_TRACE_MODE") == "2":   # -DATC_TRACE_MODE=2: stamps 1..5 dissect the step's last phase
+    names = ["everything up to the lookup resolve incl. it (stamp 0 -> 1)", "override chain: quiet test (+ the rare block) (1 -> 2)",
+             "(observation if not first) normalisation, inactive fix-up (2 -> 3)", "reductions, done logic, packet, auto-reset (3 -> 4)",
+             "observation transpose + store (4 -> 5)", "flag / reward / done stores (5 -> 6)"]
 if os.environ.get("ATC_TRACE_MODE") == "1":   # a library built with -DATC_TRACE_MODE=1: stamps 1..5 dissect the first phase
     names = ["loop top: output bases, decode, masks (stamp 0 -> 1)", "first half up to the rate limits (1 -> 2)",
              "float64 kinematics (2 -> 3)", "position -> fp32, lookup cell address, gather issued (3 -> 4)",
