@@ -590,16 +590,56 @@ def test_latency_bound_instantiation_equals_the_throughput_kernels(N, big):
     assert (big * W + 63) // 64 > 2 * 4 * n_cu >= (small * W + 63) // 64, "batch sizes no longer straddle the LAT threshold"
     envs = [AtcVecEnv(small, N, scenario=scn, seed=5), AtcVecEnv(big, N, scenario=scn, seed=5), AtcVecEnv(big + 1, N, scenario=scn, seed=5)]
     g = torch.Generator(device="cpu").manual_seed(N)
+    # every 7th aircraft of the shared envs starts at 430 deg and is told to turn on to 720 (a_phi = 3) for the whole run: its heading
+    # leaves the 32-bit field in the second step and stays WIDE (ABI 19) — in all three kernel families
+    turner = torch.arange(0, small * N, 7)
+    saw_wide = False
+    for e in envs:
+        e.pos_hp[turner.to(e.device), 3] = int(round((430.0 - 180.0) * 2 ** 23))
     for j in range(6):
-        blocks = (torch.rand((2, big + 1, N, 3), generator=g) * 2.1 - 1.05).cuda()
+        blocks = torch.rand((2, big + 1, N, 3), generator=g) * 2.1 - 1.05
+        # a tenth of the heading actions far outside the action space: saturated heading targets everywhere
+        blocks[..., 2] *= torch.where(torch.rand((2, big + 1, N), generator=g) < 0.1, 6.0, 1.0)
+        blocks.reshape(2, -1, 3)[:, turner, 2] = 3.0
+        blocks = blocks.cuda()
         outs = [e.rollout(blocks[:, :e.B].contiguous(), hold=10) for e in envs]
         for k in ("obs", "reward", "done", "flags"):
             assert torch.equal(outs[0][k], outs[1][k][:, :small]), (k, "latency-bound vs throughput")
             assert torch.equal(outs[1][k], outs[2][k][:, :big]), (k, "throughput vs general")
+        # (observation word 3 of a turner beyond 436 deg: normalised (phi - 180) / 180 > 1.4223 — only a WIDE heading gets there)
+        # (steps that ended an episode return the RAW reset observation instead: masked out)
+        o3 = outs[1]["obs"][:, :small].reshape(-1, small, N, 10)[..., 3]
+        saw_wide = saw_wide or bool(((o3 > 1.45) & (outs[1]["done"][:, :small] == 0)[..., None]).any())
     for name in ("pos_hp", "v_fix", "last_act"):
         assert torch.equal(getattr(envs[0], name), getattr(envs[1], name)[:small * N]), name
         assert torch.equal(getattr(envs[1], name), getattr(envs[2], name)[:big * N]), name
+    assert torch.equal(envs[0].phi_counts, envs[1].phi_counts[:small * N]) and torch.equal(envs[1].phi_counts, envs[2].phi_counts[:big * N])
+    assert saw_wide, "no heading left the 32-bit field: the WIDE path was not exercised"
     assert torch.equal(envs[0].env, envs[1].env[:small]) and torch.equal(envs[0].stats, envs[1].stats[:small])
     assert int(envs[0].episodes.sum()) > small
     for e in envs:
         e.close()
+
+
+def test_wide_headings_in_host_mapped_state():
+    """Small batches of the SB adapter / the single-env AtcGym keep their state in pinned host memory mapped into the device: the
+    side record of WIDE headings (ABI 19) is read and written over the host link there.  Same results as the same envs in HBM."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+    scn = scenarios.LOWW(random_entrypoints=True)
+    dev_env = AtcVecEnv(8, 4, scenario=scn, seed=2, auto_reset=False, keep_active=True)
+    map_env = AtcVecEnv(8, 4, scenario=scn, seed=2, auto_reset=False, keep_active=True, host_mapped=True)
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for t in range(300):
+        if t % 25 == 0:
+            a = torch.rand((8, 4, 3), generator=g) * 2 - 1
+            a[..., 2] *= 5.0
+        o1, r1, d1, i1 = dev_env.step(a.cuda())
+        o2, r2, d2, i2 = map_env.step(a.pin_memory())
+        assert torch.equal(o1.cpu(), o2) and torch.equal(r1.cpu(), r2) and torch.equal(i1["flags"].cpu(), i2["flags"]), t
+    assert torch.equal(dev_env.phi_counts.cpu(), map_env.phi_counts)
+    assert int(((map_env.phi_fix == -2 ** 31) | (map_env.phi_fix == 2 ** 31 - 1)).sum()) > 0
+    assert float(dev_env.phi.abs().max()) > 700.0
+    dev_env.close()
+    map_env.close()
