@@ -20,7 +20,7 @@ C_ALIGNED_OK = 93
 C_POS_X0, C_POS_Y0, C_POS_SCALE, C_POS_INV = 94, 95, 100, 101   # fixed-point position grid: nm = X0 + fix * 2^-k
 C_FAF_FIX = 124                                                 # FAF on the grid: x (hi, lo), y (hi, lo); fix = hi * 65536 + lo
 POS_MAX_K = 27
-# speed / heading state: 32-bit fixed point (include/atc_step.h, ABI 18): kt = v_fix 2^-23 (unsigned), deg = 180 + phi_fix 2^-23
+# speed / heading state: 32-bit fixed point (include/atc_step.h, ABI 18; the heading field saturates since ABI 19: below): kt = v_fix 2^-23 (unsigned), deg = 180 + phi_fix 2^-23
 V_FIX_SHIFT, PHI_FIX_SHIFT, PHI_FIX_OFFSET = 23, 23, 180.0
 # ABI 19: the heading is unbounded like the reference's (model.py:104-120) — a 32-bit field that SATURATES (INT32_MIN / INT32_MAX =
 # "WIDE") in front of the exact integer-valued float64 counts in atc_state_t.phi_wide[i][0] ([1]: the last heading target)

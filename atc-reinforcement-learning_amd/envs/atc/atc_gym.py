@@ -43,7 +43,7 @@ class _AirplaneView:
             self._env._pos_now = None
         elif key == "h":
             self._env._vec.h[0] = float(value)
-        elif key == "phi":      # speed and heading are fixed point on the device too (ABI 18)
+        elif key == "phi":      # speed and heading are fixed point on the device too (ABI 18; set_phi places any heading, also beyond the 32-bit field: ABI 19)
             self._env._vec.set_phi(0, value)
         elif key == "v":
             self._env._vec.set_v(0, value)
