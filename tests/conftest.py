@@ -10,9 +10,16 @@ for p in (ROOT, PKG, os.path.dirname(os.path.abspath(__file__))):
 
 # the sector compiler's on-disk grid cache (atc_hip/scenario.py:build_grid_cached) stays inside a per-session temporary
 # directory: tests never write to the user's ~/.cache
+_OWN_CACHE = None
 if "ATC_HIP_CACHE" not in os.environ:
     import tempfile
-    os.environ["ATC_HIP_CACHE"] = tempfile.mkdtemp(prefix="atc_hip_cache_")
+    _OWN_CACHE = os.environ["ATC_HIP_CACHE"] = tempfile.mkdtemp(prefix="atc_hip_cache_")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _OWN_CACHE:
+        import shutil
+        shutil.rmtree(_OWN_CACHE, ignore_errors=True)
 
 
 def pytest_configure(config):
