@@ -1066,6 +1066,10 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             uint64_t hit = 0;
             const v2f xs2 = {xs, xs}, ys2 = {y32, y32}, hs2 = {a.h, a.h};
             const float sep_ft = qs.sep_ft;
+            // (Round 5, rejected: a PRE-PASS that minimum-accumulates the margin max(d^2 - sep^2, |dh| - sep_ft) per lane — 5.5 vector
+            // operations per partner, no lane mask, no scalar mask arithmetic — and runs the mask form only when some lane lost its
+            // separation.  In a dense 64-aircraft env that is almost every step: 4 096 x 64 8.85 vs 7.8 us single steps, 5.3-5.6 vs 5.2
+            // fused, 32 768 x 64 38.4 vs 36.6 — profiles/r05_experiments.txt: ab_m.)
 #pragma unroll 1   // (fully unrolled, the 2 H compare masks stay live together: 140-220 spilled SGPRs)
             for (int d0 = H - U + 1; d0 >= 1; d0 -= U) {
                 v2f qx[U / 2], qy[U / 2], qh[U / 2];
