@@ -430,17 +430,31 @@ __device__ __forceinline__ int find_mva(const float* __restrict__ K, const float
 //   rel < 0  : lower bound fails
 //   rel == 0 : holds iff the rounded dot product is exactly 1.0 — the reference's own rounding luck, evaluated once on
 //              the host with the reference's expression (ATC_C_ALIGNED_OK).
-// This drops sin/cos/acos from the path and removes the fp32 noise band (|rel| < 3.5e-4 deg) a literal fp32
-// transcription would have; it differs from the float64 reference only for 0 < rel < ~1e-6 deg.
-__device__ __forceinline__ bool angle_window(const float* __restrict__ K, float rel) {
-    return (rel > 0.0f && rel <= K[ATC_C_FAF_ANGLE]) || (rel == 0.0f && K[ATC_C_ALIGNED_OK] != 0.0f);
+// This drops sin/cos/acos from the path.  Round 5: rel is evaluated EXACTLY, from the heading's counts — the wrapped difference
+// heading - to_runway in units of 2^-23 deg, float64 arithmetic on integers (the reduction of include/atc_step.h) — because its SIGN
+// decides a flag: an aircraft told to fly the runway heading holds it to within the fp32 rounding of its action (340 -/+ 1e-5 deg), which
+// an fp32 heading (ulp 3e-5 at 340) cannot tell from 340 — the reference's float64 can (G11: the intercepts flown at heading - 360).
+// It differs from the float64 reference only for 0 < rel < ~1e-6 deg (where the reference's own arccos noise decides).
+// `pc`: heading counts as a float64 (any value congruent to the heading modulo a turn: the window is periodic).
+__device__ __forceinline__ double to_runway_counts(const float* __restrict__ K) {
+    return __builtin_rint(((double)K[ATC_C_PHI_TO_RWY] - (double)ATC_PHI_FIX_OFFSET) * 8388608.0);
 }
-__device__ __forceinline__ bool inside_corridor_angle(const float* __restrict__ K, float x, float y, float phi) {
+__device__ __forceinline__ double rel_counts(double d) {   // d wrapped to within half a turn of zero (exact)
+    return __builtin_fma(__builtin_rint(d * ATC_PHI_INV_TURN), -ATC_PHI_TURN, d);
+}
+__device__ __forceinline__ bool angle_window(const float* __restrict__ K, double rel) {
+    return (rel > 0.0 && rel <= (double)K[ATC_C_FAF_ANGLE] * 8388608.0) || (rel == 0.0 && K[ATC_C_ALIGNED_OK] != 0.0f);
+}
+__device__ __forceinline__ bool inside_corridor_angle(const float* __restrict__ K, float x, float y, double pc) {
     // model.py:224-229: `if tri1 and window: True / elif tri2 and window: True / False`
-    const float to_runway = K[ATC_C_PHI_TO_RWY];
-    if (ray_tracing(x, y, K + ATC_C_TRI_1, 4) && angle_window(K, relative_angle(to_runway, phi))) return true;
-    if (ray_tracing(x, y, K + ATC_C_TRI_2, 4) && angle_window(K, relative_angle(phi, to_runway))) return true;
+    const double q = to_runway_counts(K);
+    if (ray_tracing(x, y, K + ATC_C_TRI_1, 4) && angle_window(K, rel_counts(pc - q))) return true;   // relative_angle(to_runway, phi)
+    if (ray_tracing(x, y, K + ATC_C_TRI_2, 4) && angle_window(K, rel_counts(q - pc))) return true;   // relative_angle(phi, to_runway)
     return false;
+}
+// a heading given in degrees (the query entry points): its nearest count
+__device__ __forceinline__ double heading_counts_of(float phi_deg) {
+    return __builtin_rint(((double)phi_deg - (double)ATC_PHI_FIX_OFFSET) * 8388608.0);
 }
 
 __device__ __forceinline__ float4 tri_bbox(const float* __restrict__ K) {
@@ -448,7 +462,7 @@ __device__ __forceinline__ float4 tri_bbox(const float* __restrict__ K) {
     return *reinterpret_cast<const float4*>(K + ATC_C_TRI_BBOX);
 }
 // model.py:188-210 Corridor.inside_corridor
-__device__ __forceinline__ bool inside_corridor(const float* __restrict__ K, const float4& bb, float x, float y, float h, float phi) {
+__device__ __forceinline__ bool inside_corridor(const float* __restrict__ K, const float4& bb, float x, float y, float h, double pc) {
     // exact early-out: a point the crossing test accepts lies within the ring's bounds bb = ATC_C_TRI_BBOX (precomputed on
     // the host; the step kernel has them among its arguments, so the test waits for no load)
     if (!((x >= bb.x) & (x <= bb.z) & (y >= bb.y) & (y <= bb.w))) return false;
@@ -460,7 +474,7 @@ __device__ __forceinline__ bool inside_corridor(const float* __restrict__ K, con
     const float nrm = sqrtf(dx * dx + dy * dy);
     const float h_max = nrm * K[ATC_C_GS_TAN] * K[ATC_C_NM_TO_FT] + K[ATC_C_RWY_H];
     if (!(h <= h_max)) return false;
-    return inside_corridor_angle(K, x, y, phi);
+    return inside_corridor_angle(K, x, y, pc);
 }
 
 // Uniform constants of the observation / shaping stage.  The step kernel receives them precomputed on the host with its

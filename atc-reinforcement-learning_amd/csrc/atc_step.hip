@@ -1205,7 +1205,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             fl |= conflict ? (uint32_t)ATC_F_CONFLICT : 0u;
         }
         // ---- win / timeout overrides (atc_gym.py:163-173) ---------------------------------------------------------------
-        if (!(ATC_ABLATE & 4) && inside_corridor(K, qs.tri_bbox, x32, y32, a.h, phi_real(LAT ? ww.counts : heading_counts<ONE>(m.plain, a.phi, wide_named, zk, i)))) {
+        if (!(ATC_ABLATE & 4) && inside_corridor(K, qs.tri_bbox, x32, y32, a.h, (double)(LAT ? ww.counts : heading_counts<ONE>(m.plain, a.phi, wide_named, zk, i)))) {
             int bonus = (qs.timestep_limit - es.t) * 5;
             bonus = bonus < 0 ? 0 : bonus;
             r = (float)(10000 + bonus);
@@ -1757,8 +1757,8 @@ k_query_corridor(const float* __restrict__ blob, int n, const float* __restrict_
                  const float* __restrict__ y, const float* __restrict__ h, const float* __restrict__ phi, int angle_only,
                  uint8_t* __restrict__ out) {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
-        out[i] = angle_only ? inside_corridor_angle(blob, x[i], y[i], phi[i])
-                            : inside_corridor(blob, tri_bbox(blob), x[i], y[i], h[i], phi[i]);
+        out[i] = angle_only ? inside_corridor_angle(blob, x[i], y[i], heading_counts_of(phi[i]))
+                            : inside_corridor(blob, tri_bbox(blob), x[i], y[i], h[i], heading_counts_of(phi[i]));
 }
 __global__ void __launch_bounds__(kBlock)
 k_query_shaping(const float* __restrict__ blob, int n, const float* __restrict__ d_faf,

@@ -235,6 +235,14 @@ typedef struct atc_params {
  *       -ATC_PHI_TURN, P)  (exact: the remainder of P modulo 360 deg in counts, |Pw| <= 180 deg within a count):
  *       kinematics, relative angles and the corridor window use Pw exactly like a phi_fix;  observation word 3 is
  *       (float)(180 + P 2^-23) evaluated in float64 (exact) and rounded once — the float32 of the reference's float64 heading.
+ *   - ONE angle decides a flag: the window of Corridor._inside_corridor_angle (model.py:212-231), `min_angle <= relative_angle <= 45`
+ *     with min_angle = arccos(dir_rwy . dir_plane) in radians — in exact arithmetic 0 <= rel <= 45 deg.  Its relative angle is evaluated
+ *     EXACTLY, on the counts:  rel = wrap(P - Q)  (wrap as above, float64 on integers), Q = rint((phi_to_runway - 180) 2^23);  the window
+ *     holds for 0 < rel <= 45 * 2^23 and, for rel == 0, iff ATC_C_ALIGNED_OK (the reference's own rounding luck for an exactly aligned
+ *     heading, evaluated on the host with its expression).  An fp32 heading could not decide it: an aircraft told to fly the runway
+ *     heading holds it to within the fp32 rounding of its ACTION (340 -/+ 1e-5 deg), one third of an fp32 ulp at 340 — the reference's
+ *     float64 tells the two apart, and so must the flag (tests/golden/g11: the winning intercepts flown at heading - 360).  The
+ *     relative angles of the observation and the shaping terms are values (1e-5 bar) and stay fp32;
  *   - the fp32 speed every other formula of the reference sees is (float)v_fix * 2^-23; both conversions are exact for every value
  *     with <= 24 significant bits, e.g. all integer speeds and headings;
  *   - the altitude stays fp32 (it does not feed the position; 1e-3 ft at 16 000 ft is 5e-8 in observation units);

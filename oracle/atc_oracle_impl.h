@@ -91,12 +91,11 @@ static void FN(phi_put)(int64_t P, int32_t* f, int64_t* wide) {
     *f = FN(sat32)(P);
     if (FN(is_wide)(*f)) *wide = P;
 }
-/* a WIDE heading wrapped into [-W/2, W/2), W = 360 2^23 (include/atc_step.h): what kinematics and relative angles use */
-#define ORC_PHI_TURN 3019898880ll
+/* a heading wrapped to within half a turn of the format's origin (include/atc_step.h): Pw = fma(rint(P RN(1/W)), -W, P) in float64 —
+ * exact, and the very operations of the device */
 static int32_t FN(phi_wrap)(int64_t P) {
-    int64_t a = P + ORC_PHI_TURN / 2, q = a / ORC_PHI_TURN;
-    if (a % ORC_PHI_TURN < 0) q -= 1; /* floor division */
-    return (int32_t)(P - q * ORC_PHI_TURN);
+    const double pd = (double)P;
+    return (int32_t)fma(rint(pd * ATC_PHI_INV_TURN), -ATC_PHI_TURN, pd);
 }
 /* the heading as kinematics / angles see it, and observation word 3 (atc_gym.py:269) */
 static int32_t FN(phi_eff)(int32_t f, int64_t wide) { return FN(is_wide)(f) ? FN(phi_wrap)(wide) : f; }
@@ -228,7 +227,26 @@ static int FN(find_mva)(const REAL* S, REAL x, REAL y) {
  * (dot == 1.0 -> arccos == 0 -> 0 <= 0 passes; measured: plain mul/add gives 0.9999999999999999 for 340 vs 700 deg where
  * np.dot gives 1.0).  Keeping this one expression in float64 makes the fp32 instantiation agree with the reference for
  * exactly aligned (e.g. integer, discrete-action) headings. */
-static int FN(inside_corridor_angle)(const REAL* S, REAL x, REAL y, REAL phi) {
+#if ORC_FIXED_POS
+/* fp32 spec (include/atc_step.h, round 5): the window's relative angle is evaluated EXACTLY from the heading's counts — its sign
+ * decides a flag, and an fp32 heading (ulp 3e-5 deg at 340) cannot tell 340 -/+ 1e-5 deg from 340; the window itself in its
+ * exact-arithmetic form 0 <= rel <= 45 (rel == 0: the reference's own rounding luck, ATC_C_ALIGNED_OK), like the kernels.
+ * pc = heading counts (any value congruent to the heading modulo a turn). */
+static double FN(rel_counts)(double d) { return fma(rint(d * ATC_PHI_INV_TURN), -ATC_PHI_TURN, d); }
+static int FN(angle_window)(const REAL* S, double rel) {
+    return (rel > 0.0 && rel <= (double)S[ATC_C_FAF_ANGLE] * ORC_QP) || (rel == 0.0 && S[ATC_C_ALIGNED_OK] != (REAL)0);
+}
+static int FN(inside_corridor_angle)(const REAL* S, REAL x, REAL y, double pc) {
+    const double q = rint(((double)S[ATC_C_PHI_TO_RWY] - (double)ATC_PHI_FIX_OFFSET) * ORC_QP);
+    if (FN(ray_tracing)(x, y, S + ATC_C_TRI_1, 4) && FN(angle_window)(S, FN(rel_counts)(pc - q))) return 1;
+    if (FN(ray_tracing)(x, y, S + ATC_C_TRI_2, 4) && FN(angle_window)(S, FN(rel_counts)(q - pc))) return 1;
+    return 0;
+}
+static double FN(heading_counts_of)(REAL phi) { return rint(((double)phi - (double)ATC_PHI_FIX_OFFSET) * ORC_QP); }
+#else
+static double FN(heading_counts_of)(REAL phi) { return (double)phi; } /* the reference takes degrees */
+static int FN(inside_corridor_angle)(const REAL* S, REAL x, REAL y, double phi_in) {
+    const REAL phi = (REAL)phi_in;
     REAL to_runway = S[ATC_C_PHI_TO_RWY];
     REAL faf_angle = S[ATC_C_FAF_ANGLE];
     /* rot_matrix(a) . [0,1] = (sin(rad a), cos(rad a)) */
@@ -248,9 +266,10 @@ static int FN(inside_corridor_angle)(const REAL* S, REAL x, REAL y, REAL phi) {
     }
     return 0;
 }
+#endif
 
 /* model.py:188-210  Corridor.inside_corridor */
-static int FN(inside_corridor)(const REAL* S, REAL x, REAL y, REAL h, REAL phi) {
+static int FN(inside_corridor)(const REAL* S, REAL x, REAL y, REAL h, double phi) { /* phi: degrees (f64) | heading counts (fp32 spec) */
     if (!FN(ray_tracing)(x, y, S + ATC_C_TRI_H, 4)) return 0;
     REAL fx = S[ATC_C_FAF_X], fy = S[ATC_C_FAF_Y], nx = S[ATC_C_NRM_X], ny = S[ATC_C_NRM_Y];
     REAL t = (x - fx) * nx + (y - fy) * ny;            /* np.dot(p - faf^T, normal) */
@@ -556,7 +575,7 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
                 }
             }
             /* model.py:122-129 Airplane.step, float64 from the fixed-point state */
-            FN(advance)(S, dist_a, FN(phi_eff)(st->phi[i], st->phi_wide[2 * i]), st->v[i], t, &st->x[i], &st->y[i]);
+            FN(advance)(S, dist_a, FN(is_wide)(st->phi[i]) ? FN(phi_wrap)(st->phi_wide[2 * i]) : st->phi[i], st->v[i], t, &st->x[i], &st->y[i]);
 #else
             for (int c = 0; c < 3; ++c) {   /* atc_gym.py:139-141 -> _action_with_reward :299-316 */
                 REAL a = actions[i * 3 + c];
@@ -674,7 +693,12 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
 #else
             const REAL phi_r = st->phi[i], phi_o = st->phi[i], v_r = st->v[i];
 #endif
-            if (FN(inside_corridor)(S, px, py, st->h[i], phi_r)) { /* atc_gym.py:163-169 */
+#if ORC_FIXED_POS
+            const double phi_c = (double)FN(phi_eff)(st->phi[i], st->phi_wide[2 * i]);
+#else
+            const double phi_c = (double)phi_r;
+#endif
+            if (FN(inside_corridor)(S, px, py, st->h[i], phi_c)) { /* atc_gym.py:163-169 */
                 int bonus = (p->timestep_limit - t) * 5;
                 if (bonus < 0) bonus = 0;
                 r[k] = (REAL)(10000 + bonus);
@@ -747,8 +771,8 @@ int FN(atc_oracle_query_mva)(const REAL* S, int n, const REAL* x, const REAL* y,
 int FN(atc_oracle_query_corridor)(const REAL* S, int n, const REAL* x, const REAL* y, const REAL* h, const REAL* phi,
                                   int angle_only, uint8_t* out) {
     for (int i = 0; i < n; ++i)
-        out[i] = (uint8_t)(angle_only ? FN(inside_corridor_angle)(S, x[i], y[i], phi[i])
-                                      : FN(inside_corridor)(S, x[i], y[i], h[i], phi[i]));
+        out[i] = (uint8_t)(angle_only ? FN(inside_corridor_angle)(S, x[i], y[i], FN(heading_counts_of)(phi[i]))
+                                      : FN(inside_corridor)(S, x[i], y[i], h[i], FN(heading_counts_of)(phi[i])));
     return 0;
 }
 int FN(atc_oracle_query_shaping)(const REAL* S, int n, const REAL* d_faf, const REAL* phi_rel_faf, const REAL* phi_plane,

@@ -24,8 +24,8 @@ inputs + expected outputs of the AtcGym.step() hot path as small fixtures:
                       UnitTest, dt 1/2/5, continuous and discrete, shaping x normalisation off, >= 50 each of win /
                       below-MVA / timeout terminals, episodes stepped on past `done` (incl. past a win)
   g11_unbounded.npz   actions outside the action space, replayed by the reference: sustained a_phi up to +-3 (heading to 720 / -360
-                      deg), headings wound to +-5 500 deg and back, un-clipped random actions, discrete heading indices beyond 360;
-                      the same compact form as g9
+                      deg), headings wound to +-5 500 deg and back, un-clipped random actions, discrete heading indices beyond 360,
+                      G9's winning intercepts flown at heading + 360 k; the same compact form as g9
   model_test_known_answers.json  the 8 known answers of the reference's own envs/atc/model_test.py
 
 Usage:
@@ -828,6 +828,21 @@ def gen_g11():
     for k, idx in enumerate((500, -90, 1000, -700, 436, 437, -76, -77)):
         acts = np.tile(np.array([15.0, 120.0, float(idx)]), (1400, 1))
         rec.run(e3, acts, "LOWW", 1, True, True, True, extra_after_done=240)
+    # 5. the corridor with an un-wrapped heading: the winning intercepts of G9 flown at heading + 360 k (placed so, and held by an
+    #    action outside the action space): Runway.inside_corridor and the angle window are periodic in the heading (model.py:212-231)
+    #    — every one of these must win like its wrapped twin, some stepped on past the win
+    base = [(48.9, 31.9, 3300.0, 345.0, 200.0), (47.0, 32.0, 3400.0, 10.0, 220.0), (50.6, 33.2, 3200.0, 310.0, 180.0),
+            (49.2, 30.5, 5000.0, 340.0, 250.0), (46.2, 31.8, 3600.0, 20.0, 250.0), (51.3, 33.0, 2900.0, 300.0, 160.0)]
+    rng = np.random.default_rng(45000)
+    for k in range(36):
+        b = base[k % len(base)]
+        turns = (1, -1, 2, -2, 5, -6)[(k // len(base)) % 6]
+        st = (float(np.float32(b[0] + rng.uniform(-0.25, 0.25))), float(np.float32(b[1] + rng.uniform(-0.25, 0.25))),
+              float(np.float32(b[2] + rng.uniform(-150, 150))), float(np.round(b[3] + rng.uniform(-4, 4))) + 360.0 * turns,
+              float(np.round(b[4] + rng.uniform(-20, 20))))
+        a = f32([2.0 * (st[4] - 100.0) / 200.0 - 1.0, 2.0 * 2700.0 / 38000.0 - 1.0, 2.0 * st[3] / 360.0 - 1.0])
+        rec.run(env, np.tile(a, (700, 1)), "LOWW", 1, True, True, False, init_state=st,
+                init_timesteps=int(rng.integers(0, 5800)), extra_after_done=(25 if k % 4 == 0 else 0))
     rec.save(os.path.join(HERE, "g11_unbounded.npz"))
     return rec
 

@@ -345,7 +345,7 @@ def test_unbounded_heading_fixture_batched():
     the exact counts behind the saturating 32-bit field (include/atc_step.h)."""
     fx = H.WideFixture("g11_unbounded.npz")
     n = H.replay_wide(fx, _HipLockstep, obs_tol=1e-5, state_tol=1e-5, rew_tol=1e-5)
-    assert n == len(fx.flags) > 90000
+    assert n == len(fx.flags) > 93000
     phi = fx.state[:, 3]
     assert phi.max() >= 5000 and phi.min() <= -5000
 
