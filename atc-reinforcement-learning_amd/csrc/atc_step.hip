@@ -754,11 +754,22 @@ __device__ __forceinline__ float clamp_rate(float d, float lo, float hi) { retur
 
 // _denormalized_action (atc_gym.py:318-335): action -> (v, h, phi) targets in the state's formats with the host-evaluated
 // (multiplier, offset) pairs of derive().  Speed and heading: ONE float64 fma and the saturating, truncating conversion of the
-// hardware (NaN -> 0) — the spec of include/atc_step.h; altitude: fp32, the reference's operation order.
+// hardware (NaN -> 0) — the spec of include/atc_step.h.  Altitude (round 5): the reference's float64 target  a * m + c  (ONE fma: the
+// product is exact) rounded to fp32 TOWARD MINUS INFINITY, +inf if it exceeds h_max.  The aircraft lands ON its target, and two flags
+// compare that altitude with fp32-representable thresholds (`h < mva`, the refusals `target < h_min`, `target > h_max`): x < n and
+// RD(x) < n are the same statement for representable n, round-to-nearest is not (told to descend "to the MVA", the reference's
+// target is 3 499.9995 ft — below it, atc_gym.py:149-153 — or 3 500.0005 by the last bit of the fp32 ACTION; RN makes both 3 500).
+__device__ __forceinline__ float altitude_target(double t) {
+    float f = (float)t;                                    // round to nearest ...
+    const int b = __float_as_int(f);
+    const int step = -(1 | (b >> 31));                     // ... and one step down (away from zero for a negative value) if that went up
+    f = ((double)f > t) ? __int_as_float(b + step) : f;    // (NaN: no change — a NaN target is accepted and poisons h like the reference's)
+    return (t > (double)kHMax) ? __builtin_inff() : f;     // (RD(t) could be h_max itself: the refusal `target > h_max` must see t)
+}
 __device__ __forceinline__ Targets decode_targets(const QRates& q, const Float3& act) {
     Targets t;
     t.v = cvt_u32_f64(__builtin_fma((double)act.a, q.dec_mv, q.dec_cv));
-    t.h = act.b * q.dec_mh + q.dec_ch;
+    t.h = altitude_target(__builtin_fma((double)act.b, (double)q.dec_mh, (double)q.dec_ch));
     t.p = cvt_i32_f64(__builtin_fma((double)act.c, q.dec_mp, q.dec_cp));
     return t;
 }

@@ -245,7 +245,13 @@ typedef struct atc_params {
  *     relative angles of the observation and the shaping terms are values (1e-5 bar) and stay fp32;
  *   - the fp32 speed every other formula of the reference sees is (float)v_fix * 2^-23; both conversions are exact for every value
  *     with <= 24 significant bits, e.g. all integer speeds and headings;
- *   - the altitude stays fp32 (it does not feed the position; 1e-3 ft at 16 000 ft is 5e-8 in observation units);
+ *   - the altitude stays fp32 (it does not feed the position; 1e-3 ft at 16 000 ft is 5e-8 in observation units).  Its TARGET is the
+ *     reference's float64 value  a * m + c  (one fma: the product is exact) rounded to fp32 TOWARD MINUS INFINITY, and +inf when the
+ *     float64 value exceeds h_max: an aircraft within one step's rate of its target lands ON it (fp32: h + (target - h) is exact
+ *     there), and the flags that compare that altitude with fp32-representable thresholds — below the MVA (atc_gym.py:149-153), the
+ *     refusals target < h_min / target > h_max (model.py:91-94) — come out like the reference's float64 comparisons: x < n and
+ *     RD(x) < n are the same statement for a representable n.  (Round-to-nearest is not: told to descend "to the MVA" the reference's
+ *     target lies 5e-4 ft below or above it by the last bit of the fp32 action — tests/golden/g11 has both.)
  *   - state placed from outside (entry points, fixtures) is the NEAREST count.
  * Heading kinematics (model.py:122-129, 345-348) in float64, shared bit for bit by every fp32 implementation (the HIP
  * kernels, the fp32 instantiation of the test oracle):

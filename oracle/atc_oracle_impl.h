@@ -540,10 +540,14 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
                         *la = (int32_t)tgt;                                               /* atc_gym.py:311 */
                     }
                 }
-                { /* altitude: model.py:82-102 */
-                    REAL tgt;
-                    if (discrete) tgt = ah * fac[1] + off[1];
-                    else tgt = ah * fac[1] / (REAL)2 + fac[1] / (REAL)2 + off[1];
+                { /* altitude: model.py:82-102.  fp32 spec (include/atc_step.h, round 5): the reference's float64 target rounded to fp32
+                   * TOWARD MINUS INFINITY (+inf beyond h_max): comparisons of the altitude the aircraft lands on with fp32-representable
+                   * thresholds — h < mva, the refusals — then come out like the reference's float64 ones */
+                    const double td = discrete ? fma((double)ah, (double)fac[1], (double)off[1])
+                                               : fma((double)ah, (double)fac[1] / 2.0, (double)fac[1] / 2.0 + (double)off[1]);
+                    REAL tgt = (REAL)td;
+                    if ((double)tgt > td) tgt = nextafterf(tgt, -INFINITY);
+                    if (td > (double)h_max) tgt = INFINITY;
                     if (tgt < h_min || tgt > h_max) {
                         reward -= (REAL)1.0;
                         fl[k] |= ATC_F_INVALID_H;

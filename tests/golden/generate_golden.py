@@ -25,7 +25,7 @@ inputs + expected outputs of the AtcGym.step() hot path as small fixtures:
                       below-MVA / timeout terminals, episodes stepped on past `done` (incl. past a win)
   g11_unbounded.npz   actions outside the action space, replayed by the reference: sustained a_phi up to +-3 (heading to 720 / -360
                       deg), headings wound to +-5 500 deg and back, un-clipped random actions, discrete heading indices beyond 360,
-                      G9's winning intercepts flown at heading + 360 k; the same compact form as g9
+                      G9's winning intercepts flown at heading + 360 k, altitude targets within an fp32 action step of the MVA; the compact form of g9
   model_test_known_answers.json  the 8 known answers of the reference's own envs/atc/model_test.py
 
 Usage:
@@ -843,6 +843,17 @@ def gen_g11():
         a = f32([2.0 * (st[4] - 100.0) / 200.0 - 1.0, 2.0 * 2700.0 / 38000.0 - 1.0, 2.0 * st[3] / 360.0 - 1.0])
         rec.run(env, np.tile(a, (700, 1)), "LOWW", 1, True, True, False, init_state=st,
                 init_timesteps=int(rng.integers(0, 5800)), extra_after_done=(25 if k % 4 == 0 else 0))
+    # 6. "descend to the MVA": an altitude target within one fp32 step of the action of the MVA height below the aircraft, on either side
+    #    of it and exactly on it (T = a * 19000 + 19000 in float64, atc_gym.py:333-335: 1.1e-3 ft per fp32 step of a).  The aircraft is
+    #    30 ft above, so it lands ON the target in its first step: below-MVA (atc_gym.py:149-153) iff the target is below — to the
+    #    last bit of a float64
+    its = interior_states(np.random.default_rng(46000), env, 24, 2000.0, 2001.0)
+    for k, st in enumerate(its):
+        m = mva_or_neg(env._airspace, st[0], st[1])
+        a0 = np.float32(m / 19000.0 - 1.0)
+        a = [np.nextafter(a0, np.float32(-2)), a0, np.nextafter(a0, np.float32(2)), np.nextafter(np.nextafter(a0, np.float32(-2)), np.float32(-2))][k % 4]
+        acts = np.tile(f32([2.0 * (st[4] - 100.0) / 200.0 - 1.0, a, 2.0 * st[3] / 360.0 - 1.0]), (6, 1))
+        rec.run(env, acts, "LOWW", 1, True, True, False, init_state=(st[0], st[1], float(m + 30), st[3], st[4]), extra_after_done=5)
     rec.save(os.path.join(HERE, "g11_unbounded.npz"))
     return rec
 
