@@ -266,34 +266,72 @@ template <bool WANT_MIN>
 struct PairScan16<9, WANT_MIN> {
     static __device__ __forceinline__ void run(float, float, float, float, float, float&, float&) {}
 };
-// The same scan for launches that do not report the minimum separation (the fast variant): almost every pair of a sector is
-// far apart horizontally, so each rotation first asks ONLY that — two rotated subtracts, a multiply, an fma and one compare
-// into a lane mask — and the altitude test and the hand-back to the partner run only in wavefronts where some lane has a
-// partner inside the horizontal minimum at this rotation (a wave-uniform branch on the compare's mask; about a third of
-// the rotations of the headline workload).  Conflict = (d^2 < sep^2) & (|dh| < sep_ft), the oracle's expression.
+// The same scan for launches that do not report the minimum separation (the fast variant), two forms:
+//  * NearScan16H (rounds 3-5, shipped: ATC_SCAN16_FORM = 0) asks the horizontal question first — two rotated subtracts, a multiply, an
+//    fma and one compare into a lane mask — and fetches the altitude and hands the result back to the partner only behind a
+//    wave-uniform test of that mask.
+//  * NearScan16 (round 5, developer A/B: ATC_SCAN16_FORM = 1) asks the whole question — horizontal AND vertical — on the common path
+//    as two compares whose lane masks are anded on the scalar unit (seven vector operations per rotation), optionally with HORIZON
+//    thresholds (ScanLimits: sep2_h >= sep2, sep_ft_h >= sep_ft, scan_horizon_limits): a pair outside them cannot lose its separation
+//    during the next `horizon` steps, a wavefront in which no pair is inside them skips the scan of those steps (k_step: scan_skip),
+//    one that has such a pair asks the exact question for that rotation behind the same wave-uniform test.
+//    Why it looked promising: in the BASELINE workloads aircraft enter the sector stacked over the same few entry points — 27 of a
+//    wavefront's 480 pairs are inside the horizontal minimum at any time (CPU oracle, random actions held for 20 steps), so the first
+//    form takes its branch in nearly every rotation —, and a wavefront of four 16-aircraft envs is clear for 4 more steps in half of
+//    its steps.  What came out (profiles/r05_experiments.txt: ab_s1 .. ab_s6, five boxes): 91 instead of 99 M vector instructions per
+//    T = 20 launch at 65 536 x 16 and NO time (12.0-12.4 us per step either way; even with the scan compiled out altogether: that
+//    launch is bound by its stores, tools/ubench/write_bw.hip), +0.5 % on the single-step launch, +2-4 % on the lone wavefronts of
+//    8 192 x 16 (there the scan hides the lookup gather's round trip; its masks and branches do not).  The horizon ships for the
+//    LDS-staged widths (N > 16), where the scan is 45 % of the step: 4 096 x 64 fused 4.1-4.3 vs 5.1-5.6 us.
+// Conflict = (d^2 < sep^2) & (|dh| < sep_ft), the oracle's expression, in both.
+struct ScanLimits {
+    float sep2, sep_ft;       // the separation minima (squared horizontal, vertical)
+    float sep2_h, sep_ft_h;   // the same with the horizon's closing distance added (== the minima where no horizon is used)
+};
 template <int D>
 __device__ __forceinline__ int row_ror_i(int v) {
     // (every lane of a row rotation has a source: `old` is never used — passing v itself spares the zero the compiler would
     // otherwise materialise for it)
     return __builtin_amdgcn_update_dpp(v, v, 0x120 + D, 0xf, 0xf, false);
 }
-template <int D>
+template <int D, bool HZ>
 struct NearScan16 {
+    static __device__ __forceinline__ void run(float xs, float y, float h, const ScanLimits& L, int& conf, bool& unsafe) {
+        const float dx = xs - row_ror<D>(xs), dy = y - row_ror<D>(y), dh = h - row_ror<D>(h);
+        const float d2 = fmaf(dx, dx, dy * dy);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(d2 < (HZ ? L.sep2_h : L.sep2)) &
+                           __builtin_amdgcn_ballot_w64(fabsf(dh) < (HZ ? L.sep_ft_h : L.sep_ft));
+        if (ATC_RARE(m != 0ull)) {
+            unsafe = true;
+            const int c = (d2 < L.sep2 && fabsf(dh) < L.sep_ft) ? 1 : 0;
+            conf |= c;
+            if (D < 8) conf |= row_ror_i<16 - D>(c);   // the partner's copy of the same pair (D = 8 is its own inverse)
+        }
+        NearScan16<D + 1, HZ>::run(xs, y, h, L, conf, unsafe);
+    }
+};
+template <bool HZ>
+struct NearScan16<9, HZ> {
+    static __device__ __forceinline__ void run(float, float, float, const ScanLimits&, int&, bool&) {}
+};
+// the rounds-3/4 form (horizontal question first, altitude behind the wave-uniform test): developer A/B, ATC_SCAN16_FORM = 0
+template <int D>
+struct NearScan16H {
     static __device__ __forceinline__ void run(float xs, float y, float h, float sep2, float sep_ft, int& conf) {
         const float dx = xs - row_ror<D>(xs), dy = y - row_ror<D>(y);
         const float d2 = fmaf(dx, dx, dy * dy);
         const bool near = d2 < sep2;
-        if (ATC_RARE(__builtin_amdgcn_ballot_w64(near) != 0ull)) {   // (a third of the rotations of the headline workload)
+        if (ATC_RARE(__builtin_amdgcn_ballot_w64(near) != 0ull)) {
             const float dh = h - row_ror<D>(h);
             const int c = (near && fabsf(dh) < sep_ft) ? 1 : 0;
             conf |= c;
-            if (D < 8) conf |= row_ror_i<16 - D>(c);   // the partner's copy of the same pair (D = 8 is its own inverse)
+            if (D < 8) conf |= row_ror_i<16 - D>(c);
         }
-        NearScan16<D + 1>::run(xs, y, h, sep2, sep_ft, conf);
+        NearScan16H<D + 1>::run(xs, y, h, sep2, sep_ft, conf);
     }
 };
 template <>
-struct NearScan16<9> {
+struct NearScan16H<9> {
     static __device__ __forceinline__ void run(float, float, float, float, float, int&) {}
 };
 
@@ -451,7 +489,8 @@ struct alignas(16) QScan {    // second half: separation scan, override chain
     float4 tri_bbox;      // bounds of the corridor's horizontal triangle (ATC_C_TRI_BBOX)
     int n_noise;          // number of noise-abatement areas (blob header word; read from the blob inside the step it was a
     int off_spawn;        // dependent scalar load with nothing to hide its latency behind, in every step of every wavefront);
-    int pad[2];           // word offset of the blob's spawn records (ATC_H_OFF_SPAWN)
+                          // word offset of the blob's spawn records (ATC_H_OFF_SPAWN)
+    float sep2_h, sep_ft_h;   // the minima with the closing distance of the launch's scan horizon added (scan_horizon_limits)
 };
 struct alignas(16) QNorm {
     float a[ATC_OBS_DIM], b[ATC_OBS_DIM];   // ATC_C_NORM_A / ATC_C_NORM_B
@@ -508,6 +547,7 @@ __device__ __forceinline__ StepDerived to_vector_registers(const StepDerived& q)
     v.g.pos_x0 = vg(q.g.pos_x0); v.g.pos_y0 = vg(q.g.pos_y0);
     v.g.gh.x0 = vg(q.g.gh.x0); v.g.gh.y0 = vg(q.g.gh.y0); v.g.gh.inv = vg(q.g.gh.inv);
     v.s.sep2 = vg(q.s.sep2); v.s.sep_ft = vg(q.s.sep_ft); v.s.conflict_reward = vg(q.s.conflict_reward);
+    v.s.sep2_h = vg(q.s.sep2_h); v.s.sep_ft_h = vg(q.s.sep_ft_h);
     v.oc.pos_inv = vg(q.oc.pos_inv); v.oc.to_rwy = vg(q.oc.to_rwy); v.oc.on_gp_c = vg(q.oc.on_gp_c); v.oc.sig_a = vg(q.oc.sig_a);
 #pragma unroll
     for (int c = 0; c < ATC_OBS_DIM; ++c) { v.n.a[c] = vg(q.n.a[c]); v.n.b[c] = vg(q.n.b[c]); }
@@ -525,27 +565,54 @@ static InlineAction inline_action() {
     if (t_inline_action) a = InlineAction{t_inline_action[0], t_inline_action[1], t_inline_action[2], 1};
     return a;
 }
-static StepDerived derive_uncached(const atc_params_t& p, const atc_scenario* s);
+static StepDerived derive_uncached(const atc_params_t& p, const atc_scenario* s, int horizon);
 // The uniform terms depend on the sector and on a few parameters only; a caller steps the same env thousands of times with the
 // same ones, so each thread remembers its last evaluation (the single-env path launches one tiny kernel per step: the
 // evaluation would be a measurable part of its host time).  Thread-local: the library stays free of shared mutable state.
-static const StepDerived& derive(const atc_params_t& p, const atc_scenario* s) {
+// `horizon`: the steps a multi-step launch may leave the separation scan out after one that found every pair far apart (0: none)
+static const StepDerived& derive(const atc_params_t& p, const atc_scenario* s, int horizon) {
     struct Key {
         uint64_t uid;
         float dt, sep_nm, sep_ft, conflict_reward;
         int32_t timestep_limit;
         uint32_t mode_bits;   // the mode flags the derived values depend on
+        int32_t horizon, pad;
     };
-    static thread_local Key last = {0ull, 0.0f, 0.0f, 0.0f, 0.0f, 0, 0u};
+    static thread_local Key last = {0ull, 0.0f, 0.0f, 0.0f, 0.0f, 0, 0u, 0, 0};
     static thread_local StepDerived q;
-    const Key k = {s->uid, p.dt, p.sep_nm, p.sep_ft, p.conflict_reward, p.timestep_limit, p.mode & (uint32_t)(ATC_M_DISCRETE | ATC_M_NORMALIZE)};
+    const Key k = {s->uid, p.dt, p.sep_nm, p.sep_ft, p.conflict_reward, p.timestep_limit, p.mode & (uint32_t)(ATC_M_DISCRETE | ATC_M_NORMALIZE), horizon, 0};
     if (memcmp(&k, &last, sizeof k) != 0) {
-        q = derive_uncached(p, s);
+        q = derive_uncached(p, s, horizon);
         last = k;
     }
     return q;
 }
-static StepDerived derive_uncached(const atc_params_t& p, const atc_scenario* s) {
+// Separation scan horizon (include/atc_step.h): thresholds S2 >= sep_nm^2 and SF >= sep_ft such that a pair of aircraft with
+//   d^2 >= S2  or  |dh| >= SF     (d^2, dh as the scan evaluates them, fp32)
+// now cannot satisfy (d^2 < sep_nm^2 and |dh| < sep_ft) in any of the next n steps.  Per step an aircraft moves by at most
+// (v / 3600) dt (1 + 1e-9) nm + one position count per axis (advance(): |sin|, |cos| <= 1 + 1e-9, floor of displacement + dither) with
+// v <= 300 kt as long as it is at most 300 kt now (valid targets lie in [100, 300], the rate-limited move never overshoots: the scan
+// checks the speeds it starts from), and its altitude by at most 15 dt up / 41 dt down + half an ulp (the scan checks |h| < 2^17 ft:
+// ulp <= 2^-6 ft).  So d shrinks by at most 2 (300 / 3600) dt and |dh| by at most 56 dt per step; the slack terms — 1e-5 relative
+// + 1e-3 nm, 1e-5 relative + 1 ft — are hundreds of times the fp32 evaluation error of d^2 (a few ulp + 2^-17 nm per coordinate).
+// Aircraft that are handed over stay where they are until their env is reset, and a reset ends the horizon (step_part_b).
+static void scan_horizon_limits(const atc_params_t& p, int n, float* sep2_h, float* sep_ft_h) {
+    const float sep2 = p.sep_nm * p.sep_nm;
+    *sep2_h = sep2;
+    *sep_ft_h = p.sep_ft;
+    if (n <= 0) return;
+    const double dt = (double)p.dt;
+    const double S = (sqrt((double)sep2) + n * 2.0 * ((double)kVMax / 3600.0) * dt) * (1.0 + 1e-5) + 1e-3;
+    const double F = ((double)p.sep_ft + n * ((double)kHDotMax - (double)kHDotMin) * dt) * (1.0 + 1e-5) + 1.0;
+    float s2 = (float)(S * S), f = (float)F;
+    if ((double)s2 < S * S) s2 = nextafterf(s2, INFINITY);
+    if ((double)f < F) f = nextafterf(f, INFINITY);
+    // (NaN parameters: every compare of the scan is false either way; thresholds that did not come out above the minima — overflow,
+    // NaN — become +inf: "some pair is near" in every scan, i.e. no step is skipped)
+    *sep2_h = (s2 >= sep2) ? s2 : INFINITY;
+    *sep_ft_h = (f >= p.sep_ft) ? f : INFINITY;
+}
+static StepDerived derive_uncached(const atc_params_t& p, const atc_scenario* s, int horizon) {
     const float* K = s->consts;
     StepDerived q;
     memset(&q, 0, sizeof q);
@@ -592,6 +659,7 @@ static StepDerived derive_uncached(const atc_params_t& p, const atc_scenario* s)
     q.g.gh = grid_header(s->off_grid ? s->ghdr : nullptr);
     q.s.sep2 = p.sep_nm * p.sep_nm;
     q.s.sep_ft = p.sep_ft;
+    scan_horizon_limits(p, horizon, &q.s.sep2_h, &q.s.sep_ft_h);
     q.s.conflict_reward = p.conflict_reward;
     q.s.timestep_limit = p.timestep_limit;
     q.s.tri_bbox = make_float4(K[ATC_C_TRI_BBOX], K[ATC_C_TRI_BBOX + 1], K[ATC_C_TRI_BBOX + 2], K[ATC_C_TRI_BBOX + 3]);
@@ -975,12 +1043,37 @@ __device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, con
 #endif
 #define QGET(member) ((ONE || LAT || W < ATC_QGET_REREAD_MIN_W) ? q.member : kernarg_reread<decltype(q.member)>(offsetof(StepArgs, q) + offsetof(StepDerived, member), zk))
 
+// Separation scan horizon (round 5; scan_horizon_limits): the steps a multi-step launch of the fast variant leaves the scan out after
+// one in which no pair of the wavefront was inside the horizon thresholds.  Measured on the BASELINE workloads with the CPU oracle
+// (random actions held for 20 steps, auto-reset): a 64-aircraft env (LOWWDense; one wavefront) is clear for 3 more steps in 83 % of
+// its steps (4: 77 %, 6: 66 %, 8: 55 %) and reset in 6 % of them — with a horizon of 3 the scan runs in ~30 % of the steps; measured
+// per horizon at 4 096 x 64, T = 20 (same box): 2 -> 4.19-4.22 us per step, 3 -> 4.11, 4 -> 4.22-4.25, 6 -> 4.34-4.39, no horizon
+// 5.1-5.3.  (A wavefront of four 16-aircraft envs: clear for 4 steps in 50 %, one of its envs reset in 12 % — see NearScan16.)
+#ifndef ATC_SCAN_SKIP
+#define ATC_SCAN_SKIP 1   // developer A/B: 0 = every step scans (the horizon thresholds are then the minima themselves)
+#endif
+#ifndef ATC_SCAN16_FORM
+#define ATC_SCAN16_FORM 0   // 0 = the rounds-3/4 scan of 16-aircraft envs (horizontal question first; no horizon) — shipped; 1 = the
+                            // three-dimensional question per rotation + horizon (NearScan16): developer A/B, see below
+#endif
+#ifndef ATC_SCAN_HORIZON16
+#define ATC_SCAN_HORIZON16 4
+#endif
+#ifndef ATC_SCAN_HORIZON_LDS
+#define ATC_SCAN_HORIZON_LDS 3
+#endif
+template <int W, bool FULL, bool ONE>
+constexpr int scan_horizon() {
+    return (!ATC_SCAN_SKIP || FULL || ONE) ? 0 : (W == 16 ? (ATC_SCAN16_FORM ? ATC_SCAN_HORIZON16 : 0) : W >= 32 ? ATC_SCAN_HORIZON_LDS : 0);
+}
+constexpr float kScanHMax = 131072.0f;   // |altitude| below which an altitude step rounds by less than 2^-7 ft (scan_horizon_limits)
+
 template <int W, bool FULL, bool ONE, bool LAT>
 __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const float* __restrict__ grid,
                                             const atc_params_t& p, const StepDerived& q, const QScan& qs, int zk, int N,
                                             const LaneIds& d, const Mid& m, LaneState& ls,
                                             EnvState& es, const StepOut& so, int32_t* stp, double* wide_named, float4* pos, float* obs_stage,
-                                            const float* act_next, Float3& a_next, QRates& qr_next) {
+                                            const float* act_next, Float3& a_next, QRates& qr_next, int& scan_skip) {
     Aircraft& a = ls.a;
     const bool active = m.active;
     const float x32 = m.x32, y32 = m.y32;
@@ -1025,7 +1118,18 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     if (ATC_RARE(act_next != nullptr)) a_next = *at<Float3>(act_next, times12(i));
     float min_d2 = 1e30f;
     float margin = 1e30f;  // min over partners of max(d^2 - sep^2, |dh| - sep_ft): conflict iff negative
-    if (W > 1 && !(ATC_ABLATE & 2)) {
+    // Multi-step launches of the fast variant: inside a scan horizon (scan_skip > 0) no pair of this wavefront can have lost its
+    // separation — the step runs without the scan; otherwise the scan also establishes the next horizon.
+    constexpr int kHorizon = scan_horizon<W, FULL, ONE>();
+    constexpr bool kHZ = kHorizon > 0;
+    const ScanLimits lim = {qs.sep2, qs.sep_ft, kHZ ? qs.sep2_h : qs.sep2, kHZ ? qs.sep_ft_h : qs.sep_ft};
+    bool unsafe = false;
+    bool scan_now = W > 1 && !(ATC_ABLATE & 2);
+    if (kHZ && scan_skip > 0) {
+        scan_skip -= 1;
+        scan_now = false;
+    }
+    if (scan_now) {
         float xs = x32;
         if (!m.plain) xs = active ? x32 : 1e18f;
         const float sep2 = qs.sep2;
@@ -1034,7 +1138,8 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
 #endif                        // wave-uniform tests): 12.1 vs 10.1 us per fused step at 65 536 x 16, 2.9 vs 2.6 at 8 192 x 16 — rejected
         if (W == 16 && !FULL && !ATC_SCAN16_MARGIN) {
             int conf = 0;
-            NearScan16<1>::run(xs, y32, a.h, sep2, qs.sep_ft, conf);
+            if (ATC_SCAN16_FORM) NearScan16<1, kHZ>::run(xs, y32, a.h, lim, conf, unsafe);
+            else NearScan16H<1>::run(xs, y32, a.h, sep2, qs.sep_ft, conf);
             margin = conf ? -1.0f : margin;
         } else if (W == 16) {
             PairScan16<1, FULL>::run(xs, y32, a.h, sep2, qs.sep_ft, min_d2, margin);
@@ -1094,24 +1199,29 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
                     if (FULL || !ATC_NEAR_FIRST_LDS) qh[u] = v2f{q0[2 * P], q0[2 * P + 1]};
                 }
                 uint64_t mk[U];   // mk[2 u + w]: distance d0 + 2 u + w
+                v2f d2k[U / 2], dhk[U / 2];   // (kHZ: kept for the exact question behind the wave-uniform test)
 #pragma unroll
                 for (int u = U / 2 - 1; u >= 0; --u) {
                     const v2f dx = xs2 - qx[u], dy = ys2 - qy[u];
                     const v2f d2 = __builtin_elementwise_fma(dx, dx, dy * dy);
+                    d2k[u] = d2;
                     if (FULL || !ATC_NEAR_FIRST_LDS) {
                         const v2f dh = hs2 - qh[u];
+                        dhk[u] = dh;
                         // (two ballots anded as scalars: the compare masks themselves — a ballot of the anded predicate is
                         // materialised per lane and compared again)
-                        mk[2 * u] = __builtin_amdgcn_ballot_w64(d2[0] < sep2) & __builtin_amdgcn_ballot_w64(fabsf(dh[0]) < sep_ft);
-                        mk[2 * u + 1] = __builtin_amdgcn_ballot_w64(d2[1] < sep2) & __builtin_amdgcn_ballot_w64(fabsf(dh[1]) < sep_ft);
+                        // kHZ: the horizon thresholds (scan_horizon_limits) — a superset of the pairs that lost their separation
+                        mk[2 * u] = __builtin_amdgcn_ballot_w64(d2[0] < lim.sep2_h) & __builtin_amdgcn_ballot_w64(fabsf(dh[0]) < lim.sep_ft_h);
+                        mk[2 * u + 1] = __builtin_amdgcn_ballot_w64(d2[1] < lim.sep2_h) & __builtin_amdgcn_ballot_w64(fabsf(dh[1]) < lim.sep_ft_h);
                     } else {
-                        mk[2 * u] = __builtin_amdgcn_ballot_w64(d2[0] < sep2);
-                        mk[2 * u + 1] = __builtin_amdgcn_ballot_w64(d2[1] < sep2);
+                        mk[2 * u] = __builtin_amdgcn_ballot_w64(d2[0] < lim.sep2_h);
+                        mk[2 * u + 1] = __builtin_amdgcn_ballot_w64(d2[1] < lim.sep2_h);
                         if ((mk[2 * u] | mk[2 * u + 1]) != 0ull) {   // wave-uniform
                             const float* q0 = own + d0 + 2 * u;
                             const v2f dh = hs2 - v2f{q0[2 * P], q0[2 * P + 1]};
-                            mk[2 * u] &= __builtin_amdgcn_ballot_w64(fabsf(dh[0]) < sep_ft);
-                            mk[2 * u + 1] &= __builtin_amdgcn_ballot_w64(fabsf(dh[1]) < sep_ft);
+                            dhk[u] = dh;
+                            mk[2 * u] &= __builtin_amdgcn_ballot_w64(fabsf(dh[0]) < lim.sep_ft_h);
+                            mk[2 * u + 1] &= __builtin_amdgcn_ballot_w64(fabsf(dh[1]) < lim.sep_ft_h);
                         }
                     }
                     if (FULL) {   // diagnostic minimum separation: the partner needs the VALUE -> LDS float minimum
@@ -1127,7 +1237,17 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
                 uint64_t any = mk[0];
 #pragma unroll
                 for (int j = 1; j < U; ++j) any |= mk[j];
-                if (ATC_RARE(any != 0ull)) {   // some pair of this batch lost its separation: both of its lanes are marked
+                if (ATC_RARE(any != 0ull)) {   // some pair of this batch is inside the thresholds
+                    if (kHZ) {   // ... the horizon's: no step is skipped after this one; now the exact question for this batch
+                        unsafe = true;
+                        any = 0ull;
+#pragma unroll
+                        for (int j = 0; j < U; ++j) {
+                            mk[j] = __builtin_amdgcn_ballot_w64(d2k[j / 2][j % 2] < sep2) & __builtin_amdgcn_ballot_w64(fabsf(dhk[j / 2][j % 2]) < sep_ft);
+                            any |= mk[j];
+                        }
+                    }
+                    // a pair that lost its separation: both of its lanes are marked
                     hit |= any;
 #pragma unroll
                     for (int j = 0; j < U; ++j) {
@@ -1150,6 +1270,11 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
                 min_d2 = fminf(min_d2, own[3 * P]);
             }
             __builtin_amdgcn_wave_barrier();
+        }
+        if (kHZ) {
+            // the horizon's premises (scan_horizon_limits): no aircraft faster than 300 kt, altitudes of ordinary magnitude (a NaN fails)
+            const uint64_t odd = __builtin_amdgcn_ballot_w64(a.v > kVMaxFix) | __builtin_amdgcn_ballot_w64(!(fabsf(a.h) < kScanHMax));
+            scan_skip = (unsafe || odd != 0ull) ? 0 : kHorizon;
         }
     }
     ATC_STAMP_B(2);
@@ -1295,6 +1420,8 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         if (!keep_active) es.amask &= ~won;
         env_won = keep_active ? won != 0 : es.amask == 0;
         done = d.env_valid && (term != 0 || env_won);
+        // an env that restarts inside this step puts its aircraft somewhere else: the scan horizon ends here
+        if (kHZ && (p.mode & ATC_M_AUTO_RESET) && __builtin_amdgcn_ballot_w64(done) != 0ull) scan_skip = 0;
     }
     es.total_reward += env_r;  // atc_gym.py:194-197
     es.n_actions += env_acts;
@@ -1521,6 +1648,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     uint64_t refused_blk = 0ull;  // LAT: which lanes' speed / altitude / heading targets of the current block are refused or beyond range
     bool refused_known = false;
     bool all_active = false, mask_dirty = true;
+    int scan_skip = 0;   // wave-uniform: steps the separation scan may still be left out for (step_part_b: scan horizon)
     QRates qr_next = q.r;   // the rate group of the coming step (multi-step launches fetch it one step ahead, see step_part_b)
     if (!ONE && !LAT) {
         int zn;
@@ -1647,7 +1775,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             act_t += (size_t)BN * 3;
             if (step + 1 < n_steps) act_next = act_t;
         }
-        const bool quiet = step_part_b<W, FULL, ONE, LAT>(Kl, gl, pl, q, qs, zk, N, dl, m, ls, es, so, stats_l, st.phi_wide, pos, obs_stage, act_next, nxt, qr_next);
+        const bool quiet = step_part_b<W, FULL, ONE, LAT>(Kl, gl, pl, q, qs, zk, N, dl, m, ls, es, so, stats_l, st.phi_wide, pos, obs_stage, act_next, nxt, qr_next, scan_skip);
         if (ATC_RARE(!quiet)) mask_dirty = true;
         if (kDecodeOnce && act_next) tg = decode_targets(QGET(r), nxt);
         act = nxt;
@@ -1814,7 +1942,7 @@ static int launch_step2(const atc_scenario* s, int B, int N, int T, int hold, co
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long long slots = (long long)B * W;
     const int grid = (int)((slots + kBlock - 1) / kBlock);  // one workgroup per 256 slots, no grid-stride loop
-    hipLaunchKernelGGL((k_step<W, FULL, ONE, ALLV, LAT>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->off_grid, B, N, T, hold, *st, actions, *out, *p, derive(*p, s), inline_action());
+    hipLaunchKernelGGL((k_step<W, FULL, ONE, ALLV, LAT>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->off_grid, B, N, T, hold, *st, actions, *out, *p, derive(*p, s, scan_horizon<W, FULL, ONE>()), inline_action());
     HIP_TRY(hipGetLastError());
     return ATC_OK;
 }

@@ -273,7 +273,19 @@ typedef struct atc_params {
  *   counts): dt <= 51 s for any sector; atc_step refuses larger steps.
  * Measured against the float64 reference over the 650 963 steps of tests/golden/g9_wide.npz (tools/position_error.py):
  * positions within 1.5e-7 nm (median) / 1.04e-6 nm (maximum, 6 000-step episodes), speed and heading within one count;
- * the fixture replays at the plain 1e-5 bar everywhere — no near-FAF exception. */
+ * the fixture replays at the plain 1e-5 bar everywhere — no near-FAF exception.
+ *
+ * Separation scan horizon (round 5; an implementation note, not a format: results are what a scan in every step gives).
+ * Conflict = (d^2 < sep_nm^2) and (|dh| < sep_ft) for a pair of aircraft under control, d^2 = fma(dx, dx, dy dy) and dh from the
+ * fp32 positions / altitudes.  The kinematics above bound what one step can do to a pair: an aircraft at or below 300 kt stays at or
+ * below 300 kt (accepted speed targets lie in [100, 300] kt and the rate-limited move never overshoots) and moves by at most
+ * (300 / 3600) dt nm (+ one position count per axis); its altitude moves by at most 15 dt ft up / 41 dt ft down (+ half an ulp).  A
+ * pair with  d >= |sep_nm| + n (600 / 3600) dt  or  |dh| >= sep_ft + n 56 dt  (+ slack: 1e-5 relative + 1e-3 nm / 1 ft, hundreds of
+ * times the fp32 evaluation error) therefore cannot be in conflict during the next n steps, whatever the actions.  Multi-step launches
+ * (atc_rollout, atc_rollout_hold) that do not report min_sep use this: a wavefront that finds no pair inside those thresholds —
+ * and no aircraft above 300 kt, no altitude beyond 2^17 ft in magnitude or NaN — leaves the scan out for the next n steps; an env
+ * that is reset inside the launch ends the horizon of its wavefront.  tests/test_hip_edge_cases.py
+ * (test_scan_horizon_on_the_fastest_closing_courses) drives pairs at exactly these closing rates through every phase of a horizon. */
 #define ATC_V_FIX_SHIFT 23
 #define ATC_PHI_FIX_SHIFT 23
 #define ATC_PHI_FIX_OFFSET 180.0f

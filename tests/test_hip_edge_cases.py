@@ -643,3 +643,102 @@ def test_wide_headings_in_host_mapped_state():
     assert float(dev_env.phi.abs().max()) > 700.0
     dev_env.close()
     map_env.close()
+
+
+def closing_course_formations(comp, N, phases=16):
+    """States and (held) actions for test_scan_horizon_on_the_fastest_closing_courses: [B][N] x (x, y, h, phi, v), [B][N][3].
+    B = 4 kinds of pair x `phases` gaps x the envs of one wavefront (each wavefront holds one kind at one gap)."""
+    from oracle import oracle as O
+    G = max(1, 64 // N)
+    B = 4 * phases * G
+    pitch = 7.0 if N <= 16 else 5.0
+    bx0, by0, bx1, by1 = comp.meta["bbox"]
+    gx, gy = np.meshgrid(np.arange(bx0, bx1, pitch), np.arange(by0, by1, pitch))
+    gx, gy = gx.ravel(), gy.ravel()
+    q = O.OracleQueries(comp, np.float32)
+    inside = lambda x, y: q.mva(x, y) >= 0
+    ok = np.ones(len(gx), bool)   # a point with everything within 4.5 nm of it inside the airspace: nobody leaves it during the run
+    for dx, dy in ((0, 0), (4.5, 0), (-4.5, 0), (0, 4.5), (0, -4.5), (3.2, 3.2), (-3.2, 3.2), (3.2, -3.2), (-3.2, -3.2)):
+        ok &= inside(gx + dx, gy + dy)
+    # the anchor of the pair: its row's neighbour to the east is a formation point too (the head-on partner starts near it)
+    idx = np.flatnonzero(ok)
+    anchor = next(i for i in idx if i + 1 in idx and gy[i + 1] == gy[i])
+    rest = [i for i in idx if i not in (anchor, anchor + 1)][:N - 2]
+    assert len(rest) == N - 2, "sector too small for the formation"
+    px, py = np.r_[gx[anchor], gx[anchor + 1], gx[rest]], np.r_[gy[anchor], gy[anchor + 1], gy[rest]]
+    ch, cv = 2 * 300.0 / 3600.0, 56.0
+    hold_h = float(np.float32(30000.0 / 19000.0 - 1.0))
+    st = np.zeros((B, N, 5))
+    act = np.zeros((B, N, 3), np.float32)
+    st[:, :, 0], st[:, :, 1], st[:, :, 2], st[:, :, 3], st[:, :, 4] = px, py, 30000.0, 0.0, 250.0   # the formation flies north at 250 kt
+    act[:, :, 0], act[:, :, 1], act[:, :, 2] = 0.5, hold_h, -1.0
+    for e in range(B):
+        kind, gap = (e // G) % 4, (e // (4 * G)) % phases
+        if kind in (0, 1):      # head-on along the x axis, at 300 kt / from 356 kt (the speed format's limit)
+            v = 300.0 if kind == 0 else 356.0
+            st[e, 0] = (px[0], py[0], 30000.0, 90.0, v)
+            st[e, 1] = (px[0] + 3.0 + ch * gap + 0.03, py[0], 30000.0, 270.0, v)
+            act[e, 0], act[e, 1] = (1.0, hold_h, -0.5), (1.0, hold_h, 0.5)
+        elif kind == 2:         # stacked over one point: the lower one climbs, the upper one descends
+            st[e, 0] = (px[0], py[0], 20000.0, 0.0, 250.0)
+            st[e, 1] = (px[0], py[0], 21000.0 + cv * gap + 5.0, 0.0, 250.0)
+            act[e, 0], act[e, 1] = (0.5, 1.0, -1.0), (0.5, -0.5, -1.0)
+        else:                   # crossing at right angles, meeting at one point
+            d = (3.0 + ch * gap) / np.sqrt(2.0) + 0.03
+            st[e, 0] = (px[0] - d, py[0], 30000.0, 90.0, 300.0)
+            st[e, 1] = (px[0], py[0] - d, 30000.0, 0.0, 300.0)
+            act[e, 0], act[e, 1] = (1.0, hold_h, -0.5), (1.0, hold_h, -1.0)
+    return st, act, G
+
+
+@pytest.mark.parametrize("N", [16, 64])
+def test_scan_horizon_on_the_fastest_closing_courses(N):
+    """Multi-step launches of the fast variant leave the separation scan out for a few steps after one that found every pair of the
+    wavefront beyond the horizon thresholds (csrc/atc_step.hip: scan_horizon_limits; include/atc_step.h "Separation scan horizon").
+    Here the pairs close as fast as the step allows — head-on at 300 kt each, head-on from 356 kt (the speed format's limit: the
+    horizon's premise fails and nothing may be skipped), stacked over one point at 15 ft/s up against 41 ft/s down, crossing at right
+    angles — from gaps swept so that the loss of separation falls on every phase of a horizon, in formations whose other aircraft
+    keep their distance (the wavefronts DO skip).  Every step must equal the single-step launches, which scan in every step, and the
+    oracle's flags."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from atc_hip import layout as L
+    from envs.atc import scenarios
+    from oracle import oracle as O
+    scn = scenarios.LOWWDense() if N == 64 else scenarios.LOWW(random_entrypoints=True)
+    comp = scenarios.compile_scenario(scn)
+    st, act, G = closing_course_formations(comp, N)
+    B = st.shape[0]
+    one = AtcVecEnv(B, N, scenario=scn, auto_reset=True, seed=3)
+    roll = AtcVecEnv(B, N, scenario=scn, auto_reset=True, seed=3)
+    orc = O.OracleEnv(comp, B, N, O.make_params(auto_reset=True, seed=3), np.float32)
+    for e in range(B):
+        for k in range(N):
+            orc.set_state(e, k, *st[e, k])
+    for env in (one, roll):   # (the oracle's words: one copy instead of B N x 5 scalar writes)
+        env.pos_hp[:, 0] = torch.as_tensor(orc.px).to(env.device)
+        env.pos_hp[:, 1] = torch.as_tensor(orc.py).to(env.device)
+        env.h[:] = torch.as_tensor(orc.h).to(env.device)
+        env.phi_fix[:] = torch.as_tensor(orc.phi_fix).to(env.device)
+        env.v_fix[:] = torch.as_tensor(orc.v_fix).to(env.device)
+    blocks = torch.as_tensor(act).cuda()[None]
+    kinds = (np.arange(B) // G) % 4
+    conflict_steps = set()
+    for launch in range(2):
+        out = roll.rollout(blocks, hold=20)
+        for t in range(20):
+            o, r, d, info = one.step(blocks[0])
+            orc.step(act)
+            assert torch.equal(out["flags"][t], info["flags"]) and torch.equal(out["done"][t], d), (launch, t)
+            assert torch.equal(out["obs"][t], o) and torch.equal(out["reward"][t], r), (launch, t)
+            assert np.array_equal(info["flags"].cpu().numpy().astype(np.uint32).reshape(B, N), orc.flags), (launch, t)
+            if launch == 0:
+                hit = (orc.flags[:, :2] & L.F_CONFLICT) != 0
+                conflict_steps |= {(kind, t) for kind in range(4) if hit[kinds == kind].any()}
+    for name in ("pos_hp", "v_fix", "last_act", "env", "stats"):
+        assert torch.equal(getattr(one, name), getattr(roll, name)), name
+    # every kind of pair lost its separation at many different steps of the launch (= phases of the horizon)
+    for kind in range(4):
+        assert len([1 for k, _ in conflict_steps if k == kind]) >= 10, (kind, sorted(conflict_steps))
+    one.close()
+    roll.close()

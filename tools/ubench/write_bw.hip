@@ -1,0 +1,146 @@
+// Developer micro-benchmark (gfx950): what a launch that does nothing but WRITE reaches on this part, for the output pattern of the
+// fused step launch (atc_rollout_hold, 65 536 envs x 16 aircraft, T = 20) — the question behind `roofline.frac` of that launch: its
+// algorithmic bytes are 97 % stores (44 B written per aircraft-step against 2.6 B read), and the 8 TB/s of the roofline is a
+// read-or-mixed figure.
+//   stream   : every lane stores 16 bytes, consecutive lanes consecutive addresses, one pass over the buffer (the ideal write stream)
+//   pattern  : the step launch's own stores, nothing else — per wavefront and step 2 560 contiguous bytes of observation rows as
+//              16-byte stores, 2 bytes of flags per lane, 4 + 1 bytes per env from every 16th lane; the T outputs of a wavefront are
+//              B N 40 bytes apart (the [T][B][N][10] layout), steps in order
+//   pattern + k FMAs per lane and step: the same with a dependent chain of k v_fma_f32 between the steps' stores (k = 300: the
+//              instruction count of the step) — how much of the arithmetic the stores hide
+// Buffers are 0.98 GB (beyond the 256 MiB Infinity Cache); times are HIP events over REPS launches after a warm-up.
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/write_bw.hip -o build_variants/write_bw && build_variants/write_bw
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__global__ void __launch_bounds__(256) k_stream(v4f* dst, size_t n16, float seed) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) {
+        const v4f v = {seed, seed + 1.0f, seed + 2.0f, (float)threadIdx.x};
+        if (NT) __builtin_nontemporal_store(v, dst + i);
+        else dst[i] = v;
+    }
+}
+// each thread writes `per` consecutive 16-byte pieces of a grid-strided stream (fewer, longer-lived workgroups)
+template <bool NT>
+__global__ void __launch_bounds__(256) k_stream_loop(v4f* dst, size_t n16, int per, float seed) {
+    const size_t chunk = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (int j = 0; j < per && i < n16; ++j, i += chunk) {
+        const v4f v = {seed, seed + 1.0f, seed + 2.0f, (float)j};
+        if (NT) __builtin_nontemporal_store(v, dst + i);
+        else dst[i] = v;
+    }
+}
+
+// PARTS: bit 0 observation rows, bit 1 flags, bit 2 reward + done.  SWZ: workgroup -> tile mapping that keeps neighbouring tiles on
+// ONE XCD (workgroups are dealt round-robin to the 8 XCDs: tile = (block mod 8) * (grid / 8) + block / 8), so that the partial
+// lines of the per-env outputs (16 envs per workgroup: 64 B of reward, 16 B of done) meet in one L2 before they are written back
+template <bool NT, int FMAS, int PARTS = 7, bool SWZ = false>
+__global__ void __launch_bounds__(256) k_pattern(float* obs, unsigned short* flags, float* reward, unsigned char* done, int B, int T,
+                                                 float seed) {
+    const unsigned tid = threadIdx.x, ln = tid & 63u;
+    const size_t BN = (size_t)B * 16;
+    const unsigned blk = SWZ ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const unsigned i = blk * 256u + tid;                 // aircraft
+    const unsigned wave_first = blk * 256u + (tid & ~63u);
+    float x = seed + (float)tid, y = seed * 0.5f;
+    for (int t = 0; t < T; ++t) {
+#pragma unroll 16
+        for (int k = 0; k < FMAS; ++k) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x) : "v"(y));
+        char* ob = reinterpret_cast<char*>(obs) + ((size_t)t * BN + wave_first) * 40;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned idx = (unsigned)j * 64u + ln;
+            if ((PARTS & 1) && idx < 160u) {
+                const v4f v = {x, y, (float)t, (float)idx};
+                v4f* p = reinterpret_cast<v4f*>(ob + idx * 16u);
+                if (NT) __builtin_nontemporal_store(v, p);
+                else *p = v;
+            }
+        }
+        if (PARTS & 2) {
+            if (NT) __builtin_nontemporal_store((unsigned short)t, flags + (size_t)t * BN + i);
+            else flags[(size_t)t * BN + i] = (unsigned short)t;
+        }
+        if ((PARTS & 4) && (tid & 15u) == 0) {
+            reward[(size_t)t * B + (i >> 4)] = x;
+            done[(size_t)t * B + (i >> 4)] = (unsigned char)(t & 1);
+        }
+    }
+}
+
+template <typename F>
+static double time_us(F launch, int reps) {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) launch();
+    CHECK(hipDeviceSynchronize());
+    std::vector<double> ts;
+    for (int r = 0; r < 5; ++r) {
+        CHECK(hipEventRecord(a, 0));
+        for (int i = 0; i < reps; ++i) launch();
+        CHECK(hipEventRecord(b, 0));
+        CHECK(hipEventSynchronize(b));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        ts.push_back(ms * 1e3 / reps);
+    }
+    double best = ts[0];
+    for (double t : ts) best = t < best ? t : best;
+    return best;
+}
+
+int main() {
+    const int B = 65536, N = 16, T = 20;
+    const size_t BN = (size_t)B * N;
+    const size_t obs_bytes = BN * 40 * T, flag_bytes = BN * 2 * T, rew_bytes = (size_t)B * 4 * T, done_bytes = (size_t)B * T;
+    const size_t total = obs_bytes + flag_bytes + rew_bytes + done_bytes;
+    float* obs;
+    unsigned short* flags;
+    float* reward;
+    unsigned char* done;
+    CHECK(hipMalloc(&obs, obs_bytes));
+    CHECK(hipMalloc(&flags, flag_bytes));
+    CHECK(hipMalloc(&reward, rew_bytes));
+    CHECK(hipMalloc(&done, done_bytes));
+    printf("output bytes of one T = %d launch at %d x %d: %.1f MB\n", T, B, N, total / 1e6);
+    const size_t n16 = obs_bytes / 16;
+    const int reps = 20;
+    auto report = [&](const char* name, double us, size_t bytes) {
+        printf("%-58s %8.1f us  %6.2f TB/s  (per step %.2f us)\n", name, us, bytes / us / 1e6, us / T);
+    };
+    report("stream, one 16-B store per lane, plain", time_us([&] { hipLaunchKernelGGL(k_stream<false>, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, reinterpret_cast<v4f*>(obs), n16, 1.0f); }, reps), obs_bytes);
+    report("stream, one 16-B store per lane, nontemporal", time_us([&] { hipLaunchKernelGGL(k_stream<true>, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, reinterpret_cast<v4f*>(obs), n16, 1.0f); }, reps), obs_bytes);
+    for (int per : {8, 32}) {
+        char name[96];
+        const unsigned grid = (unsigned)((n16 / per + 255) / 256);
+        snprintf(name, sizeof name, "stream, %d grid-strided stores per lane, plain", per);
+        report(name, time_us([&] { hipLaunchKernelGGL(k_stream_loop<false>, dim3(grid), dim3(256), 0, 0, reinterpret_cast<v4f*>(obs), n16, per, 1.0f); }, reps), obs_bytes);
+        snprintf(name, sizeof name, "stream, %d grid-strided stores per lane, nontemporal", per);
+        report(name, time_us([&] { hipLaunchKernelGGL(k_stream_loop<true>, dim3(grid), dim3(256), 0, 0, reinterpret_cast<v4f*>(obs), n16, per, 1.0f); }, reps), obs_bytes);
+    }
+    const unsigned grid = (unsigned)(BN / 256);
+#define PAT(NTV, F, LABEL) report(LABEL, time_us([&] { hipLaunchKernelGGL((k_pattern<NTV, F>), dim3(grid), dim3(256), 0, 0, obs, flags, reward, done, B, T, 1.0f); }, reps), total)
+    PAT(false, 0, "step-launch pattern, stores only, plain");
+    PAT(true, 0, "step-launch pattern, stores only, nontemporal");
+#define PATX(P, SW, BYTES, LABEL) report(LABEL, time_us([&] { hipLaunchKernelGGL((k_pattern<true, 0, P, SW>), dim3(grid), dim3(256), 0, 0, obs, flags, reward, done, B, T, 1.0f); }, reps), BYTES)
+    PATX(1, false, obs_bytes, "  observation rows only");
+    PATX(3, false, obs_bytes + flag_bytes, "  observation rows + flags");
+    PATX(5, false, obs_bytes + rew_bytes + done_bytes, "  observation rows + reward / done");
+    PATX(7, true, total, "step-launch pattern, XCD-contiguous tiles");
+    PATX(1, true, obs_bytes, "  observation rows only, XCD-contiguous tiles");
+    PATX(5, true, obs_bytes + rew_bytes + done_bytes, "  observation rows + reward / done, XCD-contiguous tiles");
+    PAT(true, 100, "step-launch pattern + 100 dependent FMAs per lane-step");
+    PAT(true, 200, "step-launch pattern + 200 dependent FMAs per lane-step");
+    PAT(true, 300, "step-launch pattern + 300 dependent FMAs per lane-step");
+    PAT(true, 400, "step-launch pattern + 400 dependent FMAs per lane-step");
+    return 0;
+}
