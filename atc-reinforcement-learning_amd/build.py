@@ -21,6 +21,28 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wno-unused-function", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
+# Developer micro-benchmark that bench.py runs next to the fused launch (a separate executable, never linked into the product):
+# what a launch that only WRITES that launch's outputs takes on the box at hand (tools/ubench/write_bw.hip)
+UBENCH_SRC = os.path.join(os.path.dirname(HERE), "tools", "ubench", "write_bw.hip")
+UBENCH_OUT = os.path.join(HERE, "atc_hip", "ubench_write_bw")
+
+
+def build_ubench(force=False, verbose=False):
+    if not force and os.path.exists(UBENCH_OUT) and os.path.getmtime(UBENCH_OUT) >= os.path.getmtime(UBENCH_SRC):
+        return UBENCH_OUT
+    tmp = UBENCH_OUT + ".tmp%d" % os.getpid()
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-o", tmp, UBENCH_SRC]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, UBENCH_OUT)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    return UBENCH_OUT
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True
@@ -49,3 +71,4 @@ if __name__ == "__main__":
     build_lib(force="--force" in sys.argv, verbose=True,
               extra=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else ())
     print(OUT)
+    print(build_ubench(force="--force" in sys.argv, verbose=True))

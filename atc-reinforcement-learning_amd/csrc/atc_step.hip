@@ -1043,12 +1043,16 @@ __device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, con
 #endif
 #define QGET(member) ((ONE || LAT || W < ATC_QGET_REREAD_MIN_W) ? q.member : kernarg_reread<decltype(q.member)>(offsetof(StepArgs, q) + offsetof(StepDerived, member), zk))
 
-// Separation scan horizon (round 5; scan_horizon_limits): the steps a multi-step launch of the fast variant leaves the scan out after
-// one in which no pair of the wavefront was inside the horizon thresholds.  Measured on the BASELINE workloads with the CPU oracle
-// (random actions held for 20 steps, auto-reset): a 64-aircraft env (LOWWDense; one wavefront) is clear for 3 more steps in 83 % of
-// its steps (4: 77 %, 6: 66 %, 8: 55 %) and reset in 6 % of them — with a horizon of 3 the scan runs in ~30 % of the steps; measured
-// per horizon at 4 096 x 64, T = 20 (same box): 2 -> 4.19-4.22 us per step, 3 -> 4.11, 4 -> 4.22-4.25, 6 -> 4.34-4.39, no horizon
-// 5.1-5.3.  (A wavefront of four 16-aircraft envs: clear for 4 steps in 50 %, one of its envs reset in 12 % — see NearScan16.)
+// Separation scan horizon (round 5; scan_horizon_limits).  In a multi-step launch of the fast variant a FULL scan asks its question
+// with thresholds no pair can close within the next `horizon` steps and notes which partner batches (four partner distances of the
+// LDS scan) hold a pair inside them; the following `horizon` steps scan those batches only, with the exact minima — or nothing at all
+// when none was noted.  Measured on the BASELINE workloads with the CPU oracle (random actions held for 20 steps, auto-reset): a
+// 64-aircraft env (LOWWDense; one wavefront) has NO pair inside the thresholds of 3 steps in 83 % of its steps (4: 77 %, 6: 66 %,
+// 8: 55 %) and is reset in 6 % of them.  4 096 x 64, T = 20, same box: no horizon 5.1-5.3 us per step; all-or-nothing horizons (the
+// first form: any pair inside the thresholds -> every step scans everything) 4.1-4.4 — the launch ends with its SLOWEST wavefront
+// (all 4 096 are resident from the start), and that one skipped least; the batch form 3.8-3.95 for horizons 4 .. 12 (shipped: 6),
+// 8 192 x 32 3.7 vs 4.05.  (A wavefront of four 16-aircraft envs: clear for 4 steps in 50 %, one of its envs reset in 12 % — see
+// NearScan16.)
 #ifndef ATC_SCAN_SKIP
 #define ATC_SCAN_SKIP 1   // developer A/B: 0 = every step scans (the horizon thresholds are then the minima themselves)
 #endif
@@ -1060,7 +1064,7 @@ __device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, con
 #define ATC_SCAN_HORIZON16 4
 #endif
 #ifndef ATC_SCAN_HORIZON_LDS
-#define ATC_SCAN_HORIZON_LDS 3
+#define ATC_SCAN_HORIZON_LDS 6
 #endif
 template <int W, bool FULL, bool ONE>
 constexpr int scan_horizon() {
@@ -1073,7 +1077,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
                                             const atc_params_t& p, const StepDerived& q, const QScan& qs, int zk, int N,
                                             const LaneIds& d, const Mid& m, LaneState& ls,
                                             EnvState& es, const StepOut& so, int32_t* stp, double* wide_named, float4* pos, float* obs_stage,
-                                            const float* act_next, Float3& a_next, QRates& qr_next, int& scan_skip) {
+                                            const float* act_next, Float3& a_next, QRates& qr_next, int& scan_skip, uint32_t& scan_mask) {
     Aircraft& a = ls.a;
     const bool active = m.active;
     const float x32 = m.x32, y32 = m.y32;
@@ -1118,18 +1122,18 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     if (ATC_RARE(act_next != nullptr)) a_next = *at<Float3>(act_next, times12(i));
     float min_d2 = 1e30f;
     float margin = 1e30f;  // min over partners of max(d^2 - sep^2, |dh| - sep_ft): conflict iff negative
-    // Multi-step launches of the fast variant: inside a scan horizon (scan_skip > 0) no pair of this wavefront can have lost its
-    // separation — the step runs without the scan; otherwise the scan also establishes the next horizon.
+    // Multi-step launches of the fast variant (scan horizon, see scan_horizon_limits): a FULL scan asks with the horizon thresholds
+    // and notes which partner batches hold a pair inside them (`flagged`); for the next kHorizon steps (scan_skip > 0) only those
+    // batches can hold a pair that lost its separation — they alone are scanned, with the exact minima, and nothing at all when
+    // none was flagged.
     constexpr int kHorizon = scan_horizon<W, FULL, ONE>();
     constexpr bool kHZ = kHorizon > 0;
     const ScanLimits lim = {qs.sep2, qs.sep_ft, kHZ ? qs.sep2_h : qs.sep2, kHZ ? qs.sep_ft_h : qs.sep_ft};
-    bool unsafe = false;
-    bool scan_now = W > 1 && !(ATC_ABLATE & 2);
-    if (kHZ && scan_skip > 0) {
-        scan_skip -= 1;
-        scan_now = false;
-    }
-    if (scan_now) {
+    const bool in_horizon = kHZ && scan_skip > 0;             // wave-uniform
+    const uint32_t batches = in_horizon ? scan_mask : ~0u;
+    if (in_horizon) scan_skip -= 1;
+    uint32_t flagged = 0u;
+    if (W > 1 && !(ATC_ABLATE & 2) && batches != 0u) {
         float xs = x32;
         if (!m.plain) xs = active ? x32 : 1e18f;
         const float sep2 = qs.sep2;
@@ -1138,8 +1142,11 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
 #endif                        // wave-uniform tests): 12.1 vs 10.1 us per fused step at 65 536 x 16, 2.9 vs 2.6 at 8 192 x 16 — rejected
         if (W == 16 && !FULL && !ATC_SCAN16_MARGIN) {
             int conf = 0;
-            if (ATC_SCAN16_FORM) NearScan16<1, kHZ>::run(xs, y32, a.h, lim, conf, unsafe);
+            bool unsafe = false;
+            if (ATC_SCAN16_FORM && kHZ && !in_horizon) NearScan16<1, true>::run(xs, y32, a.h, lim, conf, unsafe);
+            else if (ATC_SCAN16_FORM) NearScan16<1, false>::run(xs, y32, a.h, lim, conf, unsafe);
             else NearScan16H<1>::run(xs, y32, a.h, sep2, qs.sep_ft, conf);
+            flagged = unsafe ? ~0u : 0u;   // (one "batch": the rotations are not tracked one by one)
             margin = conf ? -1.0f : margin;
         } else if (W == 16) {
             PairScan16<1, FULL>::run(xs, y32, a.h, sep2, qs.sep_ft, min_d2, margin);
@@ -1186,8 +1193,12 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             // operations per partner, no lane mask, no scalar mask arithmetic — and runs the mask form only when some lane lost its
             // separation.  In a dense 64-aircraft env that is almost every step: 4 096 x 64 8.85 vs 7.8 us single steps, 5.3-5.6 vs 5.2
             // fused, 32 768 x 64 38.4 vs 36.6 — profiles/r05_experiments.txt: ab_m.)
+            // thresholds of this scan: the horizon's in a full scan, the minima themselves inside a horizon (and where there is none)
+            const float t2 = in_horizon ? lim.sep2 : lim.sep2_h, tf = in_horizon ? lim.sep_ft : lim.sep_ft_h;
 #pragma unroll 1   // (fully unrolled, the 2 H compare masks stay live together: 140-220 spilled SGPRs)
             for (int d0 = H - U + 1; d0 >= 1; d0 -= U) {
+                const int batch = (d0 - 1) / U;   // partners d0 .. d0 + U - 1
+                if (kHZ && !((batches >> batch) & 1u)) continue;   // wave-uniform: nobody inside the thresholds when the horizon began
                 v2f qx[U / 2], qy[U / 2], qh[U / 2];
 #pragma unroll
                 for (int u = 0; u < U / 2; ++u) {
@@ -1211,17 +1222,17 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
                         // (two ballots anded as scalars: the compare masks themselves — a ballot of the anded predicate is
                         // materialised per lane and compared again)
                         // kHZ: the horizon thresholds (scan_horizon_limits) — a superset of the pairs that lost their separation
-                        mk[2 * u] = __builtin_amdgcn_ballot_w64(d2[0] < lim.sep2_h) & __builtin_amdgcn_ballot_w64(fabsf(dh[0]) < lim.sep_ft_h);
-                        mk[2 * u + 1] = __builtin_amdgcn_ballot_w64(d2[1] < lim.sep2_h) & __builtin_amdgcn_ballot_w64(fabsf(dh[1]) < lim.sep_ft_h);
+                        mk[2 * u] = __builtin_amdgcn_ballot_w64(d2[0] < t2) & __builtin_amdgcn_ballot_w64(fabsf(dh[0]) < tf);
+                        mk[2 * u + 1] = __builtin_amdgcn_ballot_w64(d2[1] < t2) & __builtin_amdgcn_ballot_w64(fabsf(dh[1]) < tf);
                     } else {
-                        mk[2 * u] = __builtin_amdgcn_ballot_w64(d2[0] < lim.sep2_h);
-                        mk[2 * u + 1] = __builtin_amdgcn_ballot_w64(d2[1] < lim.sep2_h);
+                        mk[2 * u] = __builtin_amdgcn_ballot_w64(d2[0] < t2);
+                        mk[2 * u + 1] = __builtin_amdgcn_ballot_w64(d2[1] < t2);
                         if ((mk[2 * u] | mk[2 * u + 1]) != 0ull) {   // wave-uniform
                             const float* q0 = own + d0 + 2 * u;
                             const v2f dh = hs2 - v2f{q0[2 * P], q0[2 * P + 1]};
                             dhk[u] = dh;
-                            mk[2 * u] &= __builtin_amdgcn_ballot_w64(fabsf(dh[0]) < lim.sep_ft_h);
-                            mk[2 * u + 1] &= __builtin_amdgcn_ballot_w64(fabsf(dh[1]) < lim.sep_ft_h);
+                            mk[2 * u] &= __builtin_amdgcn_ballot_w64(fabsf(dh[0]) < tf);
+                            mk[2 * u + 1] &= __builtin_amdgcn_ballot_w64(fabsf(dh[1]) < tf);
                         }
                     }
                     if (FULL) {   // diagnostic minimum separation: the partner needs the VALUE -> LDS float minimum
@@ -1238,8 +1249,8 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
 #pragma unroll
                 for (int j = 1; j < U; ++j) any |= mk[j];
                 if (ATC_RARE(any != 0ull)) {   // some pair of this batch is inside the thresholds
-                    if (kHZ) {   // ... the horizon's: no step is skipped after this one; now the exact question for this batch
-                        unsafe = true;
+                    if (kHZ && !in_horizon) {   // ... the horizon's: the batch stays on the list; now the exact question for it
+                        flagged |= 1u << batch;
                         any = 0ull;
 #pragma unroll
                         for (int j = 0; j < U; ++j) {
@@ -1271,10 +1282,11 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (kHZ) {
+        if (kHZ && !in_horizon) {
             // the horizon's premises (scan_horizon_limits): no aircraft faster than 300 kt, altitudes of ordinary magnitude (a NaN fails)
             const uint64_t odd = __builtin_amdgcn_ballot_w64(a.v > kVMaxFix) | __builtin_amdgcn_ballot_w64(!(fabsf(a.h) < kScanHMax));
-            scan_skip = (unsafe || odd != 0ull) ? 0 : kHorizon;
+            scan_skip = (odd != 0ull) ? 0 : kHorizon;
+            scan_mask = flagged;
         }
     }
     ATC_STAMP_B(2);
@@ -1648,7 +1660,8 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     uint64_t refused_blk = 0ull;  // LAT: which lanes' speed / altitude / heading targets of the current block are refused or beyond range
     bool refused_known = false;
     bool all_active = false, mask_dirty = true;
-    int scan_skip = 0;   // wave-uniform: steps the separation scan may still be left out for (step_part_b: scan horizon)
+    int scan_skip = 0;          // wave-uniform: steps left in the separation scan's horizon (step_part_b) ...
+    uint32_t scan_mask = 0u;    // ... and the partner batches that have to be scanned inside it
     QRates qr_next = q.r;   // the rate group of the coming step (multi-step launches fetch it one step ahead, see step_part_b)
     if (!ONE && !LAT) {
         int zn;
@@ -1775,7 +1788,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             act_t += (size_t)BN * 3;
             if (step + 1 < n_steps) act_next = act_t;
         }
-        const bool quiet = step_part_b<W, FULL, ONE, LAT>(Kl, gl, pl, q, qs, zk, N, dl, m, ls, es, so, stats_l, st.phi_wide, pos, obs_stage, act_next, nxt, qr_next, scan_skip);
+        const bool quiet = step_part_b<W, FULL, ONE, LAT>(Kl, gl, pl, q, qs, zk, N, dl, m, ls, es, so, stats_l, st.phi_wide, pos, obs_stage, act_next, nxt, qr_next, scan_skip, scan_mask);
         if (ATC_RARE(!quiet)) mask_dirty = true;
         if (kDecodeOnce && act_next) tg = decode_targets(QGET(r), nxt);
         act = nxt;

@@ -43,6 +43,24 @@ def algorithmic_bytes_per_env_step(n, fused_steps=1, hold=1):
     return (44 + 40.0 / fused_steps + 12.0 / hold) * n + 13
 
 
+def store_only_reference(B, N, T):
+    """What a launch that ONLY WRITES the fused launch's outputs takes on this box, measured now (tools/ubench/write_bw.hip, a
+    separate executable built by build(); boxes of one pool differ by 25 % on it): the ideal write stream, the launch's store pattern
+    alone ([T][B][N][10] rows, flags, reward, done), and that pattern with 400 FMAs and one gather per lane-step.  A side record."""
+    import json
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "atc-reinforcement-learning_amd", "atc_hip", "ubench_write_bw")
+    if N != 16 or not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "--json", str(B), str(T)], capture_output=True, text=True, timeout=120)
+        rec = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:   # noqa: BLE001 — a reference figure, never a reason to lose the bench line
+        return {"error": repr(e)}
+    rec["source"] = "tools/ubench/write_bw.hip --json %d %d" % (B, T)
+    return rec
+
+
 def _time_oracle(n_aircraft, B, threads, seconds_target, scn=None):
     import numpy as np
     from envs.atc import scenarios
@@ -820,6 +838,12 @@ def main():
                                                "hbm_frac": fb * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                                "traffic": traffic_entry(B, N, Tf, False)[0], "parity_gate": fused_gate}
             del ro
+            torch.cuda.synchronize(dev)
+            so = store_only_reference(B, N, Tf)
+            if so is not None:
+                so["fused_launch_us"] = us * Tf
+                so["fused_over_store_pattern"] = us * Tf / so["store_pattern_us_per_launch"]
+                line["config"]["fused_rollout"]["store_only_reference"] = so
             if held_launchers is not None:
                 # the same loop without the held-action promise (every launch reads the last-action record): a side record
                 def run_plain(n):

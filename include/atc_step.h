@@ -282,8 +282,9 @@ typedef struct atc_params {
  * (300 / 3600) dt nm (+ one position count per axis); its altitude moves by at most 15 dt ft up / 41 dt ft down (+ half an ulp).  A
  * pair with  d >= |sep_nm| + n (600 / 3600) dt  or  |dh| >= sep_ft + n 56 dt  (+ slack: 1e-5 relative + 1e-3 nm / 1 ft, hundreds of
  * times the fp32 evaluation error) therefore cannot be in conflict during the next n steps, whatever the actions.  Multi-step launches
- * (atc_rollout, atc_rollout_hold) that do not report min_sep use this: a wavefront that finds no pair inside those thresholds —
- * and no aircraft above 300 kt, no altitude beyond 2^17 ft in magnitude or NaN — leaves the scan out for the next n steps; an env
+ * (atc_rollout, atc_rollout_hold) of envs of more than 16 aircraft that do not report min_sep use this: a full scan notes which
+ * groups of partners hold a pair inside those thresholds, and for the next n steps only those groups are scanned (none: no scan) —
+ * unless an aircraft is above 300 kt or an altitude is beyond 2^17 ft in magnitude or NaN (then every step scans in full); an env
  * that is reset inside the launch ends the horizon of its wavefront.  tests/test_hip_edge_cases.py
  * (test_scan_horizon_on_the_fastest_closing_courses) drives pairs at exactly these closing rates through every phase of a horizon. */
 #define ATC_V_FIX_SHIFT 23

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -76,6 +77,50 @@ __global__ void __launch_bounds__(256) k_pattern(float* obs, unsigned short* fla
     }
 }
 
+// The step kernel also LOADS once per step (the lookup-grid gather: 4 bytes per lane from a table that lives in the L2s) and has to
+// wait for the result before it can finish the step.  On gfx9 loads and stores share ONE in-order counter (vmcnt): waiting for a
+// load that was issued AFTER the previous step's stores means waiting for those stores to be acknowledged too.
+//   PIPE = false: gather(t) issued after stores(t - 1) — the step kernel's order (the gather needs step t's position)
+//   PIPE = true : gather(t + 1) issued BEFORE stores(t): its wait leaves the younger stores outstanding
+template <bool PIPE, int FMAS>
+__global__ void __launch_bounds__(256) k_pattern_ld(float* obs, unsigned short* flags, float* reward, unsigned char* done,
+                                                    const float* __restrict__ table, unsigned mask, int B, int T, float seed) {
+    const unsigned tid = threadIdx.x, ln = tid & 63u;
+    const size_t BN = (size_t)B * 16;
+    const unsigned i = blockIdx.x * 256u + tid;
+    const unsigned wave_first = blockIdx.x * 256u + (tid & ~63u);
+    float x = seed + (float)tid, y = seed * 0.5f;
+    unsigned h = i * 2654435761u;
+    float g = 0.0f;
+    if (PIPE) g = table[(h >> 8) & mask];
+    for (int t = 0; t < T; ++t) {
+        if (!PIPE) {
+            asm volatile("" ::: "memory");
+            g = table[(h >> 8) & mask];
+        }
+#pragma unroll 16
+        for (int k = 0; k < FMAS; ++k) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x) : "v"(y));
+        x += g;   // the wait
+        asm volatile("" : "+v"(x));
+        h = h * 1664525u + 1013904223u;
+        if (PIPE) {
+            g = table[(h >> 8) & mask];
+            asm volatile("" ::: "memory");
+        }
+        char* ob = reinterpret_cast<char*>(obs) + ((size_t)t * BN + wave_first) * 40;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned idx = (unsigned)j * 64u + ln;
+            if (idx < 160u) __builtin_nontemporal_store(v4f{x, y, (float)t, (float)idx}, reinterpret_cast<v4f*>(ob + idx * 16u));
+        }
+        __builtin_nontemporal_store((unsigned short)t, flags + (size_t)t * BN + i);
+        if ((tid & 15u) == 0) {
+            reward[(size_t)t * B + (i >> 4)] = x;
+            done[(size_t)t * B + (i >> 4)] = (unsigned char)(t & 1);
+        }
+    }
+}
+
 template <typename F>
 static double time_us(F launch, int reps) {
     hipEvent_t a, b;
@@ -98,7 +143,38 @@ static double time_us(F launch, int reps) {
     return best;
 }
 
-int main() {
+// --json B T: three figures for bench.py's record of the fused launch (one JSON line): the ideal write stream, the launch's store
+// pattern alone, and the pattern with 400 FMAs and one gather per lane-step (the step's instruction count and its one load)
+static int json_mode(int B, int T) {
+    const int N = 16;
+    const size_t BN = (size_t)B * N;
+    const size_t obs_bytes = BN * 40 * T, flag_bytes = BN * 2 * T, rew_bytes = (size_t)B * 4 * T, done_bytes = (size_t)B * T;
+    const size_t total = obs_bytes + flag_bytes + rew_bytes + done_bytes;
+    float *obs, *reward, *table;
+    unsigned short* flags;
+    unsigned char* done;
+    const unsigned tmask = (1u << 20) - 1u;
+    CHECK(hipMalloc(&obs, obs_bytes));
+    CHECK(hipMalloc(&flags, flag_bytes));
+    CHECK(hipMalloc(&reward, rew_bytes));
+    CHECK(hipMalloc(&done, done_bytes));
+    CHECK(hipMalloc(&table, (size_t)(tmask + 1) * 4));
+    CHECK(hipMemset(table, 0, (size_t)(tmask + 1) * 4));
+    const size_t n16 = obs_bytes / 16;
+    const unsigned grid = (unsigned)(BN / 256);
+    const int reps = 10;
+    const double stream = time_us([&] { hipLaunchKernelGGL(k_stream<false>, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, reinterpret_cast<v4f*>(obs), n16, 1.0f); }, reps);
+    const double pattern = time_us([&] { hipLaunchKernelGGL((k_pattern<true, 0>), dim3(grid), dim3(256), 0, 0, obs, flags, reward, done, B, T, 1.0f); }, reps);
+    const double loaded = time_us([&] { hipLaunchKernelGGL((k_pattern_ld<false, 400>), dim3(grid), dim3(256), 0, 0, obs, flags, reward, done, table, tmask, B, T, 1.0f); }, reps);
+    printf("{\"envs\": %d, \"aircraft\": %d, \"T\": %d, \"output_bytes_per_launch\": %zu, \"stream_tb_per_s\": %.3f, "
+           "\"store_pattern_us_per_launch\": %.1f, \"store_pattern_tb_per_s\": %.3f, "
+           "\"store_pattern_400_fma_1_gather_us_per_launch\": %.1f}\n",
+           B, N, T, total, obs_bytes / stream / 1e6, pattern, total / pattern / 1e6, loaded);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc >= 4 && std::string(argv[1]) == "--json") return json_mode(atoi(argv[2]), atoi(argv[3]));
     const int B = 65536, N = 16, T = 20;
     const size_t BN = (size_t)B * N;
     const size_t obs_bytes = BN * 40 * T, flag_bytes = BN * 2 * T, rew_bytes = (size_t)B * 4 * T, done_bytes = (size_t)B * T;
@@ -142,5 +218,14 @@ int main() {
     PAT(true, 200, "step-launch pattern + 200 dependent FMAs per lane-step");
     PAT(true, 300, "step-launch pattern + 300 dependent FMAs per lane-step");
     PAT(true, 400, "step-launch pattern + 400 dependent FMAs per lane-step");
+    float* table;
+    const unsigned tmask = (1u << 20) - 1u;   // 4 MB of floats: resident in every XCD's L2
+    CHECK(hipMalloc(&table, (size_t)(tmask + 1) * 4));
+    CHECK(hipMemset(table, 0, (size_t)(tmask + 1) * 4));
+#define PATL(PIPE, F, LABEL) report(LABEL, time_us([&] { hipLaunchKernelGGL((k_pattern_ld<PIPE, F>), dim3(grid), dim3(256), 0, 0, obs, flags, reward, done, table, tmask, B, T, 1.0f); }, reps), total)
+    PATL(false, 300, "pattern + 300 FMAs + gather(t) issued after stores(t-1)");
+    PATL(true, 300, "pattern + 300 FMAs + gather(t+1) issued before stores(t)");
+    PATL(false, 400, "pattern + 400 FMAs + gather(t) issued after stores(t-1)");
+    PATL(true, 400, "pattern + 400 FMAs + gather(t+1) issued before stores(t)");
     return 0;
 }
