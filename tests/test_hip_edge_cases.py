@@ -645,7 +645,7 @@ def test_wide_headings_in_host_mapped_state():
     map_env.close()
 
 
-def closing_course_formations(comp, N, phases=16):
+def closing_course_formations(comp, N, phases=16, pairs=True):
     """States and (held) actions for test_scan_horizon_on_the_fastest_closing_courses: [B][N] x (x, y, h, phi, v), [B][N][3].
     B = 4 kinds of pair x `phases` gaps x the envs of one wavefront (each wavefront holds one kind at one gap)."""
     from oracle import oracle as O
@@ -672,7 +672,7 @@ def closing_course_formations(comp, N, phases=16):
     act = np.zeros((B, N, 3), np.float32)
     st[:, :, 0], st[:, :, 1], st[:, :, 2], st[:, :, 3], st[:, :, 4] = px, py, 30000.0, 0.0, 250.0   # the formation flies north at 250 kt
     act[:, :, 0], act[:, :, 1], act[:, :, 2] = 0.5, hold_h, -1.0
-    for e in range(B):
+    for e in range(B if pairs else 0):
         kind, gap = (e // G) % 4, (e // (4 * G)) % phases
         if kind in (0, 1):      # head-on along the x axis, at 300 kt / from 356 kt (the speed format's limit)
             v = 300.0 if kind == 0 else 356.0
@@ -742,3 +742,76 @@ def test_scan_horizon_on_the_fastest_closing_courses(N):
         assert len([1 for k, _ in conflict_steps if k == kind]) >= 10, (kind, sorted(conflict_steps))
     one.close()
     roll.close()
+
+
+@pytest.mark.parametrize("N", [64, 32, 40])
+def test_state_written_between_launches_of_large_envs(N):
+    """Nothing about the separation scan may be carried from launch to launch behind the caller's back (the scan horizon lives inside
+    a multi-step launch only; a variant that kept it in the state between single-step launches was measured and not shipped:
+    profiles/r05_experiments.txt, ab_s19): an aircraft placed next to another one between two steps, a multi-step launch in between,
+    a separation minimum changed in the parameters — every step gives the oracle's flags."""
+    torch = _torch()
+    from atc_hip.vec_env import AtcVecEnv
+    from atc_hip import layout as L
+    from envs.atc import scenarios
+    from oracle import oracle as O
+    scn = scenarios.LOWWDense()
+    comp = scenarios.compile_scenario(scn)
+    # every env starts as the formation alone: everybody on a lattice point, north-bound at 250 kt
+    st, act, G = closing_course_formations(comp, 64 if N == 40 else N, phases=4, pairs=False)
+    st, act = st[:, :N], act[:, :N]
+    B = st.shape[0]
+    env = AtcVecEnv(B, N, scenario=scn, auto_reset=True, seed=3)
+    orc = O.OracleEnv(comp, B, N, O.make_params(auto_reset=True, seed=3), np.float32)
+
+    def place(e, k, *state):
+        env.set_state(e, k, *state)
+        orc.set_state(e, k, *state)
+
+    for e in range(B):
+        for k in range(N):
+            place(e, k, *st[e, k])
+    a = torch.as_tensor(act).cuda()
+    seen = {"conflict": 0}
+
+    def step(n=1, rollout=False):
+        for _ in range(n):
+            if rollout:
+                out = env.rollout(a[None], hold=1)
+                fl = out["flags"][0]
+            else:
+                fl = env.step(a)[3]["flags"]
+            orc.step(act)
+            f = fl.cpu().numpy().astype(np.uint32).reshape(B, N)
+            assert np.array_equal(f, orc.flags), np.argwhere(f != orc.flags)[:5]
+            seen["conflict"] += int(((orc.flags & L.F_CONFLICT) != 0).sum())
+
+    step(3)                                   # (nobody is near anybody)
+    assert seen["conflict"] == 0 and not (orc.flags != 0).any(), "the formation is not clear of the sector's own flags"
+    x, y = orc.x.reshape(B, N), orc.y.reshape(B, N)
+    place(0, 5, x[0, 9] + 0.5, y[0, 9], 30000.0, 0.0, 250.0)            # an aircraft appears half a mile from another one
+    step(1)
+    assert seen["conflict"] >= 2
+    c0 = seen["conflict"]
+    step(2)
+    x, y = orc.x.reshape(B, N), orc.y.reshape(B, N)
+    place(1, 7, x[1, 20] + 2.9, y[1, 20], 30000.0, 0.0, 250.0)
+    step(1)
+    assert seen["conflict"] >= c0 + 2
+    c0 = seen["conflict"]
+    step(3)
+    # multi-step launches in between, then an aircraft placed again
+    step(2, rollout=True)
+    x, y = orc.x.reshape(B, N), orc.y.reshape(B, N)
+    place(2, 3, x[2, 30] - 1.0, y[2, 30] + 1.0, 30000.0, 0.0, 250.0)
+    step(1)
+    assert seen["conflict"] >= c0 + 2
+    c0 = seen["conflict"]
+    step(3)
+    # the separation minimum grows beyond the lattice pitch: every env is in conflict at once
+    for p in (env.params, orc.params):
+        p.sep_nm = 5.5
+    env.refresh_params()
+    step(1)
+    assert seen["conflict"] > c0 + B
+    env.close()
