@@ -121,6 +121,25 @@ __global__ void __launch_bounds__(256) k_pattern_ld(float* obs, unsigned short* 
     }
 }
 
+// The observation rows in an ENV-major layout [B][T][N][10] (each env's T steps contiguous: 12.8 KB per env, a workgroup's 16 envs
+// 200 KB) instead of the time-major [T][B][N][10]: is the many-fronts penalty the layout's?
+__global__ void __launch_bounds__(256) k_pattern_env_major(float* obs, int B, int T, float seed) {
+    const unsigned tid = threadIdx.x, ln = tid & 63u;
+    const unsigned env0 = (blockIdx.x * 256u + (tid & ~63u)) >> 4;   // first env of the wavefront
+    float x = seed + (float)tid, y = seed * 0.5f;
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned idx = (unsigned)j * 64u + ln;
+            if (idx < 160u) {
+                const unsigned env = idx / 40u, w = idx - env * 40u;
+                char* p = reinterpret_cast<char*>(obs) + ((size_t)(env0 + env) * T + t) * 640 + w * 16u;
+                __builtin_nontemporal_store(v4f{x, y, (float)t, (float)idx}, reinterpret_cast<v4f*>(p));
+            }
+        }
+    }
+}
+
 template <typename F>
 static double time_us(F launch, int reps) {
     hipEvent_t a, b;
@@ -211,6 +230,7 @@ int main(int argc, char** argv) {
     PATX(1, false, obs_bytes, "  observation rows only");
     PATX(3, false, obs_bytes + flag_bytes, "  observation rows + flags");
     PATX(5, false, obs_bytes + rew_bytes + done_bytes, "  observation rows + reward / done");
+    report("  observation rows only, ENV-major layout [B][T][N][10]", time_us([&] { hipLaunchKernelGGL(k_pattern_env_major, dim3(grid), dim3(256), 0, 0, obs, B, T, 1.0f); }, reps), obs_bytes);
     PATX(7, true, total, "step-launch pattern, XCD-contiguous tiles");
     PATX(1, true, obs_bytes, "  observation rows only, XCD-contiguous tiles");
     PATX(5, true, obs_bytes + rew_bytes + done_bytes, "  observation rows + reward / done, XCD-contiguous tiles");
