@@ -61,3 +61,17 @@ def test_driver_command_line_parses():
     for flag in ("--gpus", "--steps", "--warmup"):
         assert 'add_argument("%s"' % flag in src
     assert 'default=ENVS_PER_GPU' in src and "ENVS_PER_GPU = 65536" in src.replace("65_536", "65536")
+
+
+def test_store_only_reference_never_costs_the_bench_line():
+    """bench.py runs tools/ubench/write_bw.hip (built by build()) next to the fused launch to say what a store-only launch takes on
+    the box at hand.  It is a side record: other shapes than 16 aircraft have none, and a failing executable (here: no GPU) comes back
+    as an error note, never as an exception."""
+    b = _bench()
+    assert b.store_only_reference(65536, 1, 20) is None
+    rec = b.store_only_reference(4096, 16, 2)
+    exe = os.path.join(ROOT, "atc-reinforcement-learning_amd", "atc_hip", "ubench_write_bw")
+    if not os.path.exists(exe):
+        assert rec is None
+    else:
+        assert isinstance(rec, dict) and ("error" in rec or rec["envs"] == 4096)
