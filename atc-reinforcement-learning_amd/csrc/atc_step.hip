@@ -275,14 +275,15 @@ struct PairScan16<9, WANT_MIN> {
 //    thresholds (ScanLimits: sep2_h >= sep2, sep_ft_h >= sep_ft, scan_horizon_limits): a pair outside them cannot lose its separation
 //    during the next `horizon` steps, a wavefront in which no pair is inside them skips the scan of those steps (k_step: scan_skip),
 //    one that has such a pair asks the exact question for that rotation behind the same wave-uniform test.
-//    Why it looked promising: in the BASELINE workloads aircraft enter the sector stacked over the same few entry points — 27 of a
-//    wavefront's 480 pairs are inside the horizontal minimum at any time (CPU oracle, random actions held for 20 steps), so the first
-//    form takes its branch in nearly every rotation —, and a wavefront of four 16-aircraft envs is clear for 4 more steps in half of
-//    its steps.  What came out (profiles/r05_experiments.txt: ab_s1 .. ab_s6, five boxes): 91 instead of 99 M vector instructions per
+//    Why it looked promising: a wavefront of four 16-aircraft envs is clear of every pair for 4 more steps in half of its steps (CPU
+//    oracle on the BASELINE workload, random actions held for 20 steps; the near pairs — 27 of a wavefront's 480 on average — sit in
+//    the envs that were reset a few steps ago, whose aircraft still fly stacked over their entry points: at slot distances that are
+//    multiples of the number of entry points, so that only one rotation in eight takes the first form's branch).
+//    What came out (profiles/r05_experiments.txt: ab_s1 .. ab_s6, five boxes): 91 instead of 99 M vector instructions per
 //    T = 20 launch at 65 536 x 16 and NO time (12.0-12.4 us per step either way; even with the scan compiled out altogether: that
 //    launch is bound by its stores, tools/ubench/write_bw.hip), +0.5 % on the single-step launch, +2-4 % on the lone wavefronts of
 //    8 192 x 16 (there the scan hides the lookup gather's round trip; its masks and branches do not).  The horizon ships for the
-//    LDS-staged widths (N > 16), where the scan is 45 % of the step: 4 096 x 64 fused 4.1-4.3 vs 5.1-5.6 us.
+//    LDS-staged widths (N > 16), where the scan is 45 % of the step: 4 096 x 64 fused 3.4-3.95 vs 5.1-5.6 us (the per-batch form below).
 // Conflict = (d^2 < sep^2) & (|dh| < sep_ft), the oracle's expression, in both.
 struct ScanLimits {
     float sep2, sep_ft;       // the separation minima (squared horizontal, vertical)
