@@ -140,6 +140,33 @@ __global__ void __launch_bounds__(256) k_pattern_env_major(float* obs, int B, in
     }
 }
 
+// Store flavours on the observation rows of the pattern (gfx950 cache-policy bits: nt, sc0, sc1 — MI355X_MICROARCH.md: plain / sc0 / nt
+// keep the line in the XCD's L2, sc1 / sc0 sc1 write it through): FLAVOUR 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 sc0 sc1 nt
+template <int FLAVOUR>
+__global__ void __launch_bounds__(256) k_rows_flavour(float* obs, int B, int T, float seed) {
+    const unsigned tid = threadIdx.x, ln = tid & 63u;
+    const size_t BN = (size_t)B * 16;
+    const unsigned wave_first = blockIdx.x * 256u + (tid & ~63u);
+    float x = seed + (float)tid, y = seed * 0.5f;
+    for (int t = 0; t < T; ++t) {
+        char* ob = reinterpret_cast<char*>(obs) + ((size_t)t * BN + wave_first) * 40;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned idx = (unsigned)j * 64u + ln;
+            if (idx < 160u) {
+                const v4f v = {x, y, (float)t, (float)idx};
+                v4f* p = reinterpret_cast<v4f*>(ob + idx * 16u);
+                if (FLAVOUR == 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+                if (FLAVOUR == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+                if (FLAVOUR == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+                if (FLAVOUR == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+                if (FLAVOUR == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+                if (FLAVOUR == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+            }
+        }
+    }
+}
+
 template <typename F>
 static double time_us(F launch, int reps) {
     hipEvent_t a, b;
@@ -231,6 +258,13 @@ int main(int argc, char** argv) {
     PATX(3, false, obs_bytes + flag_bytes, "  observation rows + flags");
     PATX(5, false, obs_bytes + rew_bytes + done_bytes, "  observation rows + reward / done");
     report("  observation rows only, ENV-major layout [B][T][N][10]", time_us([&] { hipLaunchKernelGGL(k_pattern_env_major, dim3(grid), dim3(256), 0, 0, obs, B, T, 1.0f); }, reps), obs_bytes);
+#define FLV(F, LABEL) report(LABEL, time_us([&] { hipLaunchKernelGGL((k_rows_flavour<F>), dim3(grid), dim3(256), 0, 0, obs, B, T, 1.0f); }, reps), obs_bytes)
+    FLV(0, "  observation rows only, store flavour: plain");
+    FLV(1, "  observation rows only, store flavour: nt");
+    FLV(2, "  observation rows only, store flavour: sc1");
+    FLV(3, "  observation rows only, store flavour: sc0 sc1");
+    FLV(4, "  observation rows only, store flavour: sc1 nt");
+    FLV(5, "  observation rows only, store flavour: sc0 sc1 nt");
     PATX(7, true, total, "step-launch pattern, XCD-contiguous tiles");
     PATX(1, true, obs_bytes, "  observation rows only, XCD-contiguous tiles");
     PATX(5, true, obs_bytes + rew_bytes + done_bytes, "  observation rows + reward / done, XCD-contiguous tiles");
