@@ -1192,7 +1192,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             const float sep_ft = qs.sep_ft;
             // (Round 5, rejected: a PRE-PASS that minimum-accumulates the margin max(d^2 - sep^2, |dh| - sep_ft) per lane — 5.5 vector
             // operations per partner, no lane mask, no scalar mask arithmetic — and runs the mask form only when some lane lost its
-            // separation.  In a dense 64-aircraft env that is almost every step: 4 096 x 64 8.85 vs 7.8 us single steps, 5.3-5.6 vs 5.2
+            // separation.  The pre-pass costs more than the scalar mask arithmetic it saves: 4 096 x 64 8.85 vs 7.8 us single steps, 5.3-5.6 vs 5.2
             // fused, 32 768 x 64 38.4 vs 36.6 — profiles/r05_experiments.txt: ab_m.)
             // thresholds of this scan: the horizon's in a full scan, the minima themselves inside a horizon (and where there is none)
             const float t2 = in_horizon ? lim.sep2 : lim.sep2_h, tf = in_horizon ? lim.sep_ft : lim.sep_ft_h;
