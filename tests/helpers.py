@@ -174,6 +174,84 @@ def replay_wide(fx, make_backend, obs_tol, state_tol, rew_tol, max_envs=4096):
     return total
 
 
+def replay_wide_interleaved(fx, make_backend, N, obs_tol, state_tol, rew_tol, max_envs=1024, chunk=1):
+    """The reference pins MULTI-aircraft envs too, where the extension's own rules are switched off: with a separation minimum of 0
+    nobody is ever in conflict, and with the reference's episode rule (ATC_M_KEEP_ACTIVE: no hand-over, any terminal aircraft ends the
+    episode) an env of N aircraft IS N reference episodes flown side by side on one clock.  So N episodes of the wide fixture — same
+    configuration, same starting time step, similar length — become the N aircraft of one env, each fed its own recorded actions, and
+    every aircraft must reproduce its episode's record step by step (flags exact; sampled observation and state within the bars of
+    replay_wide), the env the sums: reward = the episodes' rewards added up, actions_taken = their counters added up, done = any of
+    them done — until the shortest episode ends.  That is the lane -> aircraft mapping, the per-env reductions and the shared clock
+    of the batched step checked against the reference over whole episodes, which the one-aircraft replays cannot see.
+
+    make_backend(scen, dt, shaping, normalize, discrete, B, N) -> object with place(b, k, init_state, init_last_action),
+    set_timesteps(b, t) and step(actions[B, N, 3]) -> (obs[B, N, 10], reward[B], done[B], flags[B, N], actions_taken[B],
+    state[B, N, 5]).  chunk > 1: the backend's rollout(actions[chunk, B, N, 3]) flies `chunk` steps per call (a multi-step launch)
+    and returns the same tuple with a leading step axis, counters and state as they are after the LAST step of the chunk.
+    Returns (aircraft-steps compared, envs flown)."""
+    total = envs = 0
+    for (scen, dt, shaping, normalize, discrete), eps in fx.groups().items():
+        half = 0.5 * compiled(scen).norm_max.astype(np.float64)
+        by_t0 = {}
+        for ep in eps:
+            by_t0.setdefault(ep["init_timesteps"], []).append(ep)
+        packs = []
+        for t0, ge in by_t0.items():
+            ge = sorted(ge, key=lambda ep: ep["steps"])
+            packs += [ge[i:i + N] for i in range(0, len(ge) - N + 1, N)]   # (a remainder of fewer than N episodes stays out)
+        for lo in range(0, len(packs), max_envs):
+            pk = packs[lo:lo + max_envs]
+            B = len(pk)
+            be = make_backend(scen, dt, shaping, normalize, discrete, B, N)
+            for b, env_eps in enumerate(pk):
+                be.set_timesteps(b, env_eps[0]["init_timesteps"])
+                for k, ep in enumerate(env_eps):
+                    be.place(b, k, ep["init_state"], ep["init_last_action"])
+            starts = np.array([[ep["start"] for ep in env_eps] for env_eps in pk])       # [B, N]
+            length = np.array([min(ep["steps"] for ep in env_eps) for env_eps in pk])     # the env's episode: its shortest
+            def rows_at(t):
+                live = t < length                                                          # [B]
+                return live, np.where(live[:, None], starts + t, starts)                  # (finished envs replay a harmless row)
+
+            def compare(t, live, rows, obs, rew, done, flags, acts, state):
+                lr = rows[live]                                                            # [L, N]
+                assert np.array_equal(np.asarray(flags)[live].astype(np.uint8), fx.flags[lr]), (scen, N, t)
+                assert np.array_equal(np.asarray(done)[live].astype(bool), fx.done[lr].astype(bool).any(axis=1)), (scen, N, t)
+                gw = fx.reward[lr]
+                assert np.all(np.abs(np.asarray(rew, dtype=np.float64)[live] - gw.sum(axis=1))
+                              <= (rew_tol + 1e-7) * np.maximum(1.0, np.abs(gw)).sum(axis=1)), (scen, N, t)
+                si = fx.samp_index[lr]
+                has = si >= 0
+                if has.any():
+                    go = fx.obs[si[has]].astype(np.float64)
+                    tol = (obs_tol if normalize else obs_tol * half) * np.ones((int(has.sum()), 10))
+                    assert np.all(np.abs(np.asarray(obs, dtype=np.float64)[live][has] - go) <= tol), (scen, N, t)
+                if acts is not None:
+                    assert np.array_equal(np.asarray(acts)[live], fx.actions_taken[lr].sum(axis=1)), (scen, N, t)
+                    if has.any():
+                        gs = fx.state[si[has]]
+                        assert np.all(np.abs(np.asarray(state, dtype=np.float64)[live][has] - gs) <= state_tol * np.maximum(1.0, np.abs(gs))), (scen, N, t)
+                return int(live.sum()) * N
+
+            T = int(length.max())
+            t = 0
+            while t < T:
+                if chunk == 1:
+                    live, rows = rows_at(t)
+                    total += compare(t, live, rows, *be.step(fx.action[rows].astype(np.float32)))
+                    t += 1
+                    continue
+                lr = [rows_at(t + c) for c in range(chunk)]
+                obs, rew, done, flags, acts, state = be.rollout(np.stack([fx.action[r].astype(np.float32) for _, r in lr]))
+                for c, (live, rows) in enumerate(lr):
+                    last = c == chunk - 1
+                    total += compare(t + c, live, rows, obs[c], rew[c], done[c], flags[c], acts if last else None, state if last else None)
+                t += chunk
+            envs += B
+            be.close()
+    return total, envs
+
+
 # ---------------------------------------------------------------------------------------------- extension known answers
 # Hand-computed outcomes of ONE step for the build-defined multi-aircraft semantics (SURVEY 8a-ext: separation, hand-over,
 # override order, per-aircraft rewards summed per env), with reward shaping OFF so that every reward is a small exact sum:

@@ -328,6 +328,56 @@ class _HipLockstep:
         self.env.close()
 
 
+class _HipInterleaved:
+    def __init__(self, scen, dt, shaping, normalize, discrete, B, N):
+        from atc_hip.vec_env import AtcVecEnv
+        from envs.atc import model
+        sp = model.SimParameters(dt, reward_shaping=shaping, normalize_state=normalize, discrete_action_space=discrete)
+        self.env = AtcVecEnv(B, N, sim_parameters=sp, scenario=H.make_scenario(scen), auto_reset=False, spawn="lattice",
+                             keep_active=True, sep_nm=0.0)
+        self.B, self.N = B, N
+
+    def place(self, b, k, init_state, init_last_action):
+        self.env.set_state(b, k, *init_state)
+        self.env.set_last_action(b, k, init_last_action)
+
+    def set_timesteps(self, b, t):
+        self.env.timesteps[b] = t
+
+    def _state(self):
+        e = self.env
+        torch = e.torch
+        st = torch.stack([e.x, e.y, e.h.double(), e.phi, e.v], dim=1).cpu().numpy().reshape(self.B, self.N, 5)
+        return e.actions_taken.cpu().numpy(), st
+
+    def step(self, actions):
+        obs, rew, done, info = self.env.step(actions)
+        acts, st = self._state()
+        return (obs.cpu().numpy().reshape(self.B, self.N, 10), rew.cpu().numpy(), done.cpu().numpy(),
+                info["flags"].cpu().numpy().reshape(self.B, self.N), acts, st)
+
+    def rollout(self, actions):
+        out = self.env.rollout(self.env.torch.as_tensor(actions).to(self.env.device), hold=1)
+        T = actions.shape[0]
+        acts, st = self._state()
+        return (out["obs"].cpu().numpy().reshape(T, self.B, self.N, 10), out["reward"].cpu().numpy(), out["done"].cpu().numpy(),
+                out["flags"].cpu().numpy().reshape(T, self.B, self.N), acts, st)
+
+    def close(self):
+        self.env.close()
+
+
+@pytest.mark.parametrize("N,chunk", [(16, 1), (64, 1), (5, 1), (16, 10), (64, 10), (32, 5)])
+def test_reference_episodes_as_the_aircraft_of_one_env(N, chunk):
+    """helpers.replay_wide_interleaved through the batched kernels: N reference episodes of g9 are the N aircraft of one env
+    (separation minimum 0, the reference's episode rule), single steps and multi-step launches (the 32- / 64-aircraft ones under the
+    separation-scan horizon) — the multi-aircraft step checked against the REFERENCE over whole episodes."""
+    _torch()
+    fx = H.WideFixture()
+    n, envs = H.replay_wide_interleaved(fx, _HipInterleaved, N, obs_tol=1e-5, state_tol=1e-5, rew_tol=1e-5, chunk=chunk)
+    assert envs >= 8 and n > 100000, (n, envs)
+
+
 def test_wide_fixture_batched():
     """G9: 650 963 reference steps (LOWW / random entries / Simple / UnitTest / Dyadic, dt 1-2-5, discrete, shaping and
     normalisation off, >= 50 wins / MVA busts / timeouts, episodes stepped on past done) replayed through the batched
