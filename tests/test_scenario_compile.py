@@ -250,18 +250,21 @@ def test_compile_is_fast_cached_and_byte_identical(tmp_path, monkeypatch):
     scn = scenarios.LOWW()
     args = ([(m.area_as_list, m.height) for m in scn.mvas], (scn.runway.x, scn.runway.y, scn.runway.h, scn.runway.phi_from_runway),
             [(e.x, e.y, e.phi, list(e.levels)) for e in scn.entrypoints])
+    # (CPU time of this process, not wall time: the bound must hold on a box that is busy with something else — the compiler is
+    # single-threaded array code, so the two agree on an idle one: 0.7 s / 3 ms)
     cold = []
-    for k in range(2):
+    for k in range(3):
         monkeypatch.setenv("ATC_HIP_CACHE", str(tmp_path / ("c%d" % k)))
-        t = time.perf_counter()
+        t = time.process_time()
         c = S.compile_sector(*args, grid_cell=0.0625)
-        cold.append(time.perf_counter() - t)
+        cold.append(time.process_time() - t)
         assert (_sha(c.blob32), _sha(c.blob64)) == R04_BLOBS[0.0625]
+    monkeypatch.setenv("ATC_HIP_CACHE", str(tmp_path / "c1"))
     warm = []
     for k in range(3):
-        t = time.perf_counter()
+        t = time.process_time()
         c = S.compile_sector(*args, grid_cell=0.0625)
-        warm.append(time.perf_counter() - t)
+        warm.append(time.process_time() - t)
         assert _sha(c.blob32) == R04_BLOBS[0.0625][0]
     assert (_sha(c.blob32), _sha(c.blob64)) == R04_BLOBS[0.0625]       # (the float64 master fills its grid in on first use)
     print("cold", cold, "warm", warm)
