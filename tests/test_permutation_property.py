@@ -92,3 +92,48 @@ def test_slot_permutation_fused(N, full):
         assert torch.equal(getattr(b, name), getattr(a, name)[idx]), name
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("N", [8, 16, 32, 64])
+def test_conflict_flags_against_a_brute_force_over_the_state(N):
+    """A second oracle-independent check of the separation scans — and of the scan HORIZON of the multi-step launches, which leaves
+    scans out: the rule itself (README.md:51: 3 nm AND 1 000 ft between two aircraft under control) evaluated in numpy over the state
+    a launch leaves behind.  Envs of scattered aircraft (nobody is handed over, episodes do not restart: the traffic keeps crossing)
+    fly launches of 1 .. 15 steps, so that the last step of a launch — the one whose positions can be read back — falls on every
+    phase of a horizon; its CONFLICT flags must be exactly the brute force's, for every aircraft whose closest call is not within
+    rounding of a minimum."""
+    import torch
+    from atc_hip import layout as L
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import scenarios
+    B = {8: 64, 16: 48, 32: 32, 64: 24}[N]
+    scn = scenarios.LOWWDense() if N > 16 else scenarios.LOWW(random_entrypoints=True)
+    a = AtcVecEnv(B, N, scenario=scn, auto_reset=False, spawn="lattice", keep_active=True)
+    g = torch.Generator(device="cpu").manual_seed(77 + N)
+    # scattered over 50 x 65 nm and twelve flight levels 1 000 ft apart: a pair in a hundred is near at any time — most partner batches
+    # of a 64-aircraft env are clear when a horizon begins, a few are not
+    rnd = lambda lo, hi: lo + (hi - lo) * torch.rand(B * N, generator=g)   # noqa: E731
+    x, y, lvl, phi, v = rnd(10, 60), rnd(10, 75), torch.randint(0, 12, (B * N,), generator=g), rnd(0, 360), rnd(150, 290)
+    for i in range(B * N):
+        a.set_state(i // N, i % N, float(x[i]), float(y[i]), 9000.0 + 1000.0 * float(lvl[i]), float(phi[i]), float(v[i]))
+    seen = {"conflict": 0, "clear": 0, "launches": 0}
+    for launch in range(45):
+        T = 1 + launch % 15
+        acts = (torch.rand((1, B, N, 3), generator=g) * 2 - 1).to(a.device).expand(T, B, N, 3).contiguous()
+        out = a.rollout(acts, hold=1)
+        fl = out["flags"][T - 1].cpu().numpy().reshape(B, N)
+        x, y, h = (t.cpu().numpy().astype(np.float64).reshape(B, N) for t in (a.x, a.y, a.h))
+        d = np.hypot(x[:, :, None] - x[:, None, :], y[:, :, None] - y[:, None, :])
+        dh = np.abs(h[:, :, None] - h[:, None, :])
+        eye = np.eye(N, dtype=bool)[None]
+        conflict = ((d < 3.0) & (dh < 1000.0) & ~eye).any(axis=2)
+        # aircraft with a partner within rounding of a minimum (fp32 positions / squared distance against float64 here) stay out
+        edge = ((np.abs(d - 3.0) < 1e-3) & (dh < 1000.5) | (np.abs(dh - 1000.0) < 0.05) & (d < 3.001)) & ~eye
+        sure = ~edge.any(axis=2)
+        got = (fl & L.F_CONFLICT) != 0
+        assert np.array_equal(got[sure], conflict[sure]), (launch, T, np.argwhere((got != conflict) & sure)[:5])
+        seen["conflict"] += int(conflict[sure].sum())
+        seen["clear"] += int((~conflict[sure]).sum())
+        seen["launches"] += 1
+    assert seen["conflict"] > 200 and seen["clear"] > 5 * seen["conflict"] and seen["launches"] == 45, seen
+    a.close()
