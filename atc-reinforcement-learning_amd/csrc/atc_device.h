@@ -10,9 +10,7 @@
 
 #include "../../include/atc_step.h"
 
-#ifndef ATC_MVA_BATCH
 #define ATC_MVA_BATCH 2  // edge records fetched per L2 round trip in dirty lookup cells (8 VGPRs each)
-#endif
 
 namespace atc {
 
@@ -121,20 +119,15 @@ __device__ __forceinline__ void advance(const QKin& q, int phi_fix, uint32_t v_f
     else asm("v_fma_f64 %0, %1, %2, %3" : "=v"(t) : "v"(kd), "s"(q.neg_half_turn), "v"(pd));
     const double u = t * t;
     auto fma_c = [](double a, double b, double c) { return VG ? __builtin_fma(a, b, c) : fma_sc(a, b, c); };
-#ifndef ATC_KIN_ABL
-#define ATC_KIN_ABL 0   // developer-only timing ablations of the float64 kinematics (bit mask); the shipped build uses 0
-#endif
     // (the two Horner chains are written interleaved: each step waits for the previous one of its own chain only)
     double sp = fma_c(u, q.s5, q.s4), cp = fma_c(u, q.c5, q.c4);
-    if (!(ATC_KIN_ABL & 1)) {
-        sp = fma_c(sp, u, q.s3);
-        cp = fma_c(cp, u, q.c3);
-        sp = fma_c(sp, u, q.s2);
-        cp = fma_c(cp, u, q.c2);
-        sp = fma_c(sp, u, q.s1);
-        cp = fma_c(cp, u, q.c1);
-        sp = fma_c(sp, u, q.s0);
-    }
+    sp = fma_c(sp, u, q.s3);
+    cp = fma_c(cp, u, q.c3);
+    sp = fma_c(sp, u, q.s2);
+    cp = fma_c(cp, u, q.c2);
+    sp = fma_c(sp, u, q.s1);
+    cp = fma_c(cp, u, q.c1);
+    sp = fma_c(sp, u, q.s0);
     const double cs = __builtin_fma(cp, u, 1.0);
     const double sn = sp * t;
     const double dneg = VG ? (double)v_fix * q.dist_neg : mul_sc((double)v_fix, q.dist_neg);
@@ -373,11 +366,6 @@ __device__ __forceinline__ int mva_resolve(const float* __restrict__ K, const fl
         const bool dirty = cell.x > 0.0f;
         int res = code - 1;               // clean cell: polygon + 1 (0 = outside the airspace), height
         float h = dirty ? 0.0f : cell.y;
-#ifdef ATC_ABLATE_WALK
-        if (dirty) { res = 1; h = 3000.0f; }  // developer-only timing ablation: dirty cells answered without their records
-        *height = h;
-        return res;
-#endif
         // Some lane's cell is cut by a border (wave-uniform test; nine wavefronts in ten at the headline size).  SPLIT cells
         // (atc_hip/scenario.py:_line_split — four dirty cells in five) are answered by their LINE record: the line, a margin that
         // covers every rounding of the reference's x-intersection, and the answer of either side — one 32-byte fetch, one fma, two

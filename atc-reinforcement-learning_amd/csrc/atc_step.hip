@@ -70,50 +70,14 @@ static int fail_hip(hipError_t e, const char* what) {
         if (_e != hipSuccess) return fail_hip(_e, #expr); \
     } while (0)
 
-#ifndef ATC_WIDE_WAIT_INSIDE
-#define ATC_WIDE_WAIT_INSIDE 1
-#endif
-#ifndef ATC_WABL
-#define ATC_WABL 0   // developer-only timing ablations of the WIDE-heading code (bit mask: 1 the 64-bit move, 32 / 64 the range tests
-#endif               // of target / state): profiles/r05_experiments.txt ab1, ab3; the shipped build uses 0
-#ifndef ATC_LAT_CARRY_REFUSED
-#define ATC_LAT_CARRY_REFUSED 1   // latency-bound instantiation: the refused-target mask of a held action block is carried across its steps
-#endif
-#ifndef ATC_CARRY_REFUSED_ALL
-#define ATC_CARRY_REFUSED_ALL 1   // the throughput multi-step kernels carry the mask as well (r05: 65 536 x 16 fused -2 %); 0: developer A/B
-#endif
-#ifndef ATC_LAT_DECODE_ONCE
-#define ATC_LAT_DECODE_ONCE 1     // ... and so are the decoded targets (three vector registers it has to spare)
-#endif
-#ifndef ATC_BLOCK
-#define ATC_BLOCK 256
-#endif
+// Rejected / default-off variants of rounds 1-5 (scan forms, ablation masks, store orders, ...) were moved out of this file in
+// round 6: profiles/experiments/ holds the patch that restores them and one line per measurement.
 // Wave-uniform conditions that almost never hold (or almost always): the hint moves the rare block out of the step's straight
 // line, so that the common path FALLS THROUGH its branches instead of jumping over code (a taken branch refills the
 // instruction buffer: ~20 cycles to a wavefront alone on its SIMD, tools/ubench/valu_rates.hip).
-#ifndef ATC_BRANCH_HINTS
-#define ATC_BRANCH_HINTS 1
-#endif
-#if ATC_BRANCH_HINTS
 #define ATC_RARE(x) __builtin_expect(!!(x), 0)
 #define ATC_USUAL(x) __builtin_expect(!!(x), 1)
-#else
-#define ATC_RARE(x) (x)
-#define ATC_USUAL(x) (x)
-#endif
-#ifndef ATC_NT_LOAD
-#define ATC_NT_LOAD 0   // non-temporal action loads: measured SLOWER (36.0 vs 31.9 us)
-#endif
-#ifndef ATC_NT_STORE
-#define ATC_NT_STORE 1  // non-temporal observation / flag stores (write-once streams): 30.7 vs 31.9 us
-#endif
-constexpr int kBlock = ATC_BLOCK;
-#ifndef ATC_ABLATE
-#define ATC_ABLATE 0  // developer-only timing ablations (bit mask, see uses); the shipped build always uses 0
-#endif
-#ifndef ATC_LOOP_OPAQUE
-#define ATC_LOOP_OPAQUE 0  // bits: 1 lane ids, 2 sector pointers — see the step loop of k_step (off since the kernarg re-reads)
-#endif
+constexpr int kBlock = 256;
 #ifndef ATC_TRACE
 #define ATC_TRACE 0  // developer-only: per-wavefront s_memtime stamps at phase boundaries (pointer smuggled in params)
 #endif
@@ -137,40 +101,13 @@ constexpr int kBlock = ATC_BLOCK;
 #define ATC_TRACE_PARAM
 #define ATC_TRACE_PASS(x)
 #endif
-#ifndef ATC_NEAR_FIRST_LDS
-#define ATC_NEAR_FIRST_LDS 0   // N > 16 fast variant: horizontal test first, altitude plane only for close pairs: 459 vs 503 VALU
-                               // per wavefront at 32 768 x 64 but no faster (39.9 vs 40.2 us; 4 096 x 64 8.36 vs 8.24): off
-#endif
-#ifndef ATC_OBS_DIRECT
-#define ATC_OBS_DIRECT 0   // developer A/B: bit 0 single-step, bit 1 multi-step launches store the observation rows per lane (no LDS transpose)
-#endif
-#ifndef ATC_OBS_FIRST_W1
-#define ATC_OBS_FIRST_W1 1   // single-step launches of one-aircraft envs: observation and shaping BEFORE the MVA resolve (no scan to
-                             // cover the cell gather there): 65 536 x 1 6.65-6.87 vs 6.99-7.04 us (profiles/r03_experiments.txt)
-#endif
-#ifndef ATC_LOOP_SKIP_BOOK
-#define ATC_LOOP_SKIP_BOOK 1  // multi-step launches: no last-action bookkeeping on the steps that repeat an action block
-#endif
-#ifndef ATC_LOOP_REREAD_ARGS
-// which by-value arguments a multi-step launch re-reads from the kernarg segment inside its loop (see StepArgs) — bits:
-// 1 parameters, 2 derived constants, 4 output pointers, 8 state pointers (needed again after the loop).  Chosen per width by
-// measurement (profiles/r02_experiments.txt): the state pointers for the DPP widths, nothing for the LDS-scan widths (the
-// mode word goes through an opaque zero in either case).
-#ifdef ATC_REREAD_MASK   // developer A/B builds: one mask for every width
-#define ATC_LOOP_REREAD_ARGS(W) (ATC_REREAD_MASK)
-#else
-#define ATC_LOOP_REREAD_ARGS(W) ((W) >= 32 ? 0 : 8)
-#endif
-#endif
-#ifndef ATC_GRID_CAP
-#define ATC_GRID_CAP 8   // workgroups per CU before the reset / observe / query kernels grid-stride
-#endif
-#ifndef ATC_MIN_WAVES
-#define ATC_MIN_WAVES 4  // waves per SIMD the single-step kernel is register-budgeted for (<= 128 VGPRs; it needs 55-72)
-#endif
-#ifndef ATC_MIN_WAVES_LOOP
+// Multi-step launches of the DPP widths re-read the STATE pointers from the kernarg segment after the step loop (see StepArgs)
+// instead of carrying them across it; the LDS-scan widths name them (measured per width: profiles/r02_experiments.txt).
+constexpr bool loop_rereads_state(int W) { return W < 32; }
+#define ATC_GRID_CAP 8        // workgroups per CU before the reset / observe / query kernels grid-stride
+#define ATC_MIN_WAVES 4       // waves per SIMD the single-step kernel is register-budgeted for (<= 128 VGPRs; it needs 55-72)
 #define ATC_MIN_WAVES_LOOP 6  // multi-step launches: <= 80 VGPRs.  Without the bound the allocator keeps literal constants and
-#endif                        // other loop invariants in registers across the step loop (86-99 VGPRs, 4-5 waves per SIMD)
+                              // other loop invariants in registers across the step loop (86-99 VGPRs, 4-5 waves per SIMD)
 
 // ---------------------------------------------------------------------------------------------------------------
 // wavefront-group helpers (groups of W consecutive lanes, W a power of two <= 64)
@@ -266,25 +203,11 @@ template <bool WANT_MIN>
 struct PairScan16<9, WANT_MIN> {
     static __device__ __forceinline__ void run(float, float, float, float, float, float&, float&) {}
 };
-// The same scan for launches that do not report the minimum separation (the fast variant), two forms:
-//  * NearScan16H (rounds 3-5, shipped: ATC_SCAN16_FORM = 0) asks the horizontal question first — two rotated subtracts, a multiply, an
-//    fma and one compare into a lane mask — and fetches the altitude and hands the result back to the partner only behind a
-//    wave-uniform test of that mask.
-//  * NearScan16 (round 5, developer A/B: ATC_SCAN16_FORM = 1) asks the whole question — horizontal AND vertical — on the common path
-//    as two compares whose lane masks are anded on the scalar unit (seven vector operations per rotation), optionally with HORIZON
-//    thresholds (ScanLimits: sep2_h >= sep2, sep_ft_h >= sep_ft, scan_horizon_limits): a pair outside them cannot lose its separation
-//    during the next `horizon` steps, a wavefront in which no pair is inside them skips the scan of those steps (k_step: scan_skip),
-//    one that has such a pair asks the exact question for that rotation behind the same wave-uniform test.
-//    Why it looked promising: a wavefront of four 16-aircraft envs is clear of every pair for 4 more steps in half of its steps (CPU
-//    oracle on the BASELINE workload, random actions held for 20 steps; the near pairs — 27 of a wavefront's 480 on average — sit in
-//    the envs that were reset a few steps ago, whose aircraft still fly stacked over their entry points: at slot distances that are
-//    multiples of the number of entry points, so that only one rotation in eight takes the first form's branch).
-//    What came out (profiles/r05_experiments.txt: ab_s1 .. ab_s6, five boxes): 91 instead of 99 M vector instructions per
-//    T = 20 launch at 65 536 x 16 and NO time (12.0-12.4 us per step either way; even with the scan compiled out altogether: that
-//    launch is bound by its stores, tools/ubench/write_bw.hip), +0.5 % on the single-step launch, +2-4 % on the lone wavefronts of
-//    8 192 x 16 (there the scan hides the lookup gather's round trip; its masks and branches do not).  The horizon ships for the
-//    LDS-staged widths (N > 16), where the scan is 45 % of the step: 4 096 x 64 fused 3.4-3.95 vs 5.1-5.6 us (the per-batch form below).
-// Conflict = (d^2 < sep^2) & (|dh| < sep_ft), the oracle's expression, in both.
+// The same scan for launches that do not report the minimum separation (the fast variant): the horizontal question first — two
+// rotated subtracts, a multiply, an fma and one compare into a lane mask — and the altitude is fetched and the result handed back to
+// the partner only behind a wave-uniform test of that mask.  Conflict = (d^2 < sep^2) & (|dh| < sep_ft), the oracle's expression.
+// (Round 5 tried the three-dimensional question per rotation plus a scan horizon for this width: fewer instructions, no time —
+// profiles/experiments/README.md: scan16_form1.  The horizon ships for the LDS-staged widths only.)
 struct ScanLimits {
     float sep2, sep_ft;       // the separation minima (squared horizontal, vertical)
     float sep2_h, sep_ft_h;   // the same with the horizon's closing distance added (== the minima where no horizon is used)
@@ -295,27 +218,6 @@ __device__ __forceinline__ int row_ror_i(int v) {
     // otherwise materialise for it)
     return __builtin_amdgcn_update_dpp(v, v, 0x120 + D, 0xf, 0xf, false);
 }
-template <int D, bool HZ>
-struct NearScan16 {
-    static __device__ __forceinline__ void run(float xs, float y, float h, const ScanLimits& L, int& conf, bool& unsafe) {
-        const float dx = xs - row_ror<D>(xs), dy = y - row_ror<D>(y), dh = h - row_ror<D>(h);
-        const float d2 = fmaf(dx, dx, dy * dy);
-        const uint64_t m = __builtin_amdgcn_ballot_w64(d2 < (HZ ? L.sep2_h : L.sep2)) &
-                           __builtin_amdgcn_ballot_w64(fabsf(dh) < (HZ ? L.sep_ft_h : L.sep_ft));
-        if (ATC_RARE(m != 0ull)) {
-            unsafe = true;
-            const int c = (d2 < L.sep2 && fabsf(dh) < L.sep_ft) ? 1 : 0;
-            conf |= c;
-            if (D < 8) conf |= row_ror_i<16 - D>(c);   // the partner's copy of the same pair (D = 8 is its own inverse)
-        }
-        NearScan16<D + 1, HZ>::run(xs, y, h, L, conf, unsafe);
-    }
-};
-template <bool HZ>
-struct NearScan16<9, HZ> {
-    static __device__ __forceinline__ void run(float, float, float, const ScanLimits&, int&, bool&) {}
-};
-// the rounds-3/4 form (horizontal question first, altitude behind the wave-uniform test): developer A/B, ATC_SCAN16_FORM = 0
 template <int D>
 struct NearScan16H {
     static __device__ __forceinline__ void run(float xs, float y, float h, float sep2, float sep_ft, int& conf) {
@@ -326,7 +228,7 @@ struct NearScan16H {
             const float dh = h - row_ror<D>(h);
             const int c = (near && fabsf(dh) < sep_ft) ? 1 : 0;
             conf |= c;
-            if (D < 8) conf |= row_ror_i<16 - D>(c);
+            if (D < 8) conf |= row_ror_i<16 - D>(c);   // the partner's copy of the same pair (D = 8 is its own inverse)
         }
         NearScan16H<D + 1>::run(xs, y, h, sep2, sep_ft, conf);
     }
@@ -392,21 +294,10 @@ __device__ __forceinline__ uint32_t times40(uint32_t i) {
     asm("v_lshl_add_u32 %0, %1, 2, %1" : "=v"(t) : "v"(i));   // 5 i
     return t << 3;
 }
+// write-once output streams (observation, flag words) are stored non-temporal: 30.7 vs 31.9 us at 65 536 x 16 (r01)
 template <typename T>
 __device__ __forceinline__ void stream_store(T* p, T v) {
-#if ATC_NT_STORE
     __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
-template <typename T>
-__device__ __forceinline__ T stream_load(const T* p) {
-#if ATC_NT_LOAD
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
 }
 __device__ __forceinline__ void store_obs(float* __restrict__ dst, const float* o) {
     // 10 floats = 40 B per aircraft: 8-byte aligned -> five 8-byte stores
@@ -496,10 +387,7 @@ struct alignas(16) QScan {    // second half: separation scan, override chain
 struct alignas(16) QNorm {
     float a[ATC_OBS_DIM], b[ATC_OBS_DIM];   // ATC_C_NORM_A / ATC_C_NORM_B
 };
-#ifndef ATC_Q_ALIGN
-#define ATC_Q_ALIGN 64
-#endif
-struct alignas(ATC_Q_ALIGN) StepDerived {
+struct alignas(64) StepDerived {
     QRates r;
     QKin k;               // float64 heading kinematics + distance scale (32 words)
     QGrid g;
@@ -700,19 +588,11 @@ __device__ __forceinline__ T kernarg_reread(size_t byte_off, int opaque_zero) {
     // for scalar loads (a byte-wise copy from an address with an opaque term became per-lane vector loads).
     typedef __attribute__((address_space(4))) const char* karg_ptr;
     typedef __attribute__((address_space(4))) const T* typed_ptr;
-#ifndef ATC_KERNARG_OPAQUE_PTR
-#define ATC_KERNARG_OPAQUE_PTR 1
-#endif
-#if ATC_KERNARG_OPAQUE_PTR
-    // Round 4: the BASE POINTER is made opaque (an empty asm tied to the step's opaque zero), the member's offset stays an
-    // immediate of the scalar load.  Rounds 2-3 added `opaque_zero * alignof(T)` to the address: five scalar instructions of
-    // 64-bit address arithmetic per re-read (shift, negate, add with carry — one chain per alignment), ~40 per wavefront-step.
+    // The BASE POINTER is made opaque (an empty asm tied to the step's opaque zero), the member's offset stays an immediate of
+    // the scalar load (adding `opaque_zero * alignof(T)` to the address cost five scalar instructions per re-read).
     karg_ptr base = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(base) : "s"(opaque_zero));
     return *(typed_ptr)(base + byte_off);
-#else
-    return *(typed_ptr)((karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + byte_off + (size_t)opaque_zero * alignof(T));
-#endif
 #else
     T v;
     __builtin_memset(&v, 0, sizeof(T));
@@ -736,12 +616,10 @@ __device__ __forceinline__ int wide_view(bool plain, int phi, double* named, int
     if (ATC_RARE(!plain)) {
         if ((__builtin_amdgcn_ballot_w64(phi == INT32_MAX) | __builtin_amdgcn_ballot_w64(phi == INT32_MIN)) != 0ull) {
             if (is_wide(phi)) r = *at<int>(wide_base<ONE>(named, zk), i * 32u + (16u + 4u * WORD));   // (B N 40 < 4 GiB is guaranteed)
-#if ATC_WIDE_WAIT_INSIDE
             // The load is WAITED FOR here, inside the rare block: left pending, the join below would carry "r may be in flight" into
             // the step's straight line, where the first use of r waits for every earlier vector load as well (one counter, in
             // order) — e.g. the lookup-cell records requested ahead of the observation arithmetic that is meant to cover them.
             asm volatile("" : "+v"(r));
-#endif
         }
     }
     return r;
@@ -807,11 +685,6 @@ __device__ __forceinline__ LaneIds make_ids(uint32_t slot0, int B, int N) {
     d.e = d.env_valid ? (int)(slot / W) : B - 1;  // clamped: loads stay in bounds, results are never stored
     d.lane_valid = d.env_valid && d.k < N;
     d.i = d.lane_valid ? (uint32_t)d.e * (uint32_t)N + (uint32_t)d.k : (uint32_t)B * (uint32_t)N - 1u;
-    if (ATC_ABLATE & 64) {  // developer-only "no HBM traffic" timing: every workgroup works on the first 256 aircraft
-        d.i &= 255u;
-        d.e &= 15;
-        d.slot0 = 0;
-    }
     d.wave_full = (N == W) && (slot0 + (uint32_t)(d.tid | 63) < slots);
     return d;
 }
@@ -886,15 +759,14 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     // (the latency-bound multi-step instantiation carries this mask across the steps of a held action block: the targets do not
     // change inside one — six compares and five scalar ORs fewer on a lone wavefront's chain)
     uint64_t refused = refused_blk;
-    if (!((LAT || ATC_CARRY_REFUSED_ALL) && ATC_LAT_CARRY_REFUSED) || !refused_known) {
+    if (!refused_known) {
         refused = __builtin_amdgcn_ballot_w64(tv < kVMinFix) | __builtin_amdgcn_ballot_w64(tv > kVMaxFix) |
                   __builtin_amdgcn_ballot_w64(th < h_min) | __builtin_amdgcn_ballot_w64(th > h_max) |
-                  ((ATC_WABL & 32) ? 0ull : (__builtin_amdgcn_ballot_w64(tp == INT32_MAX) | __builtin_amdgcn_ballot_w64(tp == INT32_MIN)));
+                  (__builtin_amdgcn_ballot_w64(tp == INT32_MAX) | __builtin_amdgcn_ballot_w64(tp == INT32_MIN));
         refused_blk = refused;
     }
     uint64_t special = refused;
-    if ((ATC_WABL & 64) && !all_active) special |= __builtin_amdgcn_ballot_w64(!active);
-    else if (!all_active) {
+    if (!all_active) {
         const int hi = book ? max(a.phi, ls.la_p) : a.phi, lo = book ? min(a.phi, ls.la_p) : a.phi;
         special |= __builtin_amdgcn_ballot_w64(!active) | __builtin_amdgcn_ballot_w64(hi == INT32_MAX) | __builtin_amdgcn_ballot_w64(lo == INT32_MIN);
     }
@@ -956,7 +828,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
             phi_k = phi_new;
             // (lanes without an aircraft compute on a clamped copy of the batch's last one: they must not write its side record)
             const bool wide = d.lane_valid && (is_wide(tp) || is_wide(a.phi) || (book && is_wide(ls.la_p)));
-            if (!(ATC_WABL & 1) && ATC_RARE(__builtin_amdgcn_ballot_w64(wide) != 0ull)) {
+            if (ATC_RARE(__builtin_amdgcn_ballot_w64(wide) != 0ull)) {
                 if (wide) {
                     double* w = at<double>(wide_base<ONE>(wide_named, zk), d.i * 32u);
                     bool lim;
@@ -998,7 +870,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
         asm("" : "+v"(v_move));   // (keeps the select on the 32-bit counts: the compiler moved it behind the conversion, onto both halves of the double)
     }
     // (the kinematics are periodic in the heading: a WIDE one goes in wrapped — read back from the side record's scratch word)
-    if (!(ATC_ABLATE & 32)) advance<LAT>(qk, phi_k, v_move, es.t, a.x, a.y);
+    advance<LAT>(qk, phi_k, v_move, es.t, a.x, a.y);
     ATC_STAMP_TOP(trace_row, 3);
     m.x32 = pos_to_real(q.pos_neg_k, qg.pos_x0, a.x);
     m.y32 = pos_to_real(q.pos_neg_k, qg.pos_y0, a.y);
@@ -1019,7 +891,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
 // the areas whose bounds meet it, and almost every wavefront has no candidate at all.
 __device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, const float* __restrict__ grid, int n_areas,
                                                const MvaCell& c, float x, float y, float h) {
-    const int n_noise = (ATC_ABLATE & 256) ? 0 : n_areas;
+    const int n_noise = n_areas;
     uint32_t bits = 0;
     if (ATC_RARE(n_noise > 0)) {
         const uint32_t cand = noise_candidates(grid, c);
@@ -1039,10 +911,7 @@ __device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, con
 // A by-value kernel argument group where it is needed: the single-step kernel names the argument (the compiler places its
 // kernarg load), a multi-step launch re-reads it from the kernarg segment through this step's opaque zero — a scalar load
 // inside the step instead of registers held (and spilled to vector-register lanes) across the whole step loop.
-#ifndef ATC_QGET_REREAD_MIN_W
-#define ATC_QGET_REREAD_MIN_W 1   // developer A/B: multi-step launches of narrower envs name the argument instead of re-reading it
-#endif
-#define QGET(member) ((ONE || LAT || W < ATC_QGET_REREAD_MIN_W) ? q.member : kernarg_reread<decltype(q.member)>(offsetof(StepArgs, q) + offsetof(StepDerived, member), zk))
+#define QGET(member) ((ONE || LAT) ? q.member : kernarg_reread<decltype(q.member)>(offsetof(StepArgs, q) + offsetof(StepDerived, member), zk))
 
 // Separation scan horizon (round 5; scan_horizon_limits).  In a multi-step launch of the fast variant a FULL scan asks its question
 // with thresholds no pair can close within the next `horizon` steps and notes which partner batches (four partner distances of the
@@ -1054,22 +923,10 @@ __device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, con
 // (all 4 096 are resident from the start), and that one skipped least; the batch form 3.8-3.95 for horizons 4 .. 12 (shipped: 6),
 // 8 192 x 32 3.7 vs 4.05.  (A wavefront of four 16-aircraft envs: clear for 4 steps in 50 %, one of its envs reset in 12 % — see
 // NearScan16.)
-#ifndef ATC_SCAN_SKIP
-#define ATC_SCAN_SKIP 1   // developer A/B: 0 = every step scans (the horizon thresholds are then the minima themselves)
-#endif
-#ifndef ATC_SCAN16_FORM
-#define ATC_SCAN16_FORM 0   // 0 = the rounds-3/4 scan of 16-aircraft envs (horizontal question first; no horizon) — shipped; 1 = the
-                            // three-dimensional question per rotation + horizon (NearScan16): developer A/B, see below
-#endif
-#ifndef ATC_SCAN_HORIZON16
-#define ATC_SCAN_HORIZON16 4
-#endif
-#ifndef ATC_SCAN_HORIZON_LDS
 #define ATC_SCAN_HORIZON_LDS 6
-#endif
 template <int W, bool FULL, bool ONE>
 constexpr int scan_horizon() {
-    return (!ATC_SCAN_SKIP || FULL || ONE) ? 0 : (W == 16 ? (ATC_SCAN16_FORM ? ATC_SCAN_HORIZON16 : 0) : W >= 32 ? ATC_SCAN_HORIZON_LDS : 0);
+    return (FULL || ONE) ? 0 : (W >= 32 ? ATC_SCAN_HORIZON_LDS : 0);
 }
 constexpr float kScanHMax = 131072.0f;   // |altitude| below which an altitude step rounds by less than 2^-7 ft (scan_horizon_limits)
 
@@ -1094,26 +951,20 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     // Where the MVA cell (gather issued in the first half) is resolved: after the separation scan for the LDS-staged
     // widths, so that the L2 round trip overlaps the scan; before it for the DPP widths (W <= 16), where keeping the cell
     // in flight across the unrolled scan only costs registers.
-#ifndef ATC_RESOLVE_LATE
-#define ATC_RESOLVE_LATE 1   // resolve the MVA cell after the separation scan from W = 16 up (0: only for the LDS-scan widths):
-                             // 18.5 vs 18.9 us single steps, 11.2 vs 11.4 fused at 65 536 x 16 (profiles/r03_experiments.txt)
-#endif
+    // (from W = 16 up: 18.5 vs 18.9 us single steps, 11.2 vs 11.4 fused at 65 536 x 16, r03; one-aircraft envs have no scan to cover
+    // the gather: there the observation and shaping terms go first — 65 536 x 1 6.65-6.87 vs 6.99-7.04 us single, 3.44 vs 3.51 fused)
     // edge records fetched per L2 round trip in dirty lookup cells: W = 1 is one wavefront per SIMD at any batch size the
     // sector sees (latency-bound, registers to spare): four per trip (65 536 x 1: 7.4 vs 7.7 us single steps, 4.26 vs 4.44 fused);
     // wider envs two (four cost the fused 65 536 x 16 launch 0.5 us per step)
     constexpr int kWalkBatch = (W == 1) ? 4 : ATC_MVA_BATCH;
-#ifndef ATC_OBS_FIRST_W1_LOOP
-#define ATC_OBS_FIRST_W1_LOOP 1   // the same order in multi-step launches of one-aircraft envs: 65 536 x 1 fused 3.44-3.45 vs 3.51 us (r04)
-#endif
-    constexpr bool kResolveAfterScan = ATC_RESOLVE_LATE ? (W >= 16 || (ATC_OBS_FIRST_W1 && W == 1 && (ONE || ATC_OBS_FIRST_W1_LOOP))) : (W >= 32);   // (W = 2 .. 8: the unrolled xor scan with the cell
-                                                                                   // in flight costs 4 - 22 registers)
+    constexpr bool kResolveAfterScan = W >= 16 || W == 1;   // (W = 2 .. 8: the unrolled xor scan with the cell in flight costs 4 - 22 registers)
     WideWords ww = {0, 0};
     if (LAT) ww = wide_words<ONE>(m.plain, a.phi, wide_named, zk, i);
     float mva = 0.0f;
     int pi = 0;
     if (!kResolveAfterScan) {
         float hgt = 0.0f;
-        pi = (ATC_ABLATE & 1) ? 0 : mva_resolve<kWalkBatch>(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt);
+        pi = mva_resolve<kWalkBatch>(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt);
         mva = hgt;   // (0 when outside: mva_resolve leaves the height at 0, atc_gym.py:161)
         fl |= noise_areas(K, grid, qs.n_noise, m.cell, x32, y32, a.h);
     }
@@ -1134,20 +985,13 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     const uint32_t batches = in_horizon ? scan_mask : ~0u;
     if (in_horizon) scan_skip -= 1;
     uint32_t flagged = 0u;
-    if (W > 1 && !(ATC_ABLATE & 2) && batches != 0u) {
+    if (W > 1 && batches != 0u) {
         float xs = x32;
         if (!m.plain) xs = active ? x32 : 1e18f;
         const float sep2 = qs.sep2;
-#ifndef ATC_SCAN16_MARGIN
-#define ATC_SCAN16_MARGIN 0   // developer A/B: the fast variant scans with the branch-free margin form as well (80 VALU, no
-#endif                        // wave-uniform tests): 12.1 vs 10.1 us per fused step at 65 536 x 16, 2.9 vs 2.6 at 8 192 x 16 — rejected
-        if (W == 16 && !FULL && !ATC_SCAN16_MARGIN) {
+        if (W == 16 && !FULL) {
             int conf = 0;
-            bool unsafe = false;
-            if (ATC_SCAN16_FORM && kHZ && !in_horizon) NearScan16<1, true>::run(xs, y32, a.h, lim, conf, unsafe);
-            else if (ATC_SCAN16_FORM) NearScan16<1, false>::run(xs, y32, a.h, lim, conf, unsafe);
-            else NearScan16H<1>::run(xs, y32, a.h, sep2, qs.sep_ft, conf);
-            flagged = unsafe ? ~0u : 0u;   // (one "batch": the rotations are not tracked one by one)
+            NearScan16H<1>::run(xs, y32, a.h, sep2, qs.sep_ft, conf);
             margin = conf ? -1.0f : margin;
         } else if (W == 16) {
             PairScan16<1, FULL>::run(xs, y32, a.h, sep2, qs.sep_ft, min_d2, margin);
@@ -1206,9 +1050,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
                     const float* q0 = own + d0 + 2 * u;
                     qx[u] = v2f{q0[0], q0[1]};
                     qy[u] = v2f{q0[P], q0[P + 1]};
-                    // the fast variant asks the horizontal question first (round 3, like the N = 16 scan): the altitude plane is
-                    // only read for partner pairs some lane of the wavefront is horizontally close to
-                    if (FULL || !ATC_NEAR_FIRST_LDS) qh[u] = v2f{q0[2 * P], q0[2 * P + 1]};
+                    qh[u] = v2f{q0[2 * P], q0[2 * P + 1]};
                 }
                 uint64_t mk[U];   // mk[2 u + w]: distance d0 + 2 u + w
                 v2f d2k[U / 2], dhk[U / 2];   // (kHZ: kept for the exact question behind the wave-uniform test)
@@ -1217,7 +1059,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
                     const v2f dx = xs2 - qx[u], dy = ys2 - qy[u];
                     const v2f d2 = __builtin_elementwise_fma(dx, dx, dy * dy);
                     d2k[u] = d2;
-                    if (FULL || !ATC_NEAR_FIRST_LDS) {
+                    {
                         const v2f dh = hs2 - qh[u];
                         dhk[u] = dh;
                         // (two ballots anded as scalars: the compare masks themselves — a ballot of the anded predicate is
@@ -1225,16 +1067,6 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
                         // kHZ: the horizon thresholds (scan_horizon_limits) — a superset of the pairs that lost their separation
                         mk[2 * u] = __builtin_amdgcn_ballot_w64(d2[0] < t2) & __builtin_amdgcn_ballot_w64(fabsf(dh[0]) < tf);
                         mk[2 * u + 1] = __builtin_amdgcn_ballot_w64(d2[1] < t2) & __builtin_amdgcn_ballot_w64(fabsf(dh[1]) < tf);
-                    } else {
-                        mk[2 * u] = __builtin_amdgcn_ballot_w64(d2[0] < t2);
-                        mk[2 * u + 1] = __builtin_amdgcn_ballot_w64(d2[1] < t2);
-                        if ((mk[2 * u] | mk[2 * u + 1]) != 0ull) {   // wave-uniform
-                            const float* q0 = own + d0 + 2 * u;
-                            const v2f dh = hs2 - v2f{q0[2 * P], q0[2 * P + 1]};
-                            dhk[u] = dh;
-                            mk[2 * u] &= __builtin_amdgcn_ballot_w64(fabsf(dh[0]) < tf);
-                            mk[2 * u + 1] &= __builtin_amdgcn_ballot_w64(fabsf(dh[1]) < tf);
-                        }
                     }
                     if (FULL) {   // diagnostic minimum separation: the partner needs the VALUE -> LDS float minimum
 #pragma unroll
@@ -1291,9 +1123,6 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         }
     }
     ATC_STAMP_B(2);
-#ifndef ATC_OBS_FIRST
-#define ATC_OBS_FIRST 0   // 1: observation and shaping terms BEFORE the lookup cell is resolved (they do not depend on the MVA,
-#endif                    // only obs[5] = h - mva does).  Measured: no gain at any size (profiles/r03_experiments.txt)
     Obs ob;
     float shaping = 0.0f;
     const ObsConst oc = QGET(oc);
@@ -1303,14 +1132,11 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     // Measured per width and launch form (r04, same box, two rounds): single steps of 16-aircraft envs 17.81 vs 18.03 us at
     // 65 536 envs, one-aircraft envs 6.58-6.61 vs 6.60-6.67 single / 3.42 vs 3.47-3.50 fused; NOT the fused 16-aircraft launch
     // (8 B scratch under its 80-register bound: 2.73-2.77 vs 2.66 us at 8 192 envs) and not the 64-aircraft kernels (8.50 vs 8.30).
-#ifndef ATC_MVA_PREFETCH
-#define ATC_MVA_PREFETCH(W, ONE) ((W) == 1 || ((ONE) && (W) == 16))
-#endif
-    constexpr bool kPrefetch = ATC_MVA_PREFETCH(W, ONE) && kResolveAfterScan;
-    constexpr bool kObsFirst = ATC_OBS_FIRST || kPrefetch || (ATC_OBS_FIRST_W1 && W == 1 && (ONE || ATC_OBS_FIRST_W1_LOOP));
+    constexpr bool kPrefetch = (W == 1 || (ONE && W == 16)) && kResolveAfterScan;
+    constexpr bool kObsFirst = kPrefetch || W == 1;
     MvaPre pre;
     if (kPrefetch) pre = mva_prefetch(grid, QGET(g.gh), m.cell);
-    if (kObsFirst && !(ATC_ABLATE & 8)) {
+    if (kObsFirst) {
         // (observation word 3 first, then the heading for the angles — each its own rare look-up for a WIDE heading, before the rest
         // of the observation occupies its registers)
         const WideWords wo = LAT ? ww : wide_words<ONE>(m.plain, a.phi, wide_named, zk, i);   // (ONE test for both words)
@@ -1322,7 +1148,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     // ---- MVA floor (atc_gym.py:146-161), second half ---------------------------------------------------------------------
     if (kResolveAfterScan) {
         float hgt = 0.0f;
-        pi = (ATC_ABLATE & 1) ? 0 : mva_resolve<kWalkBatch>(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt, kPrefetch ? &pre : nullptr);
+        pi = mva_resolve<kWalkBatch>(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt, kPrefetch ? &pre : nullptr);
         mva = hgt;                                 // atc_gym.py:161: mva = 0 outside (mva_resolve leaves the height at 0)
         fl |= noise_areas(K, grid, qs.n_noise, m.cell, x32, y32, a.h);
     }
@@ -1340,7 +1166,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     const uint64_t in_tri = grid ? __builtin_amdgcn_ballot_w64(corridor_candidate(m.cell))
                                  : (__builtin_amdgcn_ballot_w64(x32 >= qs.tri_bbox.x) & __builtin_amdgcn_ballot_w64(x32 <= qs.tri_bbox.z) &
                                     __builtin_amdgcn_ballot_w64(y32 >= qs.tri_bbox.y) & __builtin_amdgcn_ballot_w64(y32 <= qs.tri_bbox.w));
-    const bool quiet = !(ATC_ABLATE & 512) && m.plain &&
+    const bool quiet = m.plain &&
                        (__builtin_amdgcn_ballot_w64(pi < 0) | __builtin_amdgcn_ballot_w64(a.h < mva) | __builtin_amdgcn_ballot_w64(margin < 0.0f) |
                         __builtin_amdgcn_ballot_w64(es.t > qs.timestep_limit) | __builtin_amdgcn_ballot_w64(fl > 0xffffu) | in_tri) == 0ull;
     if (ATC_RARE(!quiet)) {
@@ -1354,7 +1180,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             fl |= conflict ? (uint32_t)ATC_F_CONFLICT : 0u;
         }
         // ---- win / timeout overrides (atc_gym.py:163-173) ---------------------------------------------------------------
-        if (!(ATC_ABLATE & 4) && inside_corridor(K, qs.tri_bbox, x32, y32, a.h, (double)(LAT ? ww.counts : heading_counts<ONE>(m.plain, a.phi, wide_named, zk, i)))) {
+        if (inside_corridor(K, qs.tri_bbox, x32, y32, a.h, (double)(LAT ? ww.counts : heading_counts<ONE>(m.plain, a.phi, wide_named, zk, i)))) {
             int bonus = (qs.timestep_limit - es.t) * 5;
             bonus = bonus < 0 ? 0 : bonus;
             r = (float)(10000 + bonus);
@@ -1374,11 +1200,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     float o[ATC_OBS_DIM];
     float zraw[ATC_OBS_DIM];   // FULL only: raw observation (zeros for handed-over aircraft)
     {
-        if (ATC_ABLATE & 8) {
-#pragma unroll
-            for (int c = 0; c < ATC_OBS_DIM; ++c) ob.o[c] = x32;
-            ob.d_faf = ob.phi_rel_faf = ob.on_gp = y32;
-        } else if (kObsFirst) {
+        if (kObsFirst) {
             ob.o[5] = a.h - mva;
         } else {
             const WideWords wo = LAT ? ww : wide_words<ONE>(m.plain, a.phi, wide_named, zk, i);
@@ -1388,7 +1210,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         }
         // r += pos; r += ang; r += gs (atc_gym.py:179-185, after the override chain) as one addition of the factored sum
         // (value-only, within 1e-5)
-        if ((p.mode & ATC_M_REWARD_SHAPING) && !(ATC_ABLATE & 8)) r += shaping;
+        if (p.mode & ATC_M_REWARD_SHAPING) r += shaping;
         // extension (README.md:62): noise-abatement areas — which ones the aircraft is in was decided next to the MVA lookup
         // (bits 16.. of fl); the penalties are subtracted here, after the shaping terms, in area order.
         if (ATC_RARE(!quiet && __builtin_amdgcn_ballot_w64((fl >> 16) != 0u) != 0ull)) {
@@ -1499,20 +1321,15 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         asm volatile("s_mov_b32 %0, 0" : "=s"(zn));
         qr_next = kernarg_reread<QRates>(offsetof(StepArgs, q) + offsetof(StepDerived, r), zn);
     }
-#ifndef ATC_ACT_WAIT_INSIDE
-#define ATC_ACT_WAIT_INSIDE 1
-#endif
     // The next block's action (requested above, behind the MVA gathers) is WAITED FOR here, in the step that requested it and ahead
     // of this step's stores: left pending across the loop's back edge, "the action may be in flight" reaches the loop header, and the
     // decode at the top of EVERY step waits for every earlier vector-memory operation — one counter, in order — i.e. for the
     // previous step's observation stores to complete.  By now the load has long arrived.
-    if (ATC_ACT_WAIT_INSIDE && ATC_RARE(act_next != nullptr)) asm volatile("" : "+v"(a_next.a), "+v"(a_next.b), "+v"(a_next.c));
+    if (ATC_RARE(act_next != nullptr)) asm volatile("" : "+v"(a_next.a), "+v"(a_next.b), "+v"(a_next.c));
     // ---- observation store: [aircraft][10] rows are 40 B apart, so per-lane stores would scatter 8-byte pieces over 20
     //      cache lines per instruction; a full wavefront instead transposes its 64 x 10 block through LDS and writes 2 560
     //      contiguous bytes as 16-byte stores.
-    if (ATC_ABLATE & 16) {
-        if (d.lane_valid && o[0] == 12345.678f) so.obs[i] = o[1];
-    } else if (ATC_USUAL(d.wave_full && !(ATC_OBS_DIRECT & (ONE ? 1 : 2)))) {
+    if (ATC_USUAL(d.wave_full)) {
         // addresses from threadIdx itself, not from the lane ids a multi-step launch re-derives through an opaque zero: the
         // compiler then knows the ranges (lane < 64: two of the three row tests fold away, 24-bit multiplies suffice) — with
         // the opaque copies it emitted a quarter-rate 64-bit multiply-add per LDS read
@@ -1533,12 +1350,8 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             if (idx < 64u * ATC_OBS_DIM / 4u) {
                 const float4 v = src[idx];
                 float* d4 = at<float>(so.obs, wave_off + idx * 16u);
-#if ATC_NT_STORE
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(d4));
-#else
-                *reinterpret_cast<float4*>(d4) = v;
-#endif
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1584,9 +1397,7 @@ __device__ __forceinline__ void store_env_state(const atc_state_t& st, const Lan
     }
 }
 
-#ifndef ATC_LAT_WAVES
 #define ATC_LAT_WAVES 2   // wavefronts per SIMD the latency-bound instantiation is register-budgeted for (<= 256 VGPRs)
-#endif
 // ONE: single-step launch (T == 1); ALLV: every slot is an aircraft (make_ids); LAT: latency-bound multi-step instantiation (above)
 template <int W, bool FULL, bool ONE, bool ALLV, bool LAT = false>
 __global__ void __launch_bounds__(kBlock, (LAT ? ATC_LAT_WAVES : ONE ? ATC_MIN_WAVES : ((FULL || W <= 8 || W >= 32) ? ATC_MIN_WAVES_LOOP - 1 : ATC_MIN_WAVES_LOOP)))
@@ -1608,11 +1419,9 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     const unsigned long long t_launch = __builtin_amdgcn_s_memtime();
 #endif
     const uint32_t BN = (uint32_t)B * (uint32_t)N;      // host guarantees B*N*40 bytes < 4 GiB: 32-bit lane offsets
-#ifndef ATC_KARG_PREFETCH
 // single-step launches of envs of up to 16 aircraft (r05, same box: 8 192 x 16 5.15 vs 5.34 us, 65 536 x 16 17.53 vs 17.60, 65 536 x 1
 // 6.03 vs 6.13 with the argument preload; 4 096 x 64 8.0 vs 7.8 and the multi-step launches no better: off there)
 #define ATC_KARG_PREFETCH(W, ONE) ((ONE) && (W) <= 16)
-#endif
     int karg_touch = 0;
     if (ATC_KARG_PREFETCH(W, ONE)) {
         // Touch every 64-byte line of the kernarg segment NOW, in one burst of scalar loads: the step reads its ~530 bytes of
@@ -1669,10 +1478,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         asm volatile("s_mov_b32 %0, 0" : "=s"(zn));
         qr_next = kernarg_reread<QRates>(offsetof(StepArgs, q) + offsetof(StepDerived, r), zn);
     }
-#ifndef ATC_LOOP_STATE_WAIT
-#define ATC_LOOP_STATE_WAIT 1
-#endif
-    if (!ONE && ATC_LOOP_STATE_WAIT) {
+    if (!ONE) {
         // The state loads are WAITED FOR here, before the step loop.  Left pending, "a state register may still be in flight" is
         // merged into the loop header from the pre-header, and the compiler guards the first use of each in the loop body with a
         // wait that — one counter for loads and stores, in order — also waits for the PREVIOUS step's stores in every later step.
@@ -1682,18 +1488,6 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         asm volatile("" : "+v"(m_lo), "+v"(m_hi));
         es.amask = (uint64_t)m_lo | ((uint64_t)m_hi << 32);
     }
-#ifndef ATC_LOOP_RUNPTR
-#define ATC_LOOP_RUNPTR 0
-#endif
-    // Developer A/B (r05, rejected): 1 = the four per-step output bases RUN along (one 64-bit scalar add each per step), 2 = computed
-    // from the step and made opaque.  As `base + step * stride` the compiler hoists the per-lane invariant part — three 64-bit per-lane
-    // pointers (flags, reward, done) — and adds the step's offset with 64-bit vector arithmetic after two 64-bit scalar multiplies;
-    // either alternative costs 10-14 more spilled scalar registers and no time is gained (profiles/r05_experiments.txt: ab_rp).
-    constexpr bool kRunPtr = ATC_LOOP_RUNPTR == 1 && !ONE && !FULL;
-    float* run_obs = out.obs;
-    uint16_t* run_flags = out.flags;
-    float* run_reward = out.reward;
-    uint8_t* run_done = out.done;
     for (int step = 0; step < n_steps; ++step) {
 #if ATC_TRACE
         unsigned long long* trow = trace ? trace + ((size_t)(blockIdx.x * (kBlock / 64) + (tid >> 6)) * n_steps + step) * 8 : nullptr;
@@ -1711,30 +1505,12 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         atc_params_t pl = p;
         atc_out_t outl = out;
         int32_t* stats_l = st.stats;
-        constexpr int kReread = ONE ? 0 : ATC_LOOP_REREAD_ARGS(W);   // measured per width: profiles/r02_experiments.txt
         int zk = 0;   // this step's opaque zero: kernarg re-reads that depend on it cannot be hoisted out of the step loop
         if (!ONE) {   // (also makes the mode word's flag tests scalar compares inside the step, not
             asm volatile("s_mov_b32 %0, 0" : "=s"(zk));   // 64-bit lane masks kept — and spilled — across the loop)
-            if (kReread & 1) pl = kernarg_reread<atc_params_t>(offsetof(StepArgs, p), zk);
-            else pl.mode += (uint32_t)zk;
-            if (kReread & 4) outl = kernarg_reread<atc_out_t>(offsetof(StepArgs, out), zk);
+            pl.mode += (uint32_t)zk;
         }
-        if (!ONE && ATC_LOOP_OPAQUE) {
-            uint32_t zv;
-            int zs;
-            asm volatile("v_mov_b32 %0, 0" : "=v"(zv));
-            asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
-            if (ATC_LOOP_OPAQUE & 1) { dl.i += zv; dl.e += (int)zv; dl.k += (int)zv; dl.tid += (int)zv; dl.lane += (int)zv; dl.slot0 += (uint32_t)zs; }
-            if (ATC_LOOP_OPAQUE & 2) { Kl = K + zs; gl = grid ? grid + zs : nullptr; }
-        }
-        if (kRunPtr && ATC_LOOP_RUNPTR == 1) asm volatile("" : "+s"(run_obs), "+s"(run_flags), "+s"(run_reward), "+s"(run_done));
-        if (ATC_LOOP_RUNPTR == 2 && !ONE && !FULL) {   // variant: bases computed from the step, then made opaque
-            run_obs = outl.obs + sBN * ATC_OBS_DIM; run_flags = outl.flags + sBN; run_reward = outl.reward + sB; run_done = outl.done + sB;
-            asm volatile("" : "+s"(run_flags), "+s"(run_reward), "+s"(run_done));
-        }
-        constexpr bool kOpaque = (ATC_LOOP_RUNPTR == 2 && !ONE && !FULL);
-        StepOut so = {(kRunPtr || kOpaque) ? run_obs : outl.obs + sBN * ATC_OBS_DIM, (kRunPtr || kOpaque) ? run_flags : outl.flags + sBN,
-                      (kRunPtr || kOpaque) ? run_reward : outl.reward + sB, (kRunPtr || kOpaque) ? run_done : outl.done + sB,
+        StepOut so = {outl.obs + sBN * ATC_OBS_DIM, outl.flags + sBN, outl.reward + sB, outl.done + sB,
                       FULL && outl.raw_obs ? outl.raw_obs + sBN * ATC_OBS_DIM : nullptr,
                       FULL && outl.ac_reward ? outl.ac_reward + sBN : nullptr,
                       FULL && outl.min_sep ? outl.min_sep + sB : nullptr,
@@ -1744,18 +1520,13 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
                       , trow
 #endif
         };
-#ifndef ATC_LOOP_DECODE_ONCE
-#define ATC_LOOP_DECODE_ONCE 1   // carry the DECODED targets of a held block across its steps (7 operations fewer per step).  Round 3: no
-#endif                           // gain (a second re-read site of the rate group); round 5, next to the carried refused-target mask:
-                                 // 65 536 x 16 fused 11.8-12.0 -> 11.6-11.8 us, 4 096 x 64 5.32-5.35 -> 5.14-5.23
-#ifndef ATC_LOOP_ALLACT
-#define ATC_LOOP_ALLACT 1        // carry "every lane's aircraft is under control" across the steps (re-established after steps that
-#endif                           // can change a mask): 325.5 vs 331.2 VALU per wavefront-step, 11.37 vs 11.46 us at 65 536 x 16
+        // Carried across the steps of a multi-step launch: the DECODED targets and the refused-target mask of a held action block
+        // (r05: 65 536 x 16 fused 11.8-12.0 -> 11.6-11.8 us) and "every lane's aircraft is under control" (re-established after
+        // steps that can change a mask: 11.37 vs 11.46 us).
         const QRates qr = qr_next;
         const QScan qs = QGET(s);   // (requested here, consumed after the kinematics)
         if (!ONE && ATC_RARE(step == 0)) act = *at<Float3>(act_t, times12(dl.i));
-        constexpr bool kDecodeOnce = ATC_LOOP_DECODE_ONCE || (LAT && ATC_LAT_DECODE_ONCE);
-        if (ONE || !kDecodeOnce || step == 0) tg = decode_targets(qr, act);
+        if (ONE || step == 0) tg = decode_targets(qr, act);
         if (ONE && !la_live) {   // held block: the record equals the accepted targets (components that are refused are not compared)
             ls.la_v = tg.v;
             ls.la_h = tg.h;
@@ -1763,19 +1534,16 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         }
         // multi-step launches know structurally which steps repeat an action block
         const bool repeated = ONE ? (same_actions && __builtin_amdgcn_ballot_w64(la_live) == 0ull)
-                                  : (ATC_LOOP_SKIP_BOOK && !block_start && __builtin_amdgcn_ballot_w64(es.t == 0) == 0ull);
+                                  : (!block_start && __builtin_amdgcn_ballot_w64(es.t == 0) == 0ull);
         // ... and whether every lane's aircraft is under control: re-established after the steps in which a mask can change
-        if (!ONE && ATC_LOOP_ALLACT && ATC_RARE(mask_dirty)) {
+        if (!ONE && ATC_RARE(mask_dirty)) {
             // (and no lane's heading or last heading target is WIDE: include/atc_step.h ABI 19 — such lanes take the general form)
             all_active = (__builtin_amdgcn_ballot_w64(!(dl.lane_valid && ((dl.k < 32 ? ((uint32_t)es.amask >> dl.k) : ((uint32_t)(es.amask >> 32) >> (dl.k - 32))) & 1u))) |
                           __builtin_amdgcn_ballot_w64(max(ls.a.phi, ls.la_p) == INT32_MAX) | __builtin_amdgcn_ballot_w64(min(ls.a.phi, ls.la_p) == INT32_MIN)) == 0ull;
             mask_dirty = false;
         }
-#ifndef ATC_KIN_FROM_ARGS
-#define ATC_KIN_FROM_ARGS 1   // 0 (developer A/B): the kinematics constants named as the kernel argument in multi-step launches too
-#endif                        // (the compiler may then keep them in scalar registers across the step loop)
         ATC_STAMP_TOP(trow, 1);
-        const Mid m = step_part_a<ONE, LAT>(gl, qr, ATC_KIN_FROM_ARGS ? QGET(k) : q.k, QGET(g), dl, tg.v, tg.h, tg.p, act.c, ls, es, repeated, !ONE && all_active, ONE,
+        const Mid m = step_part_a<ONE, LAT>(gl, qr, QGET(k), QGET(g), dl, tg.v, tg.h, tg.p, act.c, ls, es, repeated, !ONE && all_active, ONE,
                                        st.phi_wide, zk, refused_blk, refused_known ATC_TRACE_PASS(trow));
         refused_known = true;
         ATC_STAMP(1);
@@ -1791,24 +1559,17 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         }
         const bool quiet = step_part_b<W, FULL, ONE, LAT>(Kl, gl, pl, q, qs, zk, N, dl, m, ls, es, so, stats_l, st.phi_wide, pos, obs_stage, act_next, nxt, qr_next, scan_skip, scan_mask);
         if (ATC_RARE(!quiet)) mask_dirty = true;
-        if (kDecodeOnce && act_next) tg = decode_targets(QGET(r), nxt);
+        if (act_next) tg = decode_targets(QGET(r), nxt);
         act = nxt;
         ATC_STAMP(6);
         ATC_STAMP_TOP(trow, 6);
         ATC_STAMP_END(trow, 6);
-        if (kRunPtr) {
-            run_obs += (size_t)BN * ATC_OBS_DIM;
-            run_flags += BN;
-            run_reward += (uint32_t)B;
-            run_done += (uint32_t)B;
-        }
     }
     // ---- write back persistent state -----------------------------------------------------------------------------------
     atc_state_t st_end = st;
-#ifndef ATC_ONE_REREAD_STATE
-#define ATC_ONE_REREAD_STATE 1   // single-step launches also fetch the state pointers again for the final stores (instead of
-#endif                           // carrying ten scalar registers through the body: they were spilled to vector-register lanes)
-    if ((ONE && ATC_ONE_REREAD_STATE) || (!ONE && (ATC_LOOP_REREAD_ARGS(W) & 8))) {
+    // (single-step launches also fetch the state pointers again for the final stores instead of carrying ten scalar registers
+    // through the body: they were spilled to vector-register lanes)
+    if (ONE || loop_rereads_state(W)) {
         int zk;
         asm volatile("s_mov_b32 %0, 0" : "=s"(zk));
         st_end = kernarg_reread<atc_state_t>(offsetof(StepArgs, st), zk);
@@ -1946,11 +1707,7 @@ static size_t lds_bytes(const atc_scenario*, bool pair_scan, bool step_kernel = 
 template <int W, bool FULL, bool ONE, bool ALLV, bool LAT = false>
 static int launch_step2(const atc_scenario* s, int B, int N, int T, int hold, const atc_state_t* st, const float* actions,
                         const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
-#ifdef ATC_LDS_PAD_LOOP   // developer A/B builds: cap the multi-step launch's workgroups per CU through its LDS allocation
-    const size_t lds = ONE ? lds_bytes(s, W >= 32, true) : (size_t)ATC_LDS_PAD_LOOP;
-#else
     const size_t lds = lds_bytes(s, W >= 32, true);
-#endif
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<W, FULL, ONE, ALLV, LAT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1965,17 +1722,14 @@ static int launch_step(const atc_scenario* s, int B, int N, int T, int hold, con
                        const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
     const bool full = out->raw_obs || out->ac_reward || out->min_sep || out->term_obs || out->packet;
     // every slot of the launch is an aircraft: the fast variant then runs its all-valid instantiation (make_ids)
-    const bool allv = !full && N == W && ((long long)B * W) % kBlock == 0 && !(ATC_ABLATE & 64);
+    const bool allv = !full && N == W && ((long long)B * W) % kBlock == 0;
     // Multi-step launches keep the state in registers across the steps; the run-time step loop costs the kernel its
     // occupancy (4 wavefronts per SIMD against 5-7 for the straight-line single step) but issuing T single-step launches
     // instead is slower at every size (65 536 x 16, T = 20, [T, ...] outputs: 35.0 vs 27.1 us per step).
     if (T > 1) {
         if (full) return launch_step2<W, true, false, false>(s, B, N, T, hold, st, actions, out, p, stream);
-#ifndef ATC_LAT
-#define ATC_LAT 1   // developer A/B: 0 = never choose the latency-bound instantiation
-#endif
         // at most ATC_LAT_WAVES wavefronts per SIMD: the latency-bound instantiation (uniform terms in vector registers)
-        const bool lat = ATC_LAT && allv && ((long long)B * W + 63) / 64 <= (long long)ATC_LAT_WAVES * 4 * s->n_cu;
+        const bool lat = allv && ((long long)B * W + 63) / 64 <= (long long)ATC_LAT_WAVES * 4 * s->n_cu;
         if (lat) return launch_step2<W, false, false, true, true>(s, B, N, T, hold, st, actions, out, p, stream);
         return allv ? launch_step2<W, false, false, true>(s, B, N, T, hold, st, actions, out, p, stream)
                     : launch_step2<W, false, false, false>(s, B, N, T, hold, st, actions, out, p, stream);
