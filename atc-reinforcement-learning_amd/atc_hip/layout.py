@@ -2,7 +2,7 @@
 
 tests/test_abi.py parses the header and checks that every constant here matches it.
 """
-ABI_VERSION = 19
+ABI_VERSION = 20
 BLOB_VERSION = 1014.0
 
 H_VERSION, H_NWORDS, H_N_MVA, H_N_NOISE, H_N_ENTRY, H_OFF_POLY, H_OFF_VERT, H_OFF_ENTRY, H_OFF_GRID, H_N_VERTW = range(10)
@@ -54,3 +54,7 @@ ENV_TIMESTEPS, ENV_ACTIONS_TAKEN, ENV_TOTAL_REWARD, ENV_MASK_LO, ENV_WORDS = ran
 # per-episode env record (atc_state_t.stats): 8 x 32-bit words
 STAT_EPISODES, STAT_EP_LENGTH, STAT_EP_RETURN, STAT_WIN_BITS, STAT_EP_ACTIONS, STAT_MASK_HI = range(6)
 STAT_WORDS = 8
+# aircraft record (atc_state_t.ac, 4 x int32): x / y position counts, heading counts, speed counts; atc_state_t.alt: float64 [ft];
+# last-action record (atc_state_t.last_act, 4 x int32): speed counts, heading counts, altitude target float64 in words 2..3
+AC_X, AC_Y, AC_PHI, AC_V, AC_WORDS = range(5)
+LA_V, LA_PHI, LA_H, LA_WORDS = 0, 1, 2, 4

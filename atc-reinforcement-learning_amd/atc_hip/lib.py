@@ -23,12 +23,12 @@ def use_library(path):
 
 class AtcParams(C.Structure):
     """atc_params_t"""
-    _fields_ = [("dt", C.c_float), ("timestep_limit", C.c_int32), ("mode", C.c_uint32), ("reserved0", C.c_uint32),
-                ("seed", C.c_uint64), ("sep_nm", C.c_float), ("sep_ft", C.c_float), ("conflict_reward", C.c_float),
-                ("reserved1", C.c_float)]
+    _fields_ = [("dt", C.c_double), ("timestep_limit", C.c_int32), ("mode", C.c_uint32), ("seed", C.c_uint64),
+                ("sep_nm", C.c_float), ("sep_ft", C.c_float), ("conflict_reward", C.c_float), ("reserved0", C.c_uint32),
+                ("reserved1", C.c_float), ("reserved2", C.c_uint32)]
 
 
-STATE_FIELDS = ("pos_hp", "v_fix", "last_act", "env", "stats", "phi_wide")
+STATE_FIELDS = ("ac", "alt", "last_act", "env", "stats", "phi_wide")
 OUT_FIELDS = ("obs", "raw_obs", "reward", "ac_reward", "done", "flags", "min_sep", "term_obs", "packet")
 
 
@@ -118,8 +118,8 @@ def make_params(dt=1.0, shaping=True, normalize=True, discrete=False, auto_reset
     mode = (L.M_REWARD_SHAPING if shaping else 0) | (L.M_NORMALIZE if normalize else 0) | \
            (L.M_DISCRETE if discrete else 0) | (L.M_AUTO_RESET if auto_reset else 0) | \
            (L.M_RANDOM_ENTRY if random_entry else 0) | (L.M_KEEP_ACTIVE if keep_active else 0)
-    return AtcParams(float(dt), int(timestep_limit), mode, 0, int(seed) & (2 ** 64 - 1), sep_nm, sep_ft, conflict_reward,
-                     0.0)
+    return AtcParams(float(dt), int(timestep_limit), mode, int(seed) & (2 ** 64 - 1), sep_nm, sep_ft, conflict_reward, 0,
+                     0.0, 0)
 
 
 class Scenario:

@@ -104,15 +104,16 @@ class AtcVecEnv:
         zs = (lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)) if host_mapped == "io" else z  # noqa: E731
         f32, i32 = torch.float32, torch.int32
         # persistent state (atc_state_t): packed records, see include/atc_step.h
-        self.pos_hp = zs((BN, 4), i32)         # x, y (position-grid counts), h (float bit pattern), phi (heading counts)
-        self.v_fix = zs(BN, i32)               # speed counts (unsigned 32-bit, kt = v_fix 2^-23)
-        self.last_act = zs((BN, 3), i32)       # last accepted v / h / phi targets in the state's formats
+        self.ac = zs((BN, L.AC_WORDS), i32)    # x, y (position-grid counts), phi (heading counts), v (speed counts, unsigned)
+        self.alt = zs(BN, torch.float64)       # altitude [ft]: the reference's float64 (ABI 20)
+        self.last_act = zs((BN, L.LA_WORDS), i32)   # last accepted targets: v counts, phi counts, altitude target (float64, words 2..3)
         self.env = zs((B, L.ENV_WORDS), i32)   # per-step env record
         self.stats = zs((B, L.STAT_WORDS), i32)  # per-episode env record
         self.pos_origin, self.pos_k = self.compiled.pos_origin, self.compiled.pos_k
         # named views into the records (live memory, usable for reads and in-place writes)
-        self.h = self.pos_hp[:, 2:3].view(f32).squeeze(1)
-        self.phi_fix = self.pos_hp[:, 3]       # heading counts (deg = 180 + phi_fix 2^-23); `phi` / `v` below are copies in units
+        self.h = self.alt
+        self.phi_fix = self.ac[:, L.AC_PHI]    # heading counts (deg = 180 + phi_fix 2^-23); `phi` / `v` below are copies in units
+        self.v_fix = self.ac[:, L.AC_V]        # speed counts (unsigned 32-bit in an int32 word, kt = v_fix 2^-23)
         self.timesteps = self.env[:, L.ENV_TIMESTEPS]
         self.actions_taken = self.env[:, L.ENV_ACTIONS_TAKEN]
         self.total_reward = self.env[:, L.ENV_TOTAL_REWARD:L.ENV_TOTAL_REWARD + 1].view(f32).squeeze(1)
@@ -402,11 +403,11 @@ class AtcVecEnv:
     # are float64 copies in knots / degrees (exact), written through set_state / set_v / set_phi.
     @property
     def x(self):
-        return self.pos_hp[:, 0].to(self.torch.float64) * 2.0 ** -self.pos_k + self.pos_origin[0]
+        return self.ac[:, L.AC_X].to(self.torch.float64) * 2.0 ** -self.pos_k + self.pos_origin[0]
 
     @property
     def y(self):
-        return self.pos_hp[:, 1].to(self.torch.float64) * 2.0 ** -self.pos_k + self.pos_origin[1]
+        return self.ac[:, L.AC_Y].to(self.torch.float64) * 2.0 ** -self.pos_k + self.pos_origin[1]
 
     @property
     def v(self):
@@ -447,9 +448,9 @@ class AtcVecEnv:
 
     def set_xy(self, i, x=None, y=None):
         if x is not None:
-            self.pos_hp[i, 0] = self._to_fix(x, 0)
+            self.ac[i, L.AC_X] = self._to_fix(x, 0)
         if y is not None:
-            self.pos_hp[i, 1] = self._to_fix(y, 1)
+            self.ac[i, L.AC_Y] = self._to_fix(y, 1)
 
     def set_v(self, i, v):
         # The speed's rate limit is a wrapping 32-bit difference (include/atc_step.h): exact while the speed lies within 256 kt
@@ -473,18 +474,19 @@ class AtcVecEnv:
         """AtcGym.last_action (atc_gym.py:86,311) of one aircraft: [v, h, phi] targets last accepted, in kt / ft / deg."""
         i = env * self.N + slot
         rec = self.last_act[i].cpu()
-        lp = int(rec[2])
+        lp = int(rec[L.LA_PHI])
         if lp in (L.I32_MIN, L.I32_MAX):
             lp = float(self.phi_wide[i, 1])
-        return [float(int(rec[0]) & 0xffffffff) * 2.0 ** -L.V_FIX_SHIFT, float(rec[1:2].view(self.torch.float32)[0]),
+        return [float(int(rec[L.LA_V]) & 0xffffffff) * 2.0 ** -L.V_FIX_SHIFT,
+                float(rec[L.LA_H:L.LA_H + 2].contiguous().view(self.torch.float64)[0]),
                 float(lp) * 2.0 ** -L.PHI_FIX_SHIFT + L.PHI_FIX_OFFSET]
 
     def set_last_action(self, env, slot, value):
         i = env * self.N + slot
         torch = self.torch
         f, P = self._phi_counts(value[2])
-        rec = torch.tensor([self._v_counts(value[0]), 0, f], dtype=torch.int32)
-        rec[1:2].view(torch.float32)[0] = float(value[1])
+        rec = torch.tensor([self._v_counts(value[0]), f, 0, 0], dtype=torch.int32)
+        rec[L.LA_H:L.LA_H + 2].view(torch.float64)[0] = float(value[1])
         self.last_act[i] = rec.to(self.last_act.device)
         if f in (L.I32_MIN, L.I32_MAX):
             self.phi_wide[i, 1] = float(P)

@@ -573,7 +573,7 @@ __device__ __forceinline__ float pos_to_faf(int faf, float pos_inv, int p) { ret
 
 struct Aircraft {
     int x, y;         // position grid counts
-    float h;          // altitude [ft]
+    double h;         // altitude [ft]: the reference's float64 (include/atc_step.h, ABI 20)
     int phi;          // heading, fixed point (deg = 180 + phi 2^-23)
     uint32_t v;       // speed, fixed point (kt = v 2^-23)
 };
@@ -606,7 +606,7 @@ __device__ __forceinline__ Aircraft spawn(const float* __restrict__ K, int off_s
     const int4 st = *reinterpret_cast<const int4*>(r);
     a.x = st.x;
     a.y = st.y;
-    a.h = random ? h_level : __int_as_float(st.z);
+    a.h = (double)(random ? h_level : __int_as_float(st.z));   // (flight level x 100 ft: an integer)
     a.phi = st.w;
     if (obs) {
         const float4 o0 = *reinterpret_cast<const float4*>(r + 16), o1 = *reinterpret_cast<const float4*>(r + 32);
@@ -618,14 +618,18 @@ __device__ __forceinline__ Aircraft spawn(const float* __restrict__ K, int off_s
     return a;
 }
 
+// observation word 5 (atc_gym.py:267,276): np.float32 of the float64 difference h - mva (mva: an integer height, 0 outside / at reset)
+__device__ __forceinline__ float alt_above(double h, float mva) { return (float)(h - (double)mva); }
+
 struct Obs {
     float o[ATC_OBS_DIM];
     float d_faf, phi_rel_faf, on_gp;
 };
 // atc_gym.py:262-297 _get_state.  (px, py) = grid position, (x, y) = its fp32 value
 // phi: the heading the relative angle sees; phi_obs: observation word 3 — the same number unless the heading is WIDE
+// h = (float)altitude, h_above = (float)(altitude - mva) with the difference taken in float64 like the reference's (see alt_above)
 __device__ __forceinline__ Obs get_state(const ObsConst& c, int px, int py, float x, float y, float h, float phi, float phi_obs, float v,
-                                         float mva) {
+                                         float h_above) {
     Obs r;
     const float to_faf_x = pos_to_faf(c.faf_x, c.pos_inv, px);
     const float to_faf_y = pos_to_faf(c.faf_y, c.pos_inv, py);
@@ -637,7 +641,7 @@ __device__ __forceinline__ Obs get_state(const ObsConst& c, int px, int py, floa
     r.o[2] = h;
     r.o[3] = phi_obs;
     r.o[4] = v;
-    r.o[5] = h - mva;
+    r.o[5] = h_above;
     r.o[6] = r.on_gp;
     r.o[7] = r.d_faf;
     r.o[8] = r.phi_rel_faf;

@@ -3,9 +3,9 @@
 // Work decomposition (one wavefront = 64 lanes):
 //   lane  = one aircraft slot;  W = next_pow2(N) consecutive lanes = one env;  64/W envs per wavefront
 //   (N = 64: one wavefront per env, N = 16: 4 envs per wavefront, N = 1: 64 envs per wavefront).
-//   Aircraft state lives in HBM as packed records indexed env*N + k: pos_hp = (x, y on the 32-bit fixed-point position
-//   grid, h as fp32, heading counts) 16 B, speed counts 4 B (speed and heading are 32-bit fixed point too since ABI 18:
-//   include/atc_step.h), last_act = the three last accepted targets 12 B (written back only when one changed) — a
+//   Aircraft state lives in HBM as packed records indexed env*N + k: ac = (x, y on the 32-bit fixed-point position grid,
+//   heading counts, speed counts) 16 B, alt = the altitude as the reference's float64 8 B (ABI 20: include/atc_step.h),
+//   last_act = the three last accepted targets 16 B (read and written only by steps that may change it) — a
 //   wavefront moves each array with ONE access per lane on consecutive addresses; the per-step env record (4 words) is one
 //   16-byte load that the W lanes of an env share, the per-episode record is touched only when an episode ends.
 //   All per-lane indices are 32-bit offsets from uniform base pointers.
@@ -324,17 +324,14 @@ struct LaneIds {        // who this lane is (one aircraft slot of one env)
 struct LaneState {      // persistent per-aircraft state held in registers
     Aircraft a;
     uint32_t la_v;      // last accepted targets (atc_gym.py:86,311) in the state's formats: speed counts,
-    float la_h;         // altitude [ft],
+    double la_h;        // altitude [ft] (float64),
     int la_p;           // heading counts
-    bool la_changed, v_changed;
+    bool la_changed;
 };
 struct Targets {        // decoded action of the current step / block (atc_gym.py:318-335) in the state's formats
     uint32_t v;
-    float h;
-    int p;
-};
-struct Int3 {           // the 12-byte last-action record as stored
-    int a, b, c;
+    float ah;           // the altitude's ACTION: its float64 target a * m + c is evaluated where it is used (one conversion and
+    int p;              // one fma per step instead of a register pair carried across a held block)
 };
 struct EnvState {       // per-step env record (replicated in the W lanes of the env)
     int t, n_actions;
@@ -359,13 +356,13 @@ struct Mid {            // what the first half of a step hands to the second
 // vector registers — and a multi-step launch would keep them there across its whole step loop.
 // Grouped by the stage that consumes them: a multi-step launch re-reads each group from the kernarg segment right where its
 // stage starts (QGET below) instead of keeping ~70 uniform values alive across the step loop.
-struct alignas(16) QRates {   // first half of the step (16 words)
+struct alignas(16) QRates {   // first half of the step (20 words)
     // _denormalized_action (atc_gym.py:318-335) for the fixed-point components: counts = trunc(a * m + c) in float64 (m, c the
     // reference's factor / offset in counts: integers), see decode_targets
     double dec_mv, dec_cv, dec_mp, dec_cp;
-    float dec_mh, dec_ch;   // altitude target (fp32): RN(a * m) + c, the reference's operation order (see derive())
+    double dec_mh, dec_ch;  // altitude target (float64): a * m + c as one fma = the reference's operation order (see derive())
+    double dh_hi, dh_lo;    // kHDotMax * dt, kHDotMin * dt in float64 (model.py:45-46,97-100)
     int rate_v, rate_p;     // rint(kAMax dt 2^23), rint(kPhiDotMax dt 2^23): symmetric limits (model.py:47-50,75-78,113-120)
-    float dh_hi, dh_lo;     // kHDotMax * dt, kHDotMin * dt     (model.py:45-46,97-100)
     float r_base;           // -0.05 * dt                       (atc_gym.py:137)
     int pos_neg_k;          // position grid: nm = origin + fix * 2^-k (blob: ATC_C_POS_*)
 };
@@ -462,14 +459,15 @@ static StepDerived derive_uncached(const atc_params_t& p, const atc_scenario* s,
 static const StepDerived& derive(const atc_params_t& p, const atc_scenario* s, int horizon) {
     struct Key {
         uint64_t uid;
-        float dt, sep_nm, sep_ft, conflict_reward;
+        double dt;
+        float sep_nm, sep_ft, conflict_reward;
         int32_t timestep_limit;
         uint32_t mode_bits;   // the mode flags the derived values depend on
-        int32_t horizon, pad;
+        int32_t horizon;
     };
-    static thread_local Key last = {0ull, 0.0f, 0.0f, 0.0f, 0.0f, 0, 0u, 0, 0};
+    static thread_local Key last = {0ull, 0.0, 0.0f, 0.0f, 0.0f, 0, 0u, 0};
     static thread_local StepDerived q;
-    const Key k = {s->uid, p.dt, p.sep_nm, p.sep_ft, p.conflict_reward, p.timestep_limit, p.mode & (uint32_t)(ATC_M_DISCRETE | ATC_M_NORMALIZE), horizon, 0};
+    const Key k = {s->uid, p.dt, p.sep_nm, p.sep_ft, p.conflict_reward, p.timestep_limit, p.mode & (uint32_t)(ATC_M_DISCRETE | ATC_M_NORMALIZE), horizon};
     if (memcmp(&k, &last, sizeof k) != 0) {
         q = derive_uncached(p, s, horizon);
         last = k;
@@ -490,7 +488,7 @@ static void scan_horizon_limits(const atc_params_t& p, int n, float* sep2_h, flo
     *sep2_h = sep2;
     *sep_ft_h = p.sep_ft;
     if (n <= 0) return;
-    const double dt = (double)p.dt;
+    const double dt = p.dt;
     const double S = (sqrt((double)sep2) + n * 2.0 * ((double)kVMax / 3600.0) * dt) * (1.0 + 1e-5) + 1e-3;
     const double F = ((double)p.sep_ft + n * ((double)kHDotMax - (double)kHDotMin) * dt) * (1.0 + 1e-5) + 1.0;
     float s2 = (float)(S * S), f = (float)F;
@@ -514,16 +512,16 @@ static StepDerived derive_uncached(const atc_params_t& p, const atc_scenario* s,
     }
     q.g.pos_x0 = (double)K[ATC_C_POS_X0];
     q.g.pos_y0 = (double)K[ATC_C_POS_Y0];
-    const double dtd = (double)p.dt, fixq = 8388608.0;   // 2^23: speed and heading counts per kt / deg
+    const double dtd = p.dt, fixq = 8388608.0;   // 2^23: speed and heading counts per kt / deg
     auto rate_fix = [&](float rate) {   // rint(|rate| dt 2^23), saturating (include/atc_step.h)
         const double r = rint(fabs((double)rate) * dtd * fixq);
         return r >= 2147483647.0 ? INT32_MAX : (int32_t)r;
     };
     q.r.rate_v = rate_fix(kAMax);
     q.r.rate_p = rate_fix(kPhiDotMax);
-    q.r.dh_hi = kHDotMax * p.dt;
-    q.r.dh_lo = kHDotMin * p.dt;
-    q.r.r_base = -0.05f * p.dt;
+    q.r.dh_hi = (double)kHDotMax * dtd;   // h_dot_max * timestep: an integer times a Python float (model.py:97-100)
+    q.r.dh_lo = (double)kHDotMin * dtd;
+    q.r.r_base = (float)(-0.05 * dtd);
     // atc_gym.py:64-78,318-335: offset (v_min, 0, 0); factor (10, 100, 1) discrete | (v_max - v_min, h_max, 360) continuous.
     //   discrete   : a * fac + off
     //   continuous : a * fac / 2 + fac / 2 + off
@@ -534,11 +532,11 @@ static StepDerived derive_uncached(const atc_params_t& p, const atc_scenario* s,
     q.r.dec_cv = (discrete ? (double)kVMin : (double)(kVMax - kVMin) / 2.0 + (double)kVMin) * fixq;
     q.r.dec_mp = (discrete ? 1.0 : 360.0 / 2.0) * fixq;
     q.r.dec_cp = ((discrete ? 0.0 : 360.0 / 2.0) - (double)ATC_PHI_FIX_OFFSET) * fixq;
-    // Altitude (fp32): halving is exact, so RN(a * fac) / 2 == RN(a * (fac / 2)) and fac / 2 is exact: the same bits as the
-    // reference's operation order with one multiplication and one addition (the discrete form keeps its `+ 0`: it turns a
-    // -0 product into +0, like the reference's `+ offset`).
-    q.r.dec_mh = discrete ? 100.0f : kHMax / 2.0f;
-    q.r.dec_ch = discrete ? 0.0f : kHMax / 2.0f;
+    // Altitude (float64, ABI 20): the product of an fp32 action with fac (38 000: 16 bits) is exact in float64 and halving is
+    // exact, so a * fac / 2 + fac / 2 + 0 is ONE rounding — the fma's (the discrete form keeps its `+ 0`: it turns a -0 product
+    // into +0, like the reference's `+ offset`).
+    q.r.dec_mh = discrete ? 100.0 : (double)kHMax / 2.0;
+    q.r.dec_ch = discrete ? 0.0 : (double)kHMax / 2.0;
     // float64 heading kinematics (include/atc_step.h: ATC_KIN_*) and the step's distance scale, NEGATED (see atc::advance)
     q.k.inv180 = ATC_KIN_INV180;
     q.k.neg_half_turn = -ATC_KIN_HALF_TURN;
@@ -689,31 +687,21 @@ __device__ __forceinline__ LaneIds make_ids(uint32_t slot0, int B, int N) {
     return d;
 }
 
-// max(min(d, hi), lo) for lo < hi (model.py:75-78,97-100,117-120) as ONE v_med3_f32.  fminf / fmaxf would each be preceded by a
-// canonicalisation of the uniform limit (IEEE mode: 4 instructions per clamp).  Identical for every non-NaN d; a NaN d (a NaN
-// action, outside the action space) yields lo here and hi there — unspecified input either way.
-__device__ __forceinline__ float clamp_rate(float d, float lo, float hi) { return __builtin_amdgcn_fmed3f(d, lo, hi); }
-
 // _denormalized_action (atc_gym.py:318-335): action -> (v, h, phi) targets in the state's formats with the host-evaluated
 // (multiplier, offset) pairs of derive().  Speed and heading: ONE float64 fma and the saturating, truncating conversion of the
-// hardware (NaN -> 0) — the spec of include/atc_step.h.  Altitude (round 5): the reference's float64 target  a * m + c  (ONE fma: the
-// product is exact) rounded to fp32 TOWARD MINUS INFINITY, +inf if it exceeds h_max.  The aircraft lands ON its target, and two flags
-// compare that altitude with fp32-representable thresholds (`h < mva`, the refusals `target < h_min`, `target > h_max`): x < n and
-// RD(x) < n are the same statement for representable n, round-to-nearest is not (told to descend "to the MVA", the reference's
-// target is 3 499.9995 ft — below it, atc_gym.py:149-153 — or 3 500.0005 by the last bit of the fp32 ACTION; RN makes both 3 500).
-__device__ __forceinline__ float altitude_target(double t) {
-    float f = (float)t;                                    // round to nearest ...
-    const int b = __float_as_int(f);
-    const int step = -(1 | (b >> 31));                     // ... and one step down (away from zero for a negative value) if that went up
-    f = ((double)f > t) ? __int_as_float(b + step) : f;    // (NaN: no change — a NaN target is accepted and poisons h like the reference's)
-    return (t > (double)kHMax) ? __builtin_inff() : f;     // (RD(t) could be h_max itself: the refusal `target > h_max` must see t)
-}
+// hardware (NaN -> 0) — the spec of include/atc_step.h.  Altitude (ABI 20): the reference's float64 target itself, a * m + c as one
+// fma (altitude_target: evaluated where the step uses it).
+__device__ __forceinline__ double altitude_target(const QRates& q, float a) { return __builtin_fma((double)a, q.dec_mh, q.dec_ch); }
 __device__ __forceinline__ Targets decode_targets(const QRates& q, const Float3& act) {
     Targets t;
     t.v = cvt_u32_f64(__builtin_fma((double)act.a, q.dec_mv, q.dec_cv));
-    t.h = altitude_target(__builtin_fma((double)act.b, (double)q.dec_mh, (double)q.dec_ch));
+    t.ah = act.b;
     t.p = cvt_i32_f64(__builtin_fma((double)act.c, q.dec_mp, q.dec_cp));
     return t;
+}
+// Airplane.action_h (model.py:95-102): h + max(min(target - h, 15 dt), -41 dt) in float64, the reference's operations in its order
+__device__ __forceinline__ double altitude_move(double h, double target, double dh_lo, double dh_hi) {
+    return h + __builtin_fmax(__builtin_fmin(target - h, dh_hi), dh_lo);
 }
 // max(min(d, r), -r) for integer differences (the symmetric rate limits of speed and heading)
 __device__ __forceinline__ int clamp_sym(int d, int r) { return max(min(d, r), -r); }
@@ -723,8 +711,8 @@ __device__ __forceinline__ bool within(int d, int D) { return (uint32_t)d + (uin
 // ---- first half of AtcGym.step: timestep, rate limits towards the targets, kinematics, MVA floor ---------------------
 template <bool ONE, bool LAT>
 __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const QRates& q, const QKin& qk, const QGrid& qg,
-                                           const LaneIds& d, uint32_t tv, float th, int tp, float act_p, LaneState& ls, EnvState& es,
-                                           bool repeated, bool all_active, bool track_v, double* wide_named, int zk,
+                                           const LaneIds& d, uint32_t tv, double th, int tp, float act_p, LaneState& ls, EnvState& es,
+                                           bool repeated, bool all_active, double* wide_named, int zk,
                                            uint64_t& refused_blk, bool refused_known ATC_TRACE_PARAM) {
     Mid m;
     Aircraft& a = ls.a;
@@ -745,7 +733,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     // Speed and heading are 32-bit fixed point (include/atc_step.h): the move is integer arithmetic — exact, like the
     // reference's float64 — with wrapping differences for the speed (valid speeds and the initial last_action 0 are less than
     // 2^31 counts apart) and saturating ones for the heading (its targets are not validated: any action is accepted).
-    constexpr float h_min = kHMin, h_max = kHMax;
+    constexpr double h_min = kHMin, h_max = kHMax;   // (model.py:91-94: float64 compares with the float64 target)
     const bool valid_v = !(tv < kVMinFix || tv > kVMaxFix);
     const bool valid_h = !(th < h_min || th > h_max);
     // `plain` (wave-uniform): every lane of the wavefront flies an aircraft under control towards valid targets — the normal
@@ -774,14 +762,12 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     int phi_k;   // the heading as the kinematics see it (a WIDE heading wrapped: they are periodic)
     static_assert(kAMin == -kAMax && kPhiDotMin == -kPhiDotMax, "symmetric rate limits assumed (one count limit each)");
     if (ATC_USUAL(plain)) {
-        const uint32_t v_new = a.v + (uint32_t)clamp_sym((int)(tv - a.v), q.rate_v);
-        if (track_v) ls.v_changed = ls.v_changed || v_new != a.v;
-        a.v = v_new;
-        a.h = a.h + clamp_rate(th - a.h, q.dh_lo, q.dh_hi);
+        a.v = a.v + (uint32_t)clamp_sym((int)(tv - a.v), q.rate_v);
+        a.h = altitude_move(a.h, th, q.dh_lo, q.dh_hi);
         a.phi = a.phi + clamp_sym(sat_sub(tp, a.phi), q.rate_p);
         phi_k = a.phi;
         if (book) {
-            acts = (!within((int)(tv - ls.la_v), kDiscrVFix) ? 1 : 0) + (!(fabsf(th - ls.la_h) < kDiscrH) ? 1 : 0) +
+            acts = (!within((int)(tv - ls.la_v), kDiscrVFix) ? 1 : 0) + (!(__builtin_fabs(th - ls.la_h) < (double)kDiscrH) ? 1 : 0) +
                    (!within(sat_sub(tp, ls.la_p), kDiscrPhiFix) ? 1 : 0);
             ls.la_changed = ls.la_changed || tv != ls.la_v || th != ls.la_h || tp != ls.la_p;
             ls.la_v = tv;
@@ -792,9 +778,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
         {
             const bool valid = valid_v;
             const bool ok = valid && active;
-            const uint32_t v_new = ok ? a.v + (uint32_t)clamp_sym((int)(tv - a.v), q.rate_v) : a.v;
-            ls.v_changed = ls.v_changed || v_new != a.v;
-            a.v = v_new;
+            a.v = ok ? a.v + (uint32_t)clamp_sym((int)(tv - a.v), q.rate_v) : a.v;
             if (book) {
                 acts += (ok && !within((int)(tv - ls.la_v), kDiscrVFix)) ? 1 : 0;
                 ls.la_changed = ls.la_changed || (ok && tv != ls.la_v);
@@ -806,11 +790,10 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
         {
             const bool valid = valid_h;
             const bool ok = valid && active;
-            float dd = th - a.h;
-            dd = clamp_rate(dd, q.dh_lo, q.dh_hi);
-            a.h = ok ? a.h + dd : a.h;
+            const double h_new = altitude_move(a.h, th, q.dh_lo, q.dh_hi);
+            a.h = ok ? h_new : a.h;
             if (book) {
-                acts += (ok && !(fabsf(th - ls.la_h) < kDiscrH)) ? 1 : 0;
+                acts += (ok && !(__builtin_fabs(th - ls.la_h) < (double)kDiscrH)) ? 1 : 0;
                 ls.la_changed = ls.la_changed || (ok && th != ls.la_h);
                 ls.la_h = ok ? th : ls.la_h;
             }
@@ -890,7 +873,7 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
 // bit per area in bits 16.. (consumed by the reward stage).  Evaluated while the lookup-grid cell is at hand: the cell names
 // the areas whose bounds meet it, and almost every wavefront has no candidate at all.
 __device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, const float* __restrict__ grid, int n_areas,
-                                               const MvaCell& c, float x, float y, float h) {
+                                               const MvaCell& c, float x, float y, double h) {
     const int n_noise = n_areas;
     uint32_t bits = 0;
     if (ATC_RARE(n_noise > 0)) {
@@ -898,7 +881,7 @@ __device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, con
         if (__builtin_amdgcn_ballot_w64(cand != 0u) != 0ull) {
             for (int q = 0; q < n_noise; ++q) {
                 const float* rec = K + (int)K[ATC_H_OFF_POLY] + ((int)K[ATC_H_N_MVA] + q) * ATC_P_WORDS;
-                if (((cand >> q) & 1u) && in_bounds(rec, x, y) && h < rec[ATC_P_HEIGHT] &&
+                if (((cand >> q) & 1u) && in_bounds(rec, x, y) && h < (double)rec[ATC_P_HEIGHT] &&
                     ray_tracing(x, y, K + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT]))
                     bits |= (uint32_t)ATC_F_NOISE | (0x10000u << q);
             }
@@ -939,6 +922,9 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     Aircraft& a = ls.a;
     const bool active = m.active;
     const float x32 = m.x32, y32 = m.y32;
+    // the altitude as every value-only formula sees it (glide-path test, shaping terms, separation scan, observation word 2): ONE
+    // rounding of the float64 state; the flags that depend on the altitude alone compare the float64 (include/atc_step.h, ABI 20)
+    const float hf = (float)a.h;
     float r = m.r;
     uint32_t fl = m.fl;
     int acts = m.acts;
@@ -991,12 +977,12 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         const float sep2 = qs.sep2;
         if (W == 16 && !FULL) {
             int conf = 0;
-            NearScan16H<1>::run(xs, y32, a.h, sep2, qs.sep_ft, conf);
+            NearScan16H<1>::run(xs, y32, hf, sep2, qs.sep_ft, conf);
             margin = conf ? -1.0f : margin;
         } else if (W == 16) {
-            PairScan16<1, FULL>::run(xs, y32, a.h, sep2, qs.sep_ft, min_d2, margin);
+            PairScan16<1, FULL>::run(xs, y32, hf, sep2, qs.sep_ft, min_d2, margin);
         } else if (W <= 8) {
-            pair_scan_xor<W, FULL>(xs, y32, a.h, sep2, qs.sep_ft, min_d2, margin);
+            pair_scan_xor<W, FULL>(xs, y32, hf, sep2, qs.sep_ft, min_d2, margin);
         } else {
             // W = 32 / 64: partners come from LDS and every unordered pair is evaluated ONCE — lane k visits the partners
             // k + 1 .. k + W/2 (mod W) of its group (the pair at distance W/2 is visited from both ends, harmless).  The result
@@ -1019,7 +1005,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             float* own = reinterpret_cast<float*>(pos) + 8 * gbase + k;
             own[0] = xs;          own[W] = xs;
             own[P] = y32;         own[P + W] = y32;
-            own[2 * P] = a.h;     own[2 * P + W] = a.h;
+            own[2 * P] = hf;      own[2 * P + W] = hf;
             if (FULL) { own[3 * P] = 1e36f; own[3 * P + W] = 1e36f; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1032,7 +1018,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             // test, with variable shifts, in the few batches that found a pair (rounds 2-3 rotated every mask, Horner-style by one:
             // 6-7 scalar operations per partner, 216 per wavefront-step at W = 64; now ~3).
             uint64_t hit = 0;
-            const v2f xs2 = {xs, xs}, ys2 = {y32, y32}, hs2 = {a.h, a.h};
+            const v2f xs2 = {xs, xs}, ys2 = {y32, y32}, hs2 = {hf, hf};
             const float sep_ft = qs.sep_ft;
             // (Round 5, rejected: a PRE-PASS that minimum-accumulates the margin max(d^2 - sep^2, |dh| - sep_ft) per lane — 5.5 vector
             // operations per partner, no lane mask, no scalar mask arithmetic — and runs the mask form only when some lane lost its
@@ -1117,7 +1103,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         }
         if (kHZ && !in_horizon) {
             // the horizon's premises (scan_horizon_limits): no aircraft faster than 300 kt, altitudes of ordinary magnitude (a NaN fails)
-            const uint64_t odd = __builtin_amdgcn_ballot_w64(a.v > kVMaxFix) | __builtin_amdgcn_ballot_w64(!(fabsf(a.h) < kScanHMax));
+            const uint64_t odd = __builtin_amdgcn_ballot_w64(a.v > kVMaxFix) | __builtin_amdgcn_ballot_w64(!(fabsf(hf) < kScanHMax));
             scan_skip = (odd != 0ull) ? 0 : kHorizon;
             scan_mask = flagged;
         }
@@ -1141,8 +1127,8 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         // of the observation occupies its registers)
         const WideWords wo = LAT ? ww : wide_words<ONE>(m.plain, a.phi, wide_named, zk, i);   // (ONE test for both words)
         const float phi_f = phi_real(wo.counts), phi_o = __int_as_float(wo.obs_bits);
-        ob = get_state(oc, a.x, a.y, x32, y32, a.h, phi_f, phi_o, v_real(a.v), 0.0f);
-        if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
+        ob = get_state(oc, a.x, a.y, x32, y32, hf, phi_f, phi_o, v_real(a.v), hf);   // (word 5 = h - mva follows the resolve)
+        if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], hf, ob.on_gp));
     }
     ATC_STAMP_TOP(so.trace, 5);
     // ---- MVA floor (atc_gym.py:146-161), second half ---------------------------------------------------------------------
@@ -1166,12 +1152,13 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     const uint64_t in_tri = grid ? __builtin_amdgcn_ballot_w64(corridor_candidate(m.cell))
                                  : (__builtin_amdgcn_ballot_w64(x32 >= qs.tri_bbox.x) & __builtin_amdgcn_ballot_w64(x32 <= qs.tri_bbox.z) &
                                     __builtin_amdgcn_ballot_w64(y32 >= qs.tri_bbox.y) & __builtin_amdgcn_ballot_w64(y32 <= qs.tri_bbox.w));
+    const double mva_d = (double)mva;   // (an integer height; 0 outside the airspace)
     const bool quiet = m.plain &&
-                       (__builtin_amdgcn_ballot_w64(pi < 0) | __builtin_amdgcn_ballot_w64(a.h < mva) | __builtin_amdgcn_ballot_w64(margin < 0.0f) |
+                       (__builtin_amdgcn_ballot_w64(pi < 0) | __builtin_amdgcn_ballot_w64(a.h < mva_d) | __builtin_amdgcn_ballot_w64(margin < 0.0f) |
                         __builtin_amdgcn_ballot_w64(es.t > qs.timestep_limit) | __builtin_amdgcn_ballot_w64(fl > 0xffffu) | in_tri) == 0ull;
     if (ATC_RARE(!quiet)) {
         {
-            const bool below = pi >= 0 && a.h < mva;
+            const bool below = pi >= 0 && a.h < mva_d;   // atc_gym.py:149: float64 altitude against the integer height
             r = pi < 0 ? -50.0f : (below ? -200.0f : r);
             fl |= pi < 0 ? (uint32_t)ATC_F_OUTSIDE : (below ? (uint32_t)ATC_F_BELOW_MVA : 0u);
         }
@@ -1180,7 +1167,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             fl |= conflict ? (uint32_t)ATC_F_CONFLICT : 0u;
         }
         // ---- win / timeout overrides (atc_gym.py:163-173) ---------------------------------------------------------------
-        if (inside_corridor(K, qs.tri_bbox, x32, y32, a.h, (double)(LAT ? ww.counts : heading_counts<ONE>(m.plain, a.phi, wide_named, zk, i)))) {
+        if (inside_corridor(K, qs.tri_bbox, x32, y32, hf, (double)(LAT ? ww.counts : heading_counts<ONE>(m.plain, a.phi, wide_named, zk, i)))) {
             int bonus = (qs.timestep_limit - es.t) * 5;
             bonus = bonus < 0 ? 0 : bonus;
             r = (float)(10000 + bonus);
@@ -1201,12 +1188,12 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     float zraw[ATC_OBS_DIM];   // FULL only: raw observation (zeros for handed-over aircraft)
     {
         if (kObsFirst) {
-            ob.o[5] = a.h - mva;
+            ob.o[5] = alt_above(a.h, mva);
         } else {
             const WideWords wo = LAT ? ww : wide_words<ONE>(m.plain, a.phi, wide_named, zk, i);
             const float phi_f = phi_real(wo.counts), phi_o = __int_as_float(wo.obs_bits);
-            ob = get_state(oc, a.x, a.y, x32, y32, a.h, phi_f, phi_o, v_real(a.v), mva);
-            if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], a.h, ob.on_gp));
+            ob = get_state(oc, a.x, a.y, x32, y32, hf, phi_f, phi_o, v_real(a.v), alt_above(a.h, mva));
+            if (p.mode & ATC_M_REWARD_SHAPING) shaping = shaping_total(shaping_core(oc, ob.d_faf, ob.phi_rel_faf, ob.o[9], hf, ob.on_gp));
         }
         // r += pos; r += ang; r += gs (atc_gym.py:179-185, after the override chain) as one addition of the factored sum
         // (value-only, within 1e-5)
@@ -1304,7 +1291,6 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             // (slot through this step's opaque zero: the spawn-record address is then formed here, on the rare path, instead of
             // being carried — and spilled — across the step loop as a 64-bit per-lane pointer)
             a = spawn(K, qs.off_spawn, p, e, k + zk, episode, o);   // state + raw reset observation from the blob's spawn records
-            ls.v_changed = true;
         }
         es.total_reward = 0.0f;
         es.n_actions = 0;
@@ -1374,18 +1360,15 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     return quiet;
 }
 
-__device__ __forceinline__ void store_lane_state(const atc_state_t& st, const LaneIds& d, const LaneState& ls, bool la_live,
-                                                 bool v_always) {
-    if (d.lane_valid)
-        *at<int4>(st.pos_hp, d.i * 16u) = make_int4(ls.a.x, ls.a.y, __float_as_int(ls.a.h), ls.a.phi);
-    // speed and last-action targets are typically constant for many steps (actions are held, the speed reaches its target):
-    // written back only by wavefronts in which one of them changed
-    // (multi-step launches do not track speed changes per step: one unconditional 4-byte store per aircraft and launch)
-    if ((v_always || __builtin_amdgcn_ballot_w64(ls.v_changed) != 0ull) && d.lane_valid) *at<uint32_t>(st.v_fix, d.i * 4u) = ls.a.v;
-    if (__builtin_amdgcn_ballot_w64(ls.la_changed) != 0ull && d.lane_valid && la_live) {
-        Int3 la = {(int)ls.la_v, __float_as_int(ls.la_h), ls.la_p};
-        *at<Int3>(st.last_act, times12(d.i)) = la;
+__device__ __forceinline__ void store_lane_state(const atc_state_t& st, const LaneIds& d, const LaneState& ls, bool la_live) {
+    if (d.lane_valid) {
+        *at<int4>(st.ac, d.i * 16u) = make_int4(ls.a.x, ls.a.y, ls.a.phi, (int)ls.a.v);
+        *at<double>(st.alt, d.i * 8u) = ls.a.h;
     }
+    // the last-action targets are typically constant for many steps (actions are held): written back only by wavefronts in which
+    // one of them changed
+    if (__builtin_amdgcn_ballot_w64(ls.la_changed) != 0ull && d.lane_valid && la_live)
+        *at<int4>(st.last_act, d.i * 16u) = make_int4((int)ls.la_v, ls.la_p, __double2loint(ls.la_h), __double2hiint(ls.la_h));
 }
 template <int W>
 __device__ __forceinline__ void store_env_state(const atc_state_t& st, const LaneIds& d, const EnvState& es, uint32_t hi0) {
@@ -1441,10 +1424,10 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     const int4 e0 = *at<int4>(st.env, (uint32_t)d.e * (ATC_ENV_WORDS * 4u));
     const uint32_t hi0 = (W == 64) ? *at<uint32_t>(st.stats, (uint32_t)d.e * (ATC_STAT_WORDS * 4u) + ATC_STAT_MASK_HI * 4u) : 0u;
     EnvState es = {e0.x, e0.y, __int_as_float(e0.z), (uint64_t)(uint32_t)e0.w | ((uint64_t)hi0 << 32)};
-    const int4 ps = *at<int4>(st.pos_hp, d.i * 16u);
-    const uint32_t v0 = *at<uint32_t>(st.v_fix, d.i * 4u);
+    const int4 ps = *at<int4>(st.ac, d.i * 16u);       // x, y, heading, speed
+    const double h0 = *at<double>(st.alt, d.i * 8u);
     // ATC_M_ACTIONS_HELD (single-step launches): the caller repeats the previous launch's actions, so an aircraft that was under
-    // control then has last_action == its accepted targets and cannot count an action or change the record — the 12-byte
+    // control then has last_action == its accepted targets and cannot count an action or change the record — the 16-byte
     // record is only read (and written) by envs that were reset since their last step (timesteps == 0), whose aircraft
     // may have been handed over when the action block started and still carry an older record.
     Float3 act = {0.0f, 0.0f, 0.0f};   // action of the current block (held for `hold` steps); one 12-byte load per lane
@@ -1455,9 +1438,9 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     }
     const bool same_actions = ONE && (p.mode & ATC_M_ACTIONS_HELD) != 0;
     const bool la_live = !same_actions || e0.x == 0;
-    Int3 la0 = {0, 0, 0};
-    if (la_live) la0 = *at<Int3>(st.last_act, times12(d.i));
-    LaneState ls = {{ps.x, ps.y, __int_as_float(ps.z), ps.w, v0}, (uint32_t)la0.a, __int_as_float(la0.b), la0.c, false, false};
+    int4 la0 = make_int4(0, 0, 0, 0);   // v, heading, altitude target (float64)
+    if (la_live) la0 = *at<int4>(st.last_act, d.i * 16u);
+    LaneState ls = {{ps.x, ps.y, h0, ps.z, (uint32_t)ps.w}, (uint32_t)la0.x, __hiloint2double(la0.w, la0.z), la0.y, false};
 
     // A single step is its own instantiation: with the step count a run-time value everything the loop carries (aircraft
     // and env records, output bases, hoisted sector constants) stays live across the whole body — the straight-line form
@@ -1529,7 +1512,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         if (ONE || step == 0) tg = decode_targets(qr, act);
         if (ONE && !la_live) {   // held block: the record equals the accepted targets (components that are refused are not compared)
             ls.la_v = tg.v;
-            ls.la_h = tg.h;
+            ls.la_h = altitude_target(qr, tg.ah);
             ls.la_p = tg.p;
         }
         // multi-step launches know structurally which steps repeat an action block
@@ -1543,7 +1526,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             mask_dirty = false;
         }
         ATC_STAMP_TOP(trow, 1);
-        const Mid m = step_part_a<ONE, LAT>(gl, qr, QGET(k), QGET(g), dl, tg.v, tg.h, tg.p, act.c, ls, es, repeated, !ONE && all_active, ONE,
+        const Mid m = step_part_a<ONE, LAT>(gl, qr, QGET(k), QGET(g), dl, tg.v, altitude_target(qr, tg.ah), tg.p, act.c, ls, es, repeated, !ONE && all_active,
                                        st.phi_wide, zk, refused_blk, refused_known ATC_TRACE_PASS(trow));
         refused_known = true;
         ATC_STAMP(1);
@@ -1574,7 +1557,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         asm volatile("s_mov_b32 %0, 0" : "=s"(zk));
         st_end = kernarg_reread<atc_state_t>(offsetof(StepArgs, st), zk);
     }
-    store_lane_state(st_end, d, ls, la_live, !ONE);
+    store_lane_state(st_end, d, ls, la_live);
     store_env_state<W>(st_end, d, es, hi0);
     if (ATC_KARG_PREFETCH(W, ONE)) asm volatile("" ::"s"(karg_touch));   // (keeps the touches alive; nothing waits for them before here)
 #if ATC_TRACE
@@ -1595,15 +1578,11 @@ k_reset(const float* __restrict__ blob, int B, int N, atc_state_t st, const uint
         const int episode = first ? 0 : st.stats[(size_t)e * ATC_STAT_WORDS + ATC_STAT_EPISODES];
         float o[ATC_OBS_DIM];
         const Aircraft a = spawn(blob, (int)blob[ATC_H_OFF_SPAWN], p, e, k, episode, o);
-        reinterpret_cast<int4*>(st.pos_hp)[i] = make_int4(a.x, a.y, __float_as_int(a.h), a.phi);
-        st.v_fix[i] = (int32_t)a.v;
+        reinterpret_cast<int4*>(st.ac)[i] = make_int4(a.x, a.y, a.phi, (int)a.v);
+        st.alt[i] = a.h;
         // atc_gym.py:86: last_action = [0,0,0] once, in __init__ — never on reset (quirk Q7) — in the state's formats: 0 kt = 0
-        // counts, 0 ft = the bits of 0.0f, 0 deg = the counts of 0 deg
-        if (first) {
-            st.last_act[3 * (size_t)i] = 0;
-            st.last_act[3 * (size_t)i + 1] = __float_as_int(0.0f);
-            st.last_act[3 * (size_t)i + 2] = phi_store(0.0f);
-        }
+        // counts, 0 deg = the counts of 0 deg, 0 ft = 0.0 (float64)
+        if (first) reinterpret_cast<int4*>(st.last_act)[i] = make_int4(0, phi_store(0.0f), 0, 0);
         if (obs) store_obs(obs + (size_t)i * ATC_OBS_DIM, o);   // the raw reset observation (mva = 0, atc_gym.py:351)
     }
 }
@@ -1615,15 +1594,16 @@ k_observe(const float* __restrict__ blob, int B, int N, atc_state_t st, const ui
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < BN; i += gridDim.x * kBlock) {
         const int e = (int)(i / (uint32_t)N);
         if (mask && !mask[e]) continue;
-        const int4 ps = reinterpret_cast<const int4*>(st.pos_hp)[i];
-        float ang = phi_real(ps.w), o3 = ang;
-        if (is_wide(ps.w)) {   // (include/atc_step.h, ABI 19: the exact counts are in the side record)
+        const int4 ps = reinterpret_cast<const int4*>(st.ac)[i];
+        const double h = st.alt[i];
+        float ang = phi_real(ps.z), o3 = ang;
+        if (is_wide(ps.z)) {   // (include/atc_step.h, ABI 19: the exact counts are in the side record)
             const double P = st.phi_wide[4 * (size_t)i];
             ang = phi_real(phi_wrap(P));
             o3 = phi_obs_wide(P);
         }
         const Obs ob = get_state(obs_const(blob), ps.x, ps.y, pos_to_real(blob, 0, ps.x), pos_to_real(blob, 1, ps.y),
-                                 __int_as_float(ps.z), ang, o3, v_real((uint32_t)st.v_fix[i]), 0.0f);
+                                 (float)h, ang, o3, v_real((uint32_t)ps.w), alt_above(h, 0.0f));
         store_obs(obs + (size_t)i * ATC_OBS_DIM, ob.o);
     }
 }
@@ -1743,7 +1723,7 @@ static int launch_step(const atc_scenario* s, int B, int N, int T, int hold, con
 static int check_env_args(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const atc_params_t* p) {
     if (!s || !st || !p) return fail_arg("null pointer");
     if (B < 1 || N < 1 || N > ATC_MAX_AIRCRAFT) return fail_arg("need B >= 1, 1 <= N <= 64");
-    if (!st->pos_hp || !st->v_fix || !st->last_act || !st->env || !st->stats || !st->phi_wide) return fail_arg("atc_state_t has a null field");
+    if (!st->ac || !st->alt || !st->last_act || !st->env || !st->stats || !st->phi_wide) return fail_arg("atc_state_t has a null field");
     if ((unsigned long long)B * N * ATC_OBS_DIM * 4ull >= (1ull << 32) || (unsigned long long)B * 64ull >= (1ull << 32))
         return fail_arg("B*N too large for one launch (B*N*40 bytes must stay below 4 GiB): split the batch");
     return ATC_OK;
@@ -1758,10 +1738,10 @@ static int step_common(const atc_scenario_t* s, int B, int N, int T, int hold, c
     if (T % hold != 0) return fail_arg("T must be a multiple of hold (actions holds T / hold blocks)");
     if (!out->obs || !out->reward || !out->done || !out->flags) return fail_arg("obs/reward/done/flags are required");
     if (out->packet && (N != 1 || T != 1)) return fail_arg("atc_out_t.packet is for single steps of single-aircraft envs");
-    if (!(p->dt > 0.0f)) return fail_arg("dt must be > 0");
+    if (!(p->dt > 0.0)) return fail_arg("dt must be > 0");
     // the fixed-point formats of include/atc_step.h: a step's displacement (<= 512 kt) must stay below 2^30 position-grid
     // counts and the speed's rate limit below 2^31 speed counts — dt up to 51 s for any sector (the reference uses 1 s)
-    if (!(0.1423 * (double)p->dt * (double)s->consts[ATC_C_POS_SCALE] < 1073741824.0) || !((double)kAMax * (double)p->dt < 255.9))
+    if (!(0.1423 * p->dt * (double)s->consts[ATC_C_POS_SCALE] < 1073741824.0) || !((double)kAMax * p->dt < 255.9))
         return fail_arg("dt too large for the fixed-point state formats (see include/atc_step.h)");
     hipStream_t q = (hipStream_t)stream;
     if (N == 1) return launch_step<1>(s, B, N, T, hold, st, actions, out, p, q);

@@ -89,7 +89,7 @@ class AtcGym(Env):
         self._host_act = torch.zeros(3, dtype=torch.float32).pin_memory()
         self._act_np = self._host_act.numpy()
         self._out_np = self._host_out.numpy()
-        self._pos_rec = self._vec.pos_hp       # (device memory in "io" mode: read with a copy after a reset only)
+        self._pos_rec = self._vec.ac       # (device memory in "io" mode: read with a copy after a reset only)
         self._pos_inv = 2.0 ** -self._vec.pos_k
         self._pos_origin = tuple(self._vec.pos_origin)
         lay = self._out_layout

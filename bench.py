@@ -30,10 +30,10 @@ INFINITY_CACHE_BYTES = 256 << 20  # MI355X_MICROARCH.md: 256 MiB memory-side cac
 
 
 def working_set_bytes(B, N, T=1):
-    """Bytes one launch touches: aircraft records (pos_hp 16 + v 4 + last_act 12), env records (16 + 32 per env), ONE action
+    """Bytes one launch touches: aircraft records (ac 16 + alt 8 + last_act 16), env records (16 + 32 per env), ONE action
     tensor (12 per aircraft; the other ring tensors are cold) and the outputs of its T steps (obs 40 + flags 2 per aircraft,
     reward 4 + done 1 per env)."""
-    return B * N * (32 + 12 + 42 * T) + B * (48 + 5 * T)
+    return B * N * (40 + 12 + 42 * T) + B * (48 + 5 * T)
 
 
 def algorithmic_bytes_per_env_step(n, fused_steps=1, hold=1):
@@ -246,8 +246,8 @@ def _finish_gate(tag, env, orc, worst, extra):
     if worst[0] > 1e-5 or worst[1] > 1e-5:
         raise RuntimeError("parity gate (%s): obs %.2e / reward %.2e beyond 1e-5" % (tag, worst[0], worst[1]))
     if not (np.array_equal(env.actions_taken.cpu().numpy(), orc.actions_taken)
-            and np.array_equal(env.last_act.cpu().numpy().reshape(-1, 3), orc.last_act.T.reshape(-1, 3))
-            and np.array_equal(env.pos_hp[:, 0].cpu().numpy(), orc.px) and np.array_equal(env.pos_hp[:, 1].cpu().numpy(), orc.py)):
+            and np.array_equal(env.last_act.cpu().numpy(), orc.last_act)
+            and np.array_equal(env.ac[:, 0].cpu().numpy(), orc.px) and np.array_equal(env.ac[:, 1].cpu().numpy(), orc.py)):
         raise RuntimeError("parity gate (%s): actions_taken / last_action / positions differ from the fp32 oracle" % tag)
     out = {"flags_done_exact": True, "state_and_counters_exact": True, "max_rel_obs_err": worst[0], "max_rel_reward_err": worst[1]}
     out.update(extra)

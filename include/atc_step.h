@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ATC_ABI_VERSION 19
+#define ATC_ABI_VERSION 20
 
 /* ---------------------------------------------------------------------------------------------
  * Scenario blob: one flat array of 32-bit floats (device copy) compiled on the host from the sector
@@ -160,7 +160,7 @@ enum {
     ATC_M_ACTIONS_HELD = 1u << 6     /* atc_step only — a promise of the caller: `actions` holds, for every aircraft, the same
                                         bits as in the previous step of these envs — an atc_step or the last step of a multi-step launch (frame skip,
                                         learning/atc-gym-demo.py:18-19).  Results are identical to a launch without the bit;
-                                        the kernel then skips the last_action record (12 of 110 bytes per aircraft-step):
+                                        the kernel then skips the last_action record (16 of 118 bytes per aircraft-step):
                                         an aircraft under control in the previous step has last_action == its accepted
                                         targets (atc_gym.py:305-311), so no action is counted and the record does not
                                         change.  Envs reset since their last step (timesteps == 0) are handled in full.
@@ -168,15 +168,18 @@ enum {
 };
 
 typedef struct atc_params {
-    float dt;               /* SimParameters.timestep [s], model.py:141 */
+    double dt;              /* SimParameters.timestep [s], model.py:132-145 — a Python float in the reference: float64 here too
+                               (ABI 20; 0.1 is not 0.1f), it scales every rate limit (model.py:75-78,97-100,117-120), the
+                               displacement (model.py:126) and the base reward (atc_gym.py:137) */
     int32_t timestep_limit; /* 6000, atc_gym.py:40 */
     uint32_t mode;          /* ATC_M_* */
-    uint32_t reserved0;     /* tag written into every chunk of atc_out_t.packet (ignored without a packet) */
     uint64_t seed;          /* RNG key for ATC_M_RANDOM_ENTRY */
     float sep_nm;           /* 3.0  (extension) */
     float sep_ft;           /* 1000 (extension) */
     float conflict_reward;  /* -200 (extension) */
+    uint32_t reserved0;     /* tag written into every chunk of atc_out_t.packet (ignored without a packet) */
     float reserved1;
+    uint32_t reserved2;
 } atc_params_t;
 
 /* Aircraft positions (model.py:33-34) on the fp32 path.
@@ -212,7 +215,7 @@ typedef struct atc_params {
  *                                               integer-valued float64 atc_state_t.phi_wide[i][0] (written by the step that
  *                                               left the 32-bit range; float64 holds every integer up to 2^53).
  *                                           The last accepted heading target (last_action[2], atc_gym.py:311) is stored the same way:
- *                                           sat32 in last_act[i][2], exact value in phi_wide[i][1] when that is saturated.
+ *                                           sat32 in last_act[i][1], exact value in phi_wide[i][1] when that is saturated.
  *   - a target is  counts = trunc(a * m + c):  ONE float64 fma on the fp32 action (m, c = the reference's factor / offset of
  *     atc_gym.py:64-78,318-335 in counts, both integers; exact for every fp32 action: 24 x 31 bits), truncated toward zero,
  *     NaN -> 0.  The speed's target is converted to uint32 SATURATING (gfx950: v_cvt_u32_f64): an action far outside the action
@@ -245,13 +248,19 @@ typedef struct atc_params {
  *     relative angles of the observation and the shaping terms are values (1e-5 bar) and stay fp32;
  *   - the fp32 speed every other formula of the reference sees is (float)v_fix * 2^-23; both conversions are exact for every value
  *     with <= 24 significant bits, e.g. all integer speeds and headings;
- *   - the altitude stays fp32 (it does not feed the position; 1e-3 ft at 16 000 ft is 5e-8 in observation units).  Its TARGET is the
- *     reference's float64 value  a * m + c  (one fma: the product is exact) rounded to fp32 TOWARD MINUS INFINITY, and +inf when the
- *     float64 value exceeds h_max: an aircraft within one step's rate of its target lands ON it (fp32: h + (target - h) is exact
- *     there), and the flags that compare that altitude with fp32-representable thresholds — below the MVA (atc_gym.py:149-153), the
- *     refusals target < h_min / target > h_max (model.py:91-94) — come out like the reference's float64 comparisons: x < n and
- *     RD(x) < n are the same statement for a representable n.  (Round-to-nearest is not: told to descend "to the MVA" the reference's
- *     target lies 5e-4 ft below or above it by the last bit of the fp32 action — tests/golden/g11 has both.)
+ *   - the ALTITUDE (model.py:82-102) is the reference's float64, operation for operation (ABI 20; rounds 1-5 kept an fp32
+ *     accumulator: exact for timesteps whose rate limits 41 dt / 15 dt are small multiples of an fp32 ulp — 1, 2, 5, 0.5 s — and
+ *     0.4 ulp off PER STEP for 0.1 s: the below-MVA flag came one step late in 19 of 120 sustained descents, tests/golden/g12):
+ *       target = a * m + c        one float64 fma on the fp32 action (the product is exact): the reference's a * f / 2 + f / 2 + off
+ *                                 (atc_gym.py:333-335; discrete: a * 100 + 0, :329-330) bit for bit
+ *       refused iff target < h_min or target > h_max                                        (model.py:91-94, float64 compares)
+ *       h += max(min(target - h, 15 dt), -41 dt)       three float64 operations, dt the float64 of atc_params_t (model.py:95-102)
+ *       below the MVA iff h < mva                       (atc_gym.py:149-153; the MVA height is an integer)
+ *       observation words 2 and 5 = (float)h and (float)(h - mva), the difference in float64          (atc_gym.py:266,276)
+ *     so every flag that depends on the altitude alone is the reference's for ANY timestep, including the ties it decides by its
+ *     own accumulated rounding (15 000 ft - 3 000 x 4.1 ft against the 2 700 ft MVA at dt = 0.1).  What other formulas see — the
+ *     glide-path test of the corridor (model.py:201-208), the shaping terms, the separation scan — is (float)h, one rounding.
+ *     The last accepted altitude target (last_action[1], atc_gym.py:311) is kept as the same float64.
  *   - state placed from outside (entry points, fixtures) is the NEAREST count.
  * Heading kinematics (model.py:122-129, 345-348) in float64, shared bit for bit by every fp32 implementation (the HIP
  * kernels, the fp32 instantiation of the test oracle):
@@ -311,20 +320,21 @@ typedef struct atc_params {
 
 /* Persistent environment state (all device pointers).  Aircraft arrays are indexed env * N + k and packed so that a
  * wavefront moves each with one access per lane on consecutive addresses.  Per aircraft-step the step kernel reads
- * 16 + 4 + 12 B and writes 16 + 4 B (+ 12 B only when a last-action target changed). */
+ * 16 + 8 + 12 B (record, altitude, action) and writes 16 + 8 B; the 16-byte last-action record is read and written only by
+ * steps that may change it (not under ATC_M_ACTIONS_HELD, not inside a held block of a multi-step launch). */
 typedef struct atc_state {
-    int32_t* pos_hp;  /* [B*N][4]  x_fix, y_fix (position grid counts, see above), h [ft] as a float bit pattern, phi_fix
-                         (heading, never wrapped, model.py:35-36; fixed point, INT32_MIN / INT32_MAX = WIDE: see above and
-                         phi_wide) — one 16-byte record */
-    int32_t* v_fix;   /* [B*N]     speed (model.py:37), fixed point */
-    int32_t* last_act;/* [B*N][3]  last accepted v / h / phi targets = AtcGym.last_action (atc_gym.py:86,311) in the state's
-                         own formats: v_fix, h as a float bit pattern, phi_fix (0 kt / 0 deg of atc_gym.py:86 = the counts
-                         of 0, not the integer 0) */
+    int32_t* ac;      /* [B*N][4]  x_fix, y_fix (position grid counts, see above), phi_fix (heading, never wrapped, model.py:35-36;
+                         fixed point, INT32_MIN / INT32_MAX = WIDE: see above and phi_wide), v_fix (speed, model.py:37; unsigned
+                         counts) — one 16-byte record */
+    double* alt;      /* [B*N]     altitude h [ft] (model.py:34): the reference's float64 (ABI 20, see "the ALTITUDE" above) */
+    int32_t* last_act;/* [B*N][4]  last accepted v / phi / h targets = AtcGym.last_action (atc_gym.py:86,311) in the state's
+                         own formats: word 0 v_fix, word 1 phi_fix (0 kt / 0 deg of atc_gym.py:86 = the counts of 0, not the
+                         integer 0), words 2..3 the altitude target as a float64 — one 16-byte record */
     int32_t* env;     /* [B][ATC_ENV_WORDS]  per-step env record, see ATC_ENV_* */
     int32_t* stats;   /* [B][ATC_STAT_WORDS] per-episode env record, see ATC_STAT_* (touched only when an episode ends) */
     double* phi_wide; /* [B*N][4]  side record of aircraft whose 32-bit heading fields are saturated (see "Speed and heading": WIDE):
                          word 0 = exact heading counts, word 1 = exact last heading target (integer-valued float64, valid while
-                         phi_fix / last_act[i][2] is INT32_MIN / INT32_MAX), word 2 = scratch of the step kernel (the wrapped
+                         phi_fix / last_act[i][1] is INT32_MIN / INT32_MAX), word 2 = scratch of the step kernel (the wrapped
                          counts and observation word 3 of word 0, handed from the first half of a step to the second), word 3
                          reserved.  Never read or written for an aircraft whose heading and heading targets stay inside
                          (-76, 436) deg — every action inside the action space —, so it costs memory (32 B per aircraft), not

@@ -10,13 +10,15 @@
  *   REAL = float (suffix _f32): the fp32 restatement — the same operation order in float with libm's float functions,
  *     EXCEPT the choices include/atc_step.h fixes for every fp32 implementation ("Aircraft positions", "Speed and heading":
  *     the fixed-point position grid; since ABI 18 the fixed-point speed / heading state with its integer rate limits, the
- *     truncating target conversion, the float64 heading kinematics and the dithered rounding).  With those shared, the HIP kernels' aircraft state and every
+ *     truncating target conversion, the float64 heading kinematics and the dithered rounding; since ABI 20 the ALTITUDE as the
+ *     reference's float64, operation for operation, and the timestep as a float64).  With those shared, the HIP kernels' aircraft state and every
  *     integer output match this instantiation bit for bit; it is itself pinned against the same golden vectors (integer
  *     outputs exact, fp32 values within 1e-5 — everywhere: the near-FAF exception of rounds 1-3 is retired).
  * Scalar, compiled with -ffp-contract=off.
  *
- * Pinned by: tests/golden/{g1..g9,model_test_known_answers} (see tests/test_oracle_golden.py): 48 080 + 650 963 reference
- * steps, lattices, tie-break points, shaping grids, the reference's own 8 unit-test answers.
+ * Pinned by: tests/golden/{g1..g12,model_test_known_answers} (see tests/test_oracle_golden.py): 48 080 + 650 963 + 93 879
+ * reference steps at timesteps 1 / 2 / 5 s, the g12 episodes at 0.05 .. 3.7 s, lattices, tie-break points, shaping grids, the
+ * reference's own 8 unit-test answers.
  * The multi-aircraft separation scan and noise-abatement areas have NO reference implementation
  * (README.md:51,60,62 are prose only): for those paths parity is UNPINNED and this file is the definition.
  *
@@ -325,10 +327,11 @@ static uint64_t FN(draw)(uint64_t seed, uint32_t env, uint32_t episode, uint32_t
 /* ---- structures (host pointers; same field meaning as include/atc_step.h) ----------------------------------------- */
 typedef struct FN(orc_state) {
     FN(pos_t) *x, *y;          /* [B*N] positions: float64 (reference) | 32-bit fixed point (fp32 spec), see pos_t above */
-    REAL* h;                   /* [B*N] */
+    double* h;                 /* [B*N] altitude: float64 in BOTH instantiations (include/atc_step.h, ABI 20) */
     FN(fix_t) *phi, *v;        /* [B*N] heading, speed: REAL (reference) | 32-bit fixed point (fp32 spec), see fix_t above */
-    FN(fix_t)* last_act;       /* [3][B*N] last accepted v / h / phi targets in the state's formats (fp32 spec: v_fix, the
-                                  altitude's float bit pattern, phi_fix) */
+    FN(fix_t)* last_act;       /* last accepted v / h / phi targets.  Reference instantiation: [3][B*N] float64 (v, h, phi).
+                                  fp32 spec: [B*N][4] 32-bit words in the DEVICE's record layout (atc_state_t.last_act):
+                                  v_fix, phi_fix, the altitude target's float64 in words 2..3 */
     int32_t* timesteps;
     int32_t* actions_taken;
     REAL* total_reward;
@@ -356,8 +359,10 @@ typedef struct FN(orc_out) {
 
 /* atc_gym.py:262-277 _get_state -> float32[10]; also returns the full-precision d_faf / phi_rel_faf / on_gp used by the
  * shaping rewards (atc_gym.py:179-185 read self._d_faf etc., which are not rounded to float32). */
-static void FN(get_state)(const REAL* S, FN(pos_t) px, FN(pos_t) py, REAL h, REAL phi, REAL phi_obs, REAL v, REAL mva, float* obs10,
+static void FN(get_state)(const REAL* S, FN(pos_t) px, FN(pos_t) py, double h, REAL phi, REAL phi_obs, REAL v, REAL mva, float* obs10,
                           REAL* d_faf, REAL* phi_rel_faf, REAL* on_gp) {
+    /* h: the float64 altitude (both instantiations, include/atc_step.h ABI 20): words 2 and 5 are np.float32 of the reference's
+     * float64 h and h - mva (atc_gym.py:266-267,276) */
     /* phi: the heading the relative angle sees; phi_obs: observation word 3 — the same number in the reference, the wrapped /
      * unwrapped pair of a WIDE heading in the fp32 spec (include/atc_step.h) */
     REAL x = FN(pos_to_real)(S, 0, px), y = FN(pos_to_real)(S, 1, py);
@@ -372,7 +377,7 @@ static void FN(get_state)(const REAL* S, FN(pos_t) px, FN(pos_t) py, REAL h, REA
     obs10[2] = (float)h;
     obs10[3] = (float)phi_obs;
     obs10[4] = (float)v;
-    obs10[5] = (float)(h - mva);
+    obs10[5] = (float)(h - (double)mva);
     obs10[6] = (float)*on_gp;
     obs10[7] = (float)*d_faf;
     obs10[8] = (float)*phi_rel_faf;
@@ -394,7 +399,7 @@ static void FN(normalize)(const REAL* S, const float* raw, float* out) {
  * Lattice mode: slot k -> entry k mod E, level (k div E) mod n_levels (precomputed per slot in the blob).
  * Random mode: a 64-bit draw keyed by (seed, env, episode, slot); entry = (lo32 * E) >> 32, level = (hi32 * n_levels) >> 32
  * (multiply-shift range reduction: integer-only, so every implementation agrees). */
-static void FN(spawn)(const REAL* S, const atc_params_t* p, int e, int k, int episode, REAL* x, REAL* y, REAL* h,
+static void FN(spawn)(const REAL* S, const atc_params_t* p, int e, int k, int episode, REAL* x, REAL* y, double* h,
                       REAL* phi, REAL* v) {
     *v = S[ATC_C_V_INIT];
     if (!(p->mode & ATC_M_RANDOM_ENTRY)) {
@@ -413,7 +418,7 @@ static void FN(spawn)(const REAL* S, const atc_params_t* p, int e, int k, int ep
     *x = rec[ATC_E_X];
     *y = rec[ATC_E_Y];
     *phi = rec[ATC_E_PHI];
-    *h = rec[ATC_E_LEV0 + li] * (REAL)100;
+    *h = (double)(rec[ATC_E_LEV0 + li] * (REAL)100);
 }
 
 /* AtcGym.reset (atc_gym.py:337-365) for env e; writes RAW obs computed with mva = 0 (atc_gym.py:351,365).
@@ -455,11 +460,19 @@ int FN(atc_oracle_reset)(const REAL* S, int B, int N, const FN(orc_state_t) * st
     size_t BN = (size_t)B * N;
     for (int e = 0; e < B; ++e) {
         if (mask && !mask[e]) continue;
-        if (first) /* atc_gym.py:86: last_action = [0, 0, 0] — in the state's formats (fp32 spec: the counts of 0 kt / 0 deg) */
+        if (first) /* atc_gym.py:86: last_action = [0, 0, 0] — in the state's formats (fp32 spec: the counts of 0 kt / 0 deg, 0.0 ft) */
             for (int k = 0; k < N; ++k) {
-                st->last_act[(size_t)0 * BN + (size_t)e * N + k] = FN(v_store)((REAL)0);
-                st->last_act[(size_t)1 * BN + (size_t)e * N + k] = 0; /* 0 ft (fp32 spec: the bit pattern of 0.0f) */
-                st->last_act[(size_t)2 * BN + (size_t)e * N + k] = FN(phi_store)((REAL)0);
+#if ORC_FIXED_POS
+                int32_t* la = &st->last_act[4 * ((size_t)e * N + k)];
+                la[0] = FN(v_store)((REAL)0);
+                la[1] = FN(phi_store)((REAL)0);
+                la[2] = la[3] = 0; /* the float64 0.0 */
+                (void)BN;
+#else
+                st->last_act[(size_t)0 * BN + (size_t)e * N + k] = 0;
+                st->last_act[(size_t)1 * BN + (size_t)e * N + k] = 0;
+                st->last_act[(size_t)2 * BN + (size_t)e * N + k] = 0;
+#endif
             }
         FN(reset_env)(S, N, st, p, e, obs, first);
     }
@@ -471,7 +484,8 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
                         const FN(orc_out_t) * out, const atc_params_t* p) {
     if (!S || !st || !actions || !out || !p || B < 0 || N < 1 || N > ATC_MAX_AIRCRAFT) return -1;
     const size_t BN = (size_t)B * N;
-    const REAL dt = (REAL)p->dt;
+    (void)BN;
+    const double dtd = p->dt; /* SimParameters.timestep: a float64 like the reference's Python float (ABI 20) */
     const int discrete = (p->mode & ATC_M_DISCRETE) != 0;
     const REAL v_min = S[ATC_C_V_MIN], v_max = S[ATC_C_V_MAX], h_min = S[ATC_C_H_MIN], h_max = S[ATC_C_H_MAX];
     /* atc_gym.py:64-78: offset = (v_min, 0, 0); factor = (10,100,1) discrete | (v_max - v_min, h_max, 360) continuous */
@@ -482,7 +496,6 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
     const int off_poly = (int)S[ATC_H_OFF_POLY];
 #if ORC_FIXED_POS
     /* uniform terms of the fixed-point spec (include/atc_step.h, ABI 18), evaluated in float64 from the blob's fp32 constants */
-    const double dtd = (double)p->dt;
     const FN(decode_t) dec_v = discrete ? FN(decode_consts)((double)fac[0], (double)off[0], 0.0, ORC_QV)
                                         : FN(decode_consts)((double)fac[0] / 2.0, (double)fac[0] / 2.0 + (double)off[0], 0.0, ORC_QV);
     const FN(decode_t) dec_p = discrete ? FN(decode_consts)((double)fac[2], (double)off[2], (double)ATC_PHI_FIX_OFFSET, ORC_QP)
@@ -520,10 +533,10 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
                 fl[k] = ATC_F_INACTIVE;
                 continue;
             }
-            REAL reward = (REAL)-0.05 * dt; /* atc_gym.py:137 */
+            REAL reward = (REAL)(-0.05 * dtd); /* atc_gym.py:137 */
 #if ORC_FIXED_POS
-            /* fp32 spec (include/atc_step.h, ABI 18): speed / heading targets, rate limits and the discriminator in 32-bit fixed
-             * point; altitude in fp32 as the plain transcription */
+            /* fp32 spec (include/atc_step.h): speed / heading targets, rate limits and the discriminator in 32-bit fixed point
+             * (ABI 18); the altitude in float64, the reference's own operations (ABI 20) */
             {
                 const float av = actions[i * 3 + 0], ah = actions[i * 3 + 1], ap = actions[i * 3 + 2];
                 { /* speed: model.py:60-80 */
@@ -534,33 +547,30 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
                     } else {
                         /* (differences of valid speeds and of the initial last_action 0 fit 32 bits: wrapping arithmetic) */
                         st->v[i] = (int32_t)((uint32_t)st->v[i] + (uint32_t)FN(clampi)((int32_t)(tgt - (uint32_t)st->v[i]), -rate_v, rate_v));
-                        int32_t* la = &st->last_act[(size_t)0 * BN + i];
+                        int32_t* la = &st->last_act[4 * i + 0];
                         const int32_t dd = (int32_t)(tgt - (uint32_t)*la);
                         if (!(dd > -discr_v && dd < discr_v)) st->actions_taken[e] += 1; /* atc_gym.py:305-306 */
                         *la = (int32_t)tgt;                                               /* atc_gym.py:311 */
                     }
                 }
-                { /* altitude: model.py:82-102.  fp32 spec (include/atc_step.h, round 5): the reference's float64 target rounded to fp32
-                   * TOWARD MINUS INFINITY (+inf beyond h_max): comparisons of the altitude the aircraft lands on with fp32-representable
-                   * thresholds — h < mva, the refusals — then come out like the reference's float64 ones */
+                { /* altitude: model.py:82-102 in float64, operation for operation (include/atc_step.h, ABI 20): the target is the
+                   * reference's a * f / 2 + f / 2 + off (ONE rounding: the product of an fp32 action with f is exact), the refusals,
+                   * the rate limits h_dot * timestep and the sum are its float64 operations */
                     const double td = discrete ? fma((double)ah, (double)fac[1], (double)off[1])
                                                : fma((double)ah, (double)fac[1] / 2.0, (double)fac[1] / 2.0 + (double)off[1]);
-                    REAL tgt = (REAL)td;
-                    if ((double)tgt > td) tgt = nextafterf(tgt, -INFINITY);
-                    if (td > (double)h_max) tgt = INFINITY;
-                    if (tgt < h_min || tgt > h_max) {
+                    if (td < (double)h_min || td > (double)h_max) {
                         reward -= (REAL)1.0;
                         fl[k] |= ATC_F_INVALID_H;
                     } else {
-                        REAL d = tgt - st->h[i];
-                        d = R_MIN(d, S[ATC_C_HDOT_MAX] * dt);
-                        d = R_MAX(d, S[ATC_C_HDOT_MIN] * dt);
+                        double d = td - st->h[i];
+                        d = fmin(d, (double)S[ATC_C_HDOT_MAX] * dtd);
+                        d = fmax(d, (double)S[ATC_C_HDOT_MIN] * dtd);
                         st->h[i] = st->h[i] + d;
-                        int32_t* la = &st->last_act[(size_t)1 * BN + i];
-                        float last;
+                        int32_t* la = &st->last_act[4 * i + 2];
+                        double last;
                         memcpy(&last, la, sizeof last);
-                        if (!(R_ABS(tgt - last) < S[ATC_C_ACT_DISCR + 1])) st->actions_taken[e] += 1;
-                        memcpy(la, &tgt, sizeof tgt);
+                        if (!(fabs(td - last) < (double)S[ATC_C_ACT_DISCR + 1])) st->actions_taken[e] += 1;
+                        memcpy(la, &td, sizeof td);
                     }
                 }
                 { /* heading: model.py:104-120 — no validation, no wrap: 64-bit counts (include/atc_step.h, ABI 19) */
@@ -572,7 +582,7 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
                     int64_t d = tgt - P;
                     d = d > (int64_t)rate_p ? (int64_t)rate_p : (d < -(int64_t)rate_p ? -(int64_t)rate_p : d);
                     FN(phi_put)(P + d, &st->phi[i], &wide[0]);
-                    int32_t* la = &st->last_act[(size_t)2 * BN + i];
+                    int32_t* la = &st->last_act[4 * i + 1];
                     const int64_t dd = tgt - FN(phi_load)(*la, wide[1]);
                     if (!(dd > -(int64_t)discr_p && dd < (int64_t)discr_p)) st->actions_taken[e] += 1;
                     FN(phi_put)(tgt, la, &wide[1]);
@@ -593,22 +603,22 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
                     if (tgt < v_min || tgt > v_max) valid = 0;
                     else {
                         REAL d = tgt - st->v[i];
-                        d = R_MIN(d, S[ATC_C_A_MAX] * dt);
-                        d = R_MAX(d, S[ATC_C_A_MIN] * dt);
+                        d = R_MIN(d, S[ATC_C_A_MAX] * dtd);
+                        d = R_MAX(d, S[ATC_C_A_MIN] * dtd);
                         st->v[i] = st->v[i] + d;
                     }
                 } else if (c == 1) { /* model.py:82-102 */
                     if (tgt < h_min || tgt > h_max) valid = 0;
                     else {
                         REAL d = tgt - st->h[i];
-                        d = R_MIN(d, S[ATC_C_HDOT_MAX] * dt);
-                        d = R_MAX(d, S[ATC_C_HDOT_MIN] * dt);
+                        d = R_MIN(d, S[ATC_C_HDOT_MAX] * dtd);
+                        d = R_MAX(d, S[ATC_C_HDOT_MIN] * dtd);
                         st->h[i] = st->h[i] + d;
                     }
                 } else { /* model.py:104-120: no validation, no wrap */
                     REAL d = tgt - st->phi[i];
-                    d = R_MIN(d, S[ATC_C_PHIDOT_MAX] * dt);
-                    d = R_MAX(d, S[ATC_C_PHIDOT_MIN] * dt);
+                    d = R_MIN(d, S[ATC_C_PHIDOT_MAX] * dtd);
+                    d = R_MAX(d, S[ATC_C_PHIDOT_MIN] * dtd);
                     st->phi[i] = st->phi[i] + d;
                 }
                 if (valid) {
@@ -621,7 +631,7 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
                 }
             }
             /* model.py:122-129 Airplane.step: rot_matrix(phi) . [0, (v/3600)*dt] */
-            REAL dist = (st->v[i] / (REAL)3600) * dt;
+            REAL dist = (st->v[i] / (REAL)3600) * dtd;
             REAL sn, cs;
             FN(sincos_heading)(st->phi[i], &sn, &cs);
             st->x[i] = FN(pos_advance)(S, st->x[i], sn * dist);
@@ -640,7 +650,7 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
             if (pi >= 0) {
                 REAL mva = S[off_poly + pi * ATC_P_WORDS + ATC_P_HEIGHT];
                 mva_h[k] = mva;
-                if (st->h[i] < mva) {
+                if (st->h[i] < (double)mva) { /* atc_gym.py:149: the float64 altitude against the integer height */
                     r[k] = (REAL)-200;
                     fl[k] |= ATC_F_BELOW_MVA;
                 }
@@ -661,7 +671,7 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
                 REAL dx = FN(pos_to_real)(S, 0, st->x[ia]) - FN(pos_to_real)(S, 0, st->x[ib]);
                 REAL dy = FN(pos_to_real)(S, 1, st->y[ia]) - FN(pos_to_real)(S, 1, st->y[ib]);
                 REAL d2 = R_FMA(dx, dx, dy * dy); /* fused: the definition shared with the device kernel */
-                REAL dh = R_ABS(st->h[ia] - st->h[ib]);
+                REAL dh = R_ABS((REAL)st->h[ia] - (REAL)st->h[ib]); /* (fp32 spec: the altitudes rounded once, then the difference) */
                 REAL d = R_SQRT(d2);
                 if (d < min_sep) min_sep = d;
                 if (d2 < (REAL)p->sep_nm * (REAL)p->sep_nm && dh < (REAL)p->sep_ft) {
@@ -702,7 +712,7 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
 #else
             const double phi_c = (double)phi_r;
 #endif
-            if (FN(inside_corridor)(S, px, py, st->h[i], phi_c)) { /* atc_gym.py:163-169 */
+            if (FN(inside_corridor)(S, px, py, (REAL)st->h[i], phi_c)) { /* atc_gym.py:163-169 */
                 int bonus = (p->timestep_limit - t) * 5;
                 if (bonus < 0) bonus = 0;
                 r[k] = (REAL)(10000 + bonus);
@@ -720,13 +730,13 @@ int FN(atc_oracle_step)(const REAL* S, int B, int N, const FN(orc_state_t) * st,
                 REAL pos = FN(reward_approach_position)(d_faf, S[ATC_C_PHI_TO_RWY], phi_rel_faf, S[ATC_C_WORLD_DIAG]);
                 r[k] += pos;
                 r[k] += FN(reward_approach_angle)(S[ATC_C_PHI_TO_RWY], phi_rel_faf, phi_r, pos);
-                r[k] += FN(reward_glideslope)(st->h[i], on_gp, pos);
+                r[k] += FN(reward_glideslope)((REAL)st->h[i], on_gp, pos);
             }
             /* extension: noise-abatement areas (no reference code): inside polygon and below its ceiling */
             for (int q = 0; q < n_noise; ++q) {
                 const REAL* rec = S + off_poly + (n_mva + q) * ATC_P_WORDS;
                 if (rec[ATC_P_MINX] <= px && px <= rec[ATC_P_MAXX] && rec[ATC_P_MINY] <= py && py <= rec[ATC_P_MAXY] &&
-                    st->h[i] < rec[ATC_P_HEIGHT] &&
+                    st->h[i] < (double)rec[ATC_P_HEIGHT] &&
                     FN(ray_tracing)(px, py, S + (int)rec[ATC_P_VOFF], (int)rec[ATC_P_NVERT])) {
                     r[k] -= rec[ATC_P_PENALTY];
                     fl[k] |= ATC_F_NOISE;

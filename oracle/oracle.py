@@ -18,9 +18,9 @@ F_PHI_LIMIT = 1 << 9
 
 class Params(C.Structure):
     """Mirror of atc_params_t (include/atc_step.h)."""
-    _fields_ = [("dt", C.c_float), ("timestep_limit", C.c_int32), ("mode", C.c_uint32), ("reserved0", C.c_uint32),
-                ("seed", C.c_uint64), ("sep_nm", C.c_float), ("sep_ft", C.c_float), ("conflict_reward", C.c_float),
-                ("reserved1", C.c_float)]
+    _fields_ = [("dt", C.c_double), ("timestep_limit", C.c_int32), ("mode", C.c_uint32), ("seed", C.c_uint64),
+                ("sep_nm", C.c_float), ("sep_ft", C.c_float), ("conflict_reward", C.c_float), ("reserved0", C.c_uint32),
+                ("reserved1", C.c_float), ("reserved2", C.c_uint32)]
 
 
 def make_params(dt=1.0, shaping=True, normalize=True, discrete=False, auto_reset=False, random_entry=False, seed=0,
@@ -28,7 +28,7 @@ def make_params(dt=1.0, shaping=True, normalize=True, discrete=False, auto_reset
     mode = (M_REWARD_SHAPING if shaping else 0) | (M_NORMALIZE if normalize else 0) | (M_DISCRETE if discrete else 0) | \
            (M_AUTO_RESET if auto_reset else 0) | (M_RANDOM_ENTRY if random_entry else 0) | \
            (M_KEEP_ACTIVE if keep_active else 0)
-    return Params(dt, timestep_limit, mode, 0, seed, sep_nm, sep_ft, conflict_reward, 0.0)
+    return Params(float(dt), timestep_limit, mode, seed, sep_nm, sep_ft, conflict_reward, 0, 0.0, 0)
 
 
 def build(force=False):
@@ -80,10 +80,13 @@ class OracleEnv:
         self.px, self.py = np.zeros(BN, pdt), np.zeros(BN, pdt)
         # speed / heading: float64 (reference) | 32-bit fixed point (fp32 spec, include/atc_step.h ABI 18: kt = v_fix 2^-23 (unsigned),
         # deg = 180 + phi_fix 2^-23); `.phi` / `.v` give degrees / knots either way, `.phi_fix` / `.v_fix` the stored counts.
-        # last_act = the last accepted v / h / phi targets in the state's formats (fp32 spec: v_fix, float bits of h, phi_fix)
-        self.h = np.zeros(BN, r)
+        # The altitude is float64 in BOTH instantiations (ABI 20: the reference's own arithmetic).
+        # last_act = the last accepted targets: reference instantiation [3, BN] float64 (v, h, phi); fp32 spec [BN, 4] int32 words in
+        # the device's record layout (v_fix, phi_fix, the altitude target's float64 in words 2..3) — compares directly with
+        # AtcVecEnv.last_act
+        self.h = np.zeros(BN, np.float64)
         self._phi, self._v = (np.zeros(BN, np.int32 if self.fixed else r) for _ in range(2))
-        self.last_act = np.zeros((3, BN), np.int32 if self.fixed else r)
+        self.last_act = np.zeros((BN, 4), np.int32) if self.fixed else np.zeros((3, BN), r)
         self.timesteps = np.zeros(B, np.int32)
         self.actions_taken = np.zeros(B, np.int32)
         self.total_reward = np.zeros(B, r)
@@ -201,9 +204,9 @@ class OracleEnv:
         """AtcGym.last_action (atc_gym.py:86,311) of one aircraft from [v, h, phi] in knots / feet / degrees."""
         i = e * self.N + k
         if self.fixed:
-            self.last_act[0, i] = self._fix(value[0], self.V_OFFSET, self.V_Q, True)
-            self.last_act[1, i] = np.float32(value[1]).view(np.int32)
-            self._put_phi(self.last_act[2], i, 1, value[2])
+            self.last_act[i, 0] = self._fix(value[0], self.V_OFFSET, self.V_Q, True)
+            self._put_phi(self.last_act[:, 1], i, 1, value[2])
+            self.last_act[i, 2:4] = np.array([value[1]], np.float64).view(np.int32)
         else:
             self.last_act[:, i] = value
 
@@ -211,10 +214,10 @@ class OracleEnv:
         i = e * self.N + k
         if not self.fixed:
             return [float(c) for c in self.last_act[:, i]]
-        lp = int(self.last_act[2, i])
+        lp = int(self.last_act[i, 1])
         if lp in (self.I32_MIN, self.I32_MAX):
             lp = int(self.phi_wide[i, 1])
-        return [float(np.uint32(self.last_act[0, i])) / self.V_Q, float(self.last_act[1, i:i + 1].view(np.float32)[0]),
+        return [float(np.uint32(self.last_act[i, 0])) / self.V_Q, float(self.last_act[i, 2:4].copy().view(np.float64)[0]),
                 float(lp) / self.PHI_Q + self.PHI_OFFSET]
 
     def step(self, actions):

@@ -23,6 +23,9 @@ inputs + expected outputs of the AtcGym.step() hot path as small fixtures:
                       and state every 16th step and on the last step of every episode): LOWW / LOWW_random / Simple /
                       UnitTest, dt 1/2/5, continuous and discrete, shaping x normalisation off, >= 50 each of win /
                       below-MVA / timeout terminals, episodes stepped on past `done` (incl. past a win)
+  g12_timesteps.npz   SimParameters.timestep in {0.05, 0.1, 0.15, 0.3, 0.7, 1.3, 3.7} s (round 6): sustained descents into the MVAs,
+                      altitude TIES (n x 41 dt ft above an MVA, decided by the reference's own float64 rounding), landings on
+                      targets, >= 3 000-step slow episodes (compact format of g9)
   g11_unbounded.npz   actions outside the action space, replayed by the reference: sustained a_phi up to +-3 (heading to 720 / -360
                       deg), headings wound to +-5 500 deg and back, un-clipped random actions, discrete heading indices beyond 360,
                       G9's winning intercepts flown at heading + 360 k, altitude targets within an fp32 action step of the MVA; the compact form of g9
@@ -858,8 +861,133 @@ def gen_g11():
     return rec
 
 
+# ----------------------------------------------------------------------------------------------- G12
+G12_DTS = (0.05, 0.1, 0.15, 0.3, 0.7, 1.3, 3.7)
+
+
+def disc_inside(airspace, x, y, radius, m):
+    """every point of the disc around (x, y) — sampled on three rings — lies in the MVA of height m"""
+    for rr in (radius, 0.66 * radius, 0.33 * radius):
+        for k in range(16):
+            a = 2.0 * np.pi * k / 16.0
+            if mva_or_neg(airspace, x + rr * np.cos(a), y + rr * np.sin(a)) != m:
+                return False
+    return True
+
+
+def gen_g12():
+    """SimParameters.timestep values OTHER than 1 / 2 / 5 s (model.py:132-145: any float; it scales h_dot_min / h_dot_max / a / phi_dot
+    in Airplane.action_* (model.py:75-78,97-100,117-120), the displacement (model.py:126) and the base reward (atc_gym.py:137)).
+    41 * 0.1 and 15 * 0.15 are not small multiples of an fp32 ulp of an altitude: an fp32 altitude accumulator drifts by 0.4 ulp
+    per step and the below-MVA flag (atc_gym.py:149-153) comes one step off (round-5 review: 19 of 120 descents).
+      1. sustained descents from the entry points at the maximum rate into whatever MVA lies below: fixed action
+         [U(-1, 1), U(-1, -0.7), U(-1, 1)] until done (the review's probe), LOWW and LOWW_random, every timestep above
+      2. TIES: an aircraft circling (radius 0.53 nm) inside one MVA polygon, n x 41 dt ft above its height with n x 41 dt an
+         integer: after exactly n steps the reference's altitude is the MVA height up to ITS OWN accumulated float64 rounding,
+         and `h < mva` is decided by that rounding — every polygon of LOWW that holds the circle, several (dt, n)
+      3. climbs and descents that LAND on their targets (h == target to the last bit from then on), then leave them again;
+         "descend to the MVA" (the G11 case) at dt = 0.1 / 0.15 / 0.3: the aircraft reaches a target one fp32 action step above /
+         on / below the MVA height after several rate-limited steps
+      4. >= 3 000-step episodes of slow random-held actions at dt 0.05 / 0.1 / 0.15 (the review's 2.9e-5 altitude observation
+         at step 3 698 of dt = 0.1), stepped on whatever happens; discrete actions and shaping / normalisation off at dt = 0.1"""
+    rec = WideRecorder(stride=8)
+    # 1. sustained descents
+    rng = np.random.default_rng(5)
+    for dt in G12_DTS:
+        for scen in ("LOWW", "LOWW_random"):
+            env = make_env(scen, dt=dt)
+            random.seed(int(dt * 1000) + len(scen))
+            for k in range(4 if dt < 0.1 else 8):
+                a = f32([rng.uniform(-1, 1), rng.uniform(-1, -0.7), rng.uniform(-1, 1)])
+                rec.run(env, np.tile(a, (int(16000 / (41 * dt)) + 50, 1)), scen, dt, True, True, False, extra_after_done=3)
+    # 2. ties
+    probe = make_env("LOWW")
+    asp = probe._airspace
+    x0, y0, x1, y1 = asp.get_bounding_box()
+    heights = sorted(set(int(m.height) for m in probe._mvas))
+    rng = np.random.default_rng(12000)
+    spots = {}
+    for _ in range(60000):
+        x, y = float(np.float32(rng.uniform(x0, x1))), float(np.float32(rng.uniform(y0, y1)))
+        m = mva_or_neg(asp, x, y)
+        if m < 0 or len(spots.get(m, [])) >= 3:
+            continue
+        if disc_inside(asp, x, y, 1.25, m):
+            spots.setdefault(m, []).append((x, y))
+    ties = 0
+    for dt, n in ((0.05, 2000), (0.1, 1000), (0.1, 3000), (0.15, 400), (0.3, 100), (0.3, 1000), (0.7, 100), (1.3, 100), (3.7, 100),
+                  (0.05, 400), (0.15, 2000)):
+        drop = round(n * 41 * dt * 1000) / 1000.0
+        assert drop == int(drop), (dt, n, drop)
+        env = make_env("LOWW", dt=dt)
+        for m, pts in sorted(spots.items()):
+            if m + drop > 38000:
+                continue
+            for j, (x, y) in enumerate(pts[:2 if n <= 1000 else 1]):
+                st = (x, y, float(m + int(drop)), float((37 * j + m // 100) % 360), 100.0)
+                a = f32([-1.0, -1.0, 3.0])   # 100 kt, descend at the limit, turn right for ever (target heading 720 deg)
+                rec.run(env, np.tile(a, (n + 6, 1)), "LOWW", dt, True, True, False, init_state=st, extra_after_done=4)
+                ties += 1
+    # 3. landing on targets
+    for dt in (0.05, 0.1, 0.15, 0.3, 0.7, 1.3, 3.7):
+        env = make_env("LOWW_random", dt=dt)
+        its = interior_states(np.random.default_rng(12500 + int(dt * 100)), env, 6, 9000.0, 14000.0)
+        for k, st in enumerate(its):
+            rng = np.random.default_rng(12600 + 10 * int(dt * 100) + k)
+            blocks = []
+            h = st[2]
+            for b in range(7):
+                step_ft = (15 if b % 2 == 0 else -41) * dt
+                n_land = int(rng.integers(8, 30))
+                tgt = h + step_ft * (n_land - rng.uniform(0.05, 0.95))   # reached inside step n_land, not on a multiple of the rate
+                a_h = float(np.float32(tgt / 19000.0 - 1.0))
+                blocks.append(np.tile(f32([-0.8, a_h, rng.uniform(-1, 1)]), (n_land + int(rng.integers(3, 25)), 1)))
+                h = float(np.float64(np.float32(a_h)) * 19000.0 + 19000.0)
+            rec.run(env, np.concatenate(blocks), "LOWW_random", dt, True, True, False, init_state=st, extra_after_done=400)
+    env1 = make_env("LOWW")
+    for dt in (0.1, 0.15, 0.3):
+        env = make_env("LOWW", dt=dt)
+        its = interior_states(np.random.default_rng(12900 + int(dt * 100)), env1, 12, 2000.0, 2001.0)
+        for k, st in enumerate(its):
+            m = mva_or_neg(env._airspace, st[0], st[1])
+            a0 = np.float32(m / 19000.0 - 1.0)
+            a = [np.nextafter(a0, np.float32(-2)), a0, np.nextafter(a0, np.float32(2)),
+                 np.nextafter(np.nextafter(a0, np.float32(-2)), np.float32(-2))][k % 4]
+            n_land = int(np.ceil(30.0 / (41 * dt))) + 1
+            acts = np.tile(f32([2.0 * (st[4] - 100.0) / 200.0 - 1.0, a, 2.0 * st[3] / 360.0 - 1.0]), (n_land + 6, 1))
+            rec.run(env, acts, "LOWW", dt, True, True, False, init_state=(st[0], st[1], float(m + 30), st[3], st[4]),
+                    extra_after_done=5)
+    # 4. long episodes of slow random-held actions (100 .. 150 kt: they stay inside the fixed-point position range whatever they do)
+    def slow(rng, horizon, lo, hi, discrete=False):
+        out = []
+        while sum(len(b) for b in out) < horizon:
+            hold = int(rng.integers(lo, hi))
+            if discrete:
+                a = np.array([float(rng.integers(0, 6)), float(rng.integers(70, 230)), float(rng.integers(0, 360))])
+            else:
+                a = f32([rng.uniform(-1, -0.5), rng.uniform(-0.62, 0.2), rng.uniform(-1, 1)])
+            out.append(np.tile(a, (hold, 1)))
+        return np.concatenate(out)[:horizon]
+    for dt, horizon, n_eps in ((0.05, 3600, 4), (0.1, 3800, 8), (0.15, 2600, 6), (0.3, 1300, 4)):
+        env = make_env("LOWW_random", dt=dt)
+        its = interior_states(np.random.default_rng(13000 + int(dt * 100)), env, n_eps, 9000.0, 16000.0)
+        for k in range(n_eps):
+            rng = np.random.default_rng(13100 + 10 * int(dt * 100) + k)
+            rec.run(env, slow(rng, horizon, 40, 160), "LOWW_random", dt, True, True, False, init_state=its[k],
+                    extra_after_done=horizon)
+    for (shaping, normalize, discrete) in ((True, True, True), (False, False, False)):
+        env = make_env("LOWW_random", dt=0.1, shaping=shaping, normalize=normalize, discrete=discrete)
+        its = interior_states(np.random.default_rng(13500), env, 4, 9000.0, 16000.0)
+        for k in range(4):
+            rng = np.random.default_rng(13600 + k + 10 * int(discrete))
+            rec.run(env, slow(rng, 3200, 40, 160, discrete), "LOWW_random", 0.1, shaping, normalize, discrete, init_state=its[k],
+                    extra_after_done=3200)
+    rec.save(os.path.join(HERE, "g12_timesteps.npz"))
+    return rec, ties, sorted(spots)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "mt", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "mt", "g8", "g9", "g10", "g11", "g12"]
     if "g1" in which:
         gen_g1()
     if "mt" in which:
@@ -900,6 +1028,13 @@ if __name__ == "__main__":
         phi = np.asarray(r.state)[:, 3]
         print("g11 episodes", len(r.ep), "steps", len(fl), "sampled rows", len(r.samp_rows), "heading range", phi.min(), phi.max(),
               "rows beyond [-76, 436):", int(((phi < -76) | (phi >= 436)).sum()))
+        for name, bit in (("below", 1), ("outside", 2), ("won", 4), ("timeout", 8), ("inv_v", 16), ("inv_h", 32)):
+            print(name, int(((fl & bit) != 0).sum()), "terminal:", int((((fl & bit) != 0) & (dn != 0)).sum()))
+    if "g12" in which:
+        r, ties, hts = gen_g12()
+        fl, dn = np.asarray(r.flags), np.asarray(r.done)
+        print("g12 episodes", len(r.ep), "steps", len(fl), "sampled rows", len(r.samp_rows), "tie episodes", ties, "MVA heights with a circle", hts,
+              "timesteps", sorted(set(e["dt"] for e in r.ep)))
         for name, bit in (("below", 1), ("outside", 2), ("won", 4), ("timeout", 8), ("inv_v", 16), ("inv_h", 32)):
             print(name, int(((fl & bit) != 0).sum()), "terminal:", int((((fl & bit) != 0) & (dn != 0)).sum()))
     print("done")

@@ -79,7 +79,7 @@ def test_struct_mirrors_have_header_field_order():
     assert fields("atc_state") == list(binding.STATE_FIELDS)
     assert fields("atc_out") == list(binding.OUT_FIELDS)
     assert fields("atc_params") == [f[0] for f in binding.AtcParams._fields_]
-    assert ctypes.sizeof(binding.AtcParams) == 40
+    assert ctypes.sizeof(binding.AtcParams) == 48
 
 
 def test_product_refuses_to_run_without_gpu():

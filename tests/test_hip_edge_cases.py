@@ -98,7 +98,7 @@ def test_argument_errors_are_reported_not_raised_from_c():
     assert L.atc_rollout_hold(env.sector.handle, 4, 2, 10, 4, C.byref(st), a.data_ptr(), C.byref(out), C.byref(p), stream) == -1
     assert b"multiple of hold" in L.atc_last_error()
     assert L.atc_rollout_hold(env.sector.handle, 4, 2, 3, 0, C.byref(st), a.data_ptr(), C.byref(out), C.byref(p), stream) == -1
-    bad = lib.AtcState(st.pos_hp, None, st.last_act, st.env, st.stats, st.phi_wide)
+    bad = lib.AtcState(st.ac, None, st.last_act, st.env, st.stats, st.phi_wide)
     assert L.atc_step(env.sector.handle, 4, 2, C.byref(bad), a.data_ptr(), C.byref(out), C.byref(p), stream) == -1
     assert b"null" in L.atc_last_error()
     too_big = 2 ** 27  # 2^27 x 64 aircraft x 40 B >> 4 GiB
@@ -126,17 +126,17 @@ def test_masked_reset_only_touches_selected_envs():
     a = np.random.default_rng(0).uniform(-1, 1, (8, 2, 3)).astype(np.float32)
     for _ in range(5):
         env.step(a)
-    before = (env.pos_hp.clone(), env.last_act.clone(), env.env.clone())
+    before = (env.ac.clone(), env.last_act.clone(), env.env.clone(), env.alt.clone())
     mask = np.array([0, 1, 0, 0, 1, 0, 0, 1], np.uint8)
     env.reset(mask=mask)
     m = torch.as_tensor(mask.astype(bool)).cuda()
     assert torch.equal(env.env[~m], before[2][~m])
     assert bool((env.timesteps[m] == 0).all()) and bool((env.timesteps[~m] == 5).all())
     mm = m.repeat_interleave(2)
-    assert torch.equal(env.pos_hp[~mm], before[0][~mm]) and not torch.equal(env.pos_hp[mm], before[0][mm])
+    assert torch.equal(env.ac[~mm], before[0][~mm]) and not torch.equal(env.ac[mm], before[0][mm]) and torch.equal(env.alt[~mm], before[3][~mm])
     assert bool((env.episodes[m] == 2).all()) and bool((env.episodes[~m] == 1).all())
     # last_action survives a reset (atc_gym.py:86 is only executed in __init__)
-    assert torch.equal(env.last_act, before[1]) and bool((env.last_act != 0).all())
+    assert torch.equal(env.last_act, before[1]) and bool((env.last_act[:, [0, 1, 3]] != 0).all())
     env.close()
 
 
@@ -155,7 +155,7 @@ def test_streams_and_graph_capture():
     torch.cuda.current_stream().wait_stream(s)
     for _ in range(3):
         ref.step(a)
-    assert torch.equal(env.obs, ref.obs) and torch.equal(env.pos_hp, ref.pos_hp)
+    assert torch.equal(env.obs, ref.obs) and torch.equal(env.ac, ref.ac) and torch.equal(env.alt, ref.alt)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for _ in range(4):
@@ -169,7 +169,7 @@ def test_streams_and_graph_capture():
     for _ in range(3 + 8):
         env2.step(a)
     torch.cuda.synchronize()
-    assert torch.equal(env.pos_hp, env2.pos_hp) and torch.equal(env.obs, env2.obs)
+    assert torch.equal(env.ac, env2.ac) and torch.equal(env.alt, env2.alt) and torch.equal(env.obs, env2.obs)
     env.close(); ref.close(); env2.close()
 
 
@@ -205,7 +205,7 @@ def test_fast_and_full_kernel_variants_agree(N):
             dn = d2 != 0
             if bool(dn.any()):
                 assert torch.equal(out["term_obs"][t][dn], i2["terminal_observation"][dn])
-    for name in ("pos_hp", "v_fix", "last_act", "env", "stats", "phi_wide"):
+    for name in ("ac", "alt", "last_act", "env", "stats", "phi_wide"):
         assert torch.equal(getattr(fast, name), getattr(full, name)) and torch.equal(getattr(roll, name), getattr(full, name)), name
     for e in (fast, full, roll):
         e.close()
@@ -230,7 +230,7 @@ def test_rollout_with_held_actions_equals_single_steps(N, T, hold):
             o, r, d, info = one.step(blocks[t // hold])
             assert torch.equal(out["obs"][t], o) and torch.equal(out["reward"][t], r), (launch, t)
             assert torch.equal(out["done"][t], d) and torch.equal(out["flags"][t], info["flags"]), (launch, t)
-    for name in ("pos_hp", "v_fix", "last_act", "env", "stats", "phi_wide"):
+    for name in ("ac", "alt", "last_act", "env", "stats", "phi_wide"):
         assert torch.equal(getattr(one, name), getattr(roll, name)), name
     assert N < 16 or int(one.episodes.sum()) > B
     one.close()
@@ -267,7 +267,7 @@ def test_sub_batches_on_streams_equal_one_batch():
         assert torch.equal(e.done, whole.done[sl]) and torch.equal(e.flags, whole.flags[sl])
         assert torch.equal(e.env, whole.env[sl]) and torch.equal(e.stats, whole.stats[sl])
         asl = slice(lo[i] * N, lo[i + 1] * N)
-        assert torch.equal(e.pos_hp, whole.pos_hp[asl]) and torch.equal(e.v_fix, whole.v_fix[asl])
+        assert torch.equal(e.ac, whole.ac[asl]) and torch.equal(e.alt, whole.alt[asl])
         assert torch.equal(e.last_act, whole.last_act[asl])
     assert int(whole.episodes.sum()) > B
     # a bad call in the list is reported (second call has B = 0), the ones before it were issued
@@ -303,7 +303,7 @@ def test_host_mapped_buffers_match_device_buffers(B, N):
         o2, r2, d2, i2 = hst.step(pinned if t % 2 else acts)  # pinned actions are read in place, others are uploaded
         assert torch.equal(o1.cpu(), o2) and torch.equal(r1.cpu(), r2) and torch.equal(d1.cpu(), d2)
         assert torch.equal(i1["flags"].cpu(), i2["flags"]) and torch.equal(i1["original_state"].cpu(), i2["original_state"])
-    for name in ("pos_hp", "v_fix", "last_act", "env", "stats", "phi_wide"):
+    for name in ("ac", "alt", "last_act", "env", "stats", "phi_wide"):
         assert torch.equal(getattr(dev, name).cpu(), getattr(hst, name)), name
     assert int(hst.episodes.sum()) > 0
     # a pageable host pointer is rejected by the library, not dereferenced
@@ -334,7 +334,7 @@ def test_huge_batch_uses_correct_offsets():
         os_, rs, ds, is_ = small.step(a_small)
         assert torch.equal(ob[-tail:], os_) and torch.equal(rb[-tail:], rs) and torch.equal(db[-tail:], ds)
         assert torch.equal(ib["flags"][-tail:], is_["flags"])
-    assert torch.equal(big.pos_hp[-tail * N:], small.pos_hp) and torch.equal(big.env[-tail:], small.env)
+    assert torch.equal(big.ac[-tail * N:], small.ac) and torch.equal(big.alt[-tail * N:], small.alt) and torch.equal(big.env[-tail:], small.env)
     # and the very first envs are untouched by anything the tail did
     assert bool(torch.isfinite(ob[:4]).all())
     big.close()
@@ -368,7 +368,7 @@ def test_atcgym_packet_polling_equals_synchronised_reads():
             assert not a_env._outstanding
             assert np.array_equal(oa, v.obs.numpy().reshape(-1)) and ra == float(v.reward[0]) and da == bool(v.done[0])
             assert a_env.timesteps == int(v.timesteps[0]) and a_env.actions_taken == int(v.actions_taken[0])
-            assert a_env._pos_now == (int(v.pos_hp[0, 0]), int(v.pos_hp[0, 1]))
+            assert a_env._pos_now == (int(v.ac[0, 0]), int(v.ac[0, 1]))
         if da:
             n_done += 1
             random.seed(1000 + n_done)                 # both envs draw their entry point from Python's global RNG
@@ -434,7 +434,7 @@ def test_held_actions_hint_changes_nothing(N, hold):
                 o2, r2, d2, i2 = hint.obs, hint.reward, hint.done, {"flags": hint.flags}
             assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(d, d2), (block, k)
             assert torch.equal(info["flags"], i2["flags"]), (block, k)
-            for name in ("pos_hp", "v_fix", "last_act", "env", "stats", "phi_wide"):
+            for name in ("ac", "alt", "last_act", "env", "stats", "phi_wide"):
                 assert torch.equal(getattr(plain, name), getattr(hint, name)), (name, block, k)
             handed_over += int(slot0_inactive.sum()) if t == 1 else 0
             if k == 0:
@@ -488,7 +488,7 @@ def test_held_hint_after_a_multi_step_launch():
             ra = a.step(blocks[2])
             rb = b.step(blocks[2], held=True)
             assert all(torch.equal(x, y) for x, y in zip(ra[:3], rb[:3])), (rnd, k)
-        for name in ("pos_hp", "v_fix", "last_act", "env", "stats", "phi_wide"):
+        for name in ("ac", "alt", "last_act", "env", "stats", "phi_wide"):
             assert torch.equal(getattr(a, name), getattr(b, name)), (name, rnd)
     a.close()
     b.close()
@@ -535,7 +535,7 @@ def test_envs_with_different_parameters_interleaved_on_one_thread():
                 assert np.array_equal(done.cpu().numpy(), orc.done), (c, rnd)
                 assert np.all(np.abs(rew.cpu().numpy() - orc.reward) <= 1e-5 * np.maximum(1.0, np.abs(orc.reward)) + 6e-8 * N * np.abs(orc.ac_reward).sum(1)), (c, rnd)
     for env, orc in zip(envs, orcs):
-        assert np.array_equal(env.pos_hp[:, 0].cpu().numpy(), orc.px) and np.array_equal(env.h.cpu().numpy(), orc.h)
+        assert np.array_equal(env.ac[:, 0].cpu().numpy(), orc.px) and np.array_equal(env.h.cpu().numpy(), orc.h)
         assert np.array_equal(env.timesteps.cpu().numpy(), orc.timesteps)
         env.close()
 
@@ -566,7 +566,7 @@ def test_all_valid_instantiation_equals_general_kernels(N):
         outs = [e.rollout(blocks[:, :e.B].contiguous(), hold=20) for e in envs[:2]]
         for k in ("obs", "reward", "done", "flags"):
             assert torch.equal(outs[0][k], outs[1][k][:, :B]), k
-    for name in ("pos_hp", "v_fix", "last_act"):
+    for name in ("ac", "alt", "last_act"):
         assert torch.equal(getattr(envs[0], name), getattr(envs[1], name)[:B * N]), name
     assert torch.equal(envs[0].env, envs[1].env[:B]) and torch.equal(envs[0].stats, envs[1].stats[:B])
     assert int(envs[0].episodes.sum()) > B      # episodes ended and restarted inside the comparison
@@ -595,7 +595,7 @@ def test_latency_bound_instantiation_equals_the_throughput_kernels(N, big):
     turner = torch.arange(0, small * N, 7)
     saw_wide = False
     for e in envs:
-        e.pos_hp[turner.to(e.device), 3] = int(round((430.0 - 180.0) * 2 ** 23))
+        e.ac[turner.to(e.device), 2] = int(round((430.0 - 180.0) * 2 ** 23))
     for j in range(6):
         blocks = torch.rand((2, big + 1, N, 3), generator=g) * 2.1 - 1.05
         # a tenth of the heading actions far outside the action space: saturated heading targets everywhere
@@ -610,7 +610,7 @@ def test_latency_bound_instantiation_equals_the_throughput_kernels(N, big):
         # (steps that ended an episode return the RAW reset observation instead: masked out)
         o3 = outs[1]["obs"][:, :small].reshape(-1, small, N, 10)[..., 3]
         saw_wide = saw_wide or bool(((o3 > 1.45) & (outs[1]["done"][:, :small] == 0)[..., None]).any())
-    for name in ("pos_hp", "v_fix", "last_act"):
+    for name in ("ac", "alt", "last_act"):
         assert torch.equal(getattr(envs[0], name), getattr(envs[1], name)[:small * N]), name
         assert torch.equal(getattr(envs[1], name), getattr(envs[2], name)[:big * N]), name
     assert torch.equal(envs[0].phi_counts, envs[1].phi_counts[:small * N]) and torch.equal(envs[1].phi_counts, envs[2].phi_counts[:big * N])
@@ -716,8 +716,8 @@ def test_scan_horizon_on_the_fastest_closing_courses(N):
         for k in range(N):
             orc.set_state(e, k, *st[e, k])
     for env in (one, roll):   # (the oracle's words: one copy instead of B N x 5 scalar writes)
-        env.pos_hp[:, 0] = torch.as_tensor(orc.px).to(env.device)
-        env.pos_hp[:, 1] = torch.as_tensor(orc.py).to(env.device)
+        env.ac[:, 0] = torch.as_tensor(orc.px).to(env.device)
+        env.ac[:, 1] = torch.as_tensor(orc.py).to(env.device)
         env.h[:] = torch.as_tensor(orc.h).to(env.device)
         env.phi_fix[:] = torch.as_tensor(orc.phi_fix).to(env.device)
         env.v_fix[:] = torch.as_tensor(orc.v_fix).to(env.device)
@@ -735,7 +735,7 @@ def test_scan_horizon_on_the_fastest_closing_courses(N):
             if launch == 0:
                 hit = (orc.flags[:, :2] & L.F_CONFLICT) != 0
                 conflict_steps |= {(kind, t) for kind in range(4) if hit[kinds == kind].any()}
-    for name in ("pos_hp", "v_fix", "last_act", "env", "stats"):
+    for name in ("ac", "alt", "last_act", "env", "stats"):
         assert torch.equal(getattr(one, name), getattr(roll, name)), name
     # every kind of pair lost its separation at many different steps of the launch (= phases of the horizon)
     for kind in range(4):

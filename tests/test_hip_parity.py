@@ -368,7 +368,8 @@ class _HipInterleaved:
 
 
 @pytest.mark.parametrize("N,chunk,fixture", [(16, 1, "g9_wide.npz"), (64, 1, "g9_wide.npz"), (5, 1, "g9_wide.npz"), (16, 10, "g9_wide.npz"),
-                                              (64, 10, "g9_wide.npz"), (32, 5, "g9_wide.npz"), (8, 1, "g11_unbounded.npz"), (8, 10, "g11_unbounded.npz")])
+                                              (64, 10, "g9_wide.npz"), (32, 5, "g9_wide.npz"), (8, 1, "g11_unbounded.npz"), (8, 10, "g11_unbounded.npz"),
+                                              (8, 1, "g12_timesteps.npz"), (8, 10, "g12_timesteps.npz"), (16, 5, "g12_timesteps.npz")])
 def test_reference_episodes_as_the_aircraft_of_one_env(N, chunk, fixture):
     """helpers.replay_wide_interleaved through the batched kernels: N reference episodes of g9 are the N aircraft of one env
     (separation minimum 0, the reference's episode rule), single steps and multi-step launches (the 32- / 64-aircraft ones under the
@@ -399,6 +400,49 @@ def test_unbounded_heading_fixture_batched():
     assert n == len(fx.flags) > 93000
     phi = fx.state[:, 3]
     assert phi.max() >= 5000 and phi.min() <= -5000
+
+
+def test_timestep_fixture_batched():
+    """G12: SimParameters.timestep in {0.05, 0.1, 0.15, 0.3, 0.7, 1.3, 3.7} s as the REFERENCE steps them — sustained descents into
+    the MVAs, altitude ties decided by the reference's own float64 rounding (111 flagged at step n, 89 one step later), landings on
+    targets, 3 000-step episodes — through the batched kernel: flags / done / action counters exact on every one of the 376 632
+    steps, values within 1e-5.  ABI 20: the altitude is the reference's float64, the timestep a double (include/atc_step.h)."""
+    fx = H.WideFixture("g12_timesteps.npz")
+    H.WRAP_ROWS[0] = 0
+    n = H.replay_wide(fx, _HipLockstep, obs_tol=1e-5, state_tol=1e-5, rew_tol=1e-5)
+    assert n == len(fx.flags) > 370000 and H.WRAP_ROWS[0] <= 40
+
+
+def test_timestep_fixture_single_env():
+    """The same through the drop-in AtcGym (one env, packet polling): descents and ties of G12 at dt = 0.1 / 0.15 / 0.3 step by
+    step, the altitude read back from the device equal to the reference's float64 BIT FOR BIT on every sampled row."""
+    from envs.atc import atc_gym, model
+    fx = H.WideFixture("g12_timesteps.npz")
+    n_eps = 0
+    for dt in (0.1, 0.15, 0.3):
+        eps = [ep for ep in fx.episodes if ep["scen"] == "LOWW" and ep["dt"] == dt and not ep["discrete"] and ep["shaping"]
+               and ep["steps"] <= 3100]
+        eps = eps[:2] + eps[-3:]        # two descents from the entry point, three placed episodes (ties / landings)
+        env = atc_gym.AtcGym(sim_parameters=model.SimParameters(dt))
+        for ep in eps:
+            env.reset()
+            ap = env._airplane
+            ap.x, ap.y, ap.h, ap.phi, ap.v = ep["init_state"]
+            env._vec.timesteps[0] = int(ep["init_timesteps"])
+            env.timesteps = int(ep["init_timesteps"])
+            env.last_action = ep["init_last_action"]
+            for t in range(ep["steps"]):
+                row = ep["start"] + t
+                obs, rew, done, info = env.step(fx.action[row].astype(np.float32))
+                assert bool(done) == bool(fx.done[row]) and env.actions_taken == fx.actions_taken[row], (dt, row, t)
+                assert abs(rew - fx.reward[row]) <= 1e-5 * max(1.0, abs(fx.reward[row])), (dt, row, t)
+                si = fx.samp_index[row]
+                if si >= 0:
+                    assert H.obs_close(obs[None], fx.obs[si][None].astype(np.float64), 1e-5, True), (dt, row, t, obs, fx.obs[si])
+                    assert env._airplane.h == fx.state[si][2], (dt, row, t)
+            n_eps += 1
+        env.close()
+    assert n_eps == 15
 
 
 def test_unbounded_heading_single_env():
@@ -596,14 +640,14 @@ def _run_vs_oracle(scen_obj, comp, B, N, steps, seed, dt=1.0, discrete=False, sp
     assert np.array_equal(env.ep_length.cpu().numpy(), orc.ep_length)
     # the fp32 spec (include/atc_step.h: fixed-point position grid, shared heading kinematics, exact rate-limit
     # arithmetic) makes the whole aircraft state BIT-IDENTICAL to the fp32 oracle's
-    assert np.array_equal(env.pos_hp[:, 0].cpu().numpy(), orc.px) and np.array_equal(env.pos_hp[:, 1].cpu().numpy(), orc.py)
+    assert np.array_equal(env.ac[:, 0].cpu().numpy(), orc.px) and np.array_equal(env.ac[:, 1].cpu().numpy(), orc.py)
     assert np.array_equal(env.h.cpu().numpy(), orc.h) and np.array_equal(env.phi_fix.cpu().numpy(), orc.phi_fix)
     # ... the exact counts of WIDE headings / last heading targets (beyond the 32-bit fields, ABI 19) included
     assert np.array_equal(env.phi_counts.cpu().numpy(), orc.phi_counts.astype(np.float64))
-    la_wide = np.isin(orc.last_act[2], (-2 ** 31, 2 ** 31 - 1))
+    la_wide = np.isin(orc.last_act[:, 1], (-2 ** 31, 2 ** 31 - 1))
     assert np.array_equal(env.phi_wide[:, 1].cpu().numpy()[la_wide], orc.phi_wide[la_wide, 1])
     assert np.array_equal(env.v_fix.cpu().numpy(), orc.v_fix)
-    assert np.array_equal(env.last_act.cpu().numpy(), orc.last_act.T)
+    assert np.array_equal(env.last_act.cpu().numpy(), orc.last_act)
     assert np.array_equal(env.ep_actions.cpu().numpy(), orc.ep_actions)
     assert np.allclose(env.ep_return.cpu().numpy(), orc.ep_return, rtol=1e-5, atol=1e-3)
     env.close()
@@ -710,7 +754,7 @@ def test_flying_on_beyond_the_position_grid():
         obs, rew, done, info = env.step(a)
         orc.step(a)
         if t % 50 == 0 or t > 1350:
-            assert np.array_equal(env.pos_hp[:, 0].cpu().numpy(), orc.px) and np.array_equal(env.pos_hp[:, 1].cpu().numpy(), orc.py)
+            assert np.array_equal(env.ac[:, 0].cpu().numpy(), orc.px) and np.array_equal(env.ac[:, 1].cpu().numpy(), orc.py)
             assert np.array_equal(info["flags"].cpu().numpy().astype(np.uint16), orc.flags)
     assert bool((info["flags"][:, 0] & H.F_OUTSIDE).all()) and bool(done.all())
     x, y = env.x.cpu().numpy(), env.y.cpu().numpy()
@@ -946,7 +990,7 @@ def test_full_size_rollout_hold(B, N):
         for j in range(launches):
             o = env.rollout(blocks[j][:, :nb].contiguous(), hold=T)
             outs.append({k: v.clone() for k, v in o.items()})
-        state = (env.pos_hp.clone(), env.v_fix.clone(), env.last_act.clone(), env.env.clone())
+        state = (env.ac.clone(), env.alt.clone(), env.last_act.clone(), env.env.clone())
         env.close()
         return outs, state
 
@@ -977,4 +1021,4 @@ def test_full_size_rollout_hold(B, N):
             n_done += int(orc.done.sum())
     assert np.array_equal(st_sm[0][:, 0].cpu().numpy(), orc.px) and np.array_equal(st_sm[0][:, 1].cpu().numpy(), orc.py)
     assert np.array_equal(st_sm[3][:, 1].cpu().numpy(), orc.actions_taken)
-    assert np.array_equal(st_sm[2].cpu().numpy().reshape(-1, 3), orc.last_act.T.reshape(-1, 3))
+    assert np.array_equal(st_sm[2].cpu().numpy(), orc.last_act)

@@ -29,7 +29,7 @@ def _pair(B, N, seed, **kw):
                     float(torch.randint(150, 290, (1,), generator=g)))
     perm = torch.stack([torch.randperm(N, generator=g) for _ in range(B)])        # b's slot j holds a's aircraft perm[e, j]
     idx = (torch.arange(B)[:, None] * N + perm).reshape(-1).to(a.device)
-    for name in ("pos_hp", "v_fix", "last_act", "phi_wide"):
+    for name in ("ac", "alt", "last_act", "phi_wide"):
         getattr(b, name).copy_(getattr(a, name)[idx])
     return a, b, perm.to(a.device), idx, g
 
@@ -54,7 +54,7 @@ def test_slot_permutation_single_steps(N):
         tol = 1e-6 * ia["aircraft_reward"].abs().sum(1) + 1e-6
         assert bool(((rb - ra).abs() <= tol).all()), t
         n_conf += int((ia["flags"].to(torch.int32) & H.F_CONFLICT).ne(0).any(1).sum())
-    for name in ("pos_hp", "v_fix", "last_act"):
+    for name in ("ac", "alt", "last_act"):
         assert torch.equal(getattr(b, name), getattr(a, name)[idx]), name
     assert torch.equal(a.actions_taken, b.actions_taken) and torch.equal(a.timesteps, b.timesteps)
     assert n_conf > 0
@@ -88,7 +88,7 @@ def test_slot_permutation_fused(N, full):
         if full:
             assert torch.equal(ub["ac_reward"].reshape(T, -1), ua["ac_reward"].reshape(T, -1)[:, idx]), launch
             assert torch.equal(ub["min_sep"], ua["min_sep"]), launch
-    for name in ("pos_hp", "v_fix", "last_act"):
+    for name in ("ac", "alt", "last_act"):
         assert torch.equal(getattr(b, name), getattr(a, name)[idx]), name
     a.close()
     b.close()
