@@ -407,6 +407,53 @@ def single_env_protocol(n_steps=100000):
             "steps": n_steps, "steps_per_s": n_steps / dt, "us_per_step": dt / n_steps * 1e6}
 
 
+def _sync(dev):
+    """torch.cuda.synchronize on a GPU; nothing to drain for the CPU stub flow (--stub-env)."""
+    if dev.type == "cuda":
+        import torch
+        torch.cuda.synchronize(dev)
+
+
+class _Mark:
+    """A point in time on a stream: a HIP event on the GPU, the host clock in the CPU stub flow."""
+
+    def __init__(self, dev):
+        self.dev, self.t = dev, None
+        if dev.type == "cuda":
+            import torch
+            self.ev = torch.cuda.Event(enable_timing=True)
+
+    def record(self, stream=None):
+        if self.dev.type == "cuda":
+            self.ev.record(stream) if stream is not None else self.ev.record()
+        else:
+            self.t = time.perf_counter()
+
+    def ms_until(self, other):
+        return self.ev.elapsed_time(other.ev) if self.dev.type == "cuda" else (other.t - self.t) * 1e3
+
+
+class StubEnv:
+    """TEST-ONLY stand-in for AtcVecEnv in `--stub-env` runs (tests/test_bench_contract.py: the 8-rank flow of this script over
+    gloo on a box without a GPU).  It steps nothing: a launch is a counter and 20 us of sleep; its episode statistics are CPU
+    tensors whose values encode (rank, env) so that the gathered report can be checked.  Never reachable without the flag."""
+
+    def __init__(self, B, N, rank, torch):
+        self.B, self.N, self.launches = B, N, 0
+        self.ep_return = (torch.arange(B, dtype=torch.float32) + 1000.0 * rank)
+        self.ep_length = torch.arange(B, dtype=torch.int32) + 7 * rank
+        self.episodes = torch.ones(B, dtype=torch.int32)
+
+    def make_launcher(self, actions, held=False):
+        def launch():
+            self.launches += 1
+            time.sleep(20e-6)
+        return launch
+
+    def close(self):
+        pass
+
+
 def measure_collective(D, stats, dev, force, block=None, reps=100):
     """Cost of the episode-statistics exchange on the initialised group (microseconds, mean of `reps`; wall clock around a
     stream synchronisation and HIP events on the current stream):
@@ -422,19 +469,19 @@ def measure_collective(D, stats, dev, force, block=None, reps=100):
     out = {"reps": reps, "world_size": torch.distributed.get_world_size()}
 
     def timed(fn):
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _sync(dev)
+        e0, e1 = _Mark(dev), _Mark(dev)
         t0 = time.perf_counter()
         e0.record()
         for _ in range(reps):
             fn()
         e1.record()
-        torch.cuda.synchronize(dev)
-        return {"wall": (time.perf_counter() - t0) / reps * 1e6, "hip_events": e0.elapsed_time(e1) * 1e3 / reps}
+        _sync(dev)
+        return {"wall": (time.perf_counter() - t0) / reps * 1e6, "hip_events": e0.ms_until(e1) * 1e3 / reps}
 
     def old():
         D.all_gather_stats(*stats(), force=force)
-        torch.cuda.synchronize(dev)
+        _sync(dev)
         D.barrier(force=force)
     xch = D.StatsExchange(force=force)
 
@@ -442,7 +489,7 @@ def measure_collective(D, stats, dev, force, block=None, reps=100):
         xch.rearm()      # (re-arm the snapshot taken below: the timed loop takes its snapshots outside the window too)
         xch.issue()
         xch.wait()
-        torch.cuda.synchronize(dev)
+        _sync(dev)
     xch.snapshot(*stats())
     for f in (old, packed):
         f()
@@ -455,16 +502,16 @@ def measure_collective(D, stats, dev, force, block=None, reps=100):
             xch.rearm()
             xch.issue()
             xch.wait()
-            torch.cuda.synchronize(dev)
+            _sync(dev)
 
         def without():
             block()
-            torch.cuda.synchronize(dev)
+            _sync(dev)
         with_x()
         without()
         reps_b = 60
         for name, f in (("block_without", without), ("block_with", with_x), ("block_without_2", without), ("block_with_2", with_x)):
-            torch.cuda.synchronize(dev)
+            _sync(dev)
             ts = []
             for _ in range(reps_b):   # (the median of per-block times: one scheduling hiccup in sixty must not decide a 5 us difference)
                 t0 = time.perf_counter()
@@ -482,7 +529,7 @@ def measure_collective(D, stats, dev, force, block=None, reps=100):
                 t2 = time.perf_counter()
                 xch.wait()
                 t3 = time.perf_counter()
-                torch.cuda.synchronize(dev)
+                _sync(dev)
                 t4 = time.perf_counter()
                 for k, v in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
                     seg[k].append(v * 1e6)
@@ -521,6 +568,9 @@ def main():
                     "configurations (65 536 x 1, 8 192 x 16, 4 096 x 64 + noise areas)")
     ap.add_argument("--no-collective", action="store_true", help="N = 1 only: do not create the one-rank RCCL group that "
                     "exercises the multi-GPU path's collective calls on this GPU (untimed)")
+    ap.add_argument("--stub-env", action="store_true", help="TEST ONLY (tests/test_bench_contract.py): run this script's multi-rank "
+                    "control flow — sharding, timed blocks, the asynchronous report, the line's fields — on CPU tensors with a "
+                    "stand-in env that steps nothing (StubEnv); needs ATC_DIST_BACKEND=gloo.  The line says \"data\": \"stub\"")
     ap.add_argument("--graph", action="store_true", help="replay the %d-step action-hold block as one captured HIP graph "
                     "(removes per-launch host overhead; matters for the small launch-bound configs)" % HOLD)
     args = ap.parse_args()
@@ -539,7 +589,9 @@ def main():
 
     # a fresh checkout has no native pieces yet: local rank 0 compiles them, the other ranks wait for the files
     import __graft_entry__ as entry
-    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+    if args.stub_env:
+        assert os.environ.get("ATC_DIST_BACKEND") == "gloo", "--stub-env is the CPU test flow: ATC_DIST_BACKEND=gloo"
+    elif int(os.environ.get("LOCAL_RANK", "0")) == 0:
         entry.ensure_built()
     else:
         lib_path = os.path.join(ROOT, "atc-reinforcement-learning_amd", "atc_hip", "libatcstep.so")
@@ -567,12 +619,14 @@ def main():
             collective["backend"] = D.backend_name()
         except Exception as exc:
             collective["error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
-    assert torch.cuda.is_available(), "bench.py needs the GPU (no CPU fallback)"
-    if local >= torch.cuda.device_count():  # only when ATC_DIST_BACKEND=gloo lets several ranks share the one visible GPU
+    stub = args.stub_env
+    assert stub or torch.cuda.is_available(), "bench.py needs the GPU (no CPU fallback)"
+    if not stub and local >= torch.cuda.device_count():  # only when ATC_DIST_BACKEND=gloo lets several ranks share the one visible GPU
         assert torch.cuda.device_count() == 1, "LOCAL_RANK %d >= %d visible devices" % (local, torch.cuda.device_count())
         local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if not stub:
+        torch.cuda.set_device(local)
+    dev = torch.device("cpu") if stub else torch.device("cuda", local)
     B, N, K, W = args.envs, args.aircraft, args.steps, args.warmup
     from atc_hip.vec_env import auto_grid_cell
     args.grid_cell = auto_grid_cell(B // max(1, args.streams), N) if args.grid_cell == "auto" else float(args.grid_cell)
@@ -580,14 +634,20 @@ def main():
     scn = scenarios.LOWWDense() if N > 16 else scenarios.LOWW(random_entrypoints=N > 1)
     S = args.streams
     assert S >= 1 and B % S == 0 and not (S > 1 and (args.graph or args.rollout)), "--streams: B % S == 0, no --graph/--rollout"
-    subs = [AtcVecEnv(B // S, N, scenario=scn, device=local, auto_reset=True, seed=D.rank_seed(0, rank) + 7919 * s,
-                      grid_cell=args.grid_cell, sep_nm=args.sep_nm) for s in range(S)]
+    if stub:
+        assert S == 1 and not args.graph and not args.rollout, "--stub-env: the plain launch loop only"
+        subs = [StubEnv(B, N, rank, torch)]
+    else:
+        subs = [AtcVecEnv(B // S, N, scenario=scn, device=local, auto_reset=True, seed=D.rank_seed(0, rank) + 7919 * s,
+                          grid_cell=args.grid_cell, sep_nm=args.sep_nm) for s in range(S)]
     env = subs[0]
 
     # action ring resident in HBM before timing (Philox, seed 0 + rank)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     n_ring = max(2, min(args.action_ring, (K + W) // HOLD + 1))
+    if stub:
+        n_ring = 2
     ring = [torch.rand((B, N, 3), generator=g, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(n_ring)]
 
     launchers = None
@@ -666,18 +726,18 @@ def main():
         return torch.cat([e.ep_return for e in subs]), torch.cat([e.ep_length for e in subs])
 
     gate = None
-    if rank == 0 and not args.no_parity_gate:
+    if rank == 0 and not args.no_parity_gate and not stub:
         gate = parity_gate(scn, N, args.grid_cell, args.sep_nm, local, held_hint=held_launchers is not None)   # raises if results are wrong
 
     # Untimed: bring every rank's GPU to its working clocks and the envs into their steady episode mix before the W warm-up
     # steps the caller asked for (the driver uses a handful; the first launches after start-up are not representative).
-    PREWARM = args.prewarm if args.prewarm >= 0 else (6000 if N * B >= 1 << 18 else 12000)
+    PREWARM = args.prewarm if args.prewarm >= 0 else (0 if stub else 6000 if N * B >= 1 << 18 else 12000)
     run(PREWARM - PREWARM % max(1, args.rollout, HOLD if args.graph else 1), 0)
     run(W, 0)
-    torch.cuda.synchronize(dev)
+    _sync(dev)
     forced = ws == 1 and bool(collective.get("backend")) and "error" not in collective
     warm = D.all_gather_stats(*stats(), force=True)  # untimed: creates the RCCL communicator / channels
-    torch.cuda.synchronize(dev)
+    _sync(dev)
     if forced:
         try:   # the one-rank group's collectives really ran: device tensors in, the same values out
             collective.update({"forced_single_rank": True, "gathered_shape": list(warm[0].shape), "device_tensors": bool(warm[0].is_cuda),
@@ -697,9 +757,9 @@ def main():
         last_block[0] = None
     if ws == 1:
         D.shutdown()   # the one-rank group has served its purpose: no communicator (proxy thread, streams) during the timed region
-        torch.cuda.synchronize(dev)
+        _sync(dev)
     # HIP events on the stream(s) the kernels are launched on (torch's current stream, or one per sub-batch)
-    qs = streams if S > 1 else [torch.cuda.current_stream(dev)]
+    qs = streams if S > 1 else [None if stub else torch.cuda.current_stream(dev)]
     # The path's only exchange: ONE packed all-gather of the per-env episode statistics per rollout, asynchronous
     # (atc_hip.dist.StatsExchange), and OUTSIDE the step window: a timed block queues its K step launches and synchronises — the
     # window closes there, on every rank by its own clock — and only then snapshots its statistics and issues the collective from a
@@ -714,29 +774,29 @@ def main():
     gathered = None
     for rep in range(max(1, args.repeats)):
         D.barrier()
-        torch.cuda.synchronize(dev)
+        _sync(dev)
         if rep:
             gathered = xch.wait()        # the previous rollout's statistics of every rank: complete since the synchronisation above
-        ev0 = [torch.cuda.Event(enable_timing=True) for _ in qs]
-        ev1 = [torch.cuda.Event(enable_timing=True) for _ in qs]
+        ev0 = [_Mark(dev) for _ in qs]
+        ev1 = [_Mark(dev) for _ in qs]
         t0 = time.perf_counter()
         for e, q in zip(ev0, qs):
             e.record(q)
         run(K, W + rep * K)
         for e, q in zip(ev1, qs):
             e.record(q)
-        torch.cuda.synchronize(dev)      # every local step has completed (sub-batch streams joined)
+        _sync(dev)                       # every local step has completed (sub-batch streams joined)
         t1 = time.perf_counter()         # <- the step window closes here, on every rank by its own clock; MAX over ranks below
         xch.snapshot(*stats())           # this rollout's report: one packed collective, issued asynchronously from a side stream
         xch.issue()
         D.barrier()
         t2 = time.perf_counter()
         local_windows.append(t1 - t0)
-        blocks.append((D.max_over_ranks(t1 - t0, dev), D.max_over_ranks(max(a.elapsed_time(b) for a, b in zip(ev0, ev1)), dev),
+        blocks.append((D.max_over_ranks(t1 - t0, dev), D.max_over_ranks(max(a.ms_until(b) for a, b in zip(ev0, ev1)), dev),
                        D.max_over_ranks(t2 - t0, dev)))
-    torch.cuda.synchronize(dev)
+    _sync(dev)
     returns, lengths = xch.wait()        # the last rollout's report
-    torch.cuda.synchronize(dev)
+    _sync(dev)
     rank_seeds = D.all_gather_stats(torch.tensor([D.rank_seed(0, rank) & 0x7fffffffffffffff], dtype=torch.int64, device=dev))[0]
     order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
     elapsed, kernel_ms_total, elapsed_with_barrier = blocks[order[len(order) // 2]]   # the median block
@@ -762,7 +822,7 @@ def main():
             "metric": "env-steps/sec aggregate @16 aircraft/env, 64k envs" if (N == 16 and B == 65536) else "env-steps/sec",
             "value": value, "unit": "env-steps/s", "n_gpus": ws, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "stub" if stub else "synthetic",
             "config": {"workload": "%d envs x %d aircraft per GPU (%d envs total), sector %s, dt=1 s, reward shaping + "
                                    "normalisation on, continuous actions U(-1,1) re-sampled every %d steps, auto-reset, "
                                    "O(N^2) separation scan, MVA lookup grid %g nm" % (B, N, B * ws, type(scn).__name__, HOLD, args.grid_cell),
@@ -811,6 +871,10 @@ def main():
                          "note": "HIP events on the launch stream around the %d timed launches (includes inter-launch "
                                  "gaps)" % n_launches},
         }
+        if stub:   # what the CPU test checks the report against: StubEnv encodes (rank, env) in its statistics
+            line["config"]["stub_report"] = {"first_return_of_each_rank": [float(v) for v in returns[:, 0].tolist()],
+                                             "first_length_of_each_rank": [int(v) for v in lengths[:, 0].tolist()],
+                                             "launches_rank0": subs[0].launches}
         if ws == 1 and not args.no_single_env and not args.rollout and S == 1 and graph is None:
             # the same envs with 20 steps fused per launch (atc_rollout_hold, the action held like in the timed loop): a
             # side record, not `value` — the headline stays one launch per step, what env.step() costs

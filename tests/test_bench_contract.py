@@ -75,3 +75,40 @@ def test_store_only_reference_never_costs_the_bench_line():
         assert rec is None
     else:
         assert isinstance(rec, dict) and ("error" in rec or rec["envs"] == 4096)
+
+
+def test_bench_eight_rank_flow_on_cpu():
+    """`bench.py --gpus 8` must not fail for a reason unrelated to scaling (round-5 review, next #7): the script's whole 8-rank
+    control flow — self-spawn through torch.distributed.run, contiguous env shards with distinct rank seeds, barrier-bracketed timed
+    blocks, MAX over ranks, the ONE packed asynchronous all-gather per report issued after the step window, the measured blocking
+    cost of that exchange on this very group, the three aggregate values and the per-rank windows — runs here over gloo on CPU
+    tensors with a stand-in env that steps nothing (`--stub-env`; data: "stub").  What the 8-GPU line adds is RCCL and the kernels."""
+    import subprocess
+    env = dict(os.environ, ATC_DIST_BACKEND="gloo", MASTER_PORT="29547")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "40", "--warmup", "20", "--envs", "512",
+                        "--repeats", "3", "--stub-env", "--no-cpu-baseline", "--no-single-env"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly ONE JSON line on stdout (rank 0)"
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert line["n_gpus"] == 8 and line["steps"] == 40 and line["warmup"] == 20 and line["scaling"] == "weak" and line["data"] == "stub"
+    c = line["config"]
+    assert c["gathered_returns_shape"] == [8, 512] and c["collective_backend"] == "gloo"
+    assert len(c["rank_seeds"]) == 8 and len(set(c["rank_seeds"])) == 8
+    assert len(c["rank_ms_per_step"]) == 8 and all(v > 0 for v in c["rank_ms_per_step"])
+    assert abs(max(c["rank_ms_per_step"]) - line["ms_per_step"]) <= 1e-9 * line["ms_per_step"] + 1e-12
+    # value = ranks x envs x steps / MAX over ranks of the step window; the two companions charge the barrier / the exchange
+    assert abs(line["value"] - 8 * 512 * 40 / (line["ms_per_step"] * 40 * 1e-3)) <= 1e-6 * line["value"]
+    assert 0 < c["value_between_barriers"] <= line["value"] and 0 < c["value_incl_exchange"] <= line["value"]
+    assert c["exchange"] == dict(c["exchange"], collectives_per_report=1, issued=3, reports=3, in_step_window=False)
+    us = c["collective"]["us"]
+    assert us["world_size"] == 8 and c["exchange"]["us_blocking"] == us["packed_blocking"]["wall"] > 0
+    # the report really travelled: every rank's statistics arrived in rank order on rank 0
+    assert c["stub_report"]["first_return_of_each_rank"] == [1000.0 * r_ for r_ in range(8)]
+    assert c["stub_report"]["first_length_of_each_rank"] == [7 * r_ for r_ in range(8)]
+    assert c["stub_report"]["launches_rank0"] >= 20 + 3 * 40
