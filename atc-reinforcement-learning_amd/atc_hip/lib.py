@@ -51,7 +51,7 @@ class AtcStepCall(C.Structure):
 EXPORTS = ("atc_abi_version", "atc_last_error", "atc_host_mapped_ptr", "atc_scenario_create", "atc_scenario_destroy",
            "atc_query_mva",
            "atc_query_mva_index", "atc_query_corridor", "atc_query_shaping", "atc_reset", "atc_observe", "atc_step",
-           "atc_step_multi", "atc_step_packet", "atc_rollout", "atc_rollout_hold")
+           "atc_step_multi", "atc_step_packet", "atc_rollout", "atc_rollout_hold", "atc_serve_start", "atc_serve_step", "atc_serve_stop")
 
 def load():
     """Loads libatcstep.so; raises (never falls back) when it has not been built."""
@@ -77,6 +77,9 @@ def load():
     lib.atc_observe.argtypes = [vp, ci, ci, C.POINTER(AtcState), vp, vp, C.POINTER(AtcParams), vp]
     lib.atc_step_packet.argtypes = [vp, C.POINTER(AtcState), vp, C.POINTER(AtcOut), C.POINTER(AtcParams), C.c_uint32, vp, vp, ci, vp]
     lib.atc_step.argtypes = [vp, ci, ci, C.POINTER(AtcState), vp, C.POINTER(AtcOut), C.POINTER(AtcParams), vp]
+    lib.atc_serve_start.argtypes = [vp, C.POINTER(AtcState), C.POINTER(AtcOut), C.POINTER(AtcParams), vp, C.c_uint32, ci, vp]
+    lib.atc_serve_step.argtypes = [vp, vp, C.c_uint32, vp, vp, ci]
+    lib.atc_serve_stop.argtypes = [vp, vp]
     lib.atc_step_multi.argtypes = [ci, C.POINTER(AtcStepCall)]
     lib.atc_rollout.argtypes = [vp, ci, ci, ci, C.POINTER(AtcState), vp, C.POINTER(AtcOut), C.POINTER(AtcParams), vp]
     lib.atc_rollout_hold.argtypes = [vp, ci, ci, ci, ci, C.POINTER(AtcState), vp, C.POINTER(AtcOut), C.POINTER(AtcParams), vp]

@@ -299,6 +299,13 @@ template <typename T>
 __device__ __forceinline__ void stream_store(T* p, T v) {
     __builtin_nontemporal_store(v, p);
 }
+// One 16-byte store written THROUGH to system memory (sc0 sc1): a chunk of the result packet a host polls in mapped memory.  A plain
+// store to host memory may stay in the device's L2 until the kernel ends — which a resident kernel (k_serve) never does.
+__device__ __forceinline__ void store16_system(uint4* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ void store_obs(float* __restrict__ dst, const float* o) {
     // 10 floats = 40 B per aircraft: 8-byte aligned -> five 8-byte stores
     float2* d = reinterpret_cast<float2*>(dst);
@@ -1260,7 +1267,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
         uint4* pk = at<uint4>(so.packet, (uint32_t)e * (ATC_PKT_CHUNKS * 16u));
 #pragma unroll
         for (int c = 0; c < ATC_PKT_CHUNKS; ++c)
-            pk[c] = make_uint4(__float_as_uint(w[3 * c]), __float_as_uint(w[3 * c + 1]), __float_as_uint(w[3 * c + 2]), tag);
+            store16_system(pk + c, __float_as_uint(w[3 * c]), __float_as_uint(w[3 * c + 1]), __float_as_uint(w[3 * c + 2]), tag);
     }
     if (FULL && so.min_sep) {
         const float m2 = (W > 1) ? group_min<W>(min_d2) : 1e30f;
@@ -1563,6 +1570,83 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
 #if ATC_TRACE
     if (lane == 0 && trace) trace[((size_t)(blockIdx.x * (kBlock / 64) + (tid >> 6)) * n_steps + (n_steps - 1)) * 8 + 7] = __builtin_amdgcn_s_memtime();
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent step server of ONE env x ONE aircraft (the drop-in AtcGym, atc_gym.py:128-192; include/atc_step.h: atc_serve_*).
+// One resident wavefront keeps the env's state in registers and polls a mailbox in pinned mapped host memory: the host writes
+// {action, sequence number} with ONE 16-byte store, the wavefront runs the single-step body (the same step_part_a / step_part_b
+// as k_step<1, FULL, ONE>) and answers with the self-validating result packet (atc_out_t.packet).  No launch, no kernel-argument
+// upload and no state round trip per step: what is left is two crossings of the host link and the step's own dependent chain.
+// It LEAVES — state written back, mailbox status updated — on the quit command or after `lease_ticks` of s_memrealtime (100 MHz)
+// without a command: a host that died or went to train for a minute never leaves a wavefront spinning.
+// ---------------------------------------------------------------------------------------------------------------
+enum { ATC_MB_CMD = 0, ATC_MB_SEQ = 3, ATC_MB_STATE = 4, ATC_MB_LAST = 5, ATC_MB_WORDS = 16 };
+enum { ATC_SERVE_IDLE = 0, ATC_SERVE_RUNNING = 1, ATC_SERVE_LEFT_LEASE = 2, ATC_SERVE_LEFT_QUIT = 3 };
+#define ATC_SERVE_QUIT 0xffffffffu
+__device__ __forceinline__ uint32_t mb_load(const uint32_t* w) {
+    return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void __launch_bounds__(64, 1)
+k_serve(const float* __restrict__ blob, int off_grid, atc_state_t st, atc_out_t out, atc_params_t p, StepDerived q_arg,
+        uint32_t* mailbox, uint32_t last, unsigned long long lease_ticks) {
+    // (one wavefront alone on its SIMD: the uniform terms live in vector registers like in the latency-bound instantiation — as
+    // named scalar arguments kept across the serving loop, 151 of them were spilled to vector-register lanes)
+    const StepDerived q = to_vector_registers(q_arg);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const float* __restrict__ K = blob;
+    const float* __restrict__ grid = off_grid ? blob + off_grid : nullptr;
+    const LaneIds d = make_ids<1, false>(0u, 1, 1);   // lane 0 is the aircraft; the other lanes compute on copies and store nothing
+    const int4 e0 = *at<int4>(st.env, 0u);
+    EnvState es = {e0.x, e0.y, __int_as_float(e0.z), (uint64_t)(uint32_t)e0.w};
+    const int4 ps = *at<int4>(st.ac, 0u);
+    const double h0 = *at<double>(st.alt, 0u);
+    const int4 la0 = *at<int4>(st.last_act, 0u);
+    LaneState ls = {{ps.x, ps.y, h0, ps.z, (uint32_t)ps.w}, (uint32_t)la0.x, __hiloint2double(la0.w, la0.z), la0.y, false};
+    const StepOut so = {out.obs, out.flags, out.reward, out.done, out.raw_obs, out.ac_reward, out.min_sep, out.term_obs, out.packet
+#if ATC_TRACE
+                        , nullptr
+#endif
+    };
+    if (threadIdx.x == 0) __hip_atomic_store(mailbox + ATC_MB_STATE, (uint32_t)ATC_SERVE_RUNNING, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    unsigned long long t_cmd = __builtin_amdgcn_s_memrealtime();
+    uint32_t left_as = ATC_SERVE_LEFT_LEASE;
+    for (;;) {
+        // (every lane reads the same word: one request; made wave-uniform for the control flow)
+        const uint32_t seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(mailbox + ATC_MB_SEQ, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+        if (seq == ATC_SERVE_QUIT) {
+            left_as = ATC_SERVE_LEFT_QUIT;
+            break;
+        }
+        if (seq != last + 1u) {
+            if (__builtin_amdgcn_s_memrealtime() - t_cmd > lease_ticks) break;
+            continue;
+        }
+        // the action travelled in the same 16-byte host store as its sequence number
+        const Float3 act = {__uint_as_float(mb_load(mailbox + ATC_MB_CMD)), __uint_as_float(mb_load(mailbox + ATC_MB_CMD + 1)),
+                            __uint_as_float(mb_load(mailbox + ATC_MB_CMD + 2))};
+        last = seq;
+        atc_params_t pl = p;
+        pl.reserved0 = seq;   // the packet's tag (step_part_b)
+        const Targets tg = decode_targets(q.r, act);
+        uint64_t refused = 0ull;
+        const Mid m = step_part_a<true, true>(grid, q.r, q.k, q.g, d, tg.v, altitude_target(q.r, tg.ah), tg.p, act.c, ls, es, false, false,
+                                               st.phi_wide, 0, refused, false ATC_TRACE_PASS(nullptr));
+        Float3 nxt = act;
+        QRates qn = q.r;
+        int scan_skip = 0;
+        uint32_t scan_mask = 0u;
+        step_part_b<1, true, true, true>(K, grid, pl, q, q.s, 0, 1, d, m, ls, es, so, st.stats, st.phi_wide, nullptr, smem, nullptr, nxt, qn,
+                                          scan_skip, scan_mask);
+        t_cmd = __builtin_amdgcn_s_memrealtime();
+    }
+    store_lane_state(st, d, ls, true);
+    store_env_state<1>(st, d, es, 0u);
+    __threadfence_system();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(mailbox + ATC_MB_LAST, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(mailbox + ATC_MB_STATE, left_as, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1942,6 +2026,73 @@ int atc_step_packet(const atc_scenario_t* s, const atc_state_t* st, const float*
             std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_us)
             return -3;
     }
+}
+
+// ---- persistent step server (include/atc_step.h: atc_serve_*) ------------------------------------------------------------
+int atc_serve_start(const atc_scenario_t* s, const atc_state_t* st, const atc_out_t* out, const atc_params_t* p,
+                    uint32_t* mailbox_host, uint32_t seq, int lease_us, void* stream) {
+    if (!out || !mailbox_host) return fail_arg("null pointer");
+    if (const int rc = check_env_args(s, 1, 1, st, p)) return rc;
+    if (!out->obs || !out->reward || !out->done || !out->flags || !out->packet) return fail_arg("the server needs obs/reward/done/flags and out->packet");
+    if (reinterpret_cast<uintptr_t>(mailbox_host) & 63u) return fail_arg("mailbox must be 64-byte aligned");
+    if (!(p->dt > 0.0) || !(0.1423 * p->dt * (double)s->consts[ATC_C_POS_SCALE] < 1073741824.0) || !((double)kAMax * p->dt < 255.9))
+        return fail_arg("dt out of range for the fixed-point state formats (see include/atc_step.h)");
+    if (lease_us < 1000) lease_us = 1000;
+    uint32_t* mb_dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&mb_dev), mailbox_host, 0));
+    // the command word holds the LAST served sequence number (so a stale command is not taken for a new one), no state yet
+    __atomic_store_n(mailbox_host + ATC_MB_SEQ, seq, __ATOMIC_RELAXED);
+    __atomic_store_n(mailbox_host + ATC_MB_STATE, (uint32_t)ATC_SERVE_IDLE, __ATOMIC_RELEASE);
+    hipLaunchKernelGGL(k_serve, dim3(1), dim3(64), lds_bytes(s, false, true), (hipStream_t)stream, s->d_blob, s->off_grid, *st, *out, *p,
+                       derive(*p, s, 0), mb_dev, seq, (unsigned long long)lease_us * 100ull);
+    HIP_TRY(hipGetLastError());
+    return ATC_OK;
+}
+
+int atc_serve_step(uint32_t* mailbox_host, const float* actions, uint32_t seq, const uint32_t* packet_host, uint32_t* payload, int timeout_us) {
+    if (!mailbox_host || !actions || !packet_host || !payload) return fail_arg("null pointer");
+    if (seq == ATC_SERVE_QUIT) return fail_arg("sequence number reserved for the quit command");
+    {   // {action, seq} as ONE 16-byte store: the server can never pair a new sequence number with an old action word
+        alignas(16) uint32_t w[4];
+        memcpy(w, actions, 12);
+        w[3] = seq;
+        _mm_store_si128(reinterpret_cast<__m128i*>(mailbox_host + ATC_MB_CMD), _mm_load_si128(reinterpret_cast<const __m128i*>(w)));
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned have = 0;
+    bool left_seen = false;
+    for (unsigned it = 1;; ++it) {
+        for (int c = 0; c < ATC_PKT_CHUNKS; ++c) {
+            if (have >> c & 1u) continue;
+            alignas(16) uint32_t w[4];
+            _mm_store_si128(reinterpret_cast<__m128i*>(w), _mm_load_si128(reinterpret_cast<const __m128i*>(packet_host + 4 * c)));
+            if (w[3] == seq) {
+                payload[3 * c] = w[0];
+                payload[3 * c + 1] = w[1];
+                payload[3 * c + 2] = w[2];
+                have |= 1u << c;
+            }
+        }
+        if (have == (1u << ATC_PKT_CHUNKS) - 1u) return ATC_OK;
+        if (left_seen) return -4;   // the server had left before it saw this command (lease): the caller starts it again
+        asm volatile("" ::: "memory");
+        if (it < 4096u) _mm_pause();
+        else sched_yield();
+        if ((it & 63u) == 0) {
+            // (checked once more against the packet above before giving up: a step completed just before the lease ran out counts)
+            if (have == 0 && __atomic_load_n(mailbox_host + ATC_MB_STATE, __ATOMIC_ACQUIRE) >= (uint32_t)ATC_SERVE_LEFT_LEASE) left_seen = true;
+            if ((it & 255u) == 0 &&
+                std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_us)
+                return -3;
+        }
+    }
+}
+
+int atc_serve_stop(uint32_t* mailbox_host, void* stream) {
+    if (!mailbox_host) return fail_arg("null pointer");
+    __atomic_store_n(mailbox_host + ATC_MB_SEQ, ATC_SERVE_QUIT, __ATOMIC_RELEASE);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // the state is in memory again once the kernel has ended
+    return ATC_OK;
 }
 
 int atc_step_multi(int n, const atc_step_call_t* calls) {

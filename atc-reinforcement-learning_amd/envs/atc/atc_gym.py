@@ -12,6 +12,7 @@ reference does in Python (win ring buffer, counters), in the same order, includi
   * the win buffer gets one append per terminal CAUSE (atc_gym.py:151,158,165) and reset() pops exactly one (:359-363)
 """
 import random
+import weakref
 
 import numpy as np
 
@@ -51,13 +52,38 @@ class _AirplaneView:
             object.__setattr__(self, key, value)
 
 
+# Persistent step servers of this process (AtcGym._serving): every one is a resident kernel on its own HIP stream, and a process has
+# only a few hardware queues to put streams on (4 by default) — one more resident kernel than queues and somebody's launches wait
+# behind a server until its lease runs out.  Envs beyond the cap step by the launch path (several AtcGym in one process, e.g. a
+# DummyVecEnv; the reference's own arrangement is one env per process, learning/atc-gym-stable-baselines.py:69-80).
+_SERVING = {}          # id(env) -> weakref(env)
+_MAX_SERVERS = 2
+
+
+def _server_slot_free():
+    """True if another resident kernel fits; first forgets servers that have left by themselves (lease) or whose env is gone."""
+    for key, ref in list(_SERVING.items()):
+        env = ref()
+        if env is None:
+            del _SERVING[key]
+        elif int(env._mailbox[4]) >= 2:       # left: its kernel has ended
+            env._srv_stream.synchronize()
+            env._serving = False
+            del _SERVING[key]
+    return len(_SERVING) < _MAX_SERVERS
+
+
 class AtcGym(Env):
     metadata = {
         'render.modes': ['human', 'rgb_array'],
         'video.frames_per_second': 50
     }
 
-    def __init__(self, sim_parameters=None, scenario=None, device=0):
+    def __init__(self, sim_parameters=None, scenario=None, device=0, persistent=None):
+        """persistent (build-own keyword; default: on, ATC_GYM_SERVER=0 turns it off): step through the library's persistent step
+        server (atc_serve_*: one resident wavefront polling a mailbox in mapped host memory) instead of one kernel launch per
+        step.  Same results bit for bit; the server is stopped before anything else touches the env's device state and leaves by
+        itself after 100 ms without a step."""
         # the reference evaluates its defaults once at import (atc_gym.py:28): SimParameters(1), LOWW()
         sim_parameters = sim_parameters if sim_parameters is not None else model.SimParameters(1)
         scenario = scenario if scenario is not None else scenarios.LOWW()
@@ -81,6 +107,11 @@ class AtcGym(Env):
 
         self._backend = self._make_backend(sim_parameters, scenario, device)
         self._outstanding = False
+        self._serving = False
+        if persistent is None:
+            import os
+            persistent = os.environ.get("ATC_GYM_SERVER", "1") != "0"
+        self._persistent = bool(persistent)
         torch = self._backend.torch
         # Zero-copy step: aircraft state, the action and everything step() returns live in pinned host memory that is
         # mapped into the device (AtcVecEnv(host_mapped=True)); one step = write 3 floats, one kernel launch, one stream
@@ -124,6 +155,16 @@ class AtcGym(Env):
             _a=C.c_void_p(self._host_act.data_ptr()), _o=C.byref(v._out), _p=C.byref(v.params), \
             _k=C.c_void_p(self._vec.packet.data_ptr()), _w=C.c_void_p(self._payload_i.ctypes.data): \
             _f(_h, _s, _a, _o, _p, seq, _k, _w, 20000, stream)   # 20 ms: a first launch on an idle device can take a while
+        # the persistent step server's mailbox (64 bytes of pinned mapped memory) and its three calls
+        self._mailbox = torch.zeros(16, dtype=torch.int32).pin_memory()
+        assert self._mailbox.data_ptr() % 64 == 0
+        _mb = C.c_void_p(self._mailbox.data_ptr())
+        self._serve_start = lambda stream, last, _f=v._lib.atc_serve_start, _h=v.sector.handle, _s=C.byref(v._state), _o=C.byref(v._out), \
+            _p=C.byref(v.params): _f(_h, _s, _o, _p, _mb, last, 100000, stream)
+        self._serve_step = lambda seq, _f=v._lib.atc_serve_step, _a=C.c_void_p(self._host_act.data_ptr()), \
+            _k=C.c_void_p(self._vec.packet.data_ptr()), _w=C.c_void_p(self._payload_i.ctypes.data): _f(_mb, _a, seq, _k, _w, 2000000)
+        self._serve_stop = lambda stream, _f=v._lib.atc_serve_stop: _f(_mb, stream)
+        self._srv_stream = None        # the server's own (non-blocking) stream: nothing else is ever launched on it
         self._seq = 0
         self._outstanding = False
         self._pos_now = None                   # grid position after the last step (None: read it from the state record)
@@ -222,7 +263,47 @@ class AtcGym(Env):
 
     def _launch_and_fetch(self):
         """One launch of the step kernel on host-mapped buffers, one stream synchronisation, results read in place."""
-        self._seq = seq = (self._seq + 1) & 0x7fffffff
+        if self._seq >= 0x7ffffff0:   # sequence numbers start over (every 2^31 steps): through a stopped server
+            self._settle()
+            self._seq = 0
+        self._seq = seq = self._seq + 1
+        if self._persistent:
+            # the persistent step server: write {action, seq} into the mailbox, poll the result packet — no launch per step
+            rc = -5
+            for attempt in range(2):
+                if not self._serving:
+                    if not _server_slot_free():
+                        break                      # enough resident kernels in this process: this step goes by a launch
+                    torch = self._backend.torch
+                    if self._srv_stream is None:
+                        self._srv_stream = torch.cuda.Stream(device=self._backend.device)
+                    # whatever was queued for this env before (reset kernels, placed state) comes first
+                    self._srv_stream.wait_stream(self._current_stream(self._backend.device))
+                    self._check(self._serve_start(self._srv_stream.cuda_stream, seq - 1))
+                    self._serving = True
+                    _SERVING[id(self)] = weakref.ref(self)
+                rc = self._serve_step(seq)
+                if rc != -4:
+                    break
+                # the server had left (100 ms without a step) before it saw this command: its kernel has ended, start it again
+                self._srv_stream.synchronize()
+                self._serving = False
+                _SERVING.pop(id(self), None)
+            if rc == 0:
+                w = self._payload_f.copy()
+                iw = self._payload_i
+                fd = int(iw[21])
+                self._pos_now = (int(iw[24]), int(iw[25]))
+                return (w[0:10], w[10:20], float(w[20]), bool(fd >> 16), fd & 0xffff, int(iw[22]), int(iw[23]))
+            if rc == -3:
+                # no answer in 2 s (never expected): stop serving for good and take this step by a launch; the command was not
+                # executed if the server's last sequence number is still the previous one
+                self._persistent = False
+                self._settle()
+                if int(self._mailbox[5]) == seq:
+                    raise RuntimeError("AtcGym: the step server executed step %d but its result packet never arrived" % seq)
+            elif rc != -5:
+                self._check(rc)
         self._outstanding = True
         rc = self._step_packet(self._raw_stream(), seq)   # ~10 us of kernel + host link, polled inside the library
         if rc == -3:                           # never expected: fall back to the blocking wait
@@ -241,6 +322,12 @@ class AtcGym(Env):
     def _settle(self):
         """Drains the stream before anything but step() looks at (or writes) memory the last kernel may still be writing:
         the result packet arrives before the kernel's trailing state stores."""
+        if self._serving:
+            # quit + stream synchronisation: the env's state is back in memory, the stream free for other launches
+            self._check(self._serve_stop(self._srv_stream.cuda_stream))
+            self._serving = False
+            _SERVING.pop(id(self), None)
+            self._outstanding = False
         if self._outstanding:
             self._current_stream(self._backend.device).synchronize()
             self._outstanding = False

@@ -390,21 +390,29 @@ def side_config(name, B, N, scn, sep_nm, device, held_hint, n_single=2000, n_fus
 
 def single_env_protocol(n_steps=100000):
     """The reference's own benchmark (learning/atc-gym-compute-performance.py:10-19): ONE env, 100 000 x step(one fixed
-    sampled action), no reset on done, FPS = N / wall time — through the drop-in envs.atc.atc_gym.AtcGym."""
+    sampled action), no reset on done, FPS = N / wall time — through the drop-in envs.atc.atc_gym.AtcGym: by its persistent step
+    server (atc_serve_*, the default) and, as a side figure, by one kernel launch per step (atc_step_packet, rounds 3-5)."""
     import numpy as np
     from envs.atc import atc_gym
-    env = atc_gym.AtcGym()
-    env.reset()
-    action = np.random.default_rng(0).uniform(-1, 1, 3).astype(np.float32)
-    for _ in range(200):
-        env.step(action)
-    t0 = time.perf_counter()
-    for _ in range(n_steps):
-        env.step(action)
-    dt = time.perf_counter() - t0
-    env.close()
-    return {"protocol": "learning/atc-gym-compute-performance.py:10-19 (1 env x 1 aircraft, one fixed action, no reset)",
-            "steps": n_steps, "steps_per_s": n_steps / dt, "us_per_step": dt / n_steps * 1e6}
+    out = {"protocol": "learning/atc-gym-compute-performance.py:10-19 (1 env x 1 aircraft, one fixed action, no reset)", "steps": n_steps}
+    for key, persistent in (("server", True), ("launch", False)):
+        env = atc_gym.AtcGym(persistent=persistent)
+        env.reset()
+        action = np.random.default_rng(0).uniform(-1, 1, 3).astype(np.float32)
+        for _ in range(200):
+            env.step(action)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            env.step(action)
+        dt = time.perf_counter() - t0
+        served = bool(env._serving)
+        env.close()
+        if key == "server":
+            out.update({"steps_per_s": n_steps / dt, "us_per_step": dt / n_steps * 1e6, "stepped_by": "persistent step server (atc_serve_step)"
+                        if served else "kernel launches (the server was not running)"})
+        else:
+            out["launch_per_step"] = {"steps_per_s": n_steps / dt, "us_per_step": dt / n_steps * 1e6, "stepped_by": "atc_step_packet"}
+    return out
 
 
 def _sync(dev):

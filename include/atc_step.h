@@ -463,6 +463,31 @@ int atc_step_multi(int n, const atc_step_call_t* calls);
 int atc_step_packet(const atc_scenario_t* s, const atc_state_t* st, const float* actions, const atc_out_t* out,
                     atc_params_t* p, uint32_t seq, const uint32_t* packet_host, uint32_t* payload, int timeout_us, void* stream);
 
+/* Persistent step server for ONE env x ONE aircraft (ABI 20) — what the drop-in AtcGym steps through (atc_gym.py:128-192; the
+ * reference's callers step one env per process: learning/atc-gym-stable-baselines.py:69-80, atc-gym-compute-performance.py:10-19).
+ * atc_serve_start launches ONE resident wavefront that keeps the env's state in registers and polls `mailbox` — 64 bytes of pinned
+ * mapped host memory (hipHostMalloc / a pinned torch tensor), 64-byte aligned — for commands; atc_serve_step writes {3 action
+ * floats, seq} into it with one 16-byte store and polls out->packet (see atc_out_t.packet; `packet_host` / `payload` as in
+ * atc_step_packet) for the 9 chunks tagged `seq`; no kernel launch, argument upload or state round trip per step.
+ *   mailbox words: 0..2 action (float bits), 3 sequence number (0xffffffff = quit) — written by the host;
+ *                  4 server state (0 not yet running, 1 serving, 2 left: lease ran out, 3 left: quit), 5 last served sequence
+ *                  number — written by the device.
+ *   - `seq` of atc_serve_start = the sequence number of the LAST step already taken (the first atc_serve_step uses seq + 1, every
+ *     further one the previous + 1); 0xffffffff is reserved.
+ *   - the server leaves by itself after `lease_us` microseconds (>= 1000) without a command: atc_serve_step then returns -4 for the
+ *     command it did not see and the caller starts the server again (same seq rule) and repeats the call.  -3: no answer within
+ *     `timeout_us` (the caller falls back to atc_serve_stop + atc_step_packet).
+ *   - WHILE THE SERVER RUNS the env's state lives in its registers: nothing else may read or write the env's atc_state_t buffers or
+ *     launch on `stream` (a launch would queue behind the resident kernel).  atc_serve_stop sends quit and synchronises the stream:
+ *     after it the state is in memory as after an atc_step.  Outputs other than the packet (obs, reward, ...) are written every step
+ *     like atc_step's.
+ * Results are those of atc_step on the same state and actions, bit for bit (same device functions). */
+int atc_serve_start(const atc_scenario_t* s, const atc_state_t* st, const atc_out_t* out, const atc_params_t* p,
+                    uint32_t* mailbox_host, uint32_t seq, int lease_us, void* stream);
+int atc_serve_step(uint32_t* mailbox_host, const float* actions, uint32_t seq, const uint32_t* packet_host, uint32_t* payload,
+                   int timeout_us);
+int atc_serve_stop(uint32_t* mailbox_host, void* stream);
+
 /* T consecutive steps in ONE launch with aircraft state held in registers.  actions: [T][B*N*3];
  * outputs are [T][...] versions of atc_out_t (each pointer strides by its per-step size).
  * Requires ATC_M_AUTO_RESET semantics to be meaningful for T > episode length. */

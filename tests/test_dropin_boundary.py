@@ -8,6 +8,7 @@ Everything that imports the stand-in gym runs in child processes so that this se
 import json
 import multiprocessing as mp
 import os
+import random
 import subprocess
 import sys
 import time
@@ -168,3 +169,88 @@ def test_bench_two_ranks_on_one_device():
     assert abs(c["value_between_barriers"] - 2 * 4096 * 60 / (c["ms_per_step_incl_closing_barrier"] * 60 * 1e-3)) <= 1e-6 * line["value"]
     with open(os.path.join(ROOT, "gpurun_out", "bench_2ranks_1gpu.json"), "w") as f:
         json.dump(line, f)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_step_server_equals_the_launch_path_and_survives_its_lease():
+    """The persistent step server behind AtcGym.step (atc_serve_*: one resident wavefront, a mailbox in mapped host memory) against
+    the launch-per-step path (atc_step_packet): the same 900 actions — resets, attribute pokes and reads of the device state in
+    between (each stops the server and starts it again), a pause longer than the server's 100 ms lease (it leaves by itself and
+    the next step starts it again), a seeded random-entry scenario — give bit-identical observations, rewards, flags, counters
+    and state."""
+    import time
+    from envs.atc import atc_gym, model, scenarios
+    rng = np.random.default_rng(3)
+    envs = []
+    for persistent in (True, False):
+        random.seed(11)
+        e = atc_gym.AtcGym(model.SimParameters(0.7), scenarios.LOWW(random_entrypoints=True), persistent=persistent)
+        e.seed(5)
+        envs.append(e)
+    srv, ref = envs
+    assert srv._persistent and not ref._persistent
+    draws = [0]
+
+    def reset_both():   # AtcGym.reset draws its entry point from Python's global `random` (atc_gym.py:346-348): the same draws for both
+        draws[0] += 1
+        out = []
+        for e in (srv, ref):
+            random.seed(1000 + draws[0])
+            out.append(e.reset())
+        assert np.array_equal(out[0], out[1])
+    reset_both()
+    a = rng.uniform(-1, 1, 3).astype(np.float32)
+    for t in range(900):
+        if t % 25 == 0:
+            a = rng.uniform(-1.1, 1.1, 3).astype(np.float32)
+        rs, rr = srv.step(a), ref.step(a)
+        assert np.array_equal(rs[0], rr[0]) and rs[1] == rr[1] and rs[2] == rr[2], t
+        assert np.array_equal(rs[3]["original_state"], rr[3]["original_state"]), t
+        assert (srv.timesteps, srv.actions_taken) == (ref.timesteps, ref.actions_taken), t
+        if t == 5:
+            assert srv._serving
+        if t % 97 == 50:      # reading the device state stops the server; the next step starts it again
+            assert srv._airplane.h == ref._airplane.h and srv._airplane.x == ref._airplane.x and srv.last_action == ref.last_action
+            assert not srv._serving
+        if t == 300:          # longer than the lease: the resident kernel has left on its own
+            time.sleep(0.35)
+            assert int(srv._mailbox[4]) == 2
+        if t % 211 == 210 or rs[2]:
+            reset_both()
+        if t == 600:
+            srv._airplane.h = 7000.0
+            ref._airplane.h = 7000.0
+    assert srv.winning_ratio == ref.winning_ratio and srv.total_reward == ref.total_reward
+    srv.close()
+    ref.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(120)
+def test_several_envs_in_one_process_share_the_step_servers():
+    """Four AtcGym in ONE process (a DummyVecEnv-style loop): at most two hold a resident step server (each on its own stream; a
+    process has only a few hardware queues), the others step by launches — nobody waits behind somebody else's resident kernel
+    (4 x 300 steps in well under a second of stepping), and all four reproduce one launch-path env bit for bit."""
+    import time
+    from envs.atc import atc_gym
+    envs = [atc_gym.AtcGym() for _ in range(4)]
+    ref = atc_gym.AtcGym(persistent=False)
+    for e in envs + [ref]:
+        e.reset()
+    rng = np.random.default_rng(0)
+    t0 = time.perf_counter()
+    for t in range(300):
+        a = rng.uniform(-1, 1, 3).astype(np.float32)
+        r = ref.step(a)
+        for e in envs:
+            o = e.step(a)
+            assert np.array_equal(o[0], r[0]) and o[1] == r[1] and o[2] == r[2], t
+        if t == 10:
+            assert sum(e._serving for e in envs) == 2 and len(atc_gym._SERVING) == 2
+    dt = time.perf_counter() - t0
+    assert dt < 3.0, dt
+    for e in envs + [ref]:
+        e.close()
+    assert not atc_gym._SERVING
+

@@ -341,17 +341,19 @@ def test_huge_batch_uses_correct_offsets():
     small.close()
 
 
-def test_atcgym_packet_polling_equals_synchronised_reads():
+@pytest.mark.parametrize("persistent", [True, False])
+def test_atcgym_packet_polling_equals_synchronised_reads(persistent):
     """AtcGym.step returns as soon as the self-validating result packet (atc_out_t.packet) has arrived in mapped memory —
-    before the stream is drained.  30 000 steps with resets: every value it returned equals what the ordinary output
-    buffers hold once the stream HAS been drained, and an env that drains after every step sees the same trajectory."""
+    from the persistent step server (round 6, the default) or from a launch of its own (atc_step_packet) before the stream is
+    drained.  30 000 steps with resets: every value it returned equals what the ordinary output buffers hold once the server has
+    been stopped / the stream HAS been drained, and an env that does so after every step sees the same trajectory."""
     _torch()
     from envs.atc import atc_gym, scenarios
     import random
     random.seed(3)
-    a_env = atc_gym.AtcGym(scenario=scenarios.LOWW(random_entrypoints=True))
+    a_env = atc_gym.AtcGym(scenario=scenarios.LOWW(random_entrypoints=True), persistent=persistent)
     random.seed(3)
-    b_env = atc_gym.AtcGym(scenario=scenarios.LOWW(random_entrypoints=True))
+    b_env = atc_gym.AtcGym(scenario=scenarios.LOWW(random_entrypoints=True), persistent=persistent)
     rng = np.random.default_rng(8)
     n_done = 0
     fallbacks = 0
@@ -359,13 +361,13 @@ def test_atcgym_packet_polling_equals_synchronised_reads():
         if t % 20 == 0:
             act = rng.uniform(-1.02, 1.02, 3).astype(np.float32)
         oa, ra, da, ia = a_env.step(act)
-        fallbacks += not a_env._outstanding            # returned on the packet, not on a synchronisation (20 ms time limit)
+        fallbacks += not (a_env._serving if persistent else a_env._outstanding)   # returned on the packet, not on a synchronisation
         ob, rb, db, ib = b_env.step(act)
         b_env._settle()
         assert np.array_equal(oa, ob) and ra == rb and da == db and np.array_equal(ia["original_state"], ib["original_state"])
         if t % 97 == 0:                                # the packet against the ordinary (drained) output buffers
             v = a_env._vec                             # (property: drains the stream)
-            assert not a_env._outstanding
+            assert not a_env._outstanding and not a_env._serving
             assert np.array_equal(oa, v.obs.numpy().reshape(-1)) and ra == float(v.reward[0]) and da == bool(v.done[0])
             assert a_env.timesteps == int(v.timesteps[0]) and a_env.actions_taken == int(v.actions_taken[0])
             assert a_env._pos_now == (int(v.ac[0, 0]), int(v.ac[0, 1]))
