@@ -18,9 +18,10 @@ from .vec_env import AtcVecEnv
 def _vecenv_base():
     """The VecEnv abstract base of whichever stable-baselines is importable — the reference pins stable-baselines 2.8.0
     (requirements.txt), whose BaseRLModel wraps anything that is NOT a `VecEnv` instance in DummyVecEnv([lambda: env]); its
-    trainer hands the vector env straight to PPO2 (learning/atc-gym-stable-baselines.py:76-90).  Neither library is installed in
-    this image: then the adapter is a plain class with the same surface."""
-    for mod in ("stable_baselines.common.vec_env", "stable_baselines3.common.vec_env"):
+    trainer hands the vector env straight to PPO2 (learning/atc-gym-stable-baselines.py:76-90).  Only that library is looked for: the
+    adapter has been exercised against its VecEnv contract (tests/sb_shim), not against stable-baselines3's (gymnasium spaces,
+    reset_infos / _seeds bookkeeping).  It is not installed in this image: then the adapter is a plain class with the same surface."""
+    for mod in ("stable_baselines.common.vec_env",):
         try:
             return importlib.import_module(mod).VecEnv
         except Exception:   # noqa: BLE001 — not installed, or an installation that does not import here

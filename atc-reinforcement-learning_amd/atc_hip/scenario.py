@@ -607,6 +607,12 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
     assert off_poly % 4 == 0 and L.P_WORDS % 4 == 0 and off_vert % 2 == 0
     off_entry = off_vert + n_vertw
     n_entry = len(entrypoints)
+    for ex, ey, ephi, _ in entrypoints:
+        # the device's 32-bit heading field holds (-76, 436) deg; beyond it an aircraft is WIDE with its exact counts in a side word
+        # that a reset does not write (include/atc_step.h, ABI 19).  The reference never validates an entry heading; every sector it
+        # ships uses [0, 360).  Kinematics, corridor and relative angles are periodic, only the raw heading observation is not.
+        if not -76.0 < float(ephi) < 436.0:
+            raise ValueError("entry point heading %r outside (-76, 436) deg: wrap it into [0, 360)" % (ephi,))
     off_slot = (off_entry + n_entry * L.E_WORDS + 3) & ~3  # 16-byte aligned float4 records
     end = off_slot + (4 * L.MAX_AIRCRAFT if n_entry else 0)
     off_spawn = (end + 15) & ~15   # 64-byte aligned spawn records: 64 lattice slots, then one per entry point
@@ -731,7 +737,10 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
             for val, org in ((ex, px0), (ey, py0)):   # csrc/atc_device.h: pos_spawn (fp32 like the device)
                 c = f32(f32(f32(val) - f32(org)) * f32(2.0 ** pk))
                 fix.append(int(np.rint(min(max(float(c), -2147483648.0), 2147483520.0))))
-            phi_fix = int(min(max(np.rint((float(f32(ephi)) - L.PHI_FIX_OFFSET) * 2.0 ** L.PHI_FIX_SHIFT), -2.0 ** 31), 2.0 ** 31 - 1))
+            # (an entry heading outside (-76, 436) deg would saturate the 32-bit field — the WIDE sentinels of ABI 19, with no side
+            # word written at reset: compile_sector refuses such entries above, so this stays inside the range)
+            phi_fix = int(np.rint((float(f32(ephi)) - L.PHI_FIX_OFFSET) * 2.0 ** L.PHI_FIX_SHIFT))
+            assert -2 ** 31 < phi_fix < 2 ** 31 - 1
             phi32 = f32(f32(phi_fix) * f32(2.0 ** -L.PHI_FIX_SHIFT) + f32(L.PHI_FIX_OFFSET))   # phi_real (exact for these values)
             x32, y32 = f32(px0 + fix[0] * 2.0 ** -pk), f32(py0 + fix[1] * 2.0 ** -pk)       # pos_to_real: one rounding
             tfx = f32(f32(min(max(faf_fix[0] - fix[0], -2 ** 31), 2 ** 31 - 1)) * pos_inv)
@@ -755,7 +764,7 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
         mva_rings=mva_rings, mva_heights=mva_heights, mva_bounds=bounds[:len(mva_rings)], noise_rings=noise_rings,
         bbox=bbox, world_diag=world_diag, faf_mva=faf_mva, corridor=cg, norm_min=norm_min, norm_max=norm_max,
         entrypoints=[(float(a), float(b_), float(c), [int(l) for l in lv]) for a, b_, c, lv in entrypoints],
-        n_mva=len(mva_rings), n_noise=len(noise_rings), n_entry=n_entry, has_grid=grid is not None,
+        n_mva=len(mva_rings), n_noise=len(noise_rings), n_entry=n_entry, has_grid=(grid is not None or grid_fn is not None),
         v_min=v_min, v_max=v_max, h_min=h_min, h_max=h_max, pos_origin=(px0, py0), pos_k=pk,
     )
     cs = CompiledSector(b, meta, spawn_words=spawn_i if n_spawn else None, grid_fn=grid_fn, blob32=cached32)

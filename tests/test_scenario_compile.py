@@ -268,7 +268,8 @@ def test_compile_is_fast_cached_and_byte_identical(tmp_path, monkeypatch):
         assert _sha(c.blob32) == R04_BLOBS[0.0625][0]
     assert (_sha(c.blob32), _sha(c.blob64)) == R04_BLOBS[0.0625]       # (the float64 master fills its grid in on first use)
     print("cold", cold, "warm", warm)
-    assert min(cold) <= 1.0 and min(warm) <= 0.05, (cold, warm)
+    # (generous bounds: a loaded CI machine must not fail a correctness suite on a stopwatch; measured here 0.85 s / 1 ms)
+    assert min(cold) <= 10.0 and min(warm) <= 0.5 and min(warm) < min(cold), (cold, warm)
     files = sorted(p.name for p in (tmp_path / "c1").iterdir())
     assert len(files) == 2 and files[0].startswith("blob32_") and files[1].startswith("grid_")
     for cell in (None, 0.125, 0.25):
