@@ -310,7 +310,7 @@ def multi_stream_gate(scn, N, grid_cell, sep_nm, device, held_hint, steps=2 * HO
     return rec
 
 
-def traffic_entry(B, N, rollout, held_hint, streams=1):
+def traffic_entry(B, N, rollout, held_hint, streams=1, grid_cell=None):
     """HBM bytes per launch of this workload from the committed PMC passes (profiles/pmc_traffic.json: separate rocprofv3 --pmc
     runs, FETCH_SIZE / WRITE_SIZE with the gfx950 corrections) — counters cannot be read from inside the process.  Entries are
     keyed by the ABI version of the library they were measured on: a kernel change cannot silently keep an old figure."""
@@ -321,14 +321,14 @@ def traffic_entry(B, N, rollout, held_hint, streams=1):
     try:
         for tj in json.load(open(tpath))["workloads"]:
             if (tj.get("abi") == L.ABI_VERSION and tj["envs"] == B and tj["aircraft"] == N and tj["rollout"] == (rollout or 0)
-                    and bool(tj.get("held_hint", False)) == bool(held_hint)):
+                    and bool(tj.get("held_hint", False)) == bool(held_hint) and tj.get("grid_cell_nm") == grid_cell):
                 return tj["hbm_bytes_per_launch"], tj["source"]
     except Exception:
         pass
     return None, None
 
 
-def side_config(name, B, N, scn, sep_nm, device, held_hint, n_single=2000, n_fused=100, cpu=True):
+def side_config(name, B, N, scn, sep_nm, device, held_hint, n_single=2000, n_fused=100, cpu=True, alt_grid=None):
     """One of BASELINE.json's other single-GPU configurations as a side record of the default line: the launch mode of the
     headline loop (one atc_step per step, a new action tensor every HOLD steps, the held-action hint in between) and the same
     envs with HOLD steps fused per launch — each parity-gated on its own first 256 envs before it is timed."""
@@ -359,6 +359,29 @@ def side_config(name, B, N, scn, sep_nm, device, held_hint, n_single=2000, n_fus
         torch.cuda.synchronize(dev)
         blocks.append(e0.elapsed_time(e1) * 1e3 / n_single)
     us = sorted(blocks)[1]
+    alt = None
+    if alt_grid is not None:
+        # A/B asked for by the round-5 review (next #3): the same single-step loop on a coarser lookup grid — fewer bytes from
+        # beyond the L2s (the 0.0625 nm table is 11.6 MB, the 0.125 nm one 3.2 MB) against more aircraft in cells a border cuts
+        env2 = AtcVecEnv(B, N, scenario=scn, device=device, auto_reset=True, seed=11, grid_cell=alt_grid, sep_nm=sep_nm)
+        f2 = [env2.make_launcher(a) for a in ring]
+        r2 = [env2.make_launcher(a, held=True) for a in ring] if held_hint else f2
+        for t in range(3000):
+            (r2 if t % HOLD else f2)[(t // HOLD) % len(ring)]()
+        torch.cuda.synchronize(dev)
+        b2 = []
+        for rep in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for t in range(n_single):
+                (r2 if t % HOLD else f2)[(t // HOLD) % len(ring)]()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            b2.append(e0.elapsed_time(e1) * 1e3 / n_single)
+        env2.close()
+        tr2, src2 = traffic_entry(B, N, 0, held_hint, grid_cell=alt_grid)
+        alt = {"grid_cell_nm": alt_grid, "us_per_step": sorted(b2)[1], "traffic": tr2, "traffic_source": src2,
+               "traffic_over_algorithmic": (tr2 / (algorithmic_bytes_per_env_step(N) * B)) if tr2 else None}
     ro = {"obs": torch.empty((HOLD, B, N * 10), dtype=torch.float32, device=dev),
           "reward": torch.empty((HOLD, B), dtype=torch.float32, device=dev),
           "done": torch.empty((HOLD, B), dtype=torch.uint8, device=dev),
@@ -382,7 +405,8 @@ def side_config(name, B, N, scn, sep_nm, device, held_hint, n_single=2000, n_fus
             "cpu_baseline": cpu_side_baseline(N, scn) if cpu else None,
             "single_steps": {"steps": n_single, "us_per_step": us, "env_steps_per_s": B / (us * 1e-6),
                              "algorithmic_bytes_per_env_step": b1, "hbm_frac": b1 * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                             "traffic": tr1, "traffic_source": src1, "timed_blocks_us_per_step": blocks},
+                             "traffic": tr1, "traffic_source": src1, "timed_blocks_us_per_step": blocks,
+                             "traffic_over_algorithmic": (tr1 / (b1 * B)) if tr1 else None, "coarser_grid": alt},
             "fused_rollout": {"entry": "atc_rollout_hold", "T": HOLD, "hold": HOLD, "launches": n_fused, "us_per_step": usf,
                               "env_steps_per_s": B / (usf * 1e-6), "algorithmic_bytes_per_env_step": bf,
                               "hbm_frac": bf * B / (usf * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": trf, "traffic_source": srcf}}
@@ -915,6 +939,15 @@ def main():
             if so is not None:
                 so["fused_launch_us"] = us * Tf
                 so["fused_over_store_pattern"] = us * Tf / so["store_pattern_us_per_launch"]
+                if "store_pattern_400_fma_1_gather_us_per_launch" in so:
+                    # the launch against a kernel that writes the same bytes in the same pattern AND carries the step's instruction
+                    # count and its one gather: what is left above 1.0 is the step's waits, scalar work and occupancy (6 of 8 waves)
+                    so["fused_over_pattern_with_arithmetic"] = us * Tf / so["store_pattern_400_fma_1_gather_us_per_launch"]
+                arr = so.get("arrangements_us_per_launch")
+                if arr:
+                    best = min(arr, key=arr.get)
+                    so["best_pattern"] = {"name": best, "us_per_launch": arr[best],
+                                          "hbm_frac_if_the_launch_ran_at_it": fb * B * Tf / (arr[best] * 1e-6) / 1e9 / HBM_PEAK_GBS}
                 line["config"]["fused_rollout"]["store_only_reference"] = so
             if held_launchers is not None:
                 # the same loop without the held-action promise (every launch reads the last-action record): a side record
@@ -1004,7 +1037,7 @@ def main():
             hh = not args.no_held_hint
             line["config"]["baseline_configs"] = [
                 side_config("C2: 65 536 envs x 1 aircraft (kinematics + MVA only)", 65536, 1, scenarios.LOWW(),
-                            args.sep_nm, local, hh, cpu=not args.no_cpu_baseline),
+                            args.sep_nm, local, hh, cpu=not args.no_cpu_baseline, alt_grid=0.125),
                 side_config("C3: 8 192 envs x 16 aircraft", 8192, 16, scenarios.LOWW(random_entrypoints=True),
                             args.sep_nm, local, hh, cpu=not args.no_cpu_baseline),
                 side_config("C4: 4 096 envs x 64 aircraft, multi-polygon MVA + noise-abatement areas", 4096, 64,

@@ -19,5 +19,6 @@ run n64_4096 --aircraft 64 --envs 4096
 run n64_4096_roll --aircraft 64 --envs 4096 --rollout 20 --warmup 40
 run n64_32768 --aircraft 64 --envs 32768
 run n16_262144 --envs 262144
+run n1_65536_g0125 --aircraft 1 --grid-cell 0.125
 python $ROOT/tools/pmc_traffic_table.py $TAG > $ROOT/gpurun_out/pmc_traffic_$TAG.json
 cat $ROOT/gpurun_out/pmc_traffic_$TAG.json

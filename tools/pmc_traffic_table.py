@@ -19,7 +19,10 @@ tag = sys.argv[1]
 WORK = [("n16_65536", 65536, 16, 0, True), ("n16_65536_nohint", 65536, 16, 0, False), ("n16_65536_roll", 65536, 16, 20, False),
         ("n1_65536", 65536, 1, 0, True), ("n1_65536_roll", 65536, 1, 20, False), ("n16_8192", 8192, 16, 0, True),
         ("n16_8192_roll", 8192, 16, 20, False), ("n64_4096", 4096, 64, 0, True), ("n64_4096_roll", 4096, 64, 20, False),
-        ("n64_32768", 32768, 64, 0, True), ("n16_262144", 262144, 16, 0, True)]
+        ("n64_32768", 32768, 64, 0, True), ("n16_262144", 262144, 16, 0, True),
+        # round-5 review, next #3: 65 536 x 1 single steps on the 0.125 nm lookup grid (3.2 MB: the eight L2s hold it) instead of the
+        # batch's default 0.0625 nm (11.6 MB) — an A/B of traffic against time, reported as a side record
+        ("n1_65536_g0125", 65536, 1, 0, True, 0.125)]
 
 
 def avg(d, counter):
@@ -33,7 +36,8 @@ def avg(d, counter):
 
 
 out = []
-for name, B, N, roll, held in WORK:
+for name, B, N, roll, held, *rest in WORK:
+    grid_cell = rest[0] if rest else None
     d = os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (tag, name))
     fetch, nf = avg(d, "FETCH_SIZE")
     write, nw = avg(d, "WRITE_SIZE")
@@ -54,7 +58,7 @@ for name, B, N, roll, held in WORK:
                 "read the figure as a lower bound" % ("mostly 4- / 12-byte records of one-aircraft envs" if N == 1 else
                 "16-byte state records plus 12-byte action records once per %d steps" % (roll or 1),
                 bench.working_set_bytes(B, N, roll or 1) >> 20))
-    out.append({"abi": L.ABI_VERSION, "read_correction_note": note, "envs": B, "aircraft": N, "rollout": roll, "held_hint": held,
+    out.append({"abi": L.ABI_VERSION, "grid_cell_nm": grid_cell, "read_correction_note": note, "envs": B, "aircraft": N, "rollout": roll, "held_hint": held,
                 "kernel": "k_step<%d,false,%s,%s>%s" % (W, "false" if roll else "true", "true" if N == W and (B * W) % 256 == 0 else "false",
                                                      " T=%d hold=%d" % (roll, roll) if roll else ""),
                 "FETCH_SIZE_KB_raw": round(fetch, 1), "WRITE_SIZE_KB": round(write, 1), "hbm_bytes_per_launch": hbm,

@@ -212,10 +212,17 @@ static int json_mode(int B, int T) {
     const double stream = time_us([&] { hipLaunchKernelGGL(k_stream<false>, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, reinterpret_cast<v4f*>(obs), n16, 1.0f); }, reps);
     const double pattern = time_us([&] { hipLaunchKernelGGL((k_pattern<true, 0>), dim3(grid), dim3(256), 0, 0, obs, flags, reward, done, B, T, 1.0f); }, reps);
     const double loaded = time_us([&] { hipLaunchKernelGGL((k_pattern_ld<false, 400>), dim3(grid), dim3(256), 0, 0, obs, flags, reward, done, table, tmask, B, T, 1.0f); }, reps);
+    // other arrangements of the same bytes (round-5 review, next #4): tiles kept XCD-contiguous, and the bound of ANY scheme that
+    // buffers the small per-step streams (flags, reward, done) — the observation rows alone
+    const double xcd = time_us([&] { hipLaunchKernelGGL((k_pattern<true, 0, 7, true>), dim3(grid), dim3(256), 0, 0, obs, flags, reward, done, B, T, 1.0f); }, reps);
+    const double rows = time_us([&] { hipLaunchKernelGGL((k_pattern<true, 0, 1>), dim3(grid), dim3(256), 0, 0, obs, flags, reward, done, B, T, 1.0f); }, reps);
+    const double rows400 = time_us([&] { hipLaunchKernelGGL((k_pattern<true, 400, 1>), dim3(grid), dim3(256), 0, 0, obs, flags, reward, done, B, T, 1.0f); }, reps);
     printf("{\"envs\": %d, \"aircraft\": %d, \"T\": %d, \"output_bytes_per_launch\": %zu, \"stream_tb_per_s\": %.3f, "
            "\"store_pattern_us_per_launch\": %.1f, \"store_pattern_tb_per_s\": %.3f, "
-           "\"store_pattern_400_fma_1_gather_us_per_launch\": %.1f}\n",
-           B, N, T, total, obs_bytes / stream / 1e6, pattern, total / pattern / 1e6, loaded);
+           "\"store_pattern_400_fma_1_gather_us_per_launch\": %.1f, "
+           "\"arrangements_us_per_launch\": {\"as_launched\": %.1f, \"xcd_contiguous_tiles\": %.1f, "
+           "\"observation_rows_only (bound of buffering flags / reward / done)\": %.1f, \"observation_rows_only + 400 FMAs\": %.1f}}\n",
+           B, N, T, total, obs_bytes / stream / 1e6, pattern, total / pattern / 1e6, loaded, pattern, xcd, rows, rows400);
     return 0;
 }
 
