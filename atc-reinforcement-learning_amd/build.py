@@ -11,7 +11,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "atc_step.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "atc_device.h"), os.path.join(os.path.dirname(HERE), "include", "atc_step.h")]
+DEPS = [SRC, os.path.join(HERE, "csrc", "atc_device.h"), os.path.join(HERE, "csrc", "atc_abi.inc"), os.path.join(HERE, "csrc", "atc_wave.h"),
+        os.path.join(os.path.dirname(HERE), "include", "atc_step.h")]
 OUT = os.path.join(HERE, "atc_hip", "libatcstep.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-kernarg-preload-count=16: the first 64 bytes of the kernel arguments (sector pointer, batch shape, the state record

@@ -1,28 +1,18 @@
 // atc_step.hip — libatcstep.so: hand-written gfx950 (CDNA4, MI355X) kernels + C-ABI of the batched AtcGym.step() path.
 //
-// Work decomposition (one wavefront = 64 lanes):
-//   lane  = one aircraft slot;  W = next_pow2(N) consecutive lanes = one env;  64/W envs per wavefront
-//   (N = 64: one wavefront per env, N = 16: 4 envs per wavefront, N = 1: 64 envs per wavefront).
-//   Aircraft state lives in HBM as packed records indexed env*N + k: ac = (x, y on the 32-bit fixed-point position grid,
-//   heading counts, speed counts) 16 B, alt = the altitude as the reference's float64 8 B (ABI 20: include/atc_step.h),
-//   last_act = the three last accepted targets 16 B (read and written only by steps that may change it) — a
-//   wavefront moves each array with ONE access per lane on consecutive addresses; the per-step env record (4 words) is one
-//   16-byte load that the W lanes of an env share, the per-episode record is touched only when an episode ends.
-//   All per-lane indices are 32-bit offsets from uniform base pointers.
-//   The sector blob (constants, polygons, lookup grid) stays in global memory: constants are read with uniform indices
-//   (scalar loads -> SGPRs), the MVA lookup is one 8-byte L2 gather per aircraft (+ a few 16-byte edge records in cells
-//   that touch a polygon border).  There is no per-workgroup staging prologue and no block barrier: the first thing a
-//   wavefront does is issue its state loads.
-//   The O(N^2) separation scan evaluates every unordered pair once: for N = 16 an env is one DPP row and partner state
-//   arrives by row rotation fused into the subtract (the inverse rotation hands the result back); N <= 8 pairs lanes by
-//   XOR through quad_perm / row_half_mirror; N > 16 stages (x, y, h) in LDS, visits the next W/2 partners and hands a
-//   conflict to the partner as the ballot mask rotated on the scalar unit.  Per-env reward / action count / minimum
-//   separation are reduced with DPP butterflies (wavefront shuffles beyond a row), done / won masks with a ballot — no
-//   block barrier, no atomics in the fast variant, no MFMA (there is no dense contraction on this path).
-//   Workgroup = 256 threads = 256 consecutive slots; one workgroup per tile.  The single-step kernel has NO loop around
-//   the step body (neither grid-stride nor the step loop of multi-step launches): it is its own instantiation
-//   k_step<W, FULL, ONE = true> (N = 16: 56 VGPRs); multi-step launches keep the state in registers across a run-time step
-//   loop under an 80-VGPR launch bound (6 wavefronts per SIMD) and prefetch the next step's action.
+// Work decomposition: lane = one aircraft slot, W = next_pow2(N) consecutive lanes = one env, 64 / W envs per wavefront; workgroup =
+// 256 consecutive slots, one per tile, no block barrier, no atomics in the fast variant, no MFMA (no contraction on this path).
+//   State in HBM (include/atc_step.h, ABI 20): ac = (x, y on the 32-bit position grid, heading counts, speed counts) 16 B, alt = the
+//   altitude as the reference's float64 8 B, last_act 16 B (touched only by steps that may change it), a 16-byte env record shared
+//   by the W lanes of an env; every array moves with ONE access per lane on consecutive addresses, 32-bit offsets from uniform bases.
+//   The sector blob stays in global memory: constants through scalar loads, the MVA lookup one 8-byte gather per aircraft (+ edge
+//   records in cells a border cuts).  No staging prologue: the first thing a wavefront does is issue its state loads.
+//   Separation scan, every unordered pair once: N = 16 one DPP row per env (row rotation fused into the subtract, the inverse
+//   rotation hands the result back); N <= 8 XOR partners through quad_perm / row_half_mirror; N > 16 LDS planes + packed fp32 +
+//   ballot masks rotated on the scalar unit.  Per-env sums by DPP butterflies, done / won masks by ballot.
+//   The single-step kernel has NO loop around the step body (its own instantiation, ONE); multi-step launches keep the state in
+//   registers across a run-time step loop under an 80-VGPR bound; LAT is their form for at most two wavefronts per SIMD; k_serve
+//   is the resident one-env step server.  How each choice was measured: DESIGN_HISTORY.md, profiles/experiments/.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared   (see build.py)
 #include <hip/hip_runtime.h>
@@ -109,168 +99,7 @@ constexpr bool loop_rereads_state(int W) { return W < 32; }
 #define ATC_MIN_WAVES_LOOP 6  // multi-step launches: <= 80 VGPRs.  Without the bound the allocator keeps literal constants and
                               // other loop invariants in registers across the step loop (86-99 VGPRs, 4-5 waves per SIMD)
 
-// ---------------------------------------------------------------------------------------------------------------
-// wavefront-group helpers (groups of W consecutive lanes, W a power of two <= 64)
-// ---------------------------------------------------------------------------------------------------------------
-// Butterfly exchange partner for reductions over groups of W lanes.  Inside a DPP row (W <= 16) the stages are
-// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror: after each stage both halves of the growing
-// block hold the same value, so the mirrored pairings are as good as xor pairings — and they are VALU operand modifiers
-// (no ds_bpermute, no index registers).  Wider groups fall back to __shfl_xor for the cross-row stages.
-template <int STAGE>
-__device__ __forceinline__ int dpp_stage(int v) {
-    constexpr int ctrl = STAGE == 1 ? 0xB1 : STAGE == 2 ? 0x4E : STAGE == 4 ? 0x141 : 0x140;
-    return __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, false);
-}
-template <int O>
-__device__ __forceinline__ float xchg(float v) {
-    if (O <= 8) return __int_as_float(dpp_stage<O>(__float_as_int(v)));
-    return __shfl_xor(v, O, 64);
-}
-template <int O>
-__device__ __forceinline__ int xchg(int v) {
-    if (O <= 8) return dpp_stage<O>(v);
-    return __shfl_xor(v, O, 64);
-}
-template <int W>
-__device__ __forceinline__ float group_sum(float v) {
-    if (W > 1) v += xchg<1>(v);
-    if (W > 2) v += xchg<2>(v);
-    if (W > 4) v += xchg<4>(v);
-    if (W > 8) v += xchg<8>(v);
-    if (W > 16) v += xchg<16>(v);
-    if (W > 32) v += xchg<32>(v);
-    return v;
-}
-template <int W>
-__device__ __forceinline__ int group_sum_i(int v) {
-    if (W > 1) v += xchg<1>(v);
-    if (W > 2) v += xchg<2>(v);
-    if (W > 4) v += xchg<4>(v);
-    if (W > 8) v += xchg<8>(v);
-    if (W > 16) v += xchg<16>(v);
-    if (W > 32) v += xchg<32>(v);
-    return v;
-}
-template <int W>
-__device__ __forceinline__ float group_min(float v) {
-    if (W > 1) v = fminf(v, xchg<1>(v));
-    if (W > 2) v = fminf(v, xchg<2>(v));
-    if (W > 4) v = fminf(v, xchg<4>(v));
-    if (W > 8) v = fminf(v, xchg<8>(v));
-    if (W > 16) v = fminf(v, xchg<16>(v));
-    if (W > 32) v = fminf(v, xchg<32>(v));
-    return v;
-}
-// (__builtin_amdgcn_ballot_w64 takes the predicate as the lane mask it already is; HIP's __ballot(int) first materialises
-// it per lane and compares again: two vector instructions per use)
-template <int W>
-__device__ __forceinline__ uint64_t group_ballot(bool pred, int lane) {
-    const uint64_t b = __builtin_amdgcn_ballot_w64(pred);
-    if (W == 64) return b;
-    const int base = lane & ~(W - 1);
-    return (b >> base) & ((1ull << (W & 63)) - 1ull);   // (W < 64 here; the mask keeps the W = 64 instantiation warning-free)
-}
-
-// Separation scan for N = 16: one env = one DPP row (16 lanes).  Partner state arrives by row rotation (v_*_dpp
-// row_ror:D, D = 1..15 visits every other lane of the row exactly once) — no LDS, no waits, no branches.
-template <int D>
-__device__ __forceinline__ float row_ror(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + D, 0xf, 0xf, false));
-}
-// margin = max(d^2 - sep^2, |dh| - sep_ft) is negative exactly when both separation minima are violated (the sign of an
-// IEEE difference is exact), so "any partner in conflict" is min over partners of margin < 0 — four VALU operations per
-// partner, no compares, no mask arithmetic.
-// Each unordered pair is evaluated ONCE: rotation D (1..8) makes a lane evaluate the partner D lanes away, and the inverse
-// rotation 16-D hands that pair's margin (and d^2) back to the partner, for which it is the same pair (d^2 and |dh| are
-// symmetric, so the values are bit-identical to what the partner would have computed).  D = 8 is its own inverse.
-template <int D, bool WANT_MIN>
-struct PairScan16 {
-    static __device__ __forceinline__ void run(float xs, float y, float h, float sep2, float sep_ft, float& min_d2,
-                                               float& margin) {
-        const float dx = xs - row_ror<D>(xs), dy = y - row_ror<D>(y), dh = h - row_ror<D>(h);
-        const float d2 = fmaf(dx, dx, dy * dy);
-        const float m = fmaxf(d2 - sep2, fabsf(dh) - sep_ft);
-        margin = fminf(margin, m);
-        if (D < 8) margin = fminf(margin, row_ror<16 - D>(m));
-        if (WANT_MIN) {
-            min_d2 = fminf(min_d2, d2);
-            if (D < 8) min_d2 = fminf(min_d2, row_ror<16 - D>(d2));
-        }
-        PairScan16<D + 1, WANT_MIN>::run(xs, y, h, sep2, sep_ft, min_d2, margin);
-    }
-};
-template <bool WANT_MIN>
-struct PairScan16<9, WANT_MIN> {
-    static __device__ __forceinline__ void run(float, float, float, float, float, float&, float&) {}
-};
-// The same scan for launches that do not report the minimum separation (the fast variant): the horizontal question first — two
-// rotated subtracts, a multiply, an fma and one compare into a lane mask — and the altitude is fetched and the result handed back to
-// the partner only behind a wave-uniform test of that mask.  Conflict = (d^2 < sep^2) & (|dh| < sep_ft), the oracle's expression.
-// (Round 5 tried the three-dimensional question per rotation plus a scan horizon for this width: fewer instructions, no time —
-// profiles/experiments/README.md: scan16_form1.  The horizon ships for the LDS-staged widths only.)
-struct ScanLimits {
-    float sep2, sep_ft;       // the separation minima (squared horizontal, vertical)
-    float sep2_h, sep_ft_h;   // the same with the horizon's closing distance added (== the minima where no horizon is used)
-};
-template <int D>
-__device__ __forceinline__ int row_ror_i(int v) {
-    // (every lane of a row rotation has a source: `old` is never used — passing v itself spares the zero the compiler would
-    // otherwise materialise for it)
-    return __builtin_amdgcn_update_dpp(v, v, 0x120 + D, 0xf, 0xf, false);
-}
-template <int D>
-struct NearScan16H {
-    static __device__ __forceinline__ void run(float xs, float y, float h, float sep2, float sep_ft, int& conf) {
-        const float dx = xs - row_ror<D>(xs), dy = y - row_ror<D>(y);
-        const float d2 = fmaf(dx, dx, dy * dy);
-        const bool near = d2 < sep2;
-        if (ATC_RARE(__builtin_amdgcn_ballot_w64(near) != 0ull)) {
-            const float dh = h - row_ror<D>(h);
-            const int c = (near && fabsf(dh) < sep_ft) ? 1 : 0;
-            conf |= c;
-            if (D < 8) conf |= row_ror_i<16 - D>(c);   // the partner's copy of the same pair (D = 8 is its own inverse)
-        }
-        NearScan16H<D + 1>::run(xs, y, h, sep2, sep_ft, conf);
-    }
-};
-template <>
-struct NearScan16H<9> {
-    static __device__ __forceinline__ void run(float, float, float, float, float, int&) {}
-};
-
-// Separation scan for N <= 8 (W = 2, 4, 8): the partners of lane k are the lanes k ^ m, m = 1..W-1, of its aligned group,
-// all reachable with DPP operand modifiers — quad_perm for m = 1, 2, 3, row_half_mirror for m = 7 (= 7 - k within 8 lanes)
-// and quad_perm applied to the half-mirrored copy for m = 4, 5, 6 (7 ^ 3, 7 ^ 2, 7 ^ 1).  No LDS, no waits.  Both lanes of
-// a pair evaluate it (bit-identical: d^2 and |dh| are symmetric), so no hand-back is needed.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-template <bool WANT_MIN>
-__device__ __forceinline__ void pair_eval(float xs, float y, float h, float px, float py, float ph, float sep2, float sep_ft,
-                                          float& min_d2, float& margin) {
-    const float dx = xs - px, dy = y - py;
-    const float d2 = fmaf(dx, dx, dy * dy);
-    margin = fminf(margin, fmaxf(d2 - sep2, fabsf(h - ph) - sep_ft));
-    if (WANT_MIN) min_d2 = fminf(min_d2, d2);
-}
-template <int W, bool WANT_MIN>
-__device__ __forceinline__ void pair_scan_xor(float xs, float y, float h, float sep2, float sep_ft, float& min_d2,
-                                              float& margin) {
-    constexpr int X1 = 0xB1, X2 = 0x4E, X3 = 0x1B, HALF_MIRROR = 0x141;  // quad_perm [1,0,3,2] [2,3,0,1] [3,2,1,0]
-    pair_eval<WANT_MIN>(xs, y, h, dpp_f<X1>(xs), dpp_f<X1>(y), dpp_f<X1>(h), sep2, sep_ft, min_d2, margin);
-    if (W >= 4) {
-        pair_eval<WANT_MIN>(xs, y, h, dpp_f<X2>(xs), dpp_f<X2>(y), dpp_f<X2>(h), sep2, sep_ft, min_d2, margin);
-        pair_eval<WANT_MIN>(xs, y, h, dpp_f<X3>(xs), dpp_f<X3>(y), dpp_f<X3>(h), sep2, sep_ft, min_d2, margin);
-    }
-    if (W >= 8) {
-        const float mx = dpp_f<HALF_MIRROR>(xs), my = dpp_f<HALF_MIRROR>(y), mh = dpp_f<HALF_MIRROR>(h);
-        pair_eval<WANT_MIN>(xs, y, h, mx, my, mh, sep2, sep_ft, min_d2, margin);                                      // k ^ 7
-        pair_eval<WANT_MIN>(xs, y, h, dpp_f<X3>(mx), dpp_f<X3>(my), dpp_f<X3>(mh), sep2, sep_ft, min_d2, margin);   // k ^ 4
-        pair_eval<WANT_MIN>(xs, y, h, dpp_f<X2>(mx), dpp_f<X2>(my), dpp_f<X2>(mh), sep2, sep_ft, min_d2, margin);   // k ^ 5
-        pair_eval<WANT_MIN>(xs, y, h, dpp_f<X1>(mx), dpp_f<X1>(my), dpp_f<X1>(mh), sep2, sep_ft, min_d2, margin);   // k ^ 6
-    }
-}
+#include "atc_wave.h"   // group reductions (DPP butterflies) and the DPP separation scans
 
 // Per-lane addressing = uniform 64-bit base + 32-bit BYTE offset (the host guarantees B*N*40 < 4 GiB): the compiler can
 // then use the scalar-base addressing form and does not keep a 64-bit address pair per array alive in VGPRs.
@@ -903,16 +732,11 @@ __device__ __forceinline__ uint32_t noise_areas(const float* __restrict__ K, con
 // inside the step instead of registers held (and spilled to vector-register lanes) across the whole step loop.
 #define QGET(member) ((ONE || LAT) ? q.member : kernarg_reread<decltype(q.member)>(offsetof(StepArgs, q) + offsetof(StepDerived, member), zk))
 
-// Separation scan horizon (round 5; scan_horizon_limits).  In a multi-step launch of the fast variant a FULL scan asks its question
-// with thresholds no pair can close within the next `horizon` steps and notes which partner batches (four partner distances of the
-// LDS scan) hold a pair inside them; the following `horizon` steps scan those batches only, with the exact minima — or nothing at all
-// when none was noted.  Measured on the BASELINE workloads with the CPU oracle (random actions held for 20 steps, auto-reset): a
-// 64-aircraft env (LOWWDense; one wavefront) has NO pair inside the thresholds of 3 steps in 83 % of its steps (4: 77 %, 6: 66 %,
-// 8: 55 %) and is reset in 6 % of them.  4 096 x 64, T = 20, same box: no horizon 5.1-5.3 us per step; all-or-nothing horizons (the
-// first form: any pair inside the thresholds -> every step scans everything) 4.1-4.4 — the launch ends with its SLOWEST wavefront
-// (all 4 096 are resident from the start), and that one skipped least; the batch form 3.8-3.95 for horizons 4 .. 12 (shipped: 6),
-// 8 192 x 32 3.7 vs 4.05.  (A wavefront of four 16-aircraft envs: clear for 4 steps in 50 %, one of its envs reset in 12 % — see
-// NearScan16.)
+// Separation scan horizon (scan_horizon_limits).  In a multi-step launch of the fast variant a full scan asks its question with
+// thresholds no pair can close within the next `horizon` steps and notes which partner batches (four partner distances of the LDS
+// scan) hold a pair inside them; the following `horizon` steps scan those batches only, with the exact minima — or nothing at all
+// when none was noted.  A 64-aircraft env has no pair inside the thresholds of 6 steps in 66 % of its steps: 4 096 x 64 fused
+// 3.8-3.95 vs 5.1-5.3 us per step (DESIGN_HISTORY.md §4).  Ships for the LDS-staged widths only.
 #define ATC_SCAN_HORIZON_LDS 6
 template <int W, bool FULL, bool ONE>
 constexpr int scan_horizon() {
@@ -939,16 +763,12 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     const uint32_t i = d.i;
 
     // ---- separation scan (extension; README.md:51): 3 nm / 1000 ft among aircraft active at step start ---------------
-    // Every lane visits its env's other W-1 slots (never itself); aircraft that are not under control are staged
-    // at x = 1e18 so that they neither conflict nor enter the minimum — branch-free.
-    // Where the MVA cell (gather issued in the first half) is resolved: after the separation scan for the LDS-staged
-    // widths, so that the L2 round trip overlaps the scan; before it for the DPP widths (W <= 16), where keeping the cell
-    // in flight across the unrolled scan only costs registers.
-    // (from W = 16 up: 18.5 vs 18.9 us single steps, 11.2 vs 11.4 fused at 65 536 x 16, r03; one-aircraft envs have no scan to cover
-    // the gather: there the observation and shaping terms go first — 65 536 x 1 6.65-6.87 vs 6.99-7.04 us single, 3.44 vs 3.51 fused)
-    // edge records fetched per L2 round trip in dirty lookup cells: W = 1 is one wavefront per SIMD at any batch size the
-    // sector sees (latency-bound, registers to spare): four per trip (65 536 x 1: 7.4 vs 7.7 us single steps, 4.26 vs 4.44 fused);
-    // wider envs two (four cost the fused 65 536 x 16 launch 0.5 us per step)
+    // Every lane visits its env's other W-1 slots (never itself); aircraft that are not under control are staged at x = 1e18 so
+    // that they neither conflict nor enter the minimum — branch-free.
+    // The MVA cell (gather issued in the first half) is resolved AFTER the scan from W = 16 up (the round trip overlaps the scan)
+    // and for one-aircraft envs (no scan: observation and shaping terms go first); W = 2 .. 8 resolve before it (the cell in flight
+    // across the unrolled xor scan only costs registers).  Edge records per round trip in dirty cells: four for W = 1
+    // (latency-bound, registers to spare), two otherwise.  Measurements: DESIGN_HISTORY.md §4, profiles/r03_experiments.txt.
     constexpr int kWalkBatch = (W == 1) ? 4 : ATC_MVA_BATCH;
     constexpr bool kResolveAfterScan = W >= 16 || W == 1;   // (W = 2 .. 8: the unrolled xor scan with the cell in flight costs 4 - 22 registers)
     WideWords ww = {0, 0};
@@ -992,21 +812,13 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             pair_scan_xor<W, FULL>(xs, y32, hf, sep2, qs.sep_ft, min_d2, margin);
         } else {
             // W = 32 / 64: partners come from LDS and every unordered pair is evaluated ONCE — lane k visits the partners
-            // k + 1 .. k + W/2 (mod W) of its group (the pair at distance W/2 is visited from both ends, harmless).  The result
-            // has to reach the partner as well: the conflict test of distance d over the whole wavefront is one compare into
-            // a 64-bit lane mask, and "lane j is the PARTNER of a conflict at distance d" is that mask rotated by d inside
-            // each group — scalar-unit work (3-6 SALU operations per distance), no return traffic between lanes.
-            // Each group is staged TWICE back to back (slots k and W + k of its 2 W records), so that partner k + d is the record
-            // d places after the lane's own, whatever k: one address per lane, the distance is an offset — no wrap-around
-            // arithmetic per partner.
-            // The staging is one plane per coordinate (x | y | h | d^2 minimum): two neighbouring partners are then two
-            // neighbouring floats of a plane and arrive as a register pair (ds_read2_b32), which is what the packed fp32
-            // instructions want — differences, the product and the fma of TWO pairs per instruction (v_pk_add / mul / fma_f32,
-            // IEEE per component: bit-identical to the scalar forms).  Conflict = (d^2 < sep^2) & (|dh| < sep_ft), the
-            // oracle's expression: two compares per pair whose lane masks are anded on the scalar unit — 4.5 VALU per pair.
+            // k + 1 .. k + W/2 (mod W) of its group.  The result reaches the partner as the compare's 64-bit lane mask rotated by
+            // the distance inside each group (scalar unit), no return traffic between lanes.  Each group is staged TWICE back to
+            // back, one plane per coordinate (x | y | h | d^2 minimum; 8 W floats per group): partner k + d is the float d places
+            // after the lane's own whatever k, two neighbouring partners arrive as a register pair (ds_read2_b32) for the packed
+            // fp32 instructions (IEEE per component: bit-identical to the scalar forms).  Conflict = (d^2 < sep^2) & (|dh| < sep_ft),
+            // the oracle's expression: two compares per pair, masks anded on the scalar unit — 4.5 VALU per pair.
             typedef float v2f __attribute__((ext_vector_type(2)));
-            // Layout: each group owns 8 W floats — planes x | y | h | min of 2 W floats each — so that the plane offsets fit the
-            // instructions' offset fields and the scan loop advances one address register (two for W = 64).
             const int gbase = tid & ~(W - 1);
             constexpr int P = 2 * W;                   // floats per plane of a group
             float* own = reinterpret_cast<float*>(pos) + 8 * gbase + k;
@@ -1019,18 +831,11 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             constexpr int H = W / 2;   // distances 1 .. H
             constexpr int U = 4;       // partners per LDS batch
-            // lanes that are the FIRST element of a conflicting pair, or the second: the mask of distance d rotated by d inside each
-            // group.  Round 4: a lost separation is RARE (it ends the episode), so the four compare masks of an LDS batch are only
-            // ored into the result — and into one "anything?" word — on the common path; the rotations run behind a wave-uniform
-            // test, with variable shifts, in the few batches that found a pair (rounds 2-3 rotated every mask, Horner-style by one:
-            // 6-7 scalar operations per partner, 216 per wavefront-step at W = 64; now ~3).
+            // A lost separation is RARE (it ends the episode): the four compare masks of an LDS batch are only ored into one
+            // "anything?" word on the common path; the rotations run behind a wave-uniform test in the few batches that found a pair.
             uint64_t hit = 0;
             const v2f xs2 = {xs, xs}, ys2 = {y32, y32}, hs2 = {hf, hf};
             const float sep_ft = qs.sep_ft;
-            // (Round 5, rejected: a PRE-PASS that minimum-accumulates the margin max(d^2 - sep^2, |dh| - sep_ft) per lane — 5.5 vector
-            // operations per partner, no lane mask, no scalar mask arithmetic — and runs the mask form only when some lane lost its
-            // separation.  The pre-pass costs more than the scalar mask arithmetic it saves: 4 096 x 64 8.85 vs 7.8 us single steps, 5.3-5.6 vs 5.2
-            // fused, 32 768 x 64 38.4 vs 36.6 — profiles/r05_experiments.txt: ab_m.)
             // thresholds of this scan: the horizon's in a full scan, the minima themselves inside a horizon (and where there is none)
             const float t2 = in_horizon ? lim.sep2 : lim.sep2_h, tf = in_horizon ? lim.sep_ft : lim.sep_ft_h;
 #pragma unroll 1   // (fully unrolled, the 2 H compare masks stay live together: 140-220 spilled SGPRs)
@@ -1837,282 +1642,4 @@ static int step_common(const atc_scenario_t* s, int B, int N, int T, int hold, c
     return launch_step<64>(s, B, N, T, hold, st, actions, out, p, q);
 }
 
-extern "C" {
-
-int atc_abi_version(void) { return ATC_ABI_VERSION; }
-const char* atc_last_error(void) { return g_err; }
-
-int atc_host_mapped_ptr(const void* host, void** dev) {
-    if (!host || !dev) return fail_arg("null pointer");
-    HIP_TRY(hipHostGetDevicePointer(dev, const_cast<void*>(host), 0));
-    return 0;
-}
-
-int atc_scenario_create(const float* blob_host, size_t n_words, int device, atc_scenario_t** out) {
-    if (!blob_host || !out) return fail_arg("null pointer");
-    if (n_words < ATC_C_END || blob_host[ATC_H_VERSION] != ATC_BLOB_VERSION || (size_t)blob_host[ATC_H_NWORDS] != n_words)
-        return fail_arg("not a scenario blob of this ABI version");
-    if ((int)blob_host[ATC_H_N_MVA] > 32) return fail_arg("at most 32 MVA polygons");
-    if ((int)blob_host[ATC_H_N_ENTRY] > 0) {   // the spawn records every reset reads
-        const size_t os = (size_t)blob_host[ATC_H_OFF_SPAWN];
-        if (os == 0 || os % 16 != 0 || os + (size_t)(ATC_MAX_AIRCRAFT + (int)blob_host[ATC_H_N_ENTRY]) * ATC_SPAWN_WORDS > n_words)
-            return fail_arg("spawn records (ATC_H_OFF_SPAWN) missing, misaligned or beyond the blob");
-    }
-    if ((int)blob_host[ATC_H_N_NOISE] > 16) return fail_arg("at most 16 noise-abatement areas");
-    if (const int og = (int)blob_host[ATC_H_OFF_GRID]) {   // the kernel clamps cell indices into the grid's outermost ring
-        if ((size_t)og + ATC_G_HDR > n_words) return fail_arg("lookup grid offset beyond the blob");
-        const float* g = blob_host + og;
-        const long nx = (long)g[ATC_G_NX], ny = (long)g[ATC_G_NY];
-        if (nx < 3 || ny < 3 || nx >= (1 << 20) || ny >= (1 << 20) || (size_t)og + ATC_G_HDR + 2 * (size_t)nx * ny > n_words)
-            return fail_arg("lookup grid dimensions");
-        const float* c = g + ATC_G_HDR;
-        for (long i = 0; i < nx; ++i)
-            if (c[2 * i] != 0.0f || c[2 * i + 1] != 0.0f || c[2 * ((ny - 1) * nx + i)] != 0.0f || c[2 * ((ny - 1) * nx + i) + 1] != 0.0f)
-                return fail_arg("the outermost ring of lookup cells must be clean and outside the airspace");
-        for (long j = 0; j < ny; ++j)
-            if (c[2 * j * nx] != 0.0f || c[2 * j * nx + 1] != 0.0f || c[2 * (j * nx + nx - 1)] != 0.0f || c[2 * (j * nx + nx - 1) + 1] != 0.0f)
-                return fail_arg("the outermost ring of lookup cells must be clean and outside the airspace");
-    }
-    {   // compiled-in aircraft constants (csrc/atc_device.h) must match the blob
-        const float want[] = {kVMin, kVMax, kHMin, kHMax, kAMin, kAMax, kHDotMin, kHDotMax, kPhiDotMin, kPhiDotMax, kVInit};
-        for (int c = 0; c < 11; ++c)
-            if (blob_host[ATC_C_V_MIN + c] != want[c]) return fail_arg("aircraft limits differ from the compiled-in constants");
-        if (blob_host[ATC_C_ACT_DISCR] != kDiscrV || blob_host[ATC_C_ACT_DISCR + 1] != kDiscrH ||
-            blob_host[ATC_C_ACT_DISCR + 2] != kDiscrPhi)
-            return fail_arg("action discriminator differs from the compiled-in constants");
-    }
-    HIP_TRY(hipSetDevice(device));
-    static std::atomic<uint64_t> next_uid{1};
-    atc_scenario* s = new atc_scenario();
-    s->uid = next_uid.fetch_add(1);
-    s->n_words = (int)n_words;
-    s->off_grid = (int)blob_host[ATC_H_OFF_GRID];
-    memcpy(s->consts, blob_host, sizeof s->consts);
-    memset(s->ghdr, 0, sizeof s->ghdr);
-    if (s->off_grid) memcpy(s->ghdr, blob_host + s->off_grid, sizeof s->ghdr);
-    s->device = device;
-    hipDeviceProp_t prop;
-    hipError_t e = hipGetDeviceProperties(&prop, device);
-    if (e != hipSuccess) {
-        delete s;
-        return fail_hip(e, "hipGetDeviceProperties");
-    }
-    s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    e = hipMalloc(&s->d_blob, n_words * sizeof(float));
-    if (e != hipSuccess) {
-        delete s;
-        return fail_hip(e, "hipMalloc");
-    }
-    e = hipMemcpy(s->d_blob, blob_host, n_words * sizeof(float), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        (void)hipFree(s->d_blob);
-        delete s;
-        return fail_hip(e, "hipMemcpy");
-    }
-    *out = s;
-    return ATC_OK;
-}
-
-int atc_scenario_destroy(atc_scenario_t* s) {
-    if (!s) return ATC_OK;
-    (void)hipFree(s->d_blob);
-    delete s;
-    return ATC_OK;
-}
-
-int atc_query_mva(const atc_scenario_t* s, int n, const float* x, const float* y, int32_t* out_h, int use_grid,
-                  void* stream) {
-    if (!s || !x || !y || !out_h || n < 0) return fail_arg("null pointer / negative n");
-    if (n == 0) return ATC_OK;
-    hipLaunchKernelGGL(k_query_mva, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false), (hipStream_t)stream,
-                       s->d_blob, use_grid ? s->off_grid : 0, n, x, y, out_h, (int32_t*)nullptr);
-    HIP_TRY(hipGetLastError());
-    return ATC_OK;
-}
-// index variant used by the host mirror's Airspace.find_mva (returns the polygon index, -1 outside)
-int atc_query_mva_index(const atc_scenario_t* s, int n, const float* x, const float* y, int32_t* out_idx, int use_grid,
-                        void* stream) {
-    if (!s || !x || !y || !out_idx || n < 0) return fail_arg("null pointer / negative n");
-    if (n == 0) return ATC_OK;
-    hipLaunchKernelGGL(k_query_mva, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false), (hipStream_t)stream,
-                       s->d_blob, use_grid ? s->off_grid : 0, n, x, y, (int32_t*)nullptr, out_idx);
-    HIP_TRY(hipGetLastError());
-    return ATC_OK;
-}
-
-int atc_query_corridor(const atc_scenario_t* s, int n, const float* x, const float* y, const float* h, const float* phi,
-                       int angle_only, uint8_t* out, void* stream) {
-    if (!s || !x || !y || !h || !phi || !out || n < 0) return fail_arg("null pointer / negative n");
-    if (n == 0) return ATC_OK;
-    hipLaunchKernelGGL(k_query_corridor, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false), (hipStream_t)stream,
-                       s->d_blob, n, x, y, h, phi, angle_only, out);
-    HIP_TRY(hipGetLastError());
-    return ATC_OK;
-}
-
-int atc_query_shaping(const atc_scenario_t* s, int n, const float* d_faf, const float* phi_rel_faf, const float* phi_plane,
-                      const float* h, const float* on_gp, float* out3, void* stream) {
-    if (!s || !d_faf || !phi_rel_faf || !phi_plane || !h || !on_gp || !out3 || n < 0)
-        return fail_arg("null pointer / negative n");
-    if (n == 0) return ATC_OK;
-    hipLaunchKernelGGL(k_query_shaping, dim3(grid_for(s, n)), dim3(kBlock), lds_bytes(s, false), (hipStream_t)stream,
-                       s->d_blob, n, d_faf, phi_rel_faf, phi_plane, h, on_gp, out3);
-    HIP_TRY(hipGetLastError());
-    return ATC_OK;
-}
-
-int atc_reset(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const uint8_t* mask, float* obs,
-              const atc_params_t* p, int first, void* stream) {
-    if (const int rc = check_env_args(s, B, N, st, p)) return rc;
-    hipStream_t q = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_reset, dim3(grid_for(s, (long long)B * N)), dim3(kBlock), lds_bytes(s, false), q, s->d_blob,
-                       B, N, *st, mask, obs, *p, first);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_reset_env, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, q, B, N, *st, mask, first);
-    HIP_TRY(hipGetLastError());
-    return ATC_OK;
-}
-
-int atc_observe(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const uint8_t* mask, float* obs,
-                const atc_params_t* p, void* stream) {
-    if (!obs) return fail_arg("null pointer");
-    if (const int rc = check_env_args(s, B, N, st, p)) return rc;
-    hipLaunchKernelGGL(k_observe, dim3(grid_for(s, (long long)B * N)), dim3(kBlock), lds_bytes(s, false),
-                       (hipStream_t)stream, s->d_blob, B, N, *st, mask, obs);
-    HIP_TRY(hipGetLastError());
-    return ATC_OK;
-}
-
-int atc_step(const atc_scenario_t* s, int B, int N, const atc_state_t* st, const float* actions, const atc_out_t* out,
-             const atc_params_t* p, void* stream) {
-    return step_common(s, B, N, 1, 1, st, actions, out, p, stream);
-}
-
-int atc_step_packet(const atc_scenario_t* s, const atc_state_t* st, const float* actions, const atc_out_t* out,
-                    atc_params_t* p, uint32_t seq, const uint32_t* packet_host, uint32_t* payload, int timeout_us, void* stream) {
-    if (!p || !out || !out->packet || !packet_host || !payload) return fail_arg("atc_step_packet needs out->packet, packet_host, payload");
-    if (!actions) return fail_arg("null pointer");
-    if (reinterpret_cast<uintptr_t>(packet_host) & 15u) return fail_arg("packet_host must be 16-byte aligned");
-    p->reserved0 = seq;
-    t_inline_action = actions;   // HOST pointer to the 3 action values: they travel in the kernel arguments
-    const int rc = step_common(s, 1, 1, 1, 1, st, actions, out, p, stream);
-    t_inline_action = nullptr;
-    if (rc != ATC_OK) return rc;
-    // Every chunk is ONE 16-byte device store and is read here with ONE aligned 16-byte load (movdqa: a single access on every
-    // x86-64 with AVX — the tag and the payload words it validates come from the same access, so a reader can never pair a
-    // current tag with a stale payload word, whatever order the chunks or the words of other chunks become visible in).
-    const auto t0 = std::chrono::steady_clock::now();
-    unsigned have = 0;   // bit c: chunk c taken
-    for (unsigned it = 1;; ++it) {
-        for (int c = 0; c < ATC_PKT_CHUNKS; ++c) {
-            if (have >> c & 1u) continue;
-            const __m128i v = _mm_load_si128(reinterpret_cast<const __m128i*>(packet_host + 4 * c));
-            alignas(16) uint32_t w[4];
-            _mm_store_si128(reinterpret_cast<__m128i*>(w), v);
-            if (w[3] == seq) {
-                payload[3 * c] = w[0];
-                payload[3 * c + 1] = w[1];
-                payload[3 * c + 2] = w[2];
-                have |= 1u << c;
-            }
-        }
-        if (have == (1u << ATC_PKT_CHUNKS) - 1u) return ATC_OK;
-        asm volatile("" ::: "memory");   // the buffer changes under us: reload on the next round
-        // The result arrives ~10 us after the launch: spin with the pipeline hint first, then give the core away between
-        // polls (eight SubprocVecEnv-style workers no longer pin eight cores while they wait).
-        if (it < 4096u) _mm_pause();
-        else sched_yield();
-        if ((it & 255u) == 0 &&
-            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_us)
-            return -3;
-    }
-}
-
-// ---- persistent step server (include/atc_step.h: atc_serve_*) ------------------------------------------------------------
-int atc_serve_start(const atc_scenario_t* s, const atc_state_t* st, const atc_out_t* out, const atc_params_t* p,
-                    uint32_t* mailbox_host, uint32_t seq, int lease_us, void* stream) {
-    if (!out || !mailbox_host) return fail_arg("null pointer");
-    if (const int rc = check_env_args(s, 1, 1, st, p)) return rc;
-    if (!out->obs || !out->reward || !out->done || !out->flags || !out->packet) return fail_arg("the server needs obs/reward/done/flags and out->packet");
-    if (reinterpret_cast<uintptr_t>(mailbox_host) & 63u) return fail_arg("mailbox must be 64-byte aligned");
-    if (!(p->dt > 0.0) || !(0.1423 * p->dt * (double)s->consts[ATC_C_POS_SCALE] < 1073741824.0) || !((double)kAMax * p->dt < 255.9))
-        return fail_arg("dt out of range for the fixed-point state formats (see include/atc_step.h)");
-    if (lease_us < 1000) lease_us = 1000;
-    uint32_t* mb_dev = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&mb_dev), mailbox_host, 0));
-    // the command word holds the LAST served sequence number (so a stale command is not taken for a new one), no state yet
-    __atomic_store_n(mailbox_host + ATC_MB_SEQ, seq, __ATOMIC_RELAXED);
-    __atomic_store_n(mailbox_host + ATC_MB_STATE, (uint32_t)ATC_SERVE_IDLE, __ATOMIC_RELEASE);
-    hipLaunchKernelGGL(k_serve, dim3(1), dim3(64), lds_bytes(s, false, true), (hipStream_t)stream, s->d_blob, s->off_grid, *st, *out, *p,
-                       derive(*p, s, 0), mb_dev, seq, (unsigned long long)lease_us * 100ull);
-    HIP_TRY(hipGetLastError());
-    return ATC_OK;
-}
-
-int atc_serve_step(uint32_t* mailbox_host, const float* actions, uint32_t seq, const uint32_t* packet_host, uint32_t* payload, int timeout_us) {
-    if (!mailbox_host || !actions || !packet_host || !payload) return fail_arg("null pointer");
-    if (seq == ATC_SERVE_QUIT) return fail_arg("sequence number reserved for the quit command");
-    {   // {action, seq} as ONE 16-byte store: the server can never pair a new sequence number with an old action word
-        alignas(16) uint32_t w[4];
-        memcpy(w, actions, 12);
-        w[3] = seq;
-        _mm_store_si128(reinterpret_cast<__m128i*>(mailbox_host + ATC_MB_CMD), _mm_load_si128(reinterpret_cast<const __m128i*>(w)));
-    }
-    const auto t0 = std::chrono::steady_clock::now();
-    unsigned have = 0;
-    bool left_seen = false;
-    for (unsigned it = 1;; ++it) {
-        for (int c = 0; c < ATC_PKT_CHUNKS; ++c) {
-            if (have >> c & 1u) continue;
-            alignas(16) uint32_t w[4];
-            _mm_store_si128(reinterpret_cast<__m128i*>(w), _mm_load_si128(reinterpret_cast<const __m128i*>(packet_host + 4 * c)));
-            if (w[3] == seq) {
-                payload[3 * c] = w[0];
-                payload[3 * c + 1] = w[1];
-                payload[3 * c + 2] = w[2];
-                have |= 1u << c;
-            }
-        }
-        if (have == (1u << ATC_PKT_CHUNKS) - 1u) return ATC_OK;
-        if (left_seen) return -4;   // the server had left before it saw this command (lease): the caller starts it again
-        asm volatile("" ::: "memory");
-        if (it < 4096u) _mm_pause();
-        else sched_yield();
-        if ((it & 63u) == 0) {
-            // (checked once more against the packet above before giving up: a step completed just before the lease ran out counts)
-            if (have == 0 && __atomic_load_n(mailbox_host + ATC_MB_STATE, __ATOMIC_ACQUIRE) >= (uint32_t)ATC_SERVE_LEFT_LEASE) left_seen = true;
-            if ((it & 255u) == 0 &&
-                std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_us)
-                return -3;
-        }
-    }
-}
-
-int atc_serve_stop(uint32_t* mailbox_host, void* stream) {
-    if (!mailbox_host) return fail_arg("null pointer");
-    __atomic_store_n(mailbox_host + ATC_MB_SEQ, ATC_SERVE_QUIT, __ATOMIC_RELEASE);
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // the state is in memory again once the kernel has ended
-    return ATC_OK;
-}
-
-int atc_step_multi(int n, const atc_step_call_t* calls) {
-    if (n < 0 || (n > 0 && !calls)) return fail_arg("null pointer");
-    for (int i = 0; i < n; ++i) {
-        const atc_step_call_t& c = calls[i];
-        const int rc = step_common(c.s, c.B, c.N, 1, 1, c.st, c.actions, c.out, c.p, c.stream);
-        if (rc != ATC_OK) return rc;
-    }
-    return ATC_OK;
-}
-
-int atc_rollout(const atc_scenario_t* s, int B, int N, int T, const atc_state_t* st, const float* actions,
-                const atc_out_t* out, const atc_params_t* p, void* stream) {
-    return step_common(s, B, N, T, 1, st, actions, out, p, stream);
-}
-
-int atc_rollout_hold(const atc_scenario_t* s, int B, int N, int T, int hold, const atc_state_t* st, const float* actions,
-                     const atc_out_t* out, const atc_params_t* p, void* stream) {
-    return step_common(s, B, N, T, hold, st, actions, out, p, stream);
-}
-
-}  // extern "C"
+#include "atc_abi.inc"   // the extern "C" entry points (host side)

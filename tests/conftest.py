@@ -26,6 +26,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """No GPU test may hang the box (a resident step server, a launch that never returns): 15 minutes each unless it names its own."""
+    import pytest
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(900))
+
+
 def pytest_sessionstart(session):
     """Compile the native pieces when a fresh checkout has none (hipcc cross-compiles without a GPU)."""
     import __graft_entry__ as entry
