@@ -13,6 +13,7 @@ reference does in Python (win ring buffer, counters), in the same order, includi
 """
 import random
 import weakref
+from time import perf_counter as _perf_counter
 
 import numpy as np
 
@@ -58,6 +59,13 @@ class _AirplaneView:
 # DummyVecEnv; the reference's own arrangement is one env per process, learning/atc-gym-stable-baselines.py:69-80).
 _SERVING = {}          # id(env) -> weakref(env)
 _MAX_SERVERS = 2
+# A resident kernel also blocks whatever ELSE is submitted to a stream that shares its hardware queue (streams beyond the first few
+# share queues) until it leaves.  So the server is a tight-loop device: it lingers for one short lease after a step, and a step is
+# only served when the previous one ended less than _TIGHT_GAP_S ago (the reference's FPS loop, a rollout loop with a CPU policy);
+# a caller that does other work between steps — policy inference on this GPU — steps by launches and never finds a server in its way
+# for longer than a kernel launch takes.
+_LEASE_US = 50
+_TIGHT_GAP_S = 50e-6
 
 
 def _server_slot_free():
@@ -82,8 +90,9 @@ class AtcGym(Env):
     def __init__(self, sim_parameters=None, scenario=None, device=0, persistent=None):
         """persistent (build-own keyword; default: on, ATC_GYM_SERVER=0 turns it off): step through the library's persistent step
         server (atc_serve_*: one resident wavefront polling a mailbox in mapped host memory) instead of one kernel launch per
-        step.  Same results bit for bit; the server is stopped before anything else touches the env's device state and leaves by
-        itself after 100 ms without a step."""
+        step WHILE steps follow each other within 50 us (a tight stepping loop); otherwise by launches.  Same results bit for
+        bit; the server is stopped before anything else touches the env's device state and leaves by itself 50 us after its last
+        step."""
         # the reference evaluates its defaults once at import (atc_gym.py:28): SimParameters(1), LOWW()
         sim_parameters = sim_parameters if sim_parameters is not None else model.SimParameters(1)
         scenario = scenario if scenario is not None else scenarios.LOWW()
@@ -160,11 +169,12 @@ class AtcGym(Env):
         assert self._mailbox.data_ptr() % 64 == 0
         _mb = C.c_void_p(self._mailbox.data_ptr())
         self._serve_start = lambda stream, last, _f=v._lib.atc_serve_start, _h=v.sector.handle, _s=C.byref(v._state), _o=C.byref(v._out), \
-            _p=C.byref(v.params): _f(_h, _s, _o, _p, _mb, last, 100000, stream)
+            _p=C.byref(v.params): _f(_h, _s, _o, _p, _mb, last, _LEASE_US, stream)
         self._serve_step = lambda seq, _f=v._lib.atc_serve_step, _a=C.c_void_p(self._host_act.data_ptr()), \
             _k=C.c_void_p(self._vec.packet.data_ptr()), _w=C.c_void_p(self._payload_i.ctypes.data): _f(_mb, _a, seq, _k, _w, 2000000)
         self._serve_stop = lambda stream, _f=v._lib.atc_serve_stop: _f(_mb, stream)
         self._srv_stream = None        # the server's own (non-blocking) stream: nothing else is ever launched on it
+        self._t_done = 0.0             # when the last step returned (time.perf_counter)
         self._seq = 0
         self._outstanding = False
         self._pos_now = None                   # grid position after the last step (None: read it from the state record)
@@ -267,12 +277,13 @@ class AtcGym(Env):
             self._settle()
             self._seq = 0
         self._seq = seq = self._seq + 1
-        if self._persistent:
+        tight = _perf_counter() - self._t_done < _TIGHT_GAP_S
+        if self._persistent and (tight or self._serving):
             # the persistent step server: write {action, seq} into the mailbox, poll the result packet — no launch per step
             rc = -5
             for attempt in range(2):
                 if not self._serving:
-                    if not _server_slot_free():
+                    if not tight or not _server_slot_free():
                         break                      # enough resident kernels in this process: this step goes by a launch
                     torch = self._backend.torch
                     if self._srv_stream is None:
@@ -285,7 +296,8 @@ class AtcGym(Env):
                 rc = self._serve_step(seq)
                 if rc != -4:
                     break
-                # the server had left (100 ms without a step) before it saw this command: its kernel has ended, start it again
+                # the server had left (its lease ran out) before it saw this command: its kernel has ended; start it again if
+                # the steps still follow each other closely, else take this one by a launch
                 self._srv_stream.synchronize()
                 self._serving = False
                 _SERVING.pop(id(self), None)
@@ -294,7 +306,10 @@ class AtcGym(Env):
                 iw = self._payload_i
                 fd = int(iw[21])
                 self._pos_now = (int(iw[24]), int(iw[25]))
+                self._t_done = _perf_counter()
                 return (w[0:10], w[10:20], float(w[20]), bool(fd >> 16), fd & 0xffff, int(iw[22]), int(iw[23]))
+            if rc == -4:
+                rc = -5
             if rc == -3:
                 # no answer in 2 s (never expected): stop serving for good and take this step by a launch; the command was not
                 # executed if the server's last sequence number is still the previous one
@@ -317,6 +332,7 @@ class AtcGym(Env):
         iw = self._payload_i
         fd = int(iw[21])
         self._pos_now = (int(iw[24]), int(iw[25]))
+        self._t_done = _perf_counter()
         return (w[0:10], w[10:20], float(w[20]), bool(fd >> 16), fd & 0xffff, int(iw[22]), int(iw[23]))
 
     def _settle(self):

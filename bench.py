@@ -1051,7 +1051,7 @@ def main():
                 se["cpu_oracle_steps_per_s"] = co["f32"]
                 se["cpu_oracle_f64_steps_per_s"] = co["f64"]
                 se["cpu_oracle_note"] = ("oracle/ (C restatement of the reference step) stepped 1 env x 1 aircraft from Python, "
-                                         "1 core; the GPU-backed drop-in is %.2fx of it: one env cannot amortise a kernel launch"
+                                         "1 core; the GPU-backed drop-in is %.2fx of it: one env's step is two crossings of the host link and one wavefront's serial chain"
                                          % (se["steps_per_s"] / co["f32"]))
             line["config"]["single_env"] = se
         if ws == 1 and not args.no_cpu_baseline:

@@ -474,9 +474,14 @@ int atc_step_packet(const atc_scenario_t* s, const atc_state_t* st, const float*
  *                  number — written by the device.
  *   - `seq` of atc_serve_start = the sequence number of the LAST step already taken (the first atc_serve_step uses seq + 1, every
  *     further one the previous + 1); 0xffffffff is reserved.
- *   - the server leaves by itself after `lease_us` microseconds (>= 1000) without a command: atc_serve_step then returns -4 for the
+ *   - the server leaves by itself after `lease_us` microseconds (>= 10) without a command: atc_serve_step then returns -4 for the
  *     command it did not see and the caller starts the server again (same seq rule) and repeats the call.  -3: no answer within
  *     `timeout_us` (the caller falls back to atc_serve_stop + atc_step_packet).
+ *   - CHOOSING THE LEASE.  A resident kernel occupies a hardware queue; a process has few (4 by default) and HIP streams beyond that
+ *     share them: work submitted to a stream that shares the server's queue waits until the server has left.  A caller that steps
+ *     in a tight loop and submits nothing else (the reference's FPS script) can use any lease; a caller that interleaves other GPU
+ *     work keeps it at the scale of a kernel launch — envs.atc.atc_gym.AtcGym uses 50 us and only serves while its steps follow
+ *     each other within 50 us (otherwise it steps by atc_step_packet): the worst a colliding stream can wait is one lease.
  *   - WHILE THE SERVER RUNS the env's state lives in its registers: nothing else may read or write the env's atc_state_t buffers or
  *     launch on `stream` (a launch would queue behind the resident kernel).  atc_serve_stop sends quit and synchronises the stream:
  *     after it the state is in memory as after an atc_step.  Outputs other than the packet (obs, reward, ...) are written every step

@@ -173,14 +173,15 @@ def test_bench_two_ranks_on_one_device():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
-def test_step_server_equals_the_launch_path_and_survives_its_lease():
+def test_step_server_equals_the_launch_path_and_survives_its_lease(monkeypatch):
     """The persistent step server behind AtcGym.step (atc_serve_*: one resident wavefront, a mailbox in mapped host memory) against
     the launch-per-step path (atc_step_packet): the same 900 actions — resets, attribute pokes and reads of the device state in
-    between (each stops the server and starts it again), a pause longer than the server's 100 ms lease (it leaves by itself and
-    the next step starts it again), a seeded random-entry scenario — give bit-identical observations, rewards, flags, counters
-    and state."""
+    between (each stops the server and starts it again), a pause longer than the server's lease (it leaves by itself and the next
+    steps go by a launch, then by a new server), a seeded random-entry scenario — give bit-identical observations, rewards, flags,
+    counters and state."""
     import time
     from envs.atc import atc_gym, model, scenarios
+    monkeypatch.setattr(atc_gym, "_TIGHT_GAP_S", 200e-6)   # (this loop steps two envs alternately: count that as a tight loop)
     rng = np.random.default_rng(3)
     envs = []
     for persistent in (True, False):
@@ -213,9 +214,11 @@ def test_step_server_equals_the_launch_path_and_survives_its_lease():
         if t % 97 == 50:      # reading the device state stops the server; the next step starts it again
             assert srv._airplane.h == ref._airplane.h and srv._airplane.x == ref._airplane.x and srv.last_action == ref.last_action
             assert not srv._serving
-        if t == 300:          # longer than the lease: the resident kernel has left on its own
-            time.sleep(0.35)
+        if t == 300:          # longer than the lease: the resident kernel has left on its own; the next step is a launch
+            time.sleep(0.05)
             assert int(srv._mailbox[4]) == 2
+        if t == 303:
+            assert srv._serving   # ... and the steps after it are served again
         if t % 211 == 210 or rs[2]:
             reset_both()
         if t == 600:
@@ -228,12 +231,14 @@ def test_step_server_equals_the_launch_path_and_survives_its_lease():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(120)
-def test_several_envs_in_one_process_share_the_step_servers():
+def test_several_envs_in_one_process_share_the_step_servers(monkeypatch):
     """Four AtcGym in ONE process (a DummyVecEnv-style loop): at most two hold a resident step server (each on its own stream; a
-    process has only a few hardware queues), the others step by launches — nobody waits behind somebody else's resident kernel
-    (4 x 300 steps in well under a second of stepping), and all four reproduce one launch-path env bit for bit."""
+    process has only a few hardware queues), the others step by launches — nobody waits behind somebody else's resident kernel for
+    longer than its 50 us lease (4 x 300 steps in well under a second of stepping), and all four reproduce one launch-path env bit
+    for bit."""
     import time
     from envs.atc import atc_gym
+    monkeypatch.setattr(atc_gym, "_TIGHT_GAP_S", 1e-3)   # five envs stepped in turn: still "a tight loop" for this test
     envs = [atc_gym.AtcGym() for _ in range(4)]
     ref = atc_gym.AtcGym(persistent=False)
     for e in envs + [ref]:
@@ -247,7 +252,8 @@ def test_several_envs_in_one_process_share_the_step_servers():
             o = e.step(a)
             assert np.array_equal(o[0], r[0]) and o[1] == r[1] and o[2] == r[2], t
         if t == 10:
-            assert sum(e._serving for e in envs) == 2 and len(atc_gym._SERVING) == 2
+            # (a server lingers for 50 us after its step: with five envs stepped in turn one of the two may just have left)
+            assert 1 <= sum(e._serving for e in envs) <= 2 and len(atc_gym._SERVING) <= 2
     dt = time.perf_counter() - t0
     assert dt < 3.0, dt
     for e in envs + [ref]:

@@ -79,6 +79,56 @@ def test_hostile_actions_do_not_break_the_batch():
     ref.close()
 
 
+def test_step_server_c_abi_directly():
+    """atc_serve_start / atc_serve_step / atc_serve_stop through ctypes, no AtcGym in between: argument errors are codes, a served
+    step equals atc_step on a twin env bit for bit, the lease ends the server (state 2) and a command it never saw is -4, quit ends
+    it at once (state 3) and leaves the state in memory."""
+    import ctypes as C
+    import time
+    torch = _torch()
+    from atc_hip import lib
+    from atc_hip.vec_env import AtcVecEnv
+    Lb = lib.load()
+    mk = lambda: AtcVecEnv(1, 1, auto_reset=False, spawn="lattice", want_raw_obs=True, host_mapped="io", keep_active=True, want_packet=True)  # noqa: E731
+    env, twin = mk(), mk()
+    mb = torch.zeros(16, dtype=torch.int32).pin_memory()
+    act = torch.tensor([0.2, -0.4, 0.6], dtype=torch.float32).pin_memory()
+    payload = np.zeros(27, np.int32)
+    q = torch.cuda.Stream()
+    args = lambda m=mb: (env.sector.handle, C.byref(env._state), C.byref(env._out), C.byref(env.params), m.data_ptr())  # noqa: E731
+    assert Lb.atc_serve_start(*args()[:4], mb.data_ptr() + 4, 0, 50000, q.cuda_stream) == -1 and b"64-byte" in Lb.atc_last_error()
+    no_pkt = lib.AtcOut(*[getattr(env._out, n) if n != "packet" else None for n in lib.OUT_FIELDS])
+    assert Lb.atc_serve_start(env.sector.handle, C.byref(env._state), C.byref(no_pkt), C.byref(env.params), mb.data_ptr(), 0, 50000, q.cuda_stream) == -1
+    assert Lb.atc_serve_step(mb.data_ptr(), act.data_ptr(), 0xffffffff, env.packet.data_ptr(), payload.ctypes.data, 1000) == -1
+    torch.cuda.synchronize()
+    assert Lb.atc_serve_start(*args(), 0, 2000000, q.cuda_stream) == 0      # a 2 s lease: the twin's first launch loads its module
+    for seq in range(1, 41):
+        assert Lb.atc_serve_step(mb.data_ptr(), act.data_ptr(), seq, env.packet.data_ptr(), payload.ctypes.data, 2000000) == 0
+        o, r, d, info = twin.step(act.numpy().reshape(1, 1, 3))
+        assert np.array_equal(payload[:10].view(np.float32), o.numpy().reshape(-1)) and payload[20:21].view(np.float32)[0] == float(r[0])
+        assert payload[22] == seq
+    assert int(mb[4]) == 1 and int(mb[3]) == 40
+    assert Lb.atc_serve_stop(mb.data_ptr(), q.cuda_stream) == 0             # quit: at once, the state is in memory
+    assert int(mb[4]) == 3 and int(mb[5]) == 40
+    assert torch.equal(env.ac.cpu(), twin.ac.cpu()) and torch.equal(env.alt.cpu(), twin.alt.cpu()) and torch.equal(env.env.cpu(), twin.env.cpu())
+    assert Lb.atc_serve_start(*args(), 40, 50000, q.cuda_stream) == 0        # a 50 ms lease this time
+    assert Lb.atc_serve_step(mb.data_ptr(), act.data_ptr(), 41, env.packet.data_ptr(), payload.ctypes.data, 2000000) == 0
+    twin.step(act.numpy().reshape(1, 1, 3))
+    time.sleep(0.25)
+    assert int(mb[4]) == 2 and int(mb[5]) == 41                             # left by itself
+    q.synchronize()
+    assert torch.equal(env.ac.cpu(), twin.ac.cpu()) and torch.equal(env.alt.cpu(), twin.alt.cpu()) and torch.equal(env.last_act.cpu(), twin.last_act.cpu())
+    assert Lb.atc_serve_step(mb.data_ptr(), act.data_ptr(), 42, env.packet.data_ptr(), payload.ctypes.data, 2000000) == -4   # nobody there
+    assert Lb.atc_serve_start(*args(), 41, 2000000, q.cuda_stream) == 0
+    assert Lb.atc_serve_step(mb.data_ptr(), act.data_ptr(), 42, env.packet.data_ptr(), payload.ctypes.data, 2000000) == 0
+    twin.step(act.numpy().reshape(1, 1, 3))
+    assert Lb.atc_serve_stop(mb.data_ptr(), q.cuda_stream) == 0
+    assert int(mb[4]) == 3 and int(mb[5]) == 42
+    assert torch.equal(env.ac.cpu(), twin.ac.cpu()) and torch.equal(env.alt.cpu(), twin.alt.cpu()) and torch.equal(env.env.cpu(), twin.env.cpu())
+    env.close()
+    twin.close()
+
+
 def test_argument_errors_are_reported_not_raised_from_c():
     torch = _torch()
     from atc_hip import lib
@@ -342,7 +392,7 @@ def test_huge_batch_uses_correct_offsets():
 
 
 @pytest.mark.parametrize("persistent", [True, False])
-def test_atcgym_packet_polling_equals_synchronised_reads(persistent):
+def test_atcgym_packet_polling_equals_synchronised_reads(persistent, monkeypatch):
     """AtcGym.step returns as soon as the self-validating result packet (atc_out_t.packet) has arrived in mapped memory —
     from the persistent step server (round 6, the default) or from a launch of its own (atc_step_packet) before the stream is
     drained.  30 000 steps with resets: every value it returned equals what the ordinary output buffers hold once the server has
@@ -350,6 +400,7 @@ def test_atcgym_packet_polling_equals_synchronised_reads(persistent):
     _torch()
     from envs.atc import atc_gym, scenarios
     import random
+    monkeypatch.setattr(atc_gym, "_TIGHT_GAP_S", 1.0)   # serve every step (AtcGym serves only steps that follow each other within 50 us)
     random.seed(3)
     a_env = atc_gym.AtcGym(scenario=scenarios.LOWW(random_entrypoints=True), persistent=persistent)
     random.seed(3)

@@ -12,7 +12,8 @@ import sys
 
 asm, kernel = sys.argv[1], sys.argv[2]
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "atc-reinforcement-learning_amd", "csrc")
-files = {"atc_step.hip": os.path.join(root, "atc_step.hip"), "atc_device.h": os.path.join(root, "atc_device.h")}
+files = {"atc_step.hip": os.path.join(root, "atc_step.hip"), "atc_device.h": os.path.join(root, "atc_device.h"),
+         "atc_wave.h": os.path.join(root, "atc_wave.h")}
 func_of = {}
 for short, path in files.items():
     cur, table = None, {}

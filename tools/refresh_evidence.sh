@@ -32,7 +32,7 @@ rm -rf $O/pmc_${TAG}_n*
 # the store-only reference launches (tools/ubench/write_bw.hip; the executable build() makes): which kind of box this was
 [ -x atc-reinforcement-learning_amd/atc_hip/ubench_write_bw ] && timeout 120 atc-reinforcement-learning_amd/atc_hip/ubench_write_bw > $O/${TAG}_write_bw_this_box.txt 2>&1
 if [ "$FUZZ" -gt 0 ]; then
-  ATC_FUZZ_CASES=$FUZZ ATC_FUZZ_SEED=10000000 timeout 1500 python -m pytest tests/test_fuzz_parity.py -q -m gpu -n 8 > $O/${TAG}_fuzz.txt 2>&1
+  ATC_FUZZ_CASES=$FUZZ ATC_FUZZ_SEED=${ATC_FUZZ_SEED_BASE:-10000000} timeout 1500 python -m pytest tests/test_fuzz_parity.py -q -m gpu -n 8 > $O/${TAG}_fuzz.txt 2>&1
   tail -2 $O/${TAG}_fuzz.txt
 fi
 cat $O/${TAG}_bench_default.json
