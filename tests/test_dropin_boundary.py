@@ -201,6 +201,7 @@ def test_step_server_equals_the_launch_path_and_survives_its_lease(monkeypatch):
             out.append(e.reset())
         assert np.array_equal(out[0], out[1])
     reset_both()
+    n_served = 0
     a = rng.uniform(-1, 1, 3).astype(np.float32)
     for t in range(900):
         if t % 25 == 0:
@@ -209,22 +210,21 @@ def test_step_server_equals_the_launch_path_and_survives_its_lease(monkeypatch):
         assert np.array_equal(rs[0], rr[0]) and rs[1] == rr[1] and rs[2] == rr[2], t
         assert np.array_equal(rs[3]["original_state"], rr[3]["original_state"]), t
         assert (srv.timesteps, srv.actions_taken) == (ref.timesteps, ref.actions_taken), t
-        if t == 5:
-            assert srv._serving
+        n_served += srv._serving
         if t % 97 == 50:      # reading the device state stops the server; the next step starts it again
             assert srv._airplane.h == ref._airplane.h and srv._airplane.x == ref._airplane.x and srv.last_action == ref.last_action
             assert not srv._serving
         if t == 300:          # longer than the lease: the resident kernel has left on its own; the next step is a launch
+            assert n_served >= 200, n_served
             time.sleep(0.05)
             assert int(srv._mailbox[4]) == 2
-        if t == 303:
-            assert srv._serving   # ... and the steps after it are served again
         if t % 211 == 210 or rs[2]:
             reset_both()
         if t == 600:
             srv._airplane.h = 7000.0
             ref._airplane.h = 7000.0
-    assert srv.winning_ratio == ref.winning_ratio and srv.total_reward == ref.total_reward
+    assert n_served >= 600, n_served     # ... and the steps after the pause were served again (no exact step is asserted: a scheduling
+    assert srv.winning_ratio == ref.winning_ratio and srv.total_reward == ref.total_reward   # hiccup longer than the lease is allowed)
     srv.close()
     ref.close()
 
@@ -244,6 +244,7 @@ def test_several_envs_in_one_process_share_the_step_servers(monkeypatch):
     for e in envs + [ref]:
         e.reset()
     rng = np.random.default_rng(0)
+    most = total = 0
     t0 = time.perf_counter()
     for t in range(300):
         a = rng.uniform(-1, 1, 3).astype(np.float32)
@@ -251,11 +252,12 @@ def test_several_envs_in_one_process_share_the_step_servers(monkeypatch):
         for e in envs:
             o = e.step(a)
             assert np.array_equal(o[0], r[0]) and o[1] == r[1] and o[2] == r[2], t
-        if t == 10:
-            # (a server lingers for 50 us after its step: with five envs stepped in turn one of the two may just have left)
-            assert 1 <= sum(e._serving for e in envs) <= 2 and len(atc_gym._SERVING) <= 2
+        n_now = sum(e._serving for e in envs)
+        most, total = max(most, n_now), total + n_now
+        assert len(atc_gym._SERVING) <= 2
     dt = time.perf_counter() - t0
     assert dt < 3.0, dt
+    assert 1 <= most <= 2 and total >= 150, (most, total)   # servers were used, never more than two at once
     for e in envs + [ref]:
         e.close()
     assert not atc_gym._SERVING

@@ -101,30 +101,44 @@ def test_step_server_c_abi_directly():
     assert Lb.atc_serve_start(env.sector.handle, C.byref(env._state), C.byref(no_pkt), C.byref(env.params), mb.data_ptr(), 0, 50000, q.cuda_stream) == -1
     assert Lb.atc_serve_step(mb.data_ptr(), act.data_ptr(), 0xffffffff, env.packet.data_ptr(), payload.ctypes.data, 1000) == -1
     torch.cuda.synchronize()
-    assert Lb.atc_serve_start(*args(), 0, 2000000, q.cuda_stream) == 0      # a 2 s lease: the twin's first launch loads its module
+    # (While a server is resident nothing else is submitted to the GPU here: a stream that happens to share the server's hardware
+    # queue would wait for the whole lease — include/atc_step.h "CHOOSING THE LEASE".  The twin steps afterwards.)
+    def twin_steps(n):
+        out = []
+        for _ in range(n):
+            o, r, d, info = twin.step(act.numpy().reshape(1, 1, 3))
+            out.append((o.numpy().reshape(-1).copy(), float(r[0])))
+        return out
+
+    def same_state():
+        return (torch.equal(env.ac.cpu(), twin.ac.cpu()) and torch.equal(env.alt.cpu(), twin.alt.cpu()) and torch.equal(env.env.cpu(), twin.env.cpu())
+                and torch.equal(env.last_act.cpu(), twin.last_act.cpu()))
+    assert Lb.atc_serve_start(*args(), 0, 2000000, q.cuda_stream) == 0
+    served = []
     for seq in range(1, 41):
         assert Lb.atc_serve_step(mb.data_ptr(), act.data_ptr(), seq, env.packet.data_ptr(), payload.ctypes.data, 2000000) == 0
-        o, r, d, info = twin.step(act.numpy().reshape(1, 1, 3))
-        assert np.array_equal(payload[:10].view(np.float32), o.numpy().reshape(-1)) and payload[20:21].view(np.float32)[0] == float(r[0])
         assert payload[22] == seq
+        served.append((payload[:10].view(np.float32).copy(), float(payload[20:21].view(np.float32)[0])))
     assert int(mb[4]) == 1 and int(mb[3]) == 40
     assert Lb.atc_serve_stop(mb.data_ptr(), q.cuda_stream) == 0             # quit: at once, the state is in memory
     assert int(mb[4]) == 3 and int(mb[5]) == 40
-    assert torch.equal(env.ac.cpu(), twin.ac.cpu()) and torch.equal(env.alt.cpu(), twin.alt.cpu()) and torch.equal(env.env.cpu(), twin.env.cpu())
+    for (so, sr), (to, tr) in zip(served, twin_steps(40)):
+        assert np.array_equal(so, to) and sr == tr
+    assert same_state()
     assert Lb.atc_serve_start(*args(), 40, 50000, q.cuda_stream) == 0        # a 50 ms lease this time
     assert Lb.atc_serve_step(mb.data_ptr(), act.data_ptr(), 41, env.packet.data_ptr(), payload.ctypes.data, 2000000) == 0
-    twin.step(act.numpy().reshape(1, 1, 3))
     time.sleep(0.25)
     assert int(mb[4]) == 2 and int(mb[5]) == 41                             # left by itself
     q.synchronize()
-    assert torch.equal(env.ac.cpu(), twin.ac.cpu()) and torch.equal(env.alt.cpu(), twin.alt.cpu()) and torch.equal(env.last_act.cpu(), twin.last_act.cpu())
+    twin_steps(1)
+    assert same_state()
     assert Lb.atc_serve_step(mb.data_ptr(), act.data_ptr(), 42, env.packet.data_ptr(), payload.ctypes.data, 2000000) == -4   # nobody there
     assert Lb.atc_serve_start(*args(), 41, 2000000, q.cuda_stream) == 0
     assert Lb.atc_serve_step(mb.data_ptr(), act.data_ptr(), 42, env.packet.data_ptr(), payload.ctypes.data, 2000000) == 0
-    twin.step(act.numpy().reshape(1, 1, 3))
     assert Lb.atc_serve_stop(mb.data_ptr(), q.cuda_stream) == 0
     assert int(mb[4]) == 3 and int(mb[5]) == 42
-    assert torch.equal(env.ac.cpu(), twin.ac.cpu()) and torch.equal(env.alt.cpu(), twin.alt.cpu()) and torch.equal(env.env.cpu(), twin.env.cpu())
+    twin_steps(1)
+    assert same_state()
     env.close()
     twin.close()
 
