@@ -195,8 +195,60 @@ def parity_gate(scn, N, grid_cell, sep_nm, device, held_hint=False):
         raise RuntimeError("parity gate (a): obs %.2e / reward %.2e beyond 1e-5" % (worst_o, worst_r))
     out["reference_fixture"] = {"fixture": "tests/golden/g2_scripted.npz", "episodes": len(eps), "steps": n_steps,
                                 "integer_outputs_exact": True, "max_obs_err": worst_o, "max_rel_reward_err": worst_r}
+    out["reference_fixture_timesteps"] = timestep_gate(device, grid_cell)
     out["fp32_oracle"] = oracle_gate(scn, N, grid_cell, sep_nm, device, held_hint)
     return out
+
+
+def timestep_gate(device, grid_cell, dt=0.1, max_eps=48):
+    """(a2) SimParameters.timestep = 0.1 s: episodes of tests/golden/g12_timesteps.npz (captured from the imported reference: sustained
+    descents and altitude TIES the reference decides by its own float64 rounding) replayed through the batched kernel — flags /
+    done / action counters exact on every step, sampled observations within 1e-5.  The altitude is the reference's float64 and the
+    timestep a double since ABI 20; an fp32 accumulator fails this gate."""
+    import numpy as np
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import model, scenarios
+    z = np.load(os.path.join(ROOT, "tests", "golden", "g12_timesteps.npz"), allow_pickle=False)
+    eps = [e for e in json.loads(str(z["episodes"])) if e["scen"] == "LOWW" and e["dt"] == dt and e["shaping"] and e["normalize"]
+           and not e["discrete"] and e["steps"] <= 3100][:max_eps]
+    flags, done, acts = z["flags"], z["done"], z["actions_taken"]
+    idx = np.zeros(len(flags), np.int64)
+    idx[z["act_rows"]] = np.arange(len(z["act_rows"]))
+    action = z["act_vals"][np.maximum.accumulate(idx)]
+    samp = np.full(len(flags), -1, np.int64)
+    samp[z["samp_rows"]] = np.arange(len(z["samp_rows"]))
+    env = AtcVecEnv(len(eps), 1, sim_parameters=model.SimParameters(dt), scenario=scenarios.LOWW(), device=device, auto_reset=False,
+                    spawn="lattice", keep_active=True, grid_cell=grid_cell)
+    for b, e in enumerate(eps):
+        env.set_state(b, 0, *e["init_state"])
+        env.timesteps[b] = e["init_timesteps"]
+        env.set_last_action(b, 0, e["init_last_action"])
+    steps = np.array([e["steps"] for e in eps])
+    starts = np.array([e["start"] for e in eps])
+    n_steps, worst, below = 0, 0.0, 0
+    for t in range(int(steps.max())):
+        live = t < steps
+        rows = np.where(live, starts + t, starts)
+        obs, rew, dn, info = env.step(action[rows].astype(np.float32).reshape(-1, 1, 3))
+        lr = rows[live]
+        fl = info["flags"].cpu().numpy()[live, 0].astype(np.uint8)
+        if not (np.array_equal(fl, flags[lr]) and np.array_equal(dn.cpu().numpy()[live], done[lr])
+                and np.array_equal(env.actions_taken.cpu().numpy()[live], acts[lr])):
+            raise RuntimeError("parity gate (a2): integer outputs differ from the reference at timestep %g s, step %d" % (dt, t))
+        si = samp[lr]
+        if (si >= 0).any():
+            o = obs.cpu().numpy()[live][si >= 0].astype(np.float64)
+            g = z["obs"][si[si >= 0]].astype(np.float64)
+            d = np.abs(o - g)
+            d[:, 9] = np.minimum(d[:, 9], np.abs(d[:, 9] - 2.0))   # +-180 deg are one angle (tests/helpers.py: obs_close)
+            worst = max(worst, float(d.max()))
+        below += int((fl & 1).sum())
+        n_steps += int(live.sum())
+    env.close()
+    if worst > 1e-5:
+        raise RuntimeError("parity gate (a2): obs %.2e beyond 1e-5 at timestep %g s" % (worst, dt))
+    return {"fixture": "tests/golden/g12_timesteps.npz", "timestep_s": dt, "episodes": len(eps), "steps": n_steps,
+            "below_mva_steps": below, "integer_outputs_exact": True, "max_obs_err": worst}
 
 
 def oracle_gate(scn, N, grid_cell, sep_nm, device, held_hint=False, B=256, T=40):
