@@ -121,6 +121,44 @@ __global__ void __launch_bounds__(256) k_pattern_ld(float* obs, unsigned short* 
     }
 }
 
+// The same launch with the per-step lookup served from LDS instead of global memory (round-5 review, next #2 / #4: would an
+// LDS-resident sector table lift the fused launch?).  A vector load shares the CU's in-order vector-memory pipe with the stores of
+// every resident wavefront and the vmcnt counter with the wavefront's own; a ds_read uses neither.  Each workgroup first STAGES its
+// table (LDS_KB kilobytes, 16-byte loads from a table that lives in the L2s: the cost an LDS-resident table pays per workgroup).
+template <int FMAS, int LDS_KB>
+__global__ void __launch_bounds__(256) k_pattern_lds(float* obs, unsigned short* flags, float* reward, unsigned char* done,
+                                                     const float* __restrict__ table, int B, int T, float seed) {
+    __shared__ float lds[LDS_KB * 256];
+    const unsigned tid = threadIdx.x, ln = tid & 63u;
+    for (unsigned j = tid; j < LDS_KB * 64u; j += 256u)
+        reinterpret_cast<v4f*>(lds)[j] = reinterpret_cast<const v4f*>(table)[j];
+    __syncthreads();
+    const size_t BN = (size_t)B * 16;
+    const unsigned i = blockIdx.x * 256u + tid;
+    const unsigned wave_first = blockIdx.x * 256u + (tid & ~63u);
+    float x = seed + (float)tid, y = seed * 0.5f;
+    unsigned h = i * 2654435761u;
+    for (int t = 0; t < T; ++t) {
+        const float g = lds[(h >> 8) % (LDS_KB * 256u)];
+#pragma unroll 16
+        for (int k = 0; k < FMAS; ++k) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x) : "v"(y));
+        x += g;
+        asm volatile("" : "+v"(x));
+        h = h * 1664525u + 1013904223u;
+        char* ob = reinterpret_cast<char*>(obs) + ((size_t)t * BN + wave_first) * 40;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned idx = (unsigned)j * 64u + ln;
+            if (idx < 160u) __builtin_nontemporal_store(v4f{x, y, (float)t, (float)idx}, reinterpret_cast<v4f*>(ob + idx * 16u));
+        }
+        __builtin_nontemporal_store((unsigned short)t, flags + (size_t)t * BN + i);
+        if ((tid & 15u) == 0) {
+            reward[(size_t)t * B + (i >> 4)] = x;
+            done[(size_t)t * B + (i >> 4)] = (unsigned char)(t & 1);
+        }
+    }
+}
+
 // The observation rows in an ENV-major layout [B][T][N][10] (each env's T steps contiguous: 12.8 KB per env, a workgroup's 16 envs
 // 200 KB) instead of the time-major [T][B][N][10]: is the many-fronts penalty the layout's?
 __global__ void __launch_bounds__(256) k_pattern_env_major(float* obs, int B, int T, float seed) {
@@ -288,5 +326,11 @@ int main(int argc, char** argv) {
     PATL(true, 300, "pattern + 300 FMAs + gather(t+1) issued before stores(t)");
     PATL(false, 400, "pattern + 400 FMAs + gather(t) issued after stores(t-1)");
     PATL(true, 400, "pattern + 400 FMAs + gather(t+1) issued before stores(t)");
+#define PATS(F, KB, LABEL) report(LABEL, time_us([&] { hipLaunchKernelGGL((k_pattern_lds<F, KB>), dim3(grid), dim3(256), 0, 0, obs, flags, reward, done, table, B, T, 1.0f); }, reps), total)
+    PATS(300, 16, "pattern + 300 FMAs + lookup in LDS (16 KB staged per workgroup)");
+    PATS(400, 16, "pattern + 400 FMAs + lookup in LDS (16 KB staged per workgroup)");
+    PATS(400, 24, "pattern + 400 FMAs + lookup in LDS (24 KB staged per workgroup: 6 workgroups per CU)");
+    PATS(400, 40, "pattern + 400 FMAs + lookup in LDS (40 KB staged per workgroup: 4 workgroups per CU)");
+    PATS(400, 64, "pattern + 400 FMAs + lookup in LDS (64 KB staged per workgroup: 2 workgroups per CU)");
     return 0;
 }
