@@ -2,7 +2,7 @@
 
 tests/test_abi.py parses the header and checks that every constant here matches it.
 """
-ABI_VERSION = 20
+ABI_VERSION = 21
 BLOB_VERSION = 1014.0
 
 H_VERSION, H_NWORDS, H_N_MVA, H_N_NOISE, H_N_ENTRY, H_OFF_POLY, H_OFF_VERT, H_OFF_ENTRY, H_OFF_GRID, H_N_VERTW = range(10)
@@ -58,3 +58,9 @@ STAT_WORDS = 8
 # last-action record (atc_state_t.last_act, 4 x int32): speed counts, heading counts, altitude target float64 in words 2..3
 AC_X, AC_Y, AC_PHI, AC_V, AC_WORDS = range(5)
 LA_V, LA_PHI, LA_H, LA_WORDS = 0, 1, 2, 4
+# LDS-resident lookup table (include/atc_step.h: ATC_LDS_*)
+LDS_MAGIC = 0x3154444C
+(LDS_H_MAGIC, LDS_H_BYTES, LDS_H_X0, LDS_H_Y0, LDS_H_INV, LDS_H_NX, LDS_H_NY, LDS_H_OFF_L1, LDS_H_OFF_SUB, LDS_H_N_SUB, LDS_H_OFF_LINE,
+ LDS_H_N_LINE, LDS_H_OFF_HTS, LDS_H_SUB) = range(14)
+LDS_HDR_WORDS = 16
+LDS_CLEAN, LDS_LINE, LDS_SUB, LDS_RESID = 0, 1, 2, 3

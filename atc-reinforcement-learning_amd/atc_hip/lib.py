@@ -49,7 +49,7 @@ class AtcStepCall(C.Structure):
 
 
 EXPORTS = ("atc_abi_version", "atc_last_error", "atc_host_mapped_ptr", "atc_scenario_create", "atc_scenario_destroy",
-           "atc_query_mva",
+           "atc_scenario_attach_lds_table", "atc_query_mva", "atc_query_mva_lds",
            "atc_query_mva_index", "atc_query_corridor", "atc_query_shaping", "atc_reset", "atc_observe", "atc_step",
            "atc_step_multi", "atc_step_packet", "atc_rollout", "atc_rollout_hold", "atc_serve_start", "atc_serve_step", "atc_serve_stop")
 
@@ -69,6 +69,8 @@ def load():
     lib.atc_host_mapped_ptr.argtypes = [vp, C.POINTER(vp)]
     lib.atc_scenario_create.argtypes = [vp, C.c_size_t, ci, C.POINTER(vp)]
     lib.atc_scenario_destroy.argtypes = [vp]
+    lib.atc_scenario_attach_lds_table.argtypes = [vp, vp, C.c_size_t]
+    lib.atc_query_mva_lds.argtypes = [vp, ci, vp, vp, vp, vp, vp]
     lib.atc_query_mva.argtypes = [vp, ci, vp, vp, vp, ci, vp]
     lib.atc_query_mva_index.argtypes = [vp, ci, vp, vp, vp, ci, vp]
     lib.atc_query_corridor.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, vp]
@@ -128,8 +130,12 @@ def make_params(dt=1.0, shaping=True, normalize=True, discrete=False, auto_reset
 class Scenario:
     """Device-resident sector (opaque atc_scenario_t handle) + batched geometry queries."""
 
-    def __init__(self, compiled, device=0):
+    def __init__(self, compiled, device=0, lds_table=False):
+        """lds_table=True also attaches the sector's LDS-resident lookup table (include/atc_step.h, ABI 21) where it has one and
+        the device's LDS holds it: multi-step launches of one-aircraft envs then answer the MVA lookup from LDS (same results).
+        `has_lds_table` tells whether one is attached."""
         torch = _torch_cuda()
+        self.has_lds_table = False
         self.compiled = compiled
         self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
         self._lib = load()
@@ -138,6 +144,30 @@ class Scenario:
         with torch.cuda.device(self.device):
             check(self._lib.atc_scenario_create(blob.ctypes.data_as(C.c_void_p), blob.size, self.device.index,
                                                 C.byref(self._h)))
+        if lds_table:
+            self.attach_lds_table()
+
+    def attach_lds_table(self):
+        """Builds (once per CompiledSector) and attaches the LDS-resident lookup table; a sector without one — no lookup grid, noise-
+        abatement areas, too large for the device's LDS — simply keeps stepping from the grid.  Returns has_lds_table."""
+        torch = _torch_cuda()
+        tab = self.compiled.lds_table() if self.compiled.has_grid else None
+        if tab is not None:
+            t = np.ascontiguousarray(tab)
+            with torch.cuda.device(self.device):
+                self.has_lds_table = self._lib.atc_scenario_attach_lds_table(self._h, t.ctypes.data_as(C.c_void_p), t.nbytes) == 0
+        return self.has_lds_table
+
+    def query_mva_lds(self, x, y):
+        """Airspace.get_mva_height through the attached LDS table: (heights [ft] or -1, answered-from-the-table flags)."""
+        torch = _torch_cuda()
+        x, y = self._f32(x), self._f32(y)
+        out = torch.empty(x.numel(), dtype=torch.int32, device=self.device)
+        src = torch.empty(x.numel(), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._lib.atc_query_mva_lds(self._h, x.numel(), x.data_ptr(), y.data_ptr(), out.data_ptr(), src.data_ptr(),
+                                              current_stream_ptr(self.device)))
+        return out.cpu().numpy(), src.cpu().numpy()
 
     @property
     def handle(self):

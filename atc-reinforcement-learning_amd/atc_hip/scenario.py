@@ -447,6 +447,189 @@ def build_grid(rings, bounds, heights, bbox, cell, guard=None, noise_bounds=(), 
     return np.concatenate([hdr, cells.ravel(), pad, pool_arr.ravel()])
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# LDS-resident lookup table (ABI 21; include/atc_step.h: atc_scenario_attach_lds_table) for the latency-bound multi-step launches
+# of ONE-aircraft envs — 64 envs per wavefront, one wavefront per SIMD: the lookup grid's gather is 0.8 us of exposed wait per
+# step there and its dirty cells a second / third dependent trip in 40 % of the wavefront-steps (profiles/experiments/README.md,
+# round 6).  Same answers as the ordered polygon scan (model.py:282-289), by the same construction as build_grid:
+#   level 1: cells of `cell` nm (0.5) over the padded sector, one 16-bit code each;
+#   level 2: every level-1 cell that is neither clean nor split by ONE border line is refined into sub x sub (8 x 8) sub-cells,
+#            one 16-bit code each;
+#   code   : bit 15 = corridor candidate (level 1 only), bits 14..13 = kind, bits 12..0 = payload
+#            CLEAN (0): payload = polygon + 1 (0: outside the airspace);  LINE (1): payload = index of a LINE record (_line_split:
+#            p1x, p1y, dx/dy, margin | left polygon + 1, height, right polygon + 1, height);  SUB (2, level 1 only): payload = index
+#            of the cell's sub-cell block;  RESIDUAL (3): a vertex or a second border inside the sub-cell — the kernel answers the
+#            WHOLE wavefront from the global lookup grid (0.2 % of the sub-cells' area: one wavefront-step in eight).
+# A point inside a LINE record's margin band is residual too.  Boxes are inflated by the same slack as build_grid's.
+LDS_KIND_CLEAN, LDS_KIND_LINE, LDS_KIND_SUB, LDS_KIND_RESID = L.LDS_CLEAN, L.LDS_LINE, L.LDS_SUB, L.LDS_RESID
+LDS_MAGIC, LDS_HDR_WORDS = L.LDS_MAGIC, L.LDS_HDR_WORDS
+
+
+def _near_any_edge(rings, x0s, x1s, y0s, y1s):
+    """Boxes (already inflated) some ring edge may touch — _seg_near_box, vectorised over a flat list of boxes."""
+    near = np.zeros(len(x0s), dtype=bool)
+    for ring in rings:
+        for k in range(len(ring) - 1):
+            p, q = ring[k], ring[k + 1]
+            miss = (max(p[0], q[0]) < x0s) | (min(p[0], q[0]) > x1s) | (max(p[1], q[1]) < y0s) | (min(p[1], q[1]) > y1s)
+            dx, dy = q[0] - p[0], q[1] - p[1]
+            if dx == 0.0 and dy == 0.0:
+                near |= ~miss
+                continue
+            s = [(cx - p[0]) * dy - (cy - p[1]) * dx for cx in (x0s, x1s) for cy in (y0s, y1s)]
+            lo = np.minimum(np.minimum(s[0], s[1]), np.minimum(s[2], s[3]))
+            hi = np.maximum(np.maximum(s[0], s[1]), np.maximum(s[2], s[3]))
+            near |= ~miss & ~((lo > 0.0) | (hi < 0.0))
+    return near
+
+
+def _classify_boxes(x0, x1, y0, y1, slack, rings, edges, bounds, heights, lines):
+    """Kind and payload of each box [x0, x1] x [y0, y1] (inflated by `slack` here): CLEAN / LINE / RESID (a level-1 caller turns
+    RESID into SUB).  `lines`: dict LINE record (8 float32 words as bytes) -> index, extended in place."""
+    x0s, x1s, y0s, y1s = x0 - slack, x1 + slack, y0 - slack, y1 + slack
+    n = len(x0)
+    kind = np.zeros(n, dtype=np.int64)
+    payload = np.zeros(n, dtype=np.int64)
+    near = _near_any_edge(rings, x0s, x1s, y0s, y1s)
+    far = np.nonzero(~near)[0]
+    pis = _first_polygon_many(0.5 * (x0[far] + x1[far]), 0.5 * (y0[far] + y1[far]), rings, bounds)
+    payload[far] = pis + 1
+    idx = np.nonzero(near)[0]
+    recs_all = _box_records_many(x0s[idx], x1s[idx], y0s[idx], y1s[idx], edges, bounds, heights)
+    for d, recs in zip(idx, recs_all):
+        if not recs:
+            continue                                     # no point of the box is inside any polygon: CLEAN, outside
+        if len(recs) == 1 and recs[0][0] == -_BIG:       # a single unconditional answer
+            payload[d] = int(recs[0][7]) // 16 + 1
+            continue
+        split = _line_split(recs, y0s[d], y1s[d], heights)
+        if split is None:
+            kind[d] = LDS_KIND_RESID
+            continue
+        key = np.asarray(split, dtype=np.float32).tobytes()
+        if key not in lines:
+            lines[key] = len(lines)
+        kind[d] = LDS_KIND_LINE
+        payload[d] = lines[key]
+    return kind, payload
+
+
+def build_lds_table(rings, bounds, heights, bbox, corridor_bounds=None, cell=0.5, sub=8, guard=None):
+    """The LDS-resident lookup table (see above) as a uint8 array, or None when the sector does not fit its 13-bit payloads.
+    Layout: 16 header words (magic, bytes, x0, y0, 1 / cell as fp32, nx, ny, off_l1, off_sub, n_sub, off_line, n_line, off_hts, sub,
+    0, 0; offsets in bytes), level-1 codes u16[ny * nx], sub-cell codes u16[n_sub][sub * sub], LINE records f32[n_line][8], heights
+    f32[64] (index polygon + 1; [0] = 0)."""
+    if guard is None:
+        guard = 1e-3
+    assert sub == 8, "the kernel's sub-cell index is three bits per axis"
+    x0, y0, x1, y1 = bbox
+    if corridor_bounds is not None:
+        b = corridor_bounds
+        x0, y0, x1, y1 = min(x0, b[0]), min(y0, b[1]), max(x1, b[2]), max(y1, b[3])
+    gx0, gy0 = x0 - 2 * cell, y0 - 2 * cell
+    nx = int(math.ceil((x1 - gx0) / cell)) + 2
+    ny = int(math.ceil((y1 - gy0) / cell)) + 2
+    if nx * ny >= 1 << 22 or len(rings) > 62:
+        return None
+    slack = guard + 1e-4 * max(1.0, abs(x1), abs(y1)) * 2.0 ** -10
+    assert slack < 0.5 * cell / sub
+    edges = [_ring_edges(r) for r in rings]
+    lines = {}
+    jj, ii = np.divmod(np.arange(nx * ny), nx)
+    k1, p1 = _classify_boxes(gx0 + ii * cell, gx0 + (ii + 1) * cell, gy0 + jj * cell, gy0 + (jj + 1) * cell, slack,
+                             rings, edges, bounds, heights, lines)
+    resid = np.nonzero(k1 == LDS_KIND_RESID)[0]
+    n_sub = len(resid)
+    sj, si = np.divmod(np.arange(sub * sub), sub)
+    sc = cell / sub
+    bx = (gx0 + ii[resid] * cell)[:, None] + si[None, :] * sc     # sub-cell s of block r: [bx, bx + sc] x [by, by + sc]
+    by = (gy0 + jj[resid] * cell)[:, None] + sj[None, :] * sc
+    k2, p2 = _classify_boxes(bx.ravel(), bx.ravel() + sc, by.ravel(), by.ravel() + sc, slack, rings, edges, bounds, heights, lines)
+    k1[resid] = LDS_KIND_SUB
+    p1[resid] = np.arange(n_sub)
+    if n_sub >= 1 << 13 or len(lines) >= 1 << 13:
+        return None
+    code1 = (k1 << 13) | p1
+    if corridor_bounds is not None:   # the (inflated) cell meets the bounds of the corridor's horizontal triangle (model.py:198)
+        b = corridor_bounds
+        cx0, cx1 = gx0 + ii * cell - slack, gx0 + (ii + 1) * cell + slack
+        cy0, cy1 = gy0 + jj * cell - slack, gy0 + (jj + 1) * cell + slack
+        code1 |= np.where(~((b[3] < cy0) | (b[1] > cy1) | (b[2] < cx0) | (b[0] > cx1)), 1 << 15, 0)
+    code2 = (k2 << 13) | p2
+    c1 = code1.reshape(ny, nx)
+    border = np.concatenate([c1[0, :], c1[-1, :], c1[:, 0], c1[:, -1]])
+    assert not border.any(), "the outermost ring of level-1 cells must be clean and outside the airspace"
+    line_arr = np.zeros((max(1, len(lines)), 8), dtype=np.float32)
+    for key, i in lines.items():
+        line_arr[i] = np.frombuffer(key, dtype=np.float32)
+    hts = np.zeros(64, dtype=np.float32)
+    hts[1:1 + len(heights)] = np.asarray(heights, dtype=np.float32)
+
+    def pad16(n):
+        return (n + 15) & ~15
+    off_l1 = 4 * LDS_HDR_WORDS
+    off_sub = pad16(off_l1 + 2 * nx * ny)
+    off_line = pad16(off_sub + 2 * len(code2))
+    off_hts = off_line + line_arr.nbytes
+    total = pad16(off_hts + hts.nbytes)
+    t = np.zeros(total, dtype=np.uint8)
+    hdr = np.zeros(LDS_HDR_WORDS, dtype=np.uint32)
+    hdr[0], hdr[1] = LDS_MAGIC, total
+    hdr[2:5] = np.array([gx0, gy0, 1.0 / cell], dtype=np.float32).view(np.uint32)
+    hdr[5:14] = (nx, ny, off_l1, off_sub, n_sub, off_line, len(line_arr), off_hts, sub)
+    t[:off_l1] = hdr.view(np.uint8)
+    t[off_l1:off_l1 + 2 * nx * ny] = code1.astype(np.uint16).view(np.uint8)
+    t[off_sub:off_sub + 2 * len(code2)] = code2.astype(np.uint16).view(np.uint8)
+    t[off_line:off_line + line_arr.nbytes] = line_arr.ravel().view(np.uint8)
+    t[off_hts:off_hts + hts.nbytes] = hts.view(np.uint8)
+    return t
+
+
+def lds_table_lookup(table, x, y):
+    """numpy restatement of the kernel's LDS lookup (csrc/atc_device.h: lds_lookup), the same fp32 operations: returns (polygon + 1
+    or -1 where the kernel falls back to the global grid, height, corridor candidate)."""
+    f32 = np.float32
+    t = np.asarray(table, dtype=np.uint8)
+    hdr = t[:4 * LDS_HDR_WORDS].view(np.uint32)
+    assert hdr[0] == LDS_MAGIC and hdr[1] == len(t)
+    gx0, gy0, inv = hdr[2:5].view(np.float32)
+    nx, ny, off_l1, off_sub, n_sub, off_line, n_line, off_hts, sub = (int(v) for v in hdr[5:14])
+    l1 = t[off_l1:off_l1 + 2 * nx * ny].view(np.uint16)
+    l2 = t[off_sub:off_sub + 2 * max(1, n_sub) * sub * sub].view(np.uint16) if n_sub else np.zeros(64, dtype=np.uint16)
+    lines = t[off_line:off_line + 32 * n_line].view(np.float32).reshape(-1, 8)
+    hts = t[off_hts:off_hts + 256].view(np.float32)
+    x = np.asarray(x, dtype=f32)
+    y = np.asarray(y, dtype=f32)
+
+    def cvt_i32_sat(v):   # v_cvt_i32_f32: truncation, saturation, NaN -> 0
+        v = np.nan_to_num(v.astype(np.float64), nan=0.0, posinf=2147483647.0, neginf=-2147483648.0)
+        return np.clip(np.trunc(v), -2147483648.0, 2147483647.0).astype(np.int64)
+    with np.errstate(invalid="ignore", over="ignore"):
+        fx = (x - gx0) * inv
+        fy = (y - gy0) * inv
+        ix = np.minimum(cvt_i32_sat(fx) & 0xffffffff, nx - 1)
+        iy = np.minimum(cvt_i32_sat(fy) & 0xffffffff, ny - 1)
+        sx = np.minimum(cvt_i32_sat((fx - ix.astype(f32)) * f32(sub)) & 0xffffffff, sub - 1)
+        sy = np.minimum(cvt_i32_sat((fy - iy.astype(f32)) * f32(sub)) & 0xffffffff, sub - 1)
+    c1 = l1[iy * nx + ix].astype(np.int64)
+    cand = (c1 >> 15) & 1
+    is_sub = ((c1 >> 13) & 3) == LDS_KIND_SUB
+    c2 = l2[np.where(is_sub, (c1 & 0x1fff) * sub * sub + sy * sub + sx, 0)].astype(np.int64)
+    c = np.where(is_sub, c2, c1)
+    kind, pay = (c >> 13) & 3, c & 0x1fff
+    rec = lines[np.where(kind == LDS_KIND_LINE, pay, 0)]
+    with np.errstate(invalid="ignore", over="ignore"):
+        # the kernel's fmaf: the product of two fp32 numbers is exact in float64, the sum is rounded once more — to fp32
+        xl = ((y - rec[:, 1]).astype(np.float64) * rec[:, 2].astype(np.float64) + rec[:, 0].astype(np.float64)).astype(f32)
+        left, right = x < xl - rec[:, 3], x > xl + rec[:, 3]
+    decided = (kind == LDS_KIND_LINE) & (left | right)
+    clean = kind == LDS_KIND_CLEAN
+    code = np.where(clean, pay, np.where(left, rec[:, 4], rec[:, 6]).astype(np.int64))
+    h = np.where(clean, hts[np.where(clean, pay, 0)], np.where(left, rec[:, 5], rec[:, 7]))
+    ok = clean | decided
+    return np.where(ok, code, -1), np.where(ok, h, f32(0)), cand
+
+
 _SOURCE_TAG = None
 
 
@@ -563,6 +746,19 @@ class CompiledSector:
             self._b64[og:] = self._grid_fn()
             self._grid_fn = None
         return self._b64
+
+    def lds_table(self):
+        """The LDS-resident lookup table of this sector (build_lds_table; built on first use, kept), or None: no MVA polygon, a
+        noise-abatement area (the table's codes carry no candidate masks), or payloads beyond 13 bits."""
+        if "_lds_table" not in self.__dict__:
+            m = self.meta
+            t = None
+            if m["n_mva"] and not m["n_noise"]:
+                th = m["corridor"]["tri_h"]
+                t = build_lds_table(m["mva_rings"], m["mva_bounds"], m["mva_heights"], m["bbox"],
+                                    (th[:, 0].min(), th[:, 1].min(), th[:, 0].max(), th[:, 1].max()))
+            self.__dict__["_lds_table"] = t
+        return self.__dict__["_lds_table"]
 
     def __getattr__(self, name):
         try:

@@ -40,7 +40,7 @@ class AtcVecEnv:
     def __init__(self, num_envs, num_aircraft=1, sim_parameters=None, scenario=None, device=0, auto_reset=True,
                  spawn="auto", seed=0, grid_cell="auto", want_raw_obs=False, want_ac_reward=False, want_min_sep=False,
                  want_term_obs=False, timestep_limit=6000, sep_nm=3.0, sep_ft=1000.0, conflict_reward=-200.0,
-                 host_mapped=False, keep_active=False, want_packet=False, check_held=False):
+                 host_mapped=False, keep_active=False, want_packet=False, check_held=False, lds_table=True):
         """host_mapped=True keeps state and outputs in pinned host memory mapped into the device (zero-copy): the kernels
         read / write it over the host link, every call ends with a stream synchronisation, and what is returned are CPU
         tensors.  Meant for tiny latency-bound batches (the single-env AtcGym); large batches belong in HBM.
@@ -78,7 +78,9 @@ class AtcVecEnv:
         else:
             self.compiled = scenarios.compile_scenario(self.scenario_obj, grid_cell=grid_cell)
         self.grid_cell = grid_cell
-        self.sector = _lib.Scenario(self.compiled, device)
+        # (one-aircraft envs: the sector's LDS-resident lookup table goes along — the multi-step launches of batches that fit one
+        # workgroup per CU answer the MVA lookup from LDS, include/atc_step.h ABI 21; `lds_table=False` keeps it off, for A/B runs)
+        self.sector = _lib.Scenario(self.compiled, device, lds_table=(self.N == 1 and lds_table))
         self.device = self.sector.device
         n_entry = self.compiled.n_entry
         if n_entry < 1:

@@ -410,6 +410,62 @@ __device__ __forceinline__ int find_mva(const float* __restrict__ K, const float
     return mva_resolve(K, grid, gh, c, x, y, height);
 }
 
+// ---- LDS-resident lookup table (ABI 21; include/atc_step.h: atc_scenario_attach_lds_table, built by atc_hip/scenario.py:
+//      build_lds_table).  For the latency-bound multi-step launches of ONE-aircraft envs (64 envs per wavefront, one wavefront per
+//      SIMD): there the lookup grid's gather is 0.8 us of exposed wait in every step and its dirty cells a second / third dependent
+//      trip in 40 % of the wavefront-steps (profiles/experiments/README.md, round 6).  A workgroup stages the table once per
+//      launch; a step then reads a 16-bit level-1 code (0.5 nm cells), a 16-bit sub-cell code (8 x 8 per refined cell) and — for a
+//      cell ONE border line splits — that line's 32-byte record, all from LDS: no vector-memory wait on the step's chain.  A lane the
+//      table cannot answer (RESIDUAL sub-cell: a vertex or a second border inside it; a point inside a line's margin band) sends
+//      its WHOLE wavefront to the global grid for this step — one wavefront-step in seven.  Same answers as the ordered polygon
+//      scan either way (tests/test_lds_table.py: the numpy restatement against the fp32 oracle on the CPU, the kernels on the GPU).
+struct LdsTab {             // kernel argument: where the table lives in global memory + its header terms (host-checked)
+    const uint4* src;       // 16-byte pieces; nullptr: no table attached
+    int n16;
+    float x0, y0, inv;      // level-1 origin and 1 / cell
+    int nx, nx_last, ny_last;
+    int off_l1, off_sub, off_line, off_hts;   // byte offsets from the table's start
+};
+struct LdsCode {
+    uint32_t c1, sub;       // level-1 code, sub-cell index sy * 8 + sx
+};
+// first half (with the kinematics): bin the point like mva_cell_load does (clamped indices: the outermost ring is clean and outside)
+__device__ __forceinline__ LdsCode lds_cell_load(const char* tab, const LdsTab& t, float x, float y) {
+    const float fx = (x - t.x0) * t.inv;
+    const float fy = (y - t.y0) * t.inv;
+    const uint32_t ix = min((uint32_t)cvt_i32_sat(fx), (uint32_t)t.nx_last);
+    const uint32_t iy = min((uint32_t)cvt_i32_sat(fy), (uint32_t)t.ny_last);
+    const uint32_t sx = min((uint32_t)cvt_i32_sat((fx - (float)ix) * 8.0f), 7u);
+    const uint32_t sy = min((uint32_t)cvt_i32_sat((fy - (float)iy) * 8.0f), 7u);
+    LdsCode c;
+    c.c1 = *reinterpret_cast<const uint16_t*>(tab + ((uint32_t)t.off_l1 + 2u * (__umul24(iy, (uint32_t)t.nx) + ix)));
+    c.sub = sy * 8u + sx;
+    return c;
+}
+// second half: polygon index (-1: outside) + height like mva_resolve; *resid: this lane has no answer here (the caller asks the grid)
+__device__ __forceinline__ int lds_resolve(const char* tab, const LdsTab& t, const LdsCode& lc, float x, float y, float* height,
+                                           bool* resid) {
+    const uint32_t c1 = lc.c1;
+    const bool is_sub = ((c1 >> 13) & 3u) == (uint32_t)ATC_LDS_SUB;
+    const uint32_t sidx = is_sub ? (c1 & 0x1fffu) * 64u + lc.sub : 0u;   // (lanes without a refined cell read sub-cell 0 and discard it)
+    const uint32_t c2 = *reinterpret_cast<const uint16_t*>(tab + ((uint32_t)t.off_sub + 2u * sidx));
+    const uint32_t c = is_sub ? c2 : c1;
+    const uint32_t kind = (c >> 13) & 3u, pay = c & 0x1fffu;
+    const bool clean = kind == (uint32_t)ATC_LDS_CLEAN, is_line = kind == (uint32_t)ATC_LDS_LINE;
+    const uint32_t li = is_line ? pay : 0u;
+    // LINE record (atc_hip/scenario.py:_line_split): p1x, p1y, dx/dy, margin | left polygon + 1, height, right polygon + 1, height
+    const float4 g = *reinterpret_cast<const float4*>(tab + ((uint32_t)t.off_line + 32u * li));
+    const float4 m = *reinterpret_cast<const float4*>(tab + ((uint32_t)t.off_line + 32u * li + 16u));
+    const float hc = *reinterpret_cast<const float*>(tab + ((uint32_t)t.off_hts + 4u * (clean ? pay : 0u)));
+    const float xl = fmaf(y - g.y, g.z, g.x);
+    const bool left = x < xl - g.w, right = x > xl + g.w;
+    const bool decided = is_line && (left || right);
+    *height = clean ? hc : (left ? m.y : m.w);
+    *resid = !(clean || decided);
+    return (clean ? (int)pay : (int)(left ? m.x : m.z)) - 1;
+}
+__device__ __forceinline__ bool lds_corridor_candidate(const LdsCode& lc) { return (lc.c1 & 0x8000u) != 0u; }
+
 // model.py:212-231 Corridor._inside_corridor_angle.
 // The reference compares min_angle = arccos(dir_rwy . dir_plane) [radians] with relative_angle [degrees]:
 //     min_angle <= rel <= 45.

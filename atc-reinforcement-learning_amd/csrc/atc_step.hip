@@ -37,6 +37,10 @@ struct atc_scenario {
     float consts[ATC_C_END];   // host copy of the blob's header + constants block (derive() evaluates uniform terms from it)
     float ghdr[ATC_G_HDR];     // host copy of the lookup grid's header (zeros without a grid)
     uint64_t uid;              // unique per created handle (never reused: keys the per-thread cache of derive())
+    void* d_lds;               // LDS-resident lookup table (atc_scenario_attach_lds_table): device copy, or null
+    LdsTab lt;                 // ... and the kernel argument that describes it (src == null: none)
+    size_t lds_tab_bytes;
+    int max_lds;               // the device's LDS bytes per workgroup
 };
 
 static thread_local char g_err[512] = "";
@@ -184,6 +188,7 @@ struct Mid {            // what the first half of a step hands to the second
     int acts;
     float x32, y32;
     MvaCell cell;       // MVA lookup cell, gather issued in the first half, resolved after the separation scan
+    LdsCode lc;         // ... or its codes in the LDS-resident table (LDSG instantiation)
     bool repeated;      // uniform: no action bookkeeping in this step (acts == 0 in every lane)
     bool plain;         // uniform: every lane flies an aircraft under control towards valid targets (fl == 0, no refusal)
 };
@@ -414,6 +419,7 @@ struct StepArgs {
     atc_params_t p;
     StepDerived q;
     InlineAction ia;
+    LdsTab lt;
 };
 template <typename T>
 __device__ __forceinline__ T kernarg_reread(size_t byte_off, int opaque_zero) {
@@ -545,11 +551,12 @@ __device__ __forceinline__ int clamp_sym(int d, int r) { return max(min(d, r), -
 __device__ __forceinline__ bool within(int d, int D) { return (uint32_t)d + (uint32_t)(D - 1) < (uint32_t)(2 * D - 1); }
 
 // ---- first half of AtcGym.step: timestep, rate limits towards the targets, kinematics, MVA floor ---------------------
-template <bool ONE, bool LAT>
+template <bool ONE, bool LAT, bool LDSG = false>
 __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const QRates& q, const QKin& qk, const QGrid& qg,
                                            const LaneIds& d, uint32_t tv, double th, int tp, float act_p, LaneState& ls, EnvState& es,
                                            bool repeated, bool all_active, double* wide_named, int zk,
-                                           uint64_t& refused_blk, bool refused_known ATC_TRACE_PARAM) {
+                                           uint64_t& refused_blk, bool refused_known ATC_TRACE_PARAM,
+                                           const char* ltab = nullptr, const LdsTab* lt = nullptr) {
     Mid m;
     Aircraft& a = ls.a;
     // `repeated` (wave-uniform): this step repeats the previous step's actions and no env of the wavefront was reset in
@@ -694,7 +701,13 @@ __device__ __forceinline__ Mid step_part_a(const float* __restrict__ grid, const
     m.x32 = pos_to_real(q.pos_neg_k, qg.pos_x0, a.x);
     m.y32 = pos_to_real(q.pos_neg_k, qg.pos_y0, a.y);
     // MVA floor, first half: only ISSUE the lookup-cell gather here; nothing until the override chain needs its result
-    m.cell = mva_cell_load(grid, qg.gh, m.x32, m.y32);
+    m.lc = LdsCode{0u, 0u};
+    if (LDSG) {
+        m.cell.cell = make_float2(0.0f, 0.0f);
+        m.lc = lds_cell_load(ltab, *lt, m.x32, m.y32);   // (LDS: no vector-memory operation on the step's chain)
+    } else {
+        m.cell = mva_cell_load(grid, qg.gh, m.x32, m.y32);
+    }
     m.active = active;
     m.r = r;
     m.fl = fl;
@@ -744,12 +757,13 @@ constexpr int scan_horizon() {
 }
 constexpr float kScanHMax = 131072.0f;   // |altitude| below which an altitude step rounds by less than 2^-7 ft (scan_horizon_limits)
 
-template <int W, bool FULL, bool ONE, bool LAT>
+template <int W, bool FULL, bool ONE, bool LAT, bool LDSG = false>
 __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const float* __restrict__ grid,
                                             const atc_params_t& p, const StepDerived& q, const QScan& qs, int zk, int N,
                                             const LaneIds& d, const Mid& m, LaneState& ls,
                                             EnvState& es, const StepOut& so, int32_t* stp, double* wide_named, float4* pos, float* obs_stage,
-                                            const float* act_next, Float3& a_next, QRates& qr_next, int& scan_skip, uint32_t& scan_mask) {
+                                            const float* act_next, Float3& a_next, QRates& qr_next, int& scan_skip, uint32_t& scan_mask,
+                                            const char* ltab = nullptr, const LdsTab* lt = nullptr) {
     Aircraft& a = ls.a;
     const bool active = m.active;
     const float x32 = m.x32, y32 = m.y32;
@@ -930,7 +944,7 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     // Measured per width and launch form (r04, same box, two rounds): single steps of 16-aircraft envs 17.81 vs 18.03 us at
     // 65 536 envs, one-aircraft envs 6.58-6.61 vs 6.60-6.67 single / 3.42 vs 3.47-3.50 fused; NOT the fused 16-aircraft launch
     // (8 B scratch under its 80-register bound: 2.73-2.77 vs 2.66 us at 8 192 envs) and not the 64-aircraft kernels (8.50 vs 8.30).
-    constexpr bool kPrefetch = (W == 1 || (ONE && W == 16)) && kResolveAfterScan;
+    constexpr bool kPrefetch = (W == 1 || (ONE && W == 16)) && kResolveAfterScan && !LDSG;
     constexpr bool kObsFirst = kPrefetch || W == 1;
     MvaPre pre;
     if (kPrefetch) pre = mva_prefetch(grid, QGET(g.gh), m.cell);
@@ -944,7 +958,18 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     }
     ATC_STAMP_TOP(so.trace, 5);
     // ---- MVA floor (atc_gym.py:146-161), second half ---------------------------------------------------------------------
-    if (kResolveAfterScan) {
+    if (LDSG) {
+        // the LDS-resident table (csrc/atc_device.h: lds_resolve); the host attaches one only to sectors without noise-abatement areas
+        float hgt = 0.0f;
+        bool resid;
+        pi = lds_resolve(ltab, *lt, m.lc, x32, y32, &hgt, &resid);
+        if (ATC_RARE(__builtin_amdgcn_ballot_w64(resid) != 0ull)) {   // some lane has no answer there: the wavefront asks the grid
+            const GridHdr gh = QGET(g.gh);
+            const MvaCell c = mva_cell_load(grid, gh, x32, y32);
+            pi = mva_resolve<kWalkBatch>(K, grid, gh, c, x32, y32, &hgt);
+        }
+        mva = hgt;
+    } else if (kResolveAfterScan) {
         float hgt = 0.0f;
         pi = mva_resolve<kWalkBatch>(K, grid, QGET(g.gh), m.cell, x32, y32, &hgt, kPrefetch ? &pre : nullptr);
         mva = hgt;                                 // atc_gym.py:161: mva = 0 outside (mva_resolve leaves the height at 0)
@@ -961,7 +986,8 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     const bool conflict = margin < 0.0f;
     const bool timeout = es.t > qs.timestep_limit;
     // (one lane mask per compare, combined on the scalar unit — see `plain`)
-    const uint64_t in_tri = grid ? __builtin_amdgcn_ballot_w64(corridor_candidate(m.cell))
+    const uint64_t in_tri = LDSG ? __builtin_amdgcn_ballot_w64(lds_corridor_candidate(m.lc))
+                          : grid ? __builtin_amdgcn_ballot_w64(corridor_candidate(m.cell))
                                  : (__builtin_amdgcn_ballot_w64(x32 >= qs.tri_bbox.x) & __builtin_amdgcn_ballot_w64(x32 <= qs.tri_bbox.z) &
                                     __builtin_amdgcn_ballot_w64(y32 >= qs.tri_bbox.y) & __builtin_amdgcn_ballot_w64(y32 <= qs.tri_bbox.w));
     const double mva_d = (double)mva;   // (an integer height; 0 outside the airspace)
@@ -1194,11 +1220,14 @@ __device__ __forceinline__ void store_env_state(const atc_state_t& st, const Lan
 
 #define ATC_LAT_WAVES 2   // wavefronts per SIMD the latency-bound instantiation is register-budgeted for (<= 256 VGPRs)
 // ONE: single-step launch (T == 1); ALLV: every slot is an aircraft (make_ids); LAT: latency-bound multi-step instantiation (above)
-template <int W, bool FULL, bool ONE, bool ALLV, bool LAT = false>
-__global__ void __launch_bounds__(kBlock, (LAT ? ATC_LAT_WAVES : ONE ? ATC_MIN_WAVES : ((FULL || W <= 8 || W >= 32) ? ATC_MIN_WAVES_LOOP - 1 : ATC_MIN_WAVES_LOOP)))
+// LDSG: the latency-bound launch of ONE-aircraft envs with the sector's lookup table staged in LDS (csrc/atc_device.h: LdsTab) — one
+// workgroup per CU (the table is ~105 KB for LOWW), chosen by the host when the launch has no more workgroups than the device CUs
+template <int W, bool FULL, bool ONE, bool ALLV, bool LAT = false, bool LDSG = false>
+__global__ void __launch_bounds__(kBlock, (LDSG ? 1 : LAT ? ATC_LAT_WAVES : ONE ? ATC_MIN_WAVES : ((FULL || W <= 8 || W >= 32) ? ATC_MIN_WAVES_LOOP - 1 : ATC_MIN_WAVES_LOOP)))
 k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int hold, atc_state_t st,
-       const float* __restrict__ actions, atc_out_t out, atc_params_t p, StepDerived q_arg, InlineAction ia) {
+       const float* __restrict__ actions, atc_out_t out, atc_params_t p, StepDerived q_arg, InlineAction ia, LdsTab lt_arg) {
     static_assert(!LAT || (!ONE && !FULL), "LAT is an instantiation of the fast multi-step kernels");
+    static_assert(!LDSG || (LAT && W == 1 && ALLV), "LDSG is an instantiation of the latency-bound one-aircraft kernel");
     StepDerived q_vec;
     if (LAT) q_vec = to_vector_registers(q_arg);
     const StepDerived& q = LAT ? q_vec : q_arg;
@@ -1227,7 +1256,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         typedef __attribute__((address_space(4))) const int* karg_ip;
         karg_ip kb = (karg_ip)__builtin_amdgcn_kernarg_segment_ptr();
 #pragma unroll
-        for (int ln = 1; ln < (int)((sizeof(StepArgs) + 63) / 64); ++ln) karg_touch ^= kb[16 * ln];
+        for (int ln = 1; ln < (int)((offsetof(StepArgs, lt) + 63) / 64); ++ln) karg_touch ^= kb[16 * ln];   // (lt: read by the LDSG launch only)
 #endif
     }
     const LaneIds d = make_ids<W, ALLV>(blockIdx.x * kBlock, B, N);
@@ -1272,6 +1301,33 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         int zn;
         asm volatile("s_mov_b32 %0, 0" : "=s"(zn));
         qr_next = kernarg_reread<QRates>(offsetof(StepArgs, q) + offsetof(StepDerived, r), zn);
+    }
+    // LDSG: stage the lookup table — 16 sixteen-byte pieces per lane in flight at a time (two round trips for LOWW's 105 KB), behind
+    // the state loads issued above; the terms a step reads with the table go to vector registers like the other uniform terms (LAT)
+    LdsTab ltv = lt_arg;
+    const char* ltab = nullptr;
+    if (LDSG) {
+        uint4* dst = reinterpret_cast<uint4*>(smem + (kBlock / 64) * 64 * ATC_OBS_DIM);   // behind the observation transpose stage
+        const int n16 = lt_arg.n16;
+        constexpr int kDepth = 16;
+        for (int base = 0; base < n16; base += kDepth * kBlock) {
+            uint4 v[kDepth];
+#pragma unroll
+            for (int u = 0; u < kDepth; ++u) {
+                const int j = base + u * kBlock + (int)threadIdx.x;
+                v[u] = lt_arg.src[min(j, n16 - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < kDepth; ++u) {
+                const int j = base + u * kBlock + (int)threadIdx.x;
+                if (j < n16) dst[j] = v[u];
+            }
+        }
+        __syncthreads();
+        ltab = reinterpret_cast<const char*>(dst);
+        ltv.x0 = vg(lt_arg.x0); ltv.y0 = vg(lt_arg.y0); ltv.inv = vg(lt_arg.inv);
+        ltv.nx = vg(lt_arg.nx); ltv.nx_last = vg(lt_arg.nx_last); ltv.ny_last = vg(lt_arg.ny_last);
+        ltv.off_l1 = vg(lt_arg.off_l1); ltv.off_sub = vg(lt_arg.off_sub); ltv.off_line = vg(lt_arg.off_line); ltv.off_hts = vg(lt_arg.off_hts);
     }
     if (!ONE) {
         // The state loads are WAITED FOR here, before the step loop.  Left pending, "a state register may still be in flight" is
@@ -1338,8 +1394,8 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             mask_dirty = false;
         }
         ATC_STAMP_TOP(trow, 1);
-        const Mid m = step_part_a<ONE, LAT>(gl, qr, QGET(k), QGET(g), dl, tg.v, altitude_target(qr, tg.ah), tg.p, act.c, ls, es, repeated, !ONE && all_active,
-                                       st.phi_wide, zk, refused_blk, refused_known ATC_TRACE_PASS(trow));
+        const Mid m = step_part_a<ONE, LAT, LDSG>(gl, qr, QGET(k), QGET(g), dl, tg.v, altitude_target(qr, tg.ah), tg.p, act.c, ls, es, repeated, !ONE && all_active,
+                                             st.phi_wide, zk, refused_blk, refused_known ATC_TRACE_PASS(trow), ltab, &ltv);
         refused_known = true;
         ATC_STAMP(1);
         Float3 nxt = act;
@@ -1352,7 +1408,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
             act_t += (size_t)BN * 3;
             if (step + 1 < n_steps) act_next = act_t;
         }
-        const bool quiet = step_part_b<W, FULL, ONE, LAT>(Kl, gl, pl, q, qs, zk, N, dl, m, ls, es, so, stats_l, st.phi_wide, pos, obs_stage, act_next, nxt, qr_next, scan_skip, scan_mask);
+        const bool quiet = step_part_b<W, FULL, ONE, LAT, LDSG>(Kl, gl, pl, q, qs, zk, N, dl, m, ls, es, so, stats_l, st.phi_wide, pos, obs_stage, act_next, nxt, qr_next, scan_skip, scan_mask, ltab, &ltv);
         if (ATC_RARE(!quiet)) mask_dirty = true;
         if (act_next) tg = decode_targets(QGET(r), nxt);
         act = nxt;
@@ -1535,6 +1591,37 @@ k_query_mva(const float* __restrict__ blob, int off_grid, int n, const float* __
         if (out_idx) out_idx[i] = pi;
     }
 }
+// the same lookup through the LDS-resident table (atc_query_mva_lds): from_lds[i] = 1 where the table answered, 0 where the point's
+// WAVEFRONT went to the global grid (like in the step kernel: all of its lanes then take the grid's answer)
+__global__ void __launch_bounds__(kBlock, 1)
+k_query_mva_lds(const float* __restrict__ blob, int off_grid, LdsTab lt, int n, const float* __restrict__ x,
+                const float* __restrict__ y, int32_t* __restrict__ out_h, uint8_t* __restrict__ from_lds) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (int j = threadIdx.x; j < lt.n16; j += kBlock) dst[j] = lt.src[j];
+    __syncthreads();
+    const char* tab = reinterpret_cast<const char*>(dst);
+    const float* grid = blob + off_grid;
+    const GridHdr gh = grid_header(grid);
+    const int n_up = (n + 63) & ~63;   // whole wavefronts: the fallback is a wave-uniform decision
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_up; i += gridDim.x * kBlock) {
+        const bool live = i < n;
+        const float px = live ? x[i] : 0.0f, py = live ? y[i] : 0.0f;
+        const LdsCode lc = lds_cell_load(tab, lt, px, py);
+        float hgt;
+        bool resid;
+        int pi = lds_resolve(tab, lt, lc, px, py, &hgt, &resid);
+        const bool fallback = __builtin_amdgcn_ballot_w64(resid && live) != 0ull;
+        if (fallback) {
+            const MvaCell c = mva_cell_load(grid, gh, px, py);
+            pi = mva_resolve(blob, grid, gh, c, px, py, &hgt);
+        }
+        if (live) {
+            out_h[i] = pi >= 0 ? (int32_t)hgt : -1;
+            if (from_lds) from_lds[i] = fallback ? 0 : 1;
+        }
+    }
+}
 __global__ void __launch_bounds__(kBlock)
 k_query_corridor(const float* __restrict__ blob, int n, const float* __restrict__ x,
                  const float* __restrict__ y, const float* __restrict__ h, const float* __restrict__ phi, int angle_only,
@@ -1573,16 +1660,23 @@ static size_t lds_bytes(const atc_scenario*, bool pair_scan, bool step_kernel = 
     return w * sizeof(float);
 }
 
-template <int W, bool FULL, bool ONE, bool ALLV, bool LAT = false>
+template <int W, bool FULL, bool ONE, bool ALLV, bool LAT = false, bool LDSG = false>
 static int launch_step2(const atc_scenario* s, int B, int N, int T, int hold, const atc_state_t* st, const float* actions,
                         const atc_out_t* out, const atc_params_t* p, hipStream_t stream) {
-    const size_t lds = lds_bytes(s, W >= 32, true);
-    if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<W, FULL, ONE, ALLV, LAT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = lds_bytes(s, W >= 32, true) + (LDSG ? s->lds_tab_bytes : 0);
+    if (lds > 48 * 1024) {   // (once per device and instantiation: the attribute sticks)
+        static thread_local int raised_for = -1;
+        if (raised_for != s->device) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<W, FULL, ONE, ALLV, LAT, LDSG>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, s->max_lds));
+            raised_for = s->device;
+        }
+    }
     const long long slots = (long long)B * W;
     const int grid = (int)((slots + kBlock - 1) / kBlock);  // one workgroup per 256 slots, no grid-stride loop
-    hipLaunchKernelGGL((k_step<W, FULL, ONE, ALLV, LAT>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->off_grid, B, N, T, hold, *st, actions, *out, *p, derive(*p, s, scan_horizon<W, FULL, ONE>()), inline_action());
+    LdsTab lt = s->lt;
+    if (!LDSG) lt.src = nullptr;
+    hipLaunchKernelGGL((k_step<W, FULL, ONE, ALLV, LAT, LDSG>), dim3(grid), dim3(kBlock), lds, stream, s->d_blob, s->off_grid, B, N, T, hold, *st, actions, *out, *p, derive(*p, s, scan_horizon<W, FULL, ONE>()), inline_action(), lt);
     HIP_TRY(hipGetLastError());
     return ATC_OK;
 }
@@ -1599,6 +1693,12 @@ static int launch_step(const atc_scenario* s, int B, int N, int T, int hold, con
         if (full) return launch_step2<W, true, false, false>(s, B, N, T, hold, st, actions, out, p, stream);
         // at most ATC_LAT_WAVES wavefronts per SIMD: the latency-bound instantiation (uniform terms in vector registers)
         const bool lat = allv && ((long long)B * W + 63) / 64 <= (long long)ATC_LAT_WAVES * 4 * s->n_cu;
+        // ... of one-aircraft envs, at most one workgroup per CU, a lookup table attached: the table lives in LDS for the launch
+        if constexpr (W == 1) {
+            if (lat && s->lt.src && (long long)B <= (long long)kBlock * s->n_cu && s->off_grid &&
+                lds_bytes(s, false, true) + s->lds_tab_bytes <= (size_t)s->max_lds)
+                return launch_step2<1, false, false, true, true, true>(s, B, N, T, hold, st, actions, out, p, stream);
+        }
         if (lat) return launch_step2<W, false, false, true, true>(s, B, N, T, hold, st, actions, out, p, stream);
         return allv ? launch_step2<W, false, false, true>(s, B, N, T, hold, st, actions, out, p, stream)
                     : launch_step2<W, false, false, false>(s, B, N, T, hold, st, actions, out, p, stream);

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ATC_ABI_VERSION 20
+#define ATC_ABI_VERSION 21
 
 /* ---------------------------------------------------------------------------------------------
  * Scenario blob: one flat array of 32-bit floats (device copy) compiled on the host from the sector
@@ -127,6 +127,30 @@ enum { ATC_G_X0 = 0, ATC_G_Y0 = 1, ATC_G_INV = 2, ATC_G_NX = 3, ATC_G_NY = 4, AT
 #define ATC_GE_CERTAIN 2 /* the cell lies entirely left of this edge: crossing iff the two y tests pass */
 #define ATC_GE_LAST 4    /* last edge of a polygon whose bounds contain the whole cell: parity xor BASE decides now */
 #define ATC_GE_BASE 8    /* an odd number of the polygon's edges is crossed by EVERY point of the cell (not listed) */
+
+/* ---------------------------------------------------------------------------------------------
+ * LDS-resident lookup table (ABI 21, optional; atc_scenario_attach_lds_table).  A second, compact form of Airspace.find_mva
+ * (model.py:282-289) for the multi-step launches of ONE-aircraft envs that fit one workgroup per CU (65 536 x 1): each workgroup
+ * stages the table in LDS once per launch and a step then answers from LDS instead of gathering a lookup-grid cell from global
+ * memory (one wavefront per SIMD: that gather and the records behind it are 1.2 of the step's 2.9 us).  Same answers as the
+ * ordered polygon scan, by the construction of the lookup grid (atc_hip/scenario.py:build_lds_table):
+ *   bytes [0, 64)  : 16 header words, ATC_LDS_H_* (x0, y0, 1 / cell as fp32 patterns; offsets in bytes from the table's start)
+ *   level 1        : uint16 codes [ny][nx], cells of 1 / inv nm (0.5) over the padded sector; the outermost ring is 0
+ *   level 2        : uint16 codes [n_sub][8][8], the sub-cells of every level-1 cell of kind SUB
+ *   LINE records   : float [n_line][8] = p1x, p1y, dx/dy, margin | left polygon + 1, height, right polygon + 1, height (ATC_G_CELL_LINE)
+ *   heights        : float [64], index polygon + 1 ([0] = 0)
+ *   code           : bit 15 = the cell meets the bounds of the corridor's horizontal triangle (level 1 only); bits 14..13 = kind
+ *                    (ATC_LDS_CLEAN: payload = polygon + 1, 0 = outside; ATC_LDS_LINE: payload = LINE record; ATC_LDS_SUB, level 1
+ *                    only: payload = sub-cell block; ATC_LDS_RESID, level 2 only: no answer here); bits 12..0 = payload
+ * A lane without an answer (RESID, or a point inside a LINE record's margin band) sends its whole wavefront to the lookup grid for
+ * that step, so the table is only attached to a scenario that HAS a grid — and has no noise-abatement areas (the codes carry no
+ * candidate masks).  Results are identical with and without the table.
+ * ------------------------------------------------------------------------------------------- */
+#define ATC_LDS_MAGIC 0x3154444Cu /* "LDT1" */
+enum { ATC_LDS_H_MAGIC = 0, ATC_LDS_H_BYTES = 1, ATC_LDS_H_X0 = 2, ATC_LDS_H_Y0 = 3, ATC_LDS_H_INV = 4, ATC_LDS_H_NX = 5,
+       ATC_LDS_H_NY = 6, ATC_LDS_H_OFF_L1 = 7, ATC_LDS_H_OFF_SUB = 8, ATC_LDS_H_N_SUB = 9, ATC_LDS_H_OFF_LINE = 10,
+       ATC_LDS_H_N_LINE = 11, ATC_LDS_H_OFF_HTS = 12, ATC_LDS_H_SUB = 13, ATC_LDS_HDR_WORDS = 16 };
+enum { ATC_LDS_CLEAN = 0, ATC_LDS_LINE = 1, ATC_LDS_SUB = 2, ATC_LDS_RESID = 3 };
 
 #define ATC_MAX_AIRCRAFT 64
 #define ATC_OBS_DIM 10 /* atc_gym.py:262-277 */
@@ -390,6 +414,12 @@ const char* atc_last_error(void);
  * Replaces: AtcGym.__init__ scenario unpacking, atc_gym.py:45-58. */
 int atc_scenario_create(const float* blob_host, size_t n_words, int device, atc_scenario_t** out);
 int atc_scenario_destroy(atc_scenario_t* s);
+/* Attaches (copies to the device) an LDS-resident lookup table — see "LDS-resident lookup table" above — or detaches the current
+ * one (table_host == NULL).  Every code and offset is validated here; -1 if the table is malformed, larger than the device's LDS
+ * per workgroup, or the scenario has no lookup grid / has noise-abatement areas.  With a table attached, atc_rollout[_hold] of
+ * one-aircraft envs with at most 256 envs per CU of the device (65 536 on MI355X) stage it in LDS; every other launch ignores it.
+ * Not thread-safe against launches that use the same handle concurrently (attach before stepping). */
+int atc_scenario_attach_lds_table(atc_scenario_t* s, const void* table_host, size_t n_bytes);
 
 /* Zero-copy for latency-bound callers (the single-env AtcGym, atc_gym.py:128-192, whose step is one aircraft): every
  * state / action / output pointer may also address pinned host memory (hipHostMalloc, e.g. a torch tensor with
@@ -406,6 +436,10 @@ int atc_query_mva(const atc_scenario_t* s, int n, const float* x, const float* y
 /* Airspace.find_mva, model.py:282-289: out_idx[i] = index of the MVA polygon in list order, or -1. */
 int atc_query_mva_index(const atc_scenario_t* s, int n, const float* x, const float* y, int32_t* out_idx, int use_grid,
                         void* stream);
+/* Airspace.get_mva_height through the attached LDS table (diagnostic / test entry): out_h as atc_query_mva; from_lds[i] (may be
+ * NULL) = 1 where the table answered, 0 where the point's wavefront (64 consecutive points) went to the lookup grid. */
+int atc_query_mva_lds(const atc_scenario_t* s, int n, const float* x, const float* y, int32_t* out_h, uint8_t* from_lds,
+                      void* stream);
 /* Runway.inside_corridor, model.py:248-257,188-231.  angle_only != 0 evaluates Corridor._inside_corridor_angle
  * (model.py:212-231) alone.  out[i] = 0/1. */
 int atc_query_corridor(const atc_scenario_t* s, int n, const float* x, const float* y, const float* h,
