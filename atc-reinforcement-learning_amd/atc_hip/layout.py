@@ -61,6 +61,6 @@ LA_V, LA_PHI, LA_H, LA_WORDS = 0, 1, 2, 4
 # LDS-resident lookup table (include/atc_step.h: ATC_LDS_*)
 LDS_MAGIC = 0x3154444C
 (LDS_H_MAGIC, LDS_H_BYTES, LDS_H_X0, LDS_H_Y0, LDS_H_INV, LDS_H_NX, LDS_H_NY, LDS_H_OFF_L1, LDS_H_OFF_SUB, LDS_H_N_SUB, LDS_H_OFF_LINE,
- LDS_H_N_LINE, LDS_H_OFF_HTS, LDS_H_SUB) = range(14)
-LDS_HDR_WORDS = 16
+ LDS_H_N_LINE, LDS_H_OFF_HTS, LDS_H_SUB, LDS_H_OFF_RESID, LDS_H_N_RESID, LDS_H_LDS_BYTES, LDS_H_OFF_POOL, LDS_H_N_REC) = range(19)
+LDS_HDR_WORDS = 24
 LDS_CLEAN, LDS_LINE, LDS_SUB, LDS_RESID = 0, 1, 2, 3

@@ -485,11 +485,13 @@ def _near_any_edge(rings, x0s, x1s, y0s, y1s):
 
 def _classify_boxes(x0, x1, y0, y1, slack, rings, edges, bounds, heights, lines):
     """Kind and payload of each box [x0, x1] x [y0, y1] (inflated by `slack` here): CLEAN / LINE / RESID (a level-1 caller turns
-    RESID into SUB).  `lines`: dict LINE record (8 float32 words as bytes) -> index, extended in place."""
+    RESID into SUB).  `lines`: dict LINE record (8 float32 words as bytes) -> index, extended in place.  Also returns the record
+    list (build_grid's edge records, _box_records) of every RESID box."""
     x0s, x1s, y0s, y1s = x0 - slack, x1 + slack, y0 - slack, y1 + slack
     n = len(x0)
     kind = np.zeros(n, dtype=np.int64)
     payload = np.zeros(n, dtype=np.int64)
+    walks = {}
     near = _near_any_edge(rings, x0s, x1s, y0s, y1s)
     far = np.nonzero(~near)[0]
     pis = _first_polygon_many(0.5 * (x0[far] + x1[far]), 0.5 * (y0[far] + y1[far]), rings, bounds)
@@ -505,20 +507,22 @@ def _classify_boxes(x0, x1, y0, y1, slack, rings, edges, bounds, heights, lines)
         split = _line_split(recs, y0s[d], y1s[d], heights)
         if split is None:
             kind[d] = LDS_KIND_RESID
+            walks[int(d)] = recs
             continue
         key = np.asarray(split, dtype=np.float32).tobytes()
         if key not in lines:
             lines[key] = len(lines)
         kind[d] = LDS_KIND_LINE
         payload[d] = lines[key]
-    return kind, payload
+    return kind, payload, walks
 
 
 def build_lds_table(rings, bounds, heights, bbox, corridor_bounds=None, cell=0.5, sub=8, guard=None):
     """The LDS-resident lookup table (see above) as a uint8 array, or None when the sector does not fit its 13-bit payloads.
-    Layout: 16 header words (magic, bytes, x0, y0, 1 / cell as fp32, nx, ny, off_l1, off_sub, n_sub, off_line, n_line, off_hts, sub,
-    0, 0; offsets in bytes), level-1 codes u16[ny * nx], sub-cell codes u16[n_sub][sub * sub], LINE records f32[n_line][8], heights
-    f32[64] (index polygon + 1; [0] = 0)."""
+    Layout (include/atc_step.h: ATC_LDS_H_*): 24 header words (offsets in bytes), then — the part a workgroup stages in LDS —
+    level-1 codes u16[ny * nx], sub-cell codes u16[n_sub][sub * sub], LINE records f32[n_line][8], heights f32[64] (index
+    polygon + 1; [0] = 0), the RESIDUAL sub-cells' walk words u32[n_resid] (first record | n_records << 24); behind it, read from
+    global memory: the pool of those sub-cells' edge records f32[n_rec][8] (build_grid's format, walked by mva_walk)."""
     if guard is None:
         guard = 1e-3
     assert sub == 8, "the kernel's sub-cell index is three bits per axis"
@@ -529,25 +533,35 @@ def build_lds_table(rings, bounds, heights, bbox, corridor_bounds=None, cell=0.5
     gx0, gy0 = x0 - 2 * cell, y0 - 2 * cell
     nx = int(math.ceil((x1 - gx0) / cell)) + 2
     ny = int(math.ceil((y1 - gy0) / cell)) + 2
-    if nx * ny >= 1 << 22 or len(rings) > 62:
+    if nx >= 1 << 11 or ny >= 1 << 11 or len(rings) > 62:
         return None
     slack = guard + 1e-4 * max(1.0, abs(x1), abs(y1)) * 2.0 ** -10
     assert slack < 0.5 * cell / sub
     edges = [_ring_edges(r) for r in rings]
     lines = {}
     jj, ii = np.divmod(np.arange(nx * ny), nx)
-    k1, p1 = _classify_boxes(gx0 + ii * cell, gx0 + (ii + 1) * cell, gy0 + jj * cell, gy0 + (jj + 1) * cell, slack,
-                             rings, edges, bounds, heights, lines)
+    k1, p1, _ = _classify_boxes(gx0 + ii * cell, gx0 + (ii + 1) * cell, gy0 + jj * cell, gy0 + (jj + 1) * cell, slack,
+                                rings, edges, bounds, heights, lines)
     resid = np.nonzero(k1 == LDS_KIND_RESID)[0]
     n_sub = len(resid)
     sj, si = np.divmod(np.arange(sub * sub), sub)
     sc = cell / sub
     bx = (gx0 + ii[resid] * cell)[:, None] + si[None, :] * sc     # sub-cell s of block r: [bx, bx + sc] x [by, by + sc]
     by = (gy0 + jj[resid] * cell)[:, None] + sj[None, :] * sc
-    k2, p2 = _classify_boxes(bx.ravel(), bx.ravel() + sc, by.ravel(), by.ravel() + sc, slack, rings, edges, bounds, heights, lines)
+    k2, p2, walks = _classify_boxes(bx.ravel(), bx.ravel() + sc, by.ravel(), by.ravel() + sc, slack, rings, edges, bounds,
+                                    heights, lines)
     k1[resid] = LDS_KIND_SUB
     p1[resid] = np.arange(n_sub)
-    if n_sub >= 1 << 13 or len(lines) >= 1 << 13:
+    # RESIDUAL sub-cells: their edge records go to a pool in global memory, one walk word each stays in LDS
+    pool, walk_words = [], []
+    for d in sorted(walks):
+        recs = walks[d]
+        if len(recs) >= 64:
+            return None
+        p2[d] = len(walk_words)
+        walk_words.append(len(pool) | (len(recs) << 24))
+        pool.extend(recs)
+    if n_sub >= 1 << 13 or len(lines) >= 1 << 13 or len(walk_words) >= 1 << 13 or len(pool) >= 1 << 24:
         return None
     code1 = (k1 << 13) | p1
     if corridor_bounds is not None:   # the (inflated) cell meets the bounds of the corridor's horizontal triangle (model.py:198)
@@ -564,6 +578,8 @@ def build_lds_table(rings, bounds, heights, bbox, corridor_bounds=None, cell=0.5
         line_arr[i] = np.frombuffer(key, dtype=np.float32)
     hts = np.zeros(64, dtype=np.float32)
     hts[1:1 + len(heights)] = np.asarray(heights, dtype=np.float32)
+    walk_arr = np.asarray(walk_words, dtype=np.uint32)
+    pool_arr = np.asarray(pool, dtype=np.float32).reshape(-1, GRID_EDGE_WORDS)
 
     def pad16(n):
         return (n + 15) & ~15
@@ -571,33 +587,73 @@ def build_lds_table(rings, bounds, heights, bbox, corridor_bounds=None, cell=0.5
     off_sub = pad16(off_l1 + 2 * nx * ny)
     off_line = pad16(off_sub + 2 * len(code2))
     off_hts = off_line + line_arr.nbytes
-    total = pad16(off_hts + hts.nbytes)
+    off_resid = off_hts + hts.nbytes
+    lds_bytes = pad16(off_resid + walk_arr.nbytes)
+    off_pool = lds_bytes
+    total = pad16(off_pool + pool_arr.nbytes)
     t = np.zeros(total, dtype=np.uint8)
     hdr = np.zeros(LDS_HDR_WORDS, dtype=np.uint32)
-    hdr[0], hdr[1] = LDS_MAGIC, total
-    hdr[2:5] = np.array([gx0, gy0, 1.0 / cell], dtype=np.float32).view(np.uint32)
-    hdr[5:14] = (nx, ny, off_l1, off_sub, n_sub, off_line, len(line_arr), off_hts, sub)
+    hdr[L.LDS_H_MAGIC], hdr[L.LDS_H_BYTES] = LDS_MAGIC, total
+    hdr[L.LDS_H_X0:L.LDS_H_X0 + 3] = np.array([gx0, gy0, 1.0 / cell], dtype=np.float32).view(np.uint32)
+    for k, v in ((L.LDS_H_NX, nx), (L.LDS_H_NY, ny), (L.LDS_H_OFF_L1, off_l1), (L.LDS_H_OFF_SUB, off_sub), (L.LDS_H_N_SUB, n_sub),
+                 (L.LDS_H_OFF_LINE, off_line), (L.LDS_H_N_LINE, len(line_arr)), (L.LDS_H_OFF_HTS, off_hts), (L.LDS_H_SUB, sub),
+                 (L.LDS_H_OFF_RESID, off_resid), (L.LDS_H_N_RESID, len(walk_arr)), (L.LDS_H_LDS_BYTES, lds_bytes),
+                 (L.LDS_H_OFF_POOL, off_pool), (L.LDS_H_N_REC, len(pool_arr))):
+        hdr[k] = v
     t[:off_l1] = hdr.view(np.uint8)
     t[off_l1:off_l1 + 2 * nx * ny] = code1.astype(np.uint16).view(np.uint8)
     t[off_sub:off_sub + 2 * len(code2)] = code2.astype(np.uint16).view(np.uint8)
     t[off_line:off_line + line_arr.nbytes] = line_arr.ravel().view(np.uint8)
     t[off_hts:off_hts + hts.nbytes] = hts.view(np.uint8)
+    t[off_resid:off_resid + walk_arr.nbytes] = walk_arr.view(np.uint8)
+    t[off_pool:off_pool + pool_arr.nbytes] = pool_arr.ravel().view(np.uint8)
     return t
 
 
+def _walk_records_f32(recs, x, y):
+    """mva_walk (csrc/atc_device.h) for ONE point, the same fp32 operations: (polygon index or -1, height)."""
+    f32 = np.float32
+    inside = False
+    with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+        for r in recs:
+            code = int(r[7])
+            ok = True
+            if code & 1:     # terminator: polygon bounds
+                decide = True
+                ok = bool(r[0] <= x <= r[2] and r[1] <= y <= r[3])
+            else:
+                if y > r[4] and y <= r[5] and x <= max(r[0], r[2]):
+                    cross = bool(code & 2)
+                    if not cross:
+                        xints = f32(f32(f32(f32(y - r[1]) * f32(r[2] - r[0])) / f32(r[3] - r[1])) + r[0])
+                        cross = bool(r[0] == r[2] or x <= xints)
+                    inside = inside != cross
+                decide = bool(code & 4)
+            if decide:
+                if inside != bool(code & 8) and ok:
+                    return code >> 4, r[6]
+                inside = False
+    return -1, f32(0)
+
+
 def lds_table_lookup(table, x, y):
-    """numpy restatement of the kernel's LDS lookup (csrc/atc_device.h: lds_lookup), the same fp32 operations: returns (polygon + 1
-    or -1 where the kernel falls back to the global grid, height, corridor candidate)."""
+    """numpy restatement of the kernel's LDS lookup (csrc/atc_device.h: lds_cell_load / lds_resolve + the walk of a RESIDUAL
+    sub-cell's records), the same fp32 operations: returns (polygon + 1 — or -1 where the kernel sends the wavefront to the
+    lookup grid: a point inside a LINE record's margin band —, height, corridor candidate, answered-by-a-walk)."""
     f32 = np.float32
     t = np.asarray(table, dtype=np.uint8)
     hdr = t[:4 * LDS_HDR_WORDS].view(np.uint32)
-    assert hdr[0] == LDS_MAGIC and hdr[1] == len(t)
-    gx0, gy0, inv = hdr[2:5].view(np.float32)
-    nx, ny, off_l1, off_sub, n_sub, off_line, n_line, off_hts, sub = (int(v) for v in hdr[5:14])
+    assert hdr[L.LDS_H_MAGIC] == LDS_MAGIC and hdr[L.LDS_H_BYTES] == len(t)
+    gx0, gy0, inv = hdr[L.LDS_H_X0:L.LDS_H_X0 + 3].view(np.float32)
+    nx, ny, off_l1, off_sub, n_sub, off_line, n_line, off_hts, sub, off_resid, n_resid, off_pool, n_rec = (
+        int(hdr[k]) for k in (L.LDS_H_NX, L.LDS_H_NY, L.LDS_H_OFF_L1, L.LDS_H_OFF_SUB, L.LDS_H_N_SUB, L.LDS_H_OFF_LINE, L.LDS_H_N_LINE,
+                              L.LDS_H_OFF_HTS, L.LDS_H_SUB, L.LDS_H_OFF_RESID, L.LDS_H_N_RESID, L.LDS_H_OFF_POOL, L.LDS_H_N_REC))
     l1 = t[off_l1:off_l1 + 2 * nx * ny].view(np.uint16)
-    l2 = t[off_sub:off_sub + 2 * max(1, n_sub) * sub * sub].view(np.uint16) if n_sub else np.zeros(64, dtype=np.uint16)
+    l2 = t[off_sub:off_sub + 2 * n_sub * sub * sub].view(np.uint16) if n_sub else np.zeros(64, dtype=np.uint16)
     lines = t[off_line:off_line + 32 * n_line].view(np.float32).reshape(-1, 8)
     hts = t[off_hts:off_hts + 256].view(np.float32)
+    walk_words = t[off_resid:off_resid + 4 * n_resid].view(np.uint32)
+    pool = t[off_pool:off_pool + 32 * n_rec].view(np.float32).reshape(-1, 8)
     x = np.asarray(x, dtype=f32)
     y = np.asarray(y, dtype=f32)
 
@@ -625,9 +681,15 @@ def lds_table_lookup(table, x, y):
     decided = (kind == LDS_KIND_LINE) & (left | right)
     clean = kind == LDS_KIND_CLEAN
     code = np.where(clean, pay, np.where(left, rec[:, 4], rec[:, 6]).astype(np.int64))
-    h = np.where(clean, hts[np.where(clean, pay, 0)], np.where(left, rec[:, 5], rec[:, 7]))
+    h = np.where(clean, hts[np.where(clean, pay, 0)], np.where(left, rec[:, 5], rec[:, 7])).astype(f32)
     ok = clean | decided
-    return np.where(ok, code, -1), np.where(ok, h, f32(0)), cand
+    walked = kind == LDS_KIND_RESID
+    for i in np.nonzero(walked)[0]:
+        w = int(walk_words[pay[i]])
+        pi, hh = _walk_records_f32(pool[(w & 0xffffff):(w & 0xffffff) + (w >> 24)], x[i], y[i])
+        code[i], h[i] = pi + 1, hh
+    ok = ok | walked
+    return np.where(ok, code, -1), np.where(ok, h, f32(0)), cand, walked
 
 
 _SOURCE_TAG = None

@@ -424,7 +424,8 @@ struct LdsTab {             // kernel argument: where the table lives in global 
     int n16;
     float x0, y0, inv;      // level-1 origin and 1 / cell
     int nx, nx_last, ny_last;
-    int off_l1, off_sub, off_line, off_hts;   // byte offsets from the table's start
+    int off_l1, off_sub, off_line, off_hts, off_resid;   // byte offsets from the table's start (the staged part)
+    const char* pool;       // edge records of the RESIDUAL sub-cells (global memory, the lookup grid's record format)
 };
 struct LdsCode {
     uint32_t c1, sub;       // level-1 code, sub-cell index sy * 8 + sx
@@ -442,9 +443,10 @@ __device__ __forceinline__ LdsCode lds_cell_load(const char* tab, const LdsTab& 
     c.sub = sy * 8u + sx;
     return c;
 }
-// second half: polygon index (-1: outside) + height like mva_resolve; *resid: this lane has no answer here (the caller asks the grid)
+// second half: polygon index (-1: outside) + height like mva_resolve.  *walk != 0: a RESIDUAL sub-cell — the lane walks that word's
+// records (lds_walk); *band: inside a LINE record's margin band — no answer here (the caller asks the grid)
 __device__ __forceinline__ int lds_resolve(const char* tab, const LdsTab& t, const LdsCode& lc, float x, float y, float* height,
-                                           bool* resid) {
+                                           uint32_t* walk, bool* band) {
     const uint32_t c1 = lc.c1;
     const bool is_sub = ((c1 >> 13) & 3u) == (uint32_t)ATC_LDS_SUB;
     const uint32_t sidx = is_sub ? (c1 & 0x1fffu) * 64u + lc.sub : 0u;   // (lanes without a refined cell read sub-cell 0 and discard it)
@@ -456,13 +458,21 @@ __device__ __forceinline__ int lds_resolve(const char* tab, const LdsTab& t, con
     // LINE record (atc_hip/scenario.py:_line_split): p1x, p1y, dx/dy, margin | left polygon + 1, height, right polygon + 1, height
     const float4 g = *reinterpret_cast<const float4*>(tab + ((uint32_t)t.off_line + 32u * li));
     const float4 m = *reinterpret_cast<const float4*>(tab + ((uint32_t)t.off_line + 32u * li + 16u));
-    const float hc = *reinterpret_cast<const float*>(tab + ((uint32_t)t.off_hts + 4u * (clean ? pay : 0u)));
+    const bool resid = kind == (uint32_t)ATC_LDS_RESID;
+    // ONE 4-byte read for both: a clean cell's height or a residual sub-cell's walk word (the sections are neighbours)
+    const uint32_t w4 = *reinterpret_cast<const uint32_t*>(tab + (resid ? (uint32_t)t.off_resid + 4u * pay : (uint32_t)t.off_hts + 4u * (clean ? pay : 0u)));
+    const float hc = __uint_as_float(w4);
     const float xl = fmaf(y - g.y, g.z, g.x);
     const bool left = x < xl - g.w, right = x > xl + g.w;
     const bool decided = is_line && (left || right);
     *height = clean ? hc : (left ? m.y : m.w);
-    *resid = !(clean || decided);
+    *walk = resid ? w4 : 0u;    // (a walk word is never 0: n_records >= 1)
+    *band = is_line && !decided;
     return (clean ? (int)pay : (int)(left ? m.x : m.z)) - 1;
+}
+// the walk of a RESIDUAL sub-cell's records (word = first record | n << 24): ONE batch of four records covers nine lists in ten
+__device__ __forceinline__ int lds_walk(const LdsTab& t, uint32_t word, float x, float y, float* height) {
+    return mva_walk<4>(t.pool, 32u * (word & 0xffffffu), (int)(word >> 24), x, y, height);
 }
 __device__ __forceinline__ bool lds_corridor_candidate(const LdsCode& lc) { return (lc.c1 & 0x8000u) != 0u; }
 

@@ -961,12 +961,18 @@ __device__ __forceinline__ bool step_part_b(const float* __restrict__ K, const f
     if (LDSG) {
         // the LDS-resident table (csrc/atc_device.h: lds_resolve); the host attaches one only to sectors without noise-abatement areas
         float hgt = 0.0f;
-        bool resid;
-        pi = lds_resolve(ltab, *lt, m.lc, x32, y32, &hgt, &resid);
-        if (ATC_RARE(__builtin_amdgcn_ballot_w64(resid) != 0ull)) {   // some lane has no answer there: the wavefront asks the grid
+        uint32_t walk;
+        bool band;
+        pi = lds_resolve(ltab, *lt, m.lc, x32, y32, &hgt, &walk, &band);
+        if (ATC_RARE(__builtin_amdgcn_ballot_w64(walk != 0u) != 0ull)) {   // a vertex sub-cell: those lanes walk its records (one trip)
+            if (walk != 0u) pi = lds_walk(*lt, walk, x32, y32, &hgt);
+            asm volatile("" : "+v"(pi), "+v"(hgt));   // (waited for inside the rare block: see wide_view)
+        }
+        if (ATC_RARE(__builtin_amdgcn_ballot_w64(band) != 0ull)) {   // inside a line's margin band: the wavefront asks the grid
             const GridHdr gh = QGET(g.gh);
             const MvaCell c = mva_cell_load(grid, gh, x32, y32);
             pi = mva_resolve<kWalkBatch>(K, grid, gh, c, x32, y32, &hgt);
+            asm volatile("" : "+v"(pi), "+v"(hgt));
         }
         mva = hgt;
     } else if (kResolveAfterScan) {
@@ -1309,7 +1315,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
     if (LDSG) {
         uint4* dst = reinterpret_cast<uint4*>(smem + (kBlock / 64) * 64 * ATC_OBS_DIM);   // behind the observation transpose stage
         const int n16 = lt_arg.n16;
-        constexpr int kDepth = 16;
+        constexpr int kDepth = 28;   // (LOWW: 6 713 pieces = ONE batch of 28 x 256)
         for (int base = 0; base < n16; base += kDepth * kBlock) {
             uint4 v[kDepth];
 #pragma unroll
@@ -1317,6 +1323,10 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
                 const int j = base + u * kBlock + (int)threadIdx.x;
                 v[u] = lt_arg.src[min(j, n16 - 1)];
             }
+            // (every load is USED here, unconditionally: left to the conditional stores below, the compiler sinks each load into its
+            // store's exec-mask region — one round trip per piece instead of one per batch)
+#pragma unroll
+            for (int u = 0; u < kDepth; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
 #pragma unroll
             for (int u = 0; u < kDepth; ++u) {
                 const int j = base + u * kBlock + (int)threadIdx.x;
@@ -1328,6 +1338,7 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         ltv.x0 = vg(lt_arg.x0); ltv.y0 = vg(lt_arg.y0); ltv.inv = vg(lt_arg.inv);
         ltv.nx = vg(lt_arg.nx); ltv.nx_last = vg(lt_arg.nx_last); ltv.ny_last = vg(lt_arg.ny_last);
         ltv.off_l1 = vg(lt_arg.off_l1); ltv.off_sub = vg(lt_arg.off_sub); ltv.off_line = vg(lt_arg.off_line); ltv.off_hts = vg(lt_arg.off_hts);
+        ltv.off_resid = vg(lt_arg.off_resid);
     }
     if (!ONE) {
         // The state loads are WAITED FOR here, before the step loop.  Left pending, "a state register may still be in flight" is
@@ -1591,8 +1602,9 @@ k_query_mva(const float* __restrict__ blob, int off_grid, int n, const float* __
         if (out_idx) out_idx[i] = pi;
     }
 }
-// the same lookup through the LDS-resident table (atc_query_mva_lds): from_lds[i] = 1 where the table answered, 0 where the point's
-// WAVEFRONT went to the global grid (like in the step kernel: all of its lanes then take the grid's answer)
+// the same lookup through the LDS-resident table (atc_query_mva_lds): from_lds[i] = 1 where the table (or the walk of a residual
+// sub-cell's records) answered, 0 where the point's WAVEFRONT went to the global grid (like in the step kernel: all of its lanes
+// then take the grid's answer)
 __global__ void __launch_bounds__(kBlock, 1)
 k_query_mva_lds(const float* __restrict__ blob, int off_grid, LdsTab lt, int n, const float* __restrict__ x,
                 const float* __restrict__ y, int32_t* __restrict__ out_h, uint8_t* __restrict__ from_lds) {
@@ -1609,9 +1621,11 @@ k_query_mva_lds(const float* __restrict__ blob, int off_grid, LdsTab lt, int n, 
         const float px = live ? x[i] : 0.0f, py = live ? y[i] : 0.0f;
         const LdsCode lc = lds_cell_load(tab, lt, px, py);
         float hgt;
-        bool resid;
-        int pi = lds_resolve(tab, lt, lc, px, py, &hgt, &resid);
-        const bool fallback = __builtin_amdgcn_ballot_w64(resid && live) != 0ull;
+        uint32_t walk;
+        bool band;
+        int pi = lds_resolve(tab, lt, lc, px, py, &hgt, &walk, &band);
+        if (walk != 0u) pi = lds_walk(lt, walk, px, py, &hgt);
+        const bool fallback = __builtin_amdgcn_ballot_w64(band && live) != 0ull;
         if (fallback) {
             const MvaCell c = mva_cell_load(grid, gh, px, py);
             pi = mva_resolve(blob, grid, gh, c, px, py, &hgt);

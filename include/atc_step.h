@@ -134,22 +134,28 @@ enum { ATC_G_X0 = 0, ATC_G_Y0 = 1, ATC_G_INV = 2, ATC_G_NX = 3, ATC_G_NY = 4, AT
  * stages the table in LDS once per launch and a step then answers from LDS instead of gathering a lookup-grid cell from global
  * memory (one wavefront per SIMD: that gather and the records behind it are 1.2 of the step's 2.9 us).  Same answers as the
  * ordered polygon scan, by the construction of the lookup grid (atc_hip/scenario.py:build_lds_table):
- *   bytes [0, 64)  : 16 header words, ATC_LDS_H_* (x0, y0, 1 / cell as fp32 patterns; offsets in bytes from the table's start)
+ *   bytes [0, 96)  : 24 header words, ATC_LDS_H_* (x0, y0, 1 / cell as fp32 patterns; offsets in bytes from the table's start)
+ *   -- staged in LDS (bytes [0, ATC_LDS_H_LDS_BYTES)) --
  *   level 1        : uint16 codes [ny][nx], cells of 1 / inv nm (0.5) over the padded sector; the outermost ring is 0
  *   level 2        : uint16 codes [n_sub][8][8], the sub-cells of every level-1 cell of kind SUB
  *   LINE records   : float [n_line][8] = p1x, p1y, dx/dy, margin | left polygon + 1, height, right polygon + 1, height (ATC_G_CELL_LINE)
  *   heights        : float [64], index polygon + 1 ([0] = 0)
+ *   walk words     : uint32 [n_resid] = first record | n_records << 24 of a RESID sub-cell's edge records in the pool
+ *   -- read from global memory --
+ *   pool           : float [n_rec][8], edge / terminator records in the lookup grid's format ("pool" above)
  *   code           : bit 15 = the cell meets the bounds of the corridor's horizontal triangle (level 1 only); bits 14..13 = kind
  *                    (ATC_LDS_CLEAN: payload = polygon + 1, 0 = outside; ATC_LDS_LINE: payload = LINE record; ATC_LDS_SUB, level 1
- *                    only: payload = sub-cell block; ATC_LDS_RESID, level 2 only: no answer here); bits 12..0 = payload
- * A lane without an answer (RESID, or a point inside a LINE record's margin band) sends its whole wavefront to the lookup grid for
- * that step, so the table is only attached to a scenario that HAS a grid — and has no noise-abatement areas (the codes carry no
- * candidate masks).  Results are identical with and without the table.
+ *                    only: payload = sub-cell block; ATC_LDS_RESID, level 2 only: a vertex or a second border inside the sub-cell,
+ *                    payload = walk word); bits 12..0 = payload
+ * A lane in a RESID sub-cell walks its records (ONE trip to global memory for the lanes concerned); a point inside a LINE record's
+ * margin band sends its whole wavefront to the lookup grid for that step, so the table is only attached to a scenario that HAS a
+ * grid — and has no noise-abatement areas (the codes carry no candidate masks).  Results are identical with and without the table.
  * ------------------------------------------------------------------------------------------- */
 #define ATC_LDS_MAGIC 0x3154444Cu /* "LDT1" */
 enum { ATC_LDS_H_MAGIC = 0, ATC_LDS_H_BYTES = 1, ATC_LDS_H_X0 = 2, ATC_LDS_H_Y0 = 3, ATC_LDS_H_INV = 4, ATC_LDS_H_NX = 5,
        ATC_LDS_H_NY = 6, ATC_LDS_H_OFF_L1 = 7, ATC_LDS_H_OFF_SUB = 8, ATC_LDS_H_N_SUB = 9, ATC_LDS_H_OFF_LINE = 10,
-       ATC_LDS_H_N_LINE = 11, ATC_LDS_H_OFF_HTS = 12, ATC_LDS_H_SUB = 13, ATC_LDS_HDR_WORDS = 16 };
+       ATC_LDS_H_N_LINE = 11, ATC_LDS_H_OFF_HTS = 12, ATC_LDS_H_SUB = 13, ATC_LDS_H_OFF_RESID = 14, ATC_LDS_H_N_RESID = 15,
+       ATC_LDS_H_LDS_BYTES = 16, ATC_LDS_H_OFF_POOL = 17, ATC_LDS_H_N_REC = 18, ATC_LDS_HDR_WORDS = 24 };
 enum { ATC_LDS_CLEAN = 0, ATC_LDS_LINE = 1, ATC_LDS_SUB = 2, ATC_LDS_RESID = 3 };
 
 #define ATC_MAX_AIRCRAFT 64

@@ -39,16 +39,19 @@ def test_table_lookup_equals_fp32_oracle(scen):
     assert tab is not None and tab.dtype == np.uint8 and len(tab) % 16 == 0
     pts = _points(comp, np.random.default_rng(3), 1500000)
     exp = O.OracleQueries(comp, np.float32).mva(pts[:, 0], pts[:, 1])
-    code, h, cand = S.lds_table_lookup(tab, pts[:, 0], pts[:, 1])
+    code, h, cand, walked = S.lds_table_lookup(tab, pts[:, 0], pts[:, 1])
     ok = code >= 0
     assert np.array_equal(_heights(code, h)[ok], exp[ok])
-    # ... and it answers nearly everything: a uniformly placed aircraft inside LOWW is residual in 0.24 % of the cases (the sub-cells
-    # around the vertices); the test sectors' HORIZONTAL borders have no LINE form (the crossing test never counts such an edge,
-    # model.py:328-329: the border is the y tests of its neighbours) and stay residual along their whole length
+    assert walked.sum() > 1000 and np.array_equal(_heights(code, h)[walked], exp[walked])   # (the residual sub-cells' record walks)
+    # ... and it answers nearly everything: a uniformly placed aircraft inside LOWW walks records in 0.2 % of the cases (the sub-cells
+    # around the vertices) and is inside a line's margin band — the wavefront asks the grid — in 0.04 %; the test sectors'
+    # HORIZONTAL borders have no LINE form (the crossing test never counts such an edge, model.py:328-329: the border is the y tests
+    # of its neighbours): sub-cells along them are residual over their whole length
     n = 1500000
     inside = exp[:n] >= 0
     assert inside.sum() > 100000
-    assert (~ok[:n] & inside).sum() <= (0.004 if scen == "LOWW" else 0.02) * inside.sum()
+    assert (~ok[:n] & inside).sum() <= 0.001 * inside.sum()
+    assert (walked[:n] & inside).sum() <= (0.004 if scen == "LOWW" else 0.02) * inside.sum()
     # the corridor candidate bit covers the bounds of the corridor's horizontal triangle (model.py:198)
     th = comp.corridor["tri_h"]
     inb = (pts[:, 0] >= th[:, 0].min()) & (pts[:, 0] <= th[:, 0].max()) & (pts[:, 1] >= th[:, 1].min()) & (pts[:, 1] <= th[:, 1].max())
@@ -67,9 +70,9 @@ def test_table_lookup_on_random_sectors(seed, n_poly):
     assert tab is not None
     pts = _points(comp, np.random.default_rng(100 + seed), 300000, per_edge=60)
     exp = O.OracleQueries(comp, np.float32).mva(pts[:, 0], pts[:, 1])
-    code, h, _ = S.lds_table_lookup(tab, pts[:, 0], pts[:, 1])
+    code, h, _, walked = S.lds_table_lookup(tab, pts[:, 0], pts[:, 1])
     ok = code >= 0
-    assert ok.mean() > 0.8
+    assert ok.mean() > 0.9 and walked.sum() > 100
     assert np.array_equal(_heights(code, h)[ok], exp[ok])
 
 
@@ -79,9 +82,13 @@ def test_table_structure():
     assert tab is comp.lds_table()      # built once
     hdr = tab[:4 * L.LDS_HDR_WORDS].view(np.uint32)
     assert hdr[L.LDS_H_MAGIC] == L.LDS_MAGIC and hdr[L.LDS_H_BYTES] == len(tab) and hdr[L.LDS_H_SUB] == 8
-    assert len(tab) + 10240 <= 160 * 1024, "LOWW's table and the observation stage fit the LDS of one gfx950 CU"
     nx, ny, off_l1, off_sub, n_sub, off_line, n_line = (int(hdr[k]) for k in (L.LDS_H_NX, L.LDS_H_NY, L.LDS_H_OFF_L1, L.LDS_H_OFF_SUB,
                                                                                L.LDS_H_N_SUB, L.LDS_H_OFF_LINE, L.LDS_H_N_LINE))
+    off_resid, n_resid, lds_part, off_pool, n_rec = (int(hdr[k]) for k in (L.LDS_H_OFF_RESID, L.LDS_H_N_RESID, L.LDS_H_LDS_BYTES,
+                                                                           L.LDS_H_OFF_POOL, L.LDS_H_N_REC))
+    assert lds_part + 10240 <= 160 * 1024 and off_pool >= lds_part and off_pool + 32 * n_rec <= len(tab)
+    ww = tab[off_resid:off_resid + 4 * n_resid].view(np.uint32)
+    assert np.all((ww >> 24) >= 1) and np.all((ww & 0xffffff) + (ww >> 24) <= n_rec)
     l1 = tab[off_l1:off_l1 + 2 * nx * ny].view(np.uint16).reshape(ny, nx)
     assert not l1[0].any() and not l1[-1].any() and not l1[:, 0].any() and not l1[:, -1].any()
     k1, p1 = (l1 >> 13) & 3, l1 & 0x1fff
@@ -90,6 +97,7 @@ def test_table_structure():
     l2 = tab[off_sub:off_sub + 2 * 64 * n_sub].view(np.uint16)
     k2, p2 = (l2 >> 13) & 3, l2 & 0x1fff
     assert not (k2 == L.LDS_SUB).any() and not (l2 & 0x8000).any() and np.all(p2[k2 == L.LDS_LINE] < n_line)
+    assert sorted(p2[k2 == L.LDS_RESID].tolist()) == list(range(n_resid))
     assert np.all(p1[k1 == L.LDS_CLEAN] <= comp.n_mva) and np.all(p2[k2 == L.LDS_CLEAN] <= comp.n_mva)
     # sectors the codes cannot describe get no table: noise-abatement areas (no candidate masks)
     from envs.atc import scenarios
@@ -110,9 +118,9 @@ def test_device_table_lookup_equals_oracle(scen):
     got, src = sec.query_mva_lds(pts[:, 0], pts[:, 1])
     assert np.array_equal(got, exp)
     # the table itself answered (a wavefront of 64 consecutive points goes to the grid as a whole when one of them is residual)
-    code, _, _ = S.lds_table_lookup(comp.lds_table(), pts[:, 0], pts[:, 1])
+    code, _, _, _ = S.lds_table_lookup(comp.lds_table(), pts[:, 0], pts[:, 1])
     n = 1500000 // 64 * 64
-    assert src[:n].mean() > (0.7 if scen == "LOWW" else 0.3)   # (1 % residual points = every second wavefront: the test sectors' horizontal borders)
+    assert src[:n].mean() > 0.9
     assert np.array_equal(src[:n].reshape(-1, 64).all(axis=1), (code[:n] >= 0).reshape(-1, 64).all(axis=1)), \
         "the kernel and its numpy restatement agree on which wavefronts the table answers"
     sec.close()
@@ -126,11 +134,16 @@ def test_device_table_lookup_on_random_sectors(seed, n_poly):
     mvas, runway, entries = random_sector(seed, n_poly)
     comp = S.compile_sector(mvas, runway, entries, grid_cell=0.5)
     sec = lib.Scenario(comp, lds_table=True)
+    staged = int(comp.lds_table()[:4 * L.LDS_HDR_WORDS].view(np.uint32)[L.LDS_H_LDS_BYTES])
+    if staged + 10240 > 160 * 1024:   # (22 overlapping polygons: more refined cells than one CU's LDS holds — such a sector steps from the grid)
+        assert not sec.has_lds_table
+        sec.close()
+        return
     assert sec.has_lds_table
     pts = _points(comp, np.random.default_rng(200 + seed), 400000, per_edge=60)
     exp = O.OracleQueries(comp, np.float32).mva(pts[:, 0], pts[:, 1])
     got, src = sec.query_mva_lds(pts[:, 0], pts[:, 1])
-    assert np.array_equal(got, exp) and src.mean() > 0.3
+    assert np.array_equal(got, exp) and src.mean() > 0.5
     sec.close()
 
 
@@ -156,9 +169,14 @@ def test_attach_refuses_malformed_tables():
         mutate(bad)
         assert attach(bad) == -1
     off_l1, nx = int(hdr(good)[L.LDS_H_OFF_L1]), int(hdr(good)[L.LDS_H_NX])
-    for code in ((L.LDS_LINE << 13) | 0x1fff, (L.LDS_SUB << 13) | 0x1fff, (L.LDS_RESID << 13), 64):
+    for code in ((L.LDS_LINE << 13) | 0x1fff, (L.LDS_SUB << 13) | 0x1fff, (L.LDS_RESID << 13), 64):   # (RESID: sub-cells only)
         bad = good.copy()
         bad[off_l1 + 2 * (5 * nx + 5):off_l1 + 2 * (5 * nx + 5) + 2].view(np.uint16)[0] = code
+        assert attach(bad) == -1
+    off_resid, n_rec = int(hdr(good)[L.LDS_H_OFF_RESID]), int(hdr(good)[L.LDS_H_N_REC])
+    for word in (0, n_rec | (1 << 24), (n_rec - 1) | (2 << 24), 64 << 24):       # walk words: 1 <= n < 64 records inside the pool
+        bad = good.copy()
+        bad[off_resid:off_resid + 4].view(np.uint32)[0] = word
         assert attach(bad) == -1
     bad = good.copy()
     bad[off_l1:off_l1 + 2].view(np.uint16)[0] = 1      # the border ring must stay clean and outside
