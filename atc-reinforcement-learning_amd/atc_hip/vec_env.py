@@ -80,7 +80,8 @@ class AtcVecEnv:
         self.grid_cell = grid_cell
         # (one-aircraft envs: the sector's LDS-resident lookup table goes along — the multi-step launches of batches that fit one
         # workgroup per CU answer the MVA lookup from LDS, include/atc_step.h ABI 21; `lds_table=False` keeps it off, for A/B runs)
-        self.sector = _lib.Scenario(self.compiled, device, lds_table=(self.N == 1 and lds_table))
+        # (... batches the LDSG launch can serve: whole workgroups of 256 one-aircraft envs — a single env never gets there)
+        self.sector = _lib.Scenario(self.compiled, device, lds_table=(self.N == 1 and self.B % 256 == 0 and bool(lds_table)))
         self.device = self.sector.device
         n_entry = self.compiled.n_entry
         if n_entry < 1:

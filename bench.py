@@ -448,7 +448,26 @@ def side_config(name, B, N, scn, sep_nm, device, held_hint, n_single=2000, n_fus
     e1.record()
     torch.cuda.synchronize(dev)
     usf = e0.elapsed_time(e1) * 1e3 / (n_fused * HOLD)
+    lds_tab = bool(getattr(env.sector, "has_lds_table", False))
     env.close()
+    lds_ab = None
+    if lds_tab:
+        # one-aircraft envs (ABI 21): the multi-step launch answers the MVA lookup from a table staged in LDS; the same loop
+        # without it (the lookup grid's gather) as the A/B side of the record
+        env3 = AtcVecEnv(B, N, scenario=scn, device=device, auto_reset=True, seed=11, grid_cell=grid_cell, sep_nm=sep_nm, lds_table=False)
+        for j in range(30):
+            env3.rollout(ring[j % len(ring)][None], out=ro, hold=HOLD)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for j in range(n_fused):
+            env3.rollout(ring[j % len(ring)][None], out=ro, hold=HOLD)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        lds_ab = {"us_per_step_from_the_lookup_grid": e0.elapsed_time(e1) * 1e3 / (n_fused * HOLD),
+                  "note": "atc_scenario_attach_lds_table (include/atc_step.h, ABI 21): k_step<1, ..., LDSG>, one workgroup per CU, "
+                          "the sector's two-level code table staged in LDS once per launch; results identical (tests/test_lds_table.py)"}
+        env3.close()
     b1, bf = algorithmic_bytes_per_env_step(N), algorithmic_bytes_per_env_step(N, HOLD, HOLD)
     tr1, src1 = traffic_entry(B, N, 0, held_hint)
     trf, srcf = traffic_entry(B, N, HOLD, False)
@@ -461,7 +480,8 @@ def side_config(name, B, N, scn, sep_nm, device, held_hint, n_single=2000, n_fus
                              "traffic_over_algorithmic": (tr1 / (b1 * B)) if tr1 else None, "coarser_grid": alt},
             "fused_rollout": {"entry": "atc_rollout_hold", "T": HOLD, "hold": HOLD, "launches": n_fused, "us_per_step": usf,
                               "env_steps_per_s": B / (usf * 1e-6), "algorithmic_bytes_per_env_step": bf,
-                              "hbm_frac": bf * B / (usf * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": trf, "traffic_source": srcf}}
+                              "hbm_frac": bf * B / (usf * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": trf, "traffic_source": srcf,
+                              "lds_table": lds_tab, "lds_table_ab": lds_ab}}
 
 
 def single_env_protocol(n_steps=100000):
