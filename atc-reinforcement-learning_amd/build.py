@@ -12,6 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "atc_step.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "atc_device.h"), os.path.join(HERE, "csrc", "atc_abi.inc"), os.path.join(HERE, "csrc", "atc_wave.h"),
+        os.path.join(HERE, "csrc", "atc_aux_kernels.inc"),
         os.path.join(os.path.dirname(HERE), "include", "atc_step.h")]
 OUT = os.path.join(HERE, "atc_hip", "libatcstep.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

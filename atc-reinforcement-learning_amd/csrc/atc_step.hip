@@ -1521,141 +1521,7 @@ k_serve(const float* __restrict__ blob, int off_grid, atc_state_t st, atc_out_t 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// reset kernel (AtcGym.reset, atc_gym.py:337-365)
-// ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
-k_reset(const float* __restrict__ blob, int B, int N, atc_state_t st, const uint8_t* __restrict__ mask,
-        float* __restrict__ obs, atc_params_t p, int first) {
-    const uint32_t BN = (uint32_t)B * (uint32_t)N;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < BN; i += gridDim.x * kBlock) {
-        const int e = (int)(i / (uint32_t)N), k = (int)(i % (uint32_t)N);
-        if (mask && !mask[e]) continue;
-        const int episode = first ? 0 : st.stats[(size_t)e * ATC_STAT_WORDS + ATC_STAT_EPISODES];
-        float o[ATC_OBS_DIM];
-        const Aircraft a = spawn(blob, (int)blob[ATC_H_OFF_SPAWN], p, e, k, episode, o);
-        reinterpret_cast<int4*>(st.ac)[i] = make_int4(a.x, a.y, a.phi, (int)a.v);
-        st.alt[i] = a.h;
-        // atc_gym.py:86: last_action = [0,0,0] once, in __init__ — never on reset (quirk Q7) — in the state's formats: 0 kt = 0
-        // counts, 0 deg = the counts of 0 deg, 0 ft = 0.0 (float64)
-        if (first) reinterpret_cast<int4*>(st.last_act)[i] = make_int4(0, phi_store(0.0f), 0, 0);
-        if (obs) store_obs(obs + (size_t)i * ATC_OBS_DIM, o);   // the raw reset observation (mva = 0, atc_gym.py:351)
-    }
-}
-// _get_state(0) of the current state (atc_gym.py:351)
-__global__ void __launch_bounds__(kBlock)
-k_observe(const float* __restrict__ blob, int B, int N, atc_state_t st, const uint8_t* __restrict__ mask,
-          float* __restrict__ obs) {
-    const uint32_t BN = (uint32_t)B * (uint32_t)N;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < BN; i += gridDim.x * kBlock) {
-        const int e = (int)(i / (uint32_t)N);
-        if (mask && !mask[e]) continue;
-        const int4 ps = reinterpret_cast<const int4*>(st.ac)[i];
-        const double h = st.alt[i];
-        float ang = phi_real(ps.z), o3 = ang;
-        if (is_wide(ps.z)) {   // (include/atc_step.h, ABI 19: the exact counts are in the side record)
-            const double P = st.phi_wide[4 * (size_t)i];
-            ang = phi_real(phi_wrap(P));
-            o3 = phi_obs_wide(P);
-        }
-        const Obs ob = get_state(obs_const(blob), ps.x, ps.y, pos_to_real(blob, 0, ps.x), pos_to_real(blob, 1, ps.y),
-                                 (float)h, ang, o3, v_real((uint32_t)ps.w), alt_above(h, 0.0f));
-        store_obs(obs + (size_t)i * ATC_OBS_DIM, ob.o);
-    }
-}
-// env-level part of reset runs after k_reset (the episode counter is read by k_reset's spawn)
-__global__ void __launch_bounds__(kBlock)
-k_reset_env(int B, int N, atc_state_t st, const uint8_t* __restrict__ mask, int first) {
-    const int e = blockIdx.x * kBlock + threadIdx.x;
-    if (e >= B) return;
-    if (mask && !mask[e]) return;
-    int32_t* er = st.env + (size_t)e * ATC_ENV_WORDS;
-    int32_t* sr = st.stats + (size_t)e * ATC_STAT_WORDS;
-    if (first) {
-        sr[ATC_STAT_WIN_BITS] = 0;
-        sr[ATC_STAT_EPISODES] = 0;
-        sr[ATC_STAT_EP_RETURN] = __float_as_int(0.0f);
-        sr[ATC_STAT_EP_LENGTH] = 0;
-        sr[ATC_STAT_EP_ACTIONS] = 0;
-        sr[6] = sr[7] = 0;
-    }
-    er[ATC_ENV_TOTAL_REWARD] = __float_as_int(0.0f);
-    er[ATC_ENV_ACTIONS_TAKEN] = 0;
-    er[ATC_ENV_TIMESTEPS] = 0;
-    sr[ATC_STAT_EPISODES] = sr[ATC_STAT_EPISODES] + 1;
-    const uint64_t full = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
-    er[ATC_ENV_MASK_LO] = (int)(uint32_t)(full & 0xffffffffu);
-    sr[ATC_STAT_MASK_HI] = (int)(uint32_t)(full >> 32);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// query kernels
-// ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
-k_query_mva(const float* __restrict__ blob, int off_grid, int n, const float* __restrict__ x,
-            const float* __restrict__ y, int32_t* __restrict__ out_h, int32_t* __restrict__ out_idx) {
-    const float* grid = off_grid ? blob + off_grid : nullptr;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        float hgt;
-        const int pi = find_mva(blob, grid, x[i], y[i], &hgt);
-        if (out_h) out_h[i] = pi >= 0 ? (int32_t)hgt : -1;
-        if (out_idx) out_idx[i] = pi;
-    }
-}
-// the same lookup through the LDS-resident table (atc_query_mva_lds): from_lds[i] = 1 where the table (or the walk of a residual
-// sub-cell's records) answered, 0 where the point's WAVEFRONT went to the global grid (like in the step kernel: all of its lanes
-// then take the grid's answer)
-__global__ void __launch_bounds__(kBlock, 1)
-k_query_mva_lds(const float* __restrict__ blob, int off_grid, LdsTab lt, int n, const float* __restrict__ x,
-                const float* __restrict__ y, int32_t* __restrict__ out_h, uint8_t* __restrict__ from_lds) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    uint4* dst = reinterpret_cast<uint4*>(smem);
-    for (int j = threadIdx.x; j < lt.n16; j += kBlock) dst[j] = lt.src[j];
-    __syncthreads();
-    const char* tab = reinterpret_cast<const char*>(dst);
-    const float* grid = blob + off_grid;
-    const GridHdr gh = grid_header(grid);
-    const int n_up = (n + 63) & ~63;   // whole wavefronts: the fallback is a wave-uniform decision
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_up; i += gridDim.x * kBlock) {
-        const bool live = i < n;
-        const float px = live ? x[i] : 0.0f, py = live ? y[i] : 0.0f;
-        const LdsCode lc = lds_cell_load(tab, lt, px, py);
-        float hgt;
-        uint32_t walk;
-        bool band;
-        int pi = lds_resolve(tab, lt, lc, px, py, &hgt, &walk, &band);
-        if (walk != 0u) pi = lds_walk(lt, walk, px, py, &hgt);
-        const bool fallback = __builtin_amdgcn_ballot_w64(band && live) != 0ull;
-        if (fallback) {
-            const MvaCell c = mva_cell_load(grid, gh, px, py);
-            pi = mva_resolve(blob, grid, gh, c, px, py, &hgt);
-        }
-        if (live) {
-            out_h[i] = pi >= 0 ? (int32_t)hgt : -1;
-            if (from_lds) from_lds[i] = fallback ? 0 : 1;
-        }
-    }
-}
-__global__ void __launch_bounds__(kBlock)
-k_query_corridor(const float* __restrict__ blob, int n, const float* __restrict__ x,
-                 const float* __restrict__ y, const float* __restrict__ h, const float* __restrict__ phi, int angle_only,
-                 uint8_t* __restrict__ out) {
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
-        out[i] = angle_only ? inside_corridor_angle(blob, x[i], y[i], heading_counts_of(phi[i]))
-                            : inside_corridor(blob, tri_bbox(blob), x[i], y[i], h[i], heading_counts_of(phi[i]));
-}
-__global__ void __launch_bounds__(kBlock)
-k_query_shaping(const float* __restrict__ blob, int n, const float* __restrict__ d_faf,
-                const float* __restrict__ phi_rel_faf, const float* __restrict__ phi_plane, const float* __restrict__ h,
-                const float* __restrict__ on_gp, float* __restrict__ out3) {
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const Shaping s = shaping_rewards(obs_const(blob), d_faf[i], phi_rel_faf[i], relative_angle(blob[ATC_C_PHI_TO_RWY], phi_plane[i]),
-                                          h[i], on_gp[i]);
-        out3[3 * i + 0] = s.pos;
-        out3[3 * i + 1] = s.ang;
-        out3[3 * i + 2] = s.gs;
-    }
-}
+#include "atc_aux_kernels.inc"   // k_reset, k_observe, k_reset_env, k_query_*
 
 // ---------------------------------------------------------------------------------------------------------------
 // host side of the C-ABI
