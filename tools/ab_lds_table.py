@@ -3,6 +3,8 @@
 import sys, torch, time
 import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'atc-reinforcement-learning_amd'))
+from atc_hip import lib as _binding
+if os.environ.get('ATC_AB_LIB'): _binding.use_library(os.environ['ATC_AB_LIB'])
 from atc_hip.vec_env import AtcVecEnv
 from envs.atc import scenarios
 B, T = 65536, 20
