@@ -415,9 +415,10 @@ __device__ __forceinline__ int find_mva(const float* __restrict__ K, const float
 //      SIMD): there the lookup grid's gather is 0.8 us of exposed wait in every step and its dirty cells a second / third dependent
 //      trip in 40 % of the wavefront-steps (profiles/experiments/README.md, round 6).  A workgroup stages the table once per
 //      launch; a step then reads a 16-bit level-1 code (0.5 nm cells), a 16-bit sub-cell code (8 x 8 per refined cell) and — for a
-//      cell ONE border line splits — that line's 32-byte record, all from LDS: no vector-memory wait on the step's chain.  A lane the
-//      table cannot answer (RESIDUAL sub-cell: a vertex or a second border inside it; a point inside a line's margin band) sends
-//      its WHOLE wavefront to the global grid for this step — one wavefront-step in seven.  Same answers as the ordered polygon
+//      cell ONE border line splits — that line's 32-byte record, all from LDS: no vector-memory wait on the step's chain.  A lane in
+//      a RESIDUAL sub-cell (a vertex or a second border inside it: 0.2 % of the aircraft, one wavefront-step in twelve) walks that
+//      sub-cell's own edge records — one trip to global memory for the lanes concerned; a point inside a line's margin band (one
+//      wavefront-step in sixty) sends its WHOLE wavefront to the global grid for this step.  Same answers as the ordered polygon
 //      scan either way (tests/test_lds_table.py: the numpy restatement against the fp32 oracle on the CPU, the kernels on the GPU).
 struct LdsTab {             // kernel argument: where the table lives in global memory + its header terms (host-checked)
     const uint4* src;       // 16-byte pieces; nullptr: no table attached
