@@ -1227,7 +1227,7 @@ __device__ __forceinline__ void store_env_state(const atc_state_t& st, const Lan
 #define ATC_LAT_WAVES 2   // wavefronts per SIMD the latency-bound instantiation is register-budgeted for (<= 256 VGPRs)
 // ONE: single-step launch (T == 1); ALLV: every slot is an aircraft (make_ids); LAT: latency-bound multi-step instantiation (above)
 // LDSG: the latency-bound launch of ONE-aircraft envs with the sector's lookup table staged in LDS (csrc/atc_device.h: LdsTab) — one
-// workgroup per CU (the table is ~105 KB for LOWW), chosen by the host when the launch has no more workgroups than the device CUs
+// workgroup per CU (the table's staged part is 112 KB for LOWW), chosen by the host when the launch has no more workgroups than the device CUs
 template <int W, bool FULL, bool ONE, bool ALLV, bool LAT = false, bool LDSG = false>
 __global__ void __launch_bounds__(kBlock, (LDSG ? 1 : LAT ? ATC_LAT_WAVES : ONE ? ATC_MIN_WAVES : ((FULL || W <= 8 || W >= 32) ? ATC_MIN_WAVES_LOOP - 1 : ATC_MIN_WAVES_LOOP)))
 k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int hold, atc_state_t st,
@@ -1308,14 +1308,14 @@ k_step(const float* __restrict__ blob, int off_grid, int B, int N, int T, int ho
         asm volatile("s_mov_b32 %0, 0" : "=s"(zn));
         qr_next = kernarg_reread<QRates>(offsetof(StepArgs, q) + offsetof(StepDerived, r), zn);
     }
-    // LDSG: stage the lookup table — 16 sixteen-byte pieces per lane in flight at a time (two round trips for LOWW's 105 KB), behind
+    // LDSG: stage the lookup table — 28 sixteen-byte pieces per lane in flight at a time (ONE round trip for LOWW's 112 KB), behind
     // the state loads issued above; the terms a step reads with the table go to vector registers like the other uniform terms (LAT)
     LdsTab ltv = lt_arg;
     const char* ltab = nullptr;
     if (LDSG) {
         uint4* dst = reinterpret_cast<uint4*>(smem + (kBlock / 64) * 64 * ATC_OBS_DIM);   // behind the observation transpose stage
         const int n16 = lt_arg.n16;
-        constexpr int kDepth = 28;   // (LOWW: 6 713 pieces = ONE batch of 28 x 256)
+        constexpr int kDepth = 28;   // (LOWW: 7 144 pieces = ONE batch of 28 x 256)
         for (int base = 0; base < n16; base += kDepth * kBlock) {
             uint4 v[kDepth];
 #pragma unroll
