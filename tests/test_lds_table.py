@@ -233,3 +233,57 @@ def test_rollouts_identical_with_and_without_the_table(B, scen, dt):
     if scen == "LOWW":   # (the test sector's aircraft have left it before a descent reaches a floor)
         assert int(((flags & L.F_BELOW_MVA) != 0).sum()) > 0
     assert int(sa[4][:, L.STAT_EPISODES].sum()) > B // 8
+
+
+def _scenario_of(mvas, runway, entries):
+    from envs.atc import model, scenarios
+    s = scenarios.Scenario()
+    s.mvas = [model.MinimumVectoringAltitude([tuple(map(float, p)) for p in ring], int(h)) for ring, h in mvas]
+    s.runway = model.Runway(*runway)
+    s.airspace = model.Airspace(s.mvas, s.runway)
+    s.entrypoints = [model.EntryPoint(x, y, phi, list(levels)) for x, y, phi, levels in entries]
+    s.noise_areas = []
+    return s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_poly,dt", [(21, 6, 1.0), (22, 12, 2.0), (23, 9, 0.7)])
+def test_table_rollouts_on_random_sectors_against_the_oracle(seed, n_poly, dt):
+    """The LDSG launch on arbitrary polygon sets (overlaps, shared and axis-aligned borders, horizontal edges: residual walks and
+    margin-band fall-backs in most wavefronts) against the fp32 oracle stepped once per step: flags / done exact, obs / reward
+    within 1e-5, state and counters identical afterwards."""
+    import torch
+    from atc_hip.vec_env import AtcVecEnv
+    from envs.atc import model, scenarios
+    from oracle import oracle as O
+    mvas, runway, _ = random_sector(seed, n_poly)
+    rng = np.random.default_rng(seed)
+    entries = [(float(x), float(y), float(rng.integers(0, 360)), [60, 90, 120]) for x, y in rng.uniform(15, 45, (6, 2))]
+    scn = _scenario_of(mvas, runway, entries)
+    B, T, hold = 512, 20, 10
+    env = AtcVecEnv(B, 1, sim_parameters=model.SimParameters(dt), scenario=scn, auto_reset=True, seed=3, grid_cell=0.25, spawn="random")
+    if not env.sector.has_lds_table:
+        pytest.skip("this sector's table does not fit one CU's LDS")
+    orc = O.OracleEnv(scenarios.compile_scenario(scn, grid_cell=0.25), B, 1,
+                      O.make_params(dt=dt, auto_reset=True, seed=3, random_entry=True), np.float32)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    events = 0
+    for j in range(10):
+        blocks = torch.rand((T // hold, B, 1, 3), generator=g) * 2 - 1
+        blocks[:, ::2, :, 1] = -0.95      # half of the envs descend into the floors
+        out = env.rollout(blocks, hold=hold)
+        for t in range(T):
+            orc.step(blocks[t // hold].numpy())
+            fl = out["flags"][t].cpu().numpy().astype(np.uint16).reshape(B, 1)
+            assert np.array_equal(fl, orc.flags), (j, t)
+            assert np.array_equal(out["done"][t].cpu().numpy(), orc.done), (j, t)
+            o = out["obs"][t].cpu().numpy().reshape(B, 1, 10)
+            assert np.all(np.abs(o - orc.obs) <= 1e-5 * np.maximum(1.0, np.abs(orc.obs))), (j, t)
+            r = out["reward"][t].cpu().numpy()
+            assert np.all(np.abs(r - orc.reward) <= 1e-5 * np.maximum(1.0, np.abs(orc.reward))), (j, t)
+            events += int((fl & (L.F_BELOW_MVA | L.F_OUTSIDE)).astype(bool).sum())
+    assert events > B // 4
+    assert np.array_equal(env.ac[:, 0].cpu().numpy(), orc.px) and np.array_equal(env.ac[:, 1].cpu().numpy(), orc.py)
+    assert np.array_equal(env.alt.cpu().numpy(), np.asarray(orc.h, dtype=np.float64).ravel())
+    assert np.array_equal(env.actions_taken.cpu().numpy(), orc.actions_taken)
+    env.close()
