@@ -71,6 +71,11 @@ def _case(seed):
     # only exact at 1 / 2 / 5 s; tests/golden/g12 pins the reference at these)
     if int(rng.integers(3)) == 0:
         kw["dt"] = float(rng.choice([0.05, 0.1, 0.15, 0.3, 0.7, 1.3, 3.7, 0.37, 2.1]))
+    # round 6 (ABI 21), drawn last: one-aircraft envs stepped by multi-step launches get, every second time, a batch of whole
+    # 256-env workgroups — with a lookup grid and no noise-abatement areas that launch answers the MVA lookup from the sector's
+    # LDS-resident table (k_step<1, ..., LDSG>; tests/test_lds_table.py)
+    if N == 1 and kw["use_rollout"] and int(rng.integers(2)) == 0:
+        kw["B"] = 256 * int(rng.integers(1, 3))
     return scn, comp, kw
 
 
