@@ -26,6 +26,9 @@ inputs + expected outputs of the AtcGym.step() hot path as small fixtures:
   g12_timesteps.npz   SimParameters.timestep in {0.05, 0.1, 0.15, 0.3, 0.7, 1.3, 3.7} s (round 6): sustained descents into the MVAs,
                       altitude TIES (n x 41 dt ft above an MVA, decided by the reference's own float64 rounding), landings on
                       targets, >= 3 000-step slow episodes (compact format of g9)
+  g13_timestep_sweep.npz  ten MORE timesteps, 0.01 ... 47 s (0.01, 0.033, 0.25, 0.9, 1.7, 2.5, 7.3, 13, 29, 47), each with random held actions
+                      (blocks of 1 / 5 / 20 / 100 steps) on LOWW_random / LOWW unshaped / Simple un-normalised / LOWW_random discrete / UnitTest,
+                      every second episode a descent, the last of each configuration a time-out (compact format of g9)
   g11_unbounded.npz   actions outside the action space, replayed by the reference: sustained a_phi up to +-3 (heading to 720 / -360
                       deg), headings wound to +-5 500 deg and back, un-clipped random actions, discrete heading indices beyond 360,
                       G9's winning intercepts flown at heading + 360 k, altitude targets within an fp32 action step of the MVA; the compact form of g9
@@ -986,8 +989,42 @@ def gen_g12():
     return rec, ties, sorted(spots)
 
 
+G13_DTS = (0.01, 0.033, 0.25, 0.9, 1.7, 2.5, 7.3, 13.0, 29.0, 47.0)
+
+
+def gen_g13():
+    """A sweep over SimParameters.timestep far from G12's values — 0.01 s (rate limits of a few hundredths of a unit per step) to 47 s
+    (the largest the fixed-point position format takes is 51 s: a step of 4 nm) — with ordinary inputs: random actions held for 1 /
+    5 / 20 / 100 steps, every configuration switch once (shaping off, normalisation off, discrete actions), three sectors.  The
+    probe of the round-5 review ran six timesteps against the build; this is the same question asked of ten others, kept."""
+    rec = WideRecorder(stride=8)
+    rng = np.random.default_rng(777)
+    for dt in G13_DTS:
+        for scen, shaping, normalize, discrete in (("LOWW_random", True, True, False), ("LOWW", False, True, False),
+                                                   ("Simple", True, False, False), ("LOWW_random", True, True, True),
+                                                   ("UnitTest", True, True, False)):
+            env = make_env(scen, dt=dt, shaping=shaping, normalize=normalize, discrete=discrete)
+            random.seed(int(dt * 1000) + len(scen) + 7)
+            n_ep = 3 if dt < 0.1 else 6
+            for k in range(n_ep):
+                max_steps = int(min(6500, 2500 / dt)) if dt < 1 else int(min(3000, 6000 / dt + 50))
+                hold = int(rng.choice([1, 5, 20, 100]))
+                acts = []
+                for b in range(max_steps // hold + 1):
+                    if discrete:
+                        a = np.array([rng.integers(0, 20), rng.integers(0, 380), rng.integers(0, 360)], dtype=np.float64)
+                    else:
+                        a = f32([rng.uniform(-1, 1), rng.uniform(-1, 1) if k % 2 else rng.uniform(-1, -0.6), rng.uniform(-1, 1)])
+                    acts.append(np.tile(a, (hold, 1)))
+                acts = np.concatenate(acts)[:max_steps]
+                it = (6000 - int(rng.integers(1, 40))) if k == n_ep - 1 else None      # the last episode runs into the time limit
+                rec.run(env, acts, scen, dt, shaping, normalize, discrete, init_timesteps=it, extra_after_done=3)
+    rec.save(os.path.join(HERE, "g13_timestep_sweep.npz"))
+    return rec
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "mt", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "mt", "g8", "g9", "g10", "g11", "g12", "g13"]
     if "g1" in which:
         gen_g1()
     if "mt" in which:
@@ -1035,6 +1072,12 @@ if __name__ == "__main__":
         fl, dn = np.asarray(r.flags), np.asarray(r.done)
         print("g12 episodes", len(r.ep), "steps", len(fl), "sampled rows", len(r.samp_rows), "tie episodes", ties, "MVA heights with a circle", hts,
               "timesteps", sorted(set(e["dt"] for e in r.ep)))
+        for name, bit in (("below", 1), ("outside", 2), ("won", 4), ("timeout", 8), ("inv_v", 16), ("inv_h", 32)):
+            print(name, int(((fl & bit) != 0).sum()), "terminal:", int((((fl & bit) != 0) & (dn != 0)).sum()))
+    if "g13" in which:
+        r = gen_g13()
+        fl, dn = np.asarray(r.flags), np.asarray(r.done)
+        print("g13 episodes", len(r.ep), "steps", len(fl), "sampled rows", len(r.samp_rows), "timesteps", sorted(set(e["dt"] for e in r.ep)))
         for name, bit in (("below", 1), ("outside", 2), ("won", 4), ("timeout", 8), ("inv_v", 16), ("inv_h", 32)):
             print(name, int(((fl & bit) != 0).sum()), "terminal:", int((((fl & bit) != 0) & (dn != 0)).sum()))
     print("done")

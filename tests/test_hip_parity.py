@@ -369,7 +369,8 @@ class _HipInterleaved:
 
 @pytest.mark.parametrize("N,chunk,fixture", [(16, 1, "g9_wide.npz"), (64, 1, "g9_wide.npz"), (5, 1, "g9_wide.npz"), (16, 10, "g9_wide.npz"),
                                               (64, 10, "g9_wide.npz"), (32, 5, "g9_wide.npz"), (8, 1, "g11_unbounded.npz"), (8, 10, "g11_unbounded.npz"),
-                                              (8, 1, "g12_timesteps.npz"), (8, 10, "g12_timesteps.npz"), (16, 5, "g12_timesteps.npz")])
+                                              (8, 1, "g12_timesteps.npz"), (8, 10, "g12_timesteps.npz"), (16, 5, "g12_timesteps.npz"),
+                                              (5, 1, "g13_timestep_sweep.npz"), (5, 10, "g13_timestep_sweep.npz")])
 def test_reference_episodes_as_the_aircraft_of_one_env(N, chunk, fixture):
     """helpers.replay_wide_interleaved through the batched kernels: N reference episodes of g9 are the N aircraft of one env
     (separation minimum 0, the reference's episode rule), single steps and multi-step launches (the 32- / 64-aircraft ones under the
@@ -377,7 +378,8 @@ def test_reference_episodes_as_the_aircraft_of_one_env(N, chunk, fixture):
     _torch()
     fx = H.WideFixture(fixture)   # (g11: actions outside the action space, WIDE headings in several aircraft of one env)
     n, envs = H.replay_wide_interleaved(fx, _HipInterleaved, N, obs_tol=1e-5, state_tol=1e-5, rew_tol=1e-5, chunk=chunk)
-    assert (envs >= 8 and n > 100000) if fixture == "g9_wide.npz" else (envs >= 10 and n > 20000), (n, envs)
+    least = {"g9_wide.npz": (8, 100000), "g13_timestep_sweep.npz": (30, 10000)}.get(fixture, (10, 20000))
+    assert envs >= least[0] and n > least[1], (n, envs)
 
 
 def test_wide_fixture_batched():
@@ -400,6 +402,15 @@ def test_unbounded_heading_fixture_batched():
     assert n == len(fx.flags) > 93000
     phi = fx.state[:, 3]
     assert phi.max() >= 5000 and phi.min() <= -5000
+
+
+def test_timestep_sweep_fixture_batched():
+    """G13: ten more timesteps, 0.01 ... 47 s, ordinary random-held actions, every configuration switch, three sectors (122 805
+    reference steps) through the batched kernel at g9's bars."""
+    fx = H.WideFixture("g13_timestep_sweep.npz")
+    H.WRAP_ROWS[0] = 0
+    n = H.replay_wide(fx, _HipLockstep, obs_tol=1e-5, state_tol=1e-5, rew_tol=1e-5)
+    assert n == len(fx.flags) > 120000 and H.WRAP_ROWS[0] <= 10
 
 
 def test_timestep_fixture_batched():
