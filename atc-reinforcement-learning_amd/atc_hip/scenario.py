@@ -871,6 +871,11 @@ def compile_sector(mvas, runway, entrypoints, noise=(), grid_cell=None, grid_gua
         # ships uses [0, 360).  Kinematics, corridor and relative angles are periodic, only the raw heading observation is not.
         if not -76.0 < float(ephi) < 436.0:
             raise ValueError("entry point heading %r outside (-76, 436) deg: wrap it into [0, 360)" % (ephi,))
+    for _, _, _, levels in entrypoints:
+        # model.py:35-36: Airplane.__init__ refuses an altitude outside [h_min, h_max] — the reference raises it from the reset() that
+        # draws such a level; the spawn records are evaluated here, once, so the same error comes at construction
+        if any((100.0 * float(lv) < 0.0) or (100.0 * float(lv) > 38000.0) for lv in levels):
+            raise ValueError("invalid altitude")
     off_slot = (off_entry + n_entry * L.E_WORDS + 3) & ~3  # 16-byte aligned float4 records
     end = off_slot + (4 * L.MAX_AIRCRAFT if n_entry else 0)
     off_spawn = (end + 15) & ~15   # 64-byte aligned spawn records: 64 lattice slots, then one per entry point

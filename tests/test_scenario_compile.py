@@ -297,6 +297,20 @@ def test_device_blob_cannot_be_rebuilt_without_the_spawn_image():
     assert np.array_equal(again.blob32.view(np.int32), np.asarray(c.blob32).view(np.int32))
 
 
+def test_entry_points_the_reference_would_refuse_are_refused():
+    """model.py:35-36: Airplane.__init__ raises ValueError("invalid altitude") for an altitude outside [0, 38 000] ft — in the reference
+    from the reset() that draws such a flight level; here at construction, where the spawn records are evaluated.  (The entry
+    HEADING is never validated by the reference; the device's 32-bit field holds (-76, 436) deg, compile_sector says so.)"""
+    from atc_hip import scenario as S
+    mvas = [([(0, 0), (40, 0), (40, 40), (0, 40)], 3000)]
+    for levels in ([150, 390], [-10], [381]):
+        with pytest.raises(ValueError, match="invalid altitude"):
+            S.compile_sector(mvas, (20.0, 20.0, 500.0, 90.0), [(5.0, 5.0, 45.0, levels)])
+    S.compile_sector(mvas, (20.0, 20.0, 500.0, 90.0), [(5.0, 5.0, 45.0, [0, 380])])
+    with pytest.raises(ValueError, match="heading"):
+        S.compile_sector(mvas, (20.0, 20.0, 500.0, 90.0), [(5.0, 5.0, 500.0, [150])])
+
+
 def test_oversized_sector_falls_back_to_a_coarser_grid():
     """a sector a few times LOWW's size does not fit the blob's 2^24 words at the finest lookup grid: an explicit
     request raises SectorTooLarge (a ValueError with a message), `auto` (vec_env.AtcVecEnv) takes the next size that fits."""
